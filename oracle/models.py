@@ -1,0 +1,95 @@
+"""Single-chain NumPy target densities used as oracle-side models (TEST INFRASTRUCTURE).
+
+They satisfy the reference's structural Model protocol (``bayes_kit/typing.py:15-27``):
+``dims()``, ``log_density(theta)``, ``log_density_gradient(theta)``.  The operation order
+written here is the specification the built-in HIP targets (``bk_target_*`` in
+``include/bkhip.h``) are tested against: every ``*`` and ``+`` individually rounded,
+elementwise parts bit-exact, reductions within the stated tolerance.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class StdNormal:
+    """D=1 standard normal; same arithmetic as the reference's test fixture
+    ``test/models/std_normal.py:4-13``."""
+
+    def dims(self) -> int:
+        return 1
+
+    def log_density(self, theta):
+        t = theta[0]
+        return -0.5 * t * t
+
+    def log_density_gradient(self, theta):
+        return -0.5 * theta[0] * theta[0], -theta
+
+
+class IsoGaussian:
+    """logp = -1/2 theta.theta ; grad = -theta   (BASELINE.json config 2)."""
+
+    def __init__(self, D: int):
+        self._D = int(D)
+
+    def dims(self) -> int:
+        return self._D
+
+    def log_density(self, theta):
+        return -0.5 * np.dot(theta, theta)
+
+    def log_density_gradient(self, theta):
+        return -0.5 * np.dot(theta, theta), -theta
+
+
+class DiagGaussian:
+    """logp = -1/2 sum_i lam_i theta_i^2 ; grad = -(lam * theta)   (config 3)."""
+
+    def __init__(self, lam):
+        self._lam = np.asarray(lam, dtype=np.float64)
+
+    def dims(self) -> int:
+        return self._lam.shape[0]
+
+    def log_density(self, theta):
+        t = self._lam * theta
+        return -0.5 * np.dot(theta, t)
+
+    def log_density_gradient(self, theta):
+        t = self._lam * theta
+        return -0.5 * np.dot(theta, t), -t
+
+
+class Funnel:
+    """Neal's funnel, v = theta[0] ~ N(0, 3^2), x_i ~ N(0, e^v), i = 1..D-1 (config 4).
+
+    logp = -v^2/18 - (n/2) v - 1/2 e^{-v} sum x^2,  n = D-1
+    d/dv = -v/9 - n/2 + 1/2 e^{-v} sum x^2 ;  d/dx_i = -e^{-v} x_i
+    """
+
+    def __init__(self, D: int):
+        self._D = int(D)
+
+    def dims(self) -> int:
+        return self._D
+
+    def _parts(self, theta):
+        v = theta[0]
+        x = theta[1:]
+        ev = np.exp(-v)
+        s = np.dot(x, x)
+        hn = 0.5 * (self._D - 1)
+        he = 0.5 * ev
+        return v, x, ev, s, hn, he
+
+    def log_density(self, theta):
+        v, x, ev, s, hn, he = self._parts(theta)
+        return ((-(v * v) / 18.0) - hn * v) - he * s
+
+    def log_density_gradient(self, theta):
+        v, x, ev, s, hn, he = self._parts(theta)
+        lp = ((-(v * v) / 18.0) - hn * v) - he * s
+        g = np.empty(self._D, dtype=np.float64)
+        g[0] = ((-v / 9.0) - hn) + he * s
+        g[1:] = -(ev * x)
+        return lp, g

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (flatironinstitute/bayes-kit).
+
+Build-container only: imports ``bayes_kit`` from ``/root/reference`` (read-only; never
+copied, never shipped) and runs its samplers / diagnostics on seeded inputs.  Outputs are
+small ``.npz`` fixtures (inputs + expected outputs) committed under ``tests/golden/``.
+
+Seeding: every chain c of a case is the reference sampler constructed with
+``seed=np.random.Philox(key=[case_seed, c])`` (``bayes_kit/typing.py:11`` admits a
+BitGenerator), which is exactly the per-chain device stream of the HIP engine.  Cases
+with ``pcg_seed`` use an int seed (PCG64) like the reference's README and tests.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import bayes_kit as ref  # noqa: E402  (the reference)
+from oracle import models  # noqa: E402  (targets are user code from the reference's view)
+
+
+def make_model(spec):
+    kind = spec["kind"]
+    if kind == "std_normal":
+        return models.StdNormal()
+    if kind == "iso_gaussian":
+        return models.IsoGaussian(spec["D"])
+    if kind == "diag_gaussian":
+        return models.DiagGaussian(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"]))
+    if kind == "funnel":
+        return models.Funnel(spec["D"])
+    raise KeyError(kind)
+
+
+def make_metric(spec, D):
+    if spec is None:
+        return None
+    if spec["kind"] == "linspace":
+        return np.linspace(spec["lo"], spec["hi"], D)
+    if spec["kind"] == "ones":
+        return np.ones(D)
+    raise KeyError(spec)
+
+
+class CountingModel:
+    """Counts gradient evaluations per draw (control-flow fixture for DRGHMC)."""
+
+    def __init__(self, inner):
+        self._inner = inner
+        self.grad_calls = 0
+
+    def dims(self):
+        return self._inner.dims()
+
+    def log_density(self, theta):
+        return self._inner.log_density(theta)
+
+    def log_density_gradient(self, theta):
+        self.grad_calls += 1
+        return self._inner.log_density_gradient(theta)
+
+
+def rng_state(gen):
+    st = gen.bit_generator.state
+    if st["bit_generator"] == "Philox":
+        return np.concatenate(
+            [
+                np.asarray(st["state"]["key"], dtype=np.uint64),
+                np.asarray(st["state"]["counter"], dtype=np.uint64),
+                np.asarray(st["buffer"], dtype=np.uint64),
+                np.asarray([st["buffer_pos"]], dtype=np.uint64),
+            ]
+        )
+    s = st["state"]  # PCG64: 128-bit state and increment as (hi, lo) words
+    return np.asarray(
+        [s["state"] >> 64, s["state"] & (2**64 - 1), s["inc"] >> 64, s["inc"] & (2**64 - 1)],
+        dtype=np.uint64,
+    )
+
+
+def run_sampler_case(case):
+    C, N = case["chains"], case["draws"]
+    model0 = make_model(case["model"])
+    D = model0.dims()
+    draws = np.empty((N, C, D))
+    logps = np.empty((N, C))
+    grad_calls = np.zeros((N, C), dtype=np.int64)
+    theta0 = np.empty((C, D))
+    states = []
+    rho_final = np.zeros((C, D))
+    for c in range(C):
+        model = CountingModel(make_model(case["model"]))
+        if "pcg_seed" in case:
+            seed = case["pcg_seed"] + c
+        else:
+            seed = np.random.Philox(key=[case["seed"], c])
+        init = None
+        if case.get("init") is not None:
+            init = np.asarray(case["init"], dtype=np.float64).copy()
+        alg = case["alg"]
+        if alg == "hmc":
+            s = ref.HMCDiag(model, stepsize=case["stepsize"], steps=case["steps"], init=init, seed=seed)
+        elif alg == "mala":
+            s = ref.MALA(model, epsilon=case["epsilon"], init=init, seed=seed)
+        elif alg == "drghmc":
+            s = ref.DrGhmcDiag(
+                model,
+                max_proposals=case["max_proposals"],
+                leapfrog_step_sizes=case["leapfrog_step_sizes"],
+                leapfrog_step_counts=case["leapfrog_step_counts"],
+                damping=case["damping"],
+                init=init,
+                seed=seed,
+                prob_retry=case.get("prob_retry", True),
+            )
+        else:
+            raise KeyError(alg)
+        metric = make_metric(case.get("metric"), D)
+        if metric is not None:
+            s._metric = metric  # the reference cannot take a D>1 metric in its constructor
+        theta0[c] = np.asarray(s._theta, dtype=np.float64)
+        for n in range(N):
+            before = model.grad_calls
+            th, lp = s.sample()
+            draws[n, c] = th
+            logps[n, c] = lp
+            grad_calls[n, c] = model.grad_calls - before
+        states.append(rng_state(s._rng))
+        if alg == "drghmc":
+            rho_final[c] = s._rho
+    return dict(
+        case=np.array(json.dumps(case)),
+        theta0=theta0,
+        draws=draws,
+        logp=logps,
+        grad_calls=grad_calls,
+        rng_state=np.stack(states),
+        rho_final=rho_final,
+    )
+
+
+SAMPLER_CASES = [
+    # --- HMC (bayes_kit/hmc.py) ---
+    dict(name="hmc_stdnormal", alg="hmc", model=dict(kind="std_normal"), stepsize=0.25, steps=10,
+         chains=4, draws=50, seed=101),
+    dict(name="hmc_steps0", alg="hmc", model=dict(kind="std_normal"), stepsize=0.25, steps=0,
+         chains=2, draws=10, seed=102),
+    dict(name="hmc_iso4", alg="hmc", model=dict(kind="iso_gaussian", D=4), stepsize=0.3, steps=5,
+         chains=8, draws=50, seed=103),
+    dict(name="hmc_iso128_cfg2", alg="hmc", model=dict(kind="iso_gaussian", D=128), stepsize=0.05,
+         steps=32, chains=8, draws=20, seed=20240, metric=dict(kind="ones")),
+    dict(name="hmc_diag16_metric", alg="hmc",
+         model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), stepsize=0.05, steps=8,
+         chains=8, draws=40, seed=104, metric=dict(kind="linspace", lo=0.5, hi=1.5)),
+    dict(name="hmc_diag1024_cfg3", alg="hmc",
+         model=dict(kind="diag_gaussian", D=1024, log10_lo=0, log10_hi=4), stepsize=0.006, steps=64,
+         chains=2, draws=4, seed=20241, metric=dict(kind="ones")),
+    dict(name="hmc_pcg_seed", alg="hmc", model=dict(kind="iso_gaussian", D=3), stepsize=0.3, steps=4,
+         chains=2, draws=25, pcg_seed=123),
+    # --- MALA (bayes_kit/mala.py) ---
+    dict(name="mala_readme_cfg1", alg="mala", model=dict(kind="std_normal"), epsilon=0.2,
+         chains=1, draws=1000, pcg_seed=12345),
+    dict(name="mala_stdnormal", alg="mala", model=dict(kind="std_normal"), epsilon=0.2,
+         chains=4, draws=100, seed=201),
+    dict(name="mala_iso8", alg="mala", model=dict(kind="iso_gaussian", D=8), epsilon=0.1,
+         chains=8, draws=60, seed=202),
+    dict(name="mala_diag16", alg="mala",
+         model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), epsilon=0.02,
+         chains=8, draws=60, seed=203),
+    dict(name="mala_init", alg="mala", model=dict(kind="iso_gaussian", D=3), epsilon=0.15,
+         init=[0.2, -1.0, 0.5], chains=3, draws=30, seed=204),
+    # --- DRGHMC (bayes_kit/drghmc.py) ---
+    dict(name="drghmc_stdnormal_k3", alg="drghmc", model=dict(kind="std_normal"), max_proposals=3,
+         leapfrog_step_sizes=[0.9, 0.45, 0.225], leapfrog_step_counts=[2, 4, 8], damping=0.2,
+         chains=4, draws=200, seed=301),
+    dict(name="drghmc_iso4_k2_noretry", alg="drghmc", model=dict(kind="iso_gaussian", D=4),
+         max_proposals=2, leapfrog_step_sizes=[1.2, 0.4], leapfrog_step_counts=[2, 6], damping=1.0,
+         prob_retry=False, chains=4, draws=100, seed=302),
+    dict(name="drghmc_k1", alg="drghmc", model=dict(kind="iso_gaussian", D=5), max_proposals=1,
+         leapfrog_step_sizes=[0.4], leapfrog_step_counts=[5], damping=0.5,
+         chains=4, draws=60, seed=303),
+    dict(name="drghmc_funnel11_k3", alg="drghmc", model=dict(kind="funnel", D=11), max_proposals=3,
+         leapfrog_step_sizes=[0.2, 0.05, 0.0125], leapfrog_step_counts=[10, 40, 160], damping=0.1,
+         chains=8, draws=150, seed=304),
+    dict(name="drghmc_funnel101_cfg4", alg="drghmc", model=dict(kind="funnel", D=101),
+         max_proposals=3, leapfrog_step_sizes=[0.2, 0.05, 0.0125],
+         leapfrog_step_counts=[10, 40, 160], damping=0.1, chains=4, draws=40, seed=20242),
+    dict(name="drghmc_diag16_metric", alg="drghmc",
+         model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), max_proposals=3,
+         leapfrog_step_sizes=[0.5, 0.25, 0.1], leapfrog_step_counts=[3, 6, 12], damping=0.3,
+         metric=dict(kind="linspace", lo=0.5, hi=1.5), chains=8, draws=80, seed=305),
+]
+
+
+def ar1(rng, n, phi):
+    x = np.empty(n)
+    x[0] = rng.normal()
+    for i in range(1, n):
+        x[i] = phi * x[i - 1] + rng.normal()
+    return x
+
+
+def run_diagnostics():
+    rng = np.random.default_rng(777)
+    out = {}
+    # rhat on 64 chains x 200 draws of mildly different locations (bayes_kit/rhat.py:111-171)
+    chains = [rng.normal(loc=0.05 * rng.normal(), size=200) for _ in range(64)]
+    out["rhat_chains"] = np.stack(chains)
+    out["rhat"] = np.float64(ref.rhat(chains))
+    out["split_rhat"] = np.float64(ref.rhat.__globals__["split_rhat"](chains))
+    # ragged chains (allowed by rhat.py:163-171)
+    lens = [50, 61, 73, 40, 97]
+    ragged = [rng.normal(size=n) for n in lens]
+    out["ragged_lens"] = np.asarray(lens)
+    out["ragged_flat"] = np.concatenate(ragged)
+    out["ragged_rhat"] = np.float64(ref.rhat(ragged))
+    out["ragged_split_rhat"] = np.float64(ref.rhat.__globals__["split_rhat"](ragged))
+    # rank-normalised rhat, small (scalar ppf is slow in the reference)
+    rk = [rng.standard_cauchy(size=100) for _ in range(8)]
+    out["rank_chains"] = np.stack(rk)
+    out["rank_normalized_rhat"] = np.float64(ref.rhat.__globals__["rank_normalized_rhat"](rk))
+    out["rank_normalized"] = np.asarray(ref.rhat.__globals__["rank_normalize_chains"](rk))
+    # ESS / IAT / autocorr on 16 AR(1) chains x 1000 (ess.py, iat.py, autocorr.py)
+    phis = np.linspace(-0.6, 0.9, 16)
+    ar = np.stack([ar1(rng, 1000, p) for p in phis])
+    out["ar_chains"] = ar
+    out["ar_phi"] = phis
+    out["ar_autocorr"] = np.stack([ref.autocorr(c) for c in ar])
+    out["ar_ess"] = np.asarray([ref.ess(c) for c in ar])
+    out["ar_ess_ipse"] = np.asarray([ref.ess_ipse(c) for c in ar])
+    out["ar_ess_imse"] = np.asarray([ref.ess_imse(c) for c in ar])
+    out["ar_iat"] = np.asarray([ref.iat(c) for c in ar])
+    out["ar_iat_ipse"] = np.asarray([ref.iat_ipse(c) for c in ar])
+    # odd / short lengths
+    short = [rng.normal(size=n) for n in (4, 5, 7, 33)]
+    out["short_lens"] = np.asarray([4, 5, 7, 33])
+    out["short_flat"] = np.concatenate(short)
+    out["short_ess"] = np.asarray([ref.ess(c) for c in short])
+    out["short_autocorr_flat"] = np.concatenate([ref.autocorr(c) for c in short])
+    return out
+
+
+def main():
+    for case in SAMPLER_CASES:
+        res = run_sampler_case(case)
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **res)
+        print("%-28s draws %s  mean grad calls/draw %.1f  size %d B"
+              % (case["name"], res["draws"].shape, res["grad_calls"].mean(), os.path.getsize(path)))
+    d = run_diagnostics()
+    path = os.path.join(HERE, "diagnostics.npz")
+    np.savez_compressed(path, **d)
+    print("diagnostics", os.path.getsize(path), "B")
+
+
+if __name__ == "__main__":
+    main()

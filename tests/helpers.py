@@ -1,0 +1,84 @@
+"""Shared test helpers: load golden cases and rebuild their oracle-side objects."""
+import json
+import os
+
+import numpy as np
+
+from oracle import models as omodels
+from oracle import samplers as osamplers
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+SAMPLER_CASES = [
+    "hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric",
+    "hmc_diag1024_cfg3", "hmc_pcg_seed",
+    "mala_readme_cfg1", "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init",
+    "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
+    "drghmc_funnel101_cfg4", "drghmc_diag16_metric",
+]
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    case = json.loads(str(z["case"]))
+    return case, z
+
+
+def oracle_model(spec):
+    kind = spec["kind"]
+    if kind == "std_normal":
+        return omodels.StdNormal()
+    if kind == "iso_gaussian":
+        return omodels.IsoGaussian(spec["D"])
+    if kind == "diag_gaussian":
+        return omodels.DiagGaussian(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"]))
+    if kind == "funnel":
+        return omodels.Funnel(spec["D"])
+    raise KeyError(kind)
+
+
+def case_metric(case, D):
+    spec = case.get("metric")
+    if spec is None:
+        return None
+    if spec["kind"] == "linspace":
+        return np.linspace(spec["lo"], spec["hi"], D)
+    return np.ones(D)
+
+
+def case_seed(case, c):
+    if "pcg_seed" in case:
+        return case["pcg_seed"] + c
+    return np.random.Philox(key=[case["seed"], c])
+
+
+def oracle_sampler(case, c, model=None):
+    """Oracle sampler for chain c of a golden case."""
+    model = model or oracle_model(case["model"])
+    D = model.dims()
+    init = None if case.get("init") is None else np.asarray(case["init"], dtype=np.float64).copy()
+    metric = case_metric(case, D)
+    seed = case_seed(case, c)
+    alg = case["alg"]
+    if alg == "hmc":
+        return osamplers.HMCDiag(model, case["stepsize"], case["steps"], metric_diag=metric, init=init, seed=seed)
+    if alg == "mala":
+        return osamplers.MALA(model, case["epsilon"], init=init, seed=seed)
+    if alg == "drghmc":
+        return osamplers.DrGhmcDiag(
+            model, case["max_proposals"], case["leapfrog_step_sizes"], case["leapfrog_step_counts"],
+            case["damping"], metric_diag=metric, init=init, seed=seed, prob_retry=case.get("prob_retry", True))
+    raise KeyError(alg)
+
+
+def rng_state_words(gen):
+    st = gen.bit_generator.state
+    if st["bit_generator"] == "Philox":
+        return np.concatenate([
+            np.asarray(st["state"]["key"], dtype=np.uint64),
+            np.asarray(st["state"]["counter"], dtype=np.uint64),
+            np.asarray(st["buffer"], dtype=np.uint64),
+            np.asarray([st["buffer_pos"]], dtype=np.uint64)])
+    s = st["state"]
+    m = 2**64 - 1
+    return np.asarray([s["state"] >> 64, s["state"] & m, s["inc"] >> 64, s["inc"] & m], dtype=np.uint64)

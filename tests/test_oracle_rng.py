@@ -1,0 +1,62 @@
+"""oracle/rng.py vs numpy.random itself (the un-vendored dependency the reference uses)."""
+import math
+
+import numpy as np
+
+from oracle.rng import PhiloxStream, log1p_glibc, philox4x64_10, ziggurat_tables
+
+
+def test_tables_check_values():
+    ki, wi, fi = ziggurat_tables()
+    assert ki[0] == 0x000EF33D8025EF6A and ki[1] == 0
+    assert wi[0] == 8.683627060801306e-16 and wi[255] == 8.113849337656484e-16
+    assert fi[255] == 0.001260285930498598 and fi[0] == 1.0
+
+
+def test_philox_raw_words_incl_carry():
+    for key in ([1, 2], [2**64 - 1, 0x9E3779B97F4A7C15]):
+        raw = np.random.Philox(key=key).random_raw(41)
+        s = PhiloxStream(*key)
+        assert [s.next_u64() for _ in range(41)] == [int(v) for v in raw]
+    # carry out of the low counter word
+    bg = np.random.Philox(key=[7, 9], counter=np.array([2**64 - 1, 2**64 - 1, 5, 0], dtype=np.uint64))
+    s = PhiloxStream(7, 9)
+    s.counter = [2**64 - 1, 2**64 - 1, 5, 0]
+    assert [s.next_u64() for _ in range(9)] == [int(v) for v in bg.random_raw(9)]
+    assert s.counter == [2, 0, 6, 0]
+    assert [int(v) for v in bg.state["state"]["counter"]] == s.counter
+    assert philox4x64_10([0, 0, 0, 0], [0, 0]) != [0, 0, 0, 0]
+
+
+def test_normals_uniforms_and_state_bit_exact():
+    key = [20240, 17]
+    g = np.random.Generator(np.random.Philox(key=key))
+    s = PhiloxStream(*key, log1p=log1p_glibc)
+    n = 150_000  # ~37 tail draws, ~2200 wedge draws
+    ref = g.normal(size=n)
+    mine = np.array([s.normal() for _ in range(n)])
+    assert np.array_equal(ref.view(np.uint64), mine.view(np.uint64))
+    # interleaved normal(size=7) / uniform() as HMC consumes them (hmc.py:56,60)
+    for _ in range(50):
+        a = g.normal(size=7)
+        b = np.array([s.normal() for _ in range(7)])
+        assert np.array_equal(a, b)
+        assert g.uniform() == s.uniform()
+    # loc/scale form used by DRGHMC (drghmc.py:360-364): loc + scale*z
+    loc = np.linspace(-1, 1, 5)
+    a = g.normal(loc=loc, scale=0.3, size=5)
+    b = np.array([loc[i] + 0.3 * s.normal() for i in range(5)])
+    assert np.array_equal(a, b)
+    st = g.bit_generator.state
+    assert [int(v) for v in st["state"]["counter"]] == s.counter
+    assert [int(v) for v in st["buffer"]] == s.buffer
+    assert st["buffer_pos"] == s.buffer_pos
+
+
+def test_log1p_restatement_matches_libm():
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([
+        -rng.random(60000), -rng.random(20000) * 1e-3, -(1 - rng.random(20000) * 1e-6),
+        -rng.random(10000) * 2.0**-30, -rng.random(2000) * 2.0**-55, [0.0, -0.5, -0.2929, -0.29290001]])
+    for x in xs:
+        assert log1p_glibc(float(x)) == math.log1p(float(x)), x
