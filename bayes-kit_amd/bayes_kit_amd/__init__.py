@@ -1,0 +1,21 @@
+"""bayes_kit_amd -- MI355X-native many-chain engine behind bayes-kit's sampler API.
+
+Drop-in for the hot path of flatironinstitute/bayes-kit (``bayes_kit/__init__.py:15-30``
+export list): ``HMCDiag``, ``MALA``, ``DrGhmcDiag`` keep the reference's constructor
+signatures and ``sample()`` protocol, and ``rhat`` / ``ess`` / ``iat`` keep its function
+signatures, while the arithmetic runs in hand-written HIP kernels for gfx950
+(``libbkhip.so``, C ABI in ``include/bkhip.h``).  There is no CPU fallback.
+"""
+from . import _lib  # noqa: F401
+from .hmc import HMCDiag
+from .mala import MALA
+from .targets import DiagGaussian, Funnel, IsoGaussian, TorchModel
+
+__all__ = [
+    "HMCDiag",
+    "MALA",
+    "IsoGaussian",
+    "DiagGaussian",
+    "Funnel",
+    "TorchModel",
+]

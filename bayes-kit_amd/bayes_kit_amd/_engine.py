@@ -1,0 +1,268 @@
+"""Shared many-chain machinery: chain-contiguous state buffers, per-chain random streams,
+and the bridge between the reference's Model protocol and the device.
+
+State layout: every phase-space array is a float64 ``[D, C]`` tensor with the chain index
+contiguous (one chain per GPU lane; a wavefront reads 64 consecutive doubles for each d).
+A model sees the ``(C, D)`` transpose view with strides ``(1, ld)``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_M64 = (1 << 64) - 1
+
+
+# ---------------------------------------------------------------------------------------
+# per-chain random streams
+# ---------------------------------------------------------------------------------------
+def _bitgen_words(bg) -> tuple:
+    """(kind, uint64[RNG_WORDS]) for a numpy BitGenerator (Philox or PCG64)."""
+    st = bg.state
+    w = np.zeros(_lib.RNG_WORDS, dtype=np.uint64)
+    name = st["bit_generator"]
+    if name == "Philox":
+        w[0:2] = st["state"]["key"]
+        w[2:6] = st["state"]["counter"]
+        w[6:10] = st["buffer"]
+        w[10] = st["buffer_pos"]
+        return _lib.RNG_PHILOX, w
+    if name == "PCG64":
+        if st.get("has_uint32", 0):
+            raise ValueError("PCG64 generator holds a cached 32-bit half draw; not supported")
+        s, inc = st["state"]["state"], st["state"]["inc"]
+        w[0], w[1], w[2], w[3] = s >> 64, s & _M64, inc >> 64, inc & _M64
+        return _lib.RNG_PCG64, w
+    raise TypeError(f"unsupported bit generator {name}; use Philox or PCG64")
+
+
+def _as_bitgen(seed):
+    if isinstance(seed, np.random.Generator):
+        return seed.bit_generator
+    if isinstance(seed, np.random.BitGenerator):
+        return seed
+    return None
+
+
+def make_streams(seed, C: int, chain_id0: int, reference_int_seed: bool, device):
+    """Build the per-chain RNG table.
+
+    Returns ``(kind, state)`` with ``state`` an int64 tensor ``[RNG_WORDS, C]`` holding the
+    uint64 words of include/bkhip.h.
+
+    * ``None``  -> Philox with a key from ``os.urandom`` (non-reproducible, like
+      ``np.random.default_rng(None)``, bayes_kit/hmc.py:23).
+    * ``int``   -> chain c uses ``np.random.Philox(key=[seed, chain_id0 + c])``; with
+      ``reference_int_seed`` (single-chain drop-in mode) the stream is instead
+      ``np.random.default_rng(seed)`` itself, i.e. PCG64, exactly as the reference.
+    * a numpy ``BitGenerator``/``Generator`` (Philox or PCG64), or a sequence of C of them:
+      the stream continues from that object's current state (the object itself is not
+      advanced afterwards).
+    """
+    if seed is None:
+        seed = int.from_bytes(os.urandom(8), "little")
+        reference_int_seed = False
+    if isinstance(seed, (int, np.integer)) and not isinstance(seed, bool):
+        if reference_int_seed:
+            if C != 1:
+                raise ValueError("an int seed selects the reference's PCG64 stream only for one chain")
+            kind, w = _bitgen_words(np.random.default_rng(int(seed)).bit_generator)
+            words = w[:, None]
+        else:
+            kind = _lib.RNG_PHILOX
+            words = np.zeros((_lib.RNG_WORDS, C), dtype=np.uint64)
+            words[0, :] = np.uint64(int(seed) & _M64)
+            words[1, :] = (np.arange(C, dtype=np.uint64) + np.uint64(chain_id0 & _M64))
+            words[10, :] = 4
+    else:
+        gens: Sequence
+        bg = _as_bitgen(seed)
+        if bg is not None:
+            gens = [bg]
+        else:
+            gens = [_as_bitgen(s) for s in seed]
+            if any(g is None for g in gens):
+                raise TypeError("seed must be None, an int, a numpy (Bit)Generator or a sequence of them")
+        if len(gens) != C:
+            raise ValueError(f"{len(gens)} bit generators given for {C} chains")
+        parts = [_bitgen_words(g) for g in gens]
+        kinds = {k for k, _ in parts}
+        if len(kinds) != 1:
+            raise ValueError("all chains must use the same kind of bit generator")
+        kind = kinds.pop()
+        words = np.stack([w for _, w in parts], axis=1)
+    state = torch.from_numpy(np.ascontiguousarray(words).view(np.int64)).to(device)
+    return kind, state
+
+
+def numpy_generator_from_words(kind: int, w: np.ndarray) -> np.random.Generator:
+    """Rebuild a numpy Generator positioned exactly where a device stream is."""
+    w = [int(v) for v in w]
+    if kind == _lib.RNG_PHILOX:
+        bg = np.random.Philox()
+        st = bg.state
+        st["state"]["key"] = np.array(w[0:2], dtype=np.uint64)
+        st["state"]["counter"] = np.array(w[2:6], dtype=np.uint64)
+        st["buffer"] = np.array(w[6:10], dtype=np.uint64)
+        st["buffer_pos"] = w[10]
+        st["has_uint32"], st["uinteger"] = 0, 0
+        bg.state = st
+    else:
+        bg = np.random.PCG64()
+        st = bg.state
+        st["state"]["state"] = (w[0] << 64) | w[1]
+        st["state"]["inc"] = (w[2] << 64) | w[3]
+        st["has_uint32"], st["uinteger"] = 0, 0
+        bg.state = st
+    return np.random.Generator(bg)
+
+
+# ---------------------------------------------------------------------------------------
+# engine base
+# ---------------------------------------------------------------------------------------
+class ManyChainSampler:
+    """Common state of the HIP samplers (not part of the reference's API surface)."""
+
+    def _setup(self, model, metric_diag, init, seed, chains, chain_id0, ops):
+        self._model = model
+        self._dim = int(model.dims())
+        self._batched = bool(getattr(model, "batched", False))
+        self._ops = ops if ops is not None else _lib.default_ops()
+        dev = self._ops.device
+        D = self._dim
+        init_t = None
+        if init is not None:
+            init_t = torch.as_tensor(init)
+            if tuple(init_t.shape) == (0,):  # bayes_kit/hmc.py:24-28: an empty init is "absent"
+                init_t = None
+        if self._batched:
+            if chains is None:
+                if init_t is not None and init_t.dim() == 2:
+                    chains = init_t.shape[0]
+                else:
+                    raise ValueError("a batched model needs chains=<number of chains> (or a (C, D) init)")
+        else:
+            if chains not in (None, 1):
+                raise ValueError("a single-chain (reference-style) model runs exactly one chain; "
+                                 "wrap the density in a batched model to run many")
+            chains = 1
+        C = self._C = int(chains)
+        self._chain_id0 = int(chain_id0)
+        self._rng_kind, self._rng_state = make_streams(seed, C, chain_id0, not self._batched, dev)
+        self._metric_dev: Optional[torch.Tensor] = None
+        if metric_diag is not None:
+            self._set_metric(metric_diag)
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._theta_dc = torch.empty((D, C), **f64)
+        if init_t is not None:
+            src = init_t.to(dtype=torch.float64)
+            if src.dim() == 1:
+                if src.shape[0] != D:
+                    raise ValueError(f"init has {src.shape[0]} elements, model has {D} dims")
+                src = src.reshape(1, D).expand(C, D)
+            if tuple(src.shape) != (C, D):
+                raise ValueError(f"init must have shape ({C}, {D}) or ({D},), got {tuple(src.shape)}")
+            self._theta_dc.copy_(src.t().to(dev))
+        else:
+            # theta0 = rng.normal(size=D) from the chain's own stream (hmc.py:24-28)
+            self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._theta_dc,
+                                       None, None)
+        self._grad_calls = 0
+
+    # -- metric ----------------------------------------------------------------------------
+    def _set_metric(self, m):
+        mt = torch.as_tensor(m, dtype=torch.float64).reshape(-1)
+        if mt.shape[0] != self._dim:
+            raise ValueError(f"metric_diag has {mt.shape[0]} entries, model has {self._dim} dims")
+        self._metric_dev = mt.to(self._ops.device).contiguous()
+
+    @property
+    def _metric(self):
+        """Diagonal metric as the reference stores it (hmc.py:22): ones when not given."""
+        if self._metric_dev is None:
+            return np.ones(self._dim)
+        return self._metric_dev.cpu().numpy()
+
+    @_metric.setter
+    def _metric(self, m):
+        # the reference can only be given a D>1 metric by assigning _metric
+        self._set_metric(m)
+
+    # -- views of the state -------------------------------------------------------------------
+    @property
+    def _theta(self):
+        if self._batched:
+            return self._theta_dc.t()
+        return np.array(self._theta_dc[:, 0].cpu().numpy())
+
+    @property
+    def chains(self) -> int:
+        return self._C
+
+    def rng_state(self) -> np.ndarray:
+        """uint64 [RNG_WORDS, C] snapshot of the per-chain streams (numpy field order)."""
+        return self._rng_state.cpu().numpy().view(np.uint64)
+
+    @property
+    def _rng(self):
+        """A numpy Generator positioned where chain 0's device stream is (read-only view)."""
+        return numpy_generator_from_words(self._rng_kind, self.rng_state()[:, 0])
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.sample()
+
+    # -- model bridge ----------------------------------------------------------------------------
+    def _eval_grad(self, theta_dc, grad_out, logp_out):
+        """Gradient (and, if logp_out is given, log density) at theta_dc [D, n].
+
+        Returns the tensor that holds the gradient as a logical [D, n] array: ``grad_out``
+        itself for built-in targets and host models, or the model's own output (any
+        strides, not copied) for generic batched PyTorch models.
+        """
+        self._grad_calls += 1
+        m = self._model
+        if hasattr(m, "bk_eval"):
+            m.bk_eval(theta_dc, grad_out, logp_out)
+            return grad_out
+        if self._batched:
+            lp, g = m.log_density_gradient(theta_dc.t())
+            if logp_out is not None:
+                logp_out.copy_(lp)
+            return g.t()
+        th = np.array(theta_dc[:, 0].cpu().numpy())
+        lp, g = m.log_density_gradient(th)
+        g = np.array(np.broadcast_to(np.asarray(g, dtype=np.float64), (self._dim,)))  # array-likes allowed (mala.py:32)
+        grad_out[:, 0].copy_(torch.from_numpy(g))
+        if logp_out is not None:
+            logp_out.fill_(float(lp))
+        return grad_out
+
+    def _eval_logp(self, theta_dc, logp_out):
+        m = self._model
+        if hasattr(m, "bk_eval"):
+            m.bk_eval(theta_dc, None, logp_out)
+        elif self._batched:
+            logp_out.copy_(m.log_density(theta_dc.t()))
+        else:
+            logp_out.fill_(float(m.log_density(np.array(theta_dc[:, 0].cpu().numpy()))))
+
+    def _materialize(self, g, grad_out):
+        """Make sure the gradient lives in grad_out ([D, n], chain-contiguous)."""
+        if g is grad_out or g.data_ptr() == grad_out.data_ptr():
+            return grad_out
+        self._ops.relayout(g, grad_out)
+        return grad_out
+
+    def _draw_out(self, theta_dc, logp):
+        """What sample() hands back: stable copies, shaped like the reference's return."""
+        if self._batched:
+            return theta_dc.t().clone(), logp.clone()
+        return np.array(theta_dc[:, 0].cpu().numpy()), np.float64(logp[0].item())

@@ -1,0 +1,276 @@
+"""ctypes binding of libbkhip.so (the C ABI declared in include/bkhip.h).
+
+There is NO fallback: if the shared library is missing, or a sampler is asked to run
+without a visible MI355X, the error is raised to the caller.  ``import torch`` happens
+before the library is loaded so that libbkhip.so binds to the HIP runtime PyTorch already
+brought into the process (same SONAME), which is what makes PyTorch's stream handles and
+device pointers valid inside the library.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_int, c_int64, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must precede the CDLL below)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libbkhip.so")
+
+RNG_WORDS = 11
+RNG_PHILOX = 0
+RNG_PCG64 = 1
+ACCEPT_HMC = 0
+ACCEPT_MALA = 1
+
+P = c_void_p
+I = c_int64
+F = c_double
+
+# name -> argument types (every function returns int unless listed in _RESTYPE)
+SIGNATURES = {
+    "bk_version": [],
+    "bk_rng_init_philox": [P, I, c_uint64, c_uint64, I, P],
+    "bk_momentum_refresh": [c_int, P, I, P, F, F, P, I, P, P, P, I, I, P],
+    "bk_log_uniform": [c_int, P, I, P, P, I, P],
+    "bk_leapfrog_kick_drift": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P],
+    "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P],
+    "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
+    "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
+    "bk_select_columns": [P, P, P, P, P, I, I, I, P],
+    "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
+    "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
+    "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
+    "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
+    "bk_target_funnel_grad": [P, P, P, I, I, I, P],
+    "bk_relayout": [P, I, I, P, I, I, I, I, P],
+    "bk_welford_update": [P, P, P, I, I, I, I, P],
+    "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
+    "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
+    "bk_ess": [P, I, I, c_int, P, P, I, P],
+    "bk_host_normals": [c_int, P, P, I],
+    "bk_host_uniforms": [c_int, P, P, I],
+    "bk_host_log1p": [F],
+}
+_RESTYPE = {"bk_host_log1p": c_double}
+
+
+class BkHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load libbkhip.so (once) and attach the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise BkHipError(
+            f"{_LIB_PATH} is missing: build it with `python bayes-kit_amd/build.py` "
+            "(or __graft_entry__.build()).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def require_gpu() -> torch.device:
+    """The sampler path needs a real device; fail loudly otherwise."""
+    load()
+    if not torch.cuda.is_available():
+        raise BkHipError(
+            "bayes_kit_amd needs an AMD Instinct GPU (gfx950) visible to PyTorch-ROCm; "
+            "no device found and there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        kind = "argument/layout error" if status < 0 else "hipError_t"
+        raise BkHipError(f"{what} failed: {kind} {status}")
+
+
+def ptr(t) -> int:
+    """Raw device (or host) pointer of a tensor, 0 for None."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_handle() -> int:
+    """hipStream_t of PyTorch's current stream (all kernels are enqueued on it)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t) -> int:
+    """Leading dimension of a [D, n] chain-contiguous tensor."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise BkHipError(f"expected a [D, C] tensor with contiguous chains, got strides {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+class Ops:
+    """Tensor-level call layer over the C ABI (one method per entry point).
+
+    Samplers talk to the device only through an ``Ops`` object.  The one shipped here is
+    the HIP library and nothing else; tests may inject an object with the same methods to
+    exercise the host-side control flow of a sampler on a machine without a GPU.
+
+    Tensor conventions: phase-space arrays are fp64 ``[D, n]`` tensors whose chain axis is
+    contiguous (``stride == (ld, 1)``); per-chain vectors are ``[n]``; RNG tables are
+    uint64-as-int64 ``[RNG_WORDS, C]``; masks are uint8 ``[n]``.
+    """
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load()
+        self.device = require_gpu()
+        # optional per-launch HIP-event timing: {entry point: [(start, end), ...]} on the
+        # stream the kernels are enqueued on (bench.py's roofline measurement)
+        self.timed = None
+
+    # -- helpers ---------------------------------------------------------------------
+    def _call(self, name, *args):
+        rec = self.timed.get(name) if self.timed is not None else None
+        if rec is None:
+            check(getattr(self.lib, name)(*args), name)
+            return
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(getattr(self.lib, name)(*args), name)
+        e1.record()
+        rec.append((e0, e1))
+
+    @staticmethod
+    def _s():
+        return stream_handle()
+
+    # -- RNG ---------------------------------------------------------------------------
+    def rng_init_philox(self, state, key0, chain_id0):
+        self._call("bk_rng_init_philox", ptr(state), state.stride(0), key0 & (2**64 - 1),
+                   chain_id0 & (2**64 - 1), state.shape[1], self._s())
+
+    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None):
+        D, C = out.shape
+        self._call("bk_momentum_refresh", kind, ptr(state), state.stride(0), ptr(loc_in), loc_mul, scale,
+                   ptr(out), _ld(out), ptr(metric), ptr(kin_out), ptr(active), C, D, self._s())
+
+    def log_uniform(self, kind, state, out, active=None):
+        self._call("bk_log_uniform", kind, ptr(state), state.stride(0), ptr(out), ptr(active),
+                   out.shape[0], self._s())
+
+    # -- integrator -----------------------------------------------------------------------
+    def kick_drift(self, theta_in, theta_out, rho_in, rho_out, grad, metric, eps,
+                   use_pre, pre, use_kick, kick):
+        D, C = theta_out.shape
+        ld = _ld(theta_out)
+        assert _ld(theta_in) == ld and _ld(rho_in) == ld and _ld(rho_out) == ld
+        self._call("bk_leapfrog_kick_drift", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
+                   ptr(grad), grad.stride(0), grad.stride(1), ptr(metric), eps, int(use_pre), pre,
+                   int(use_kick), kick, C, D, self._s())
+
+    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre):
+        D, n = theta_out.shape
+        ld_in = _ld(theta_in)
+        assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in and _ld(rho_out) == _ld(theta_out)
+        self._call("bk_leapfrog_first_step_gather", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in,
+                   ptr(src_index), ptr(theta_out), ptr(rho_out), _ld(theta_out), ptr(metric), eps, pre,
+                   n, D, self._s())
+
+    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out):
+        D, C = rho_in.shape
+        if rho_out is not None:
+            assert _ld(rho_out) == _ld(rho_in)
+        self._call("bk_leapfrog_finish", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), grad.stride(0),
+                   grad.stride(1), ptr(metric), half, int(negate), ptr(kin_out), C, D, self._s())
+
+    def mh_accept(self, mode, lp_cur, a_cur, lp_prop, a_prop, log_u, mask, ret, count):
+        self._call("bk_mh_accept", mode, ptr(lp_cur), ptr(a_cur), ptr(lp_prop), ptr(a_prop), ptr(log_u),
+                   ptr(mask), ptr(ret), ptr(count), lp_cur.shape[0], self._s())
+
+    def select_columns(self, mask, dst0, src0, dst1=None, src1=None):
+        D, C = dst0.shape
+        ld = _ld(dst0)
+        assert _ld(src0) == ld and (dst1 is None or (_ld(dst1) == ld and _ld(src1) == ld))
+        self._call("bk_select_columns", ptr(mask), ptr(dst0), ptr(src0), ptr(dst1), ptr(src1), ld, C, D,
+                   self._s())
+
+    # -- MALA --------------------------------------------------------------------------------
+    def mala_propose(self, kind, state, theta, grad, theta_prop, eps, sqrt2eps):
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(grad) == ld and _ld(theta_prop) == ld
+        self._call("bk_mala_propose", kind, ptr(state), state.stride(0), ptr(theta), ptr(grad),
+                   ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
+
+    def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(grad) == ld and _ld(theta_prop) == ld and _ld(grad_prop) == ld
+        self._call("bk_mala_logq", ptr(theta), ptr(grad), ptr(theta_prop), ptr(grad_prop), ld, eps,
+                   ptr(lp_forward), ptr(lp_reverse), C, D, self._s())
+
+    # -- built-in targets -----------------------------------------------------------------------
+    def target_grad(self, kind, params, theta, grad, logp):
+        D, C = theta.shape
+        ld = _ld(theta)
+        if grad is not None:
+            assert _ld(grad) == ld
+        if kind == "iso_gaussian":
+            self._call("bk_target_iso_gaussian_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
+        elif kind == "diag_gaussian":
+            self._call("bk_target_diag_gaussian_grad", ptr(theta), ptr(grad), ptr(logp), ld, ptr(params),
+                       C, D, self._s())
+        elif kind == "funnel":
+            self._call("bk_target_funnel_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
+        else:
+            raise BkHipError(f"unknown built-in target {kind!r}")
+
+    def relayout(self, src, dst):
+        """dst[d, c] = src[d, c] for logical [D, C] tensors of any strides (LDS-tiled)."""
+        D, C = dst.shape
+        self._call("bk_relayout", ptr(src), src.stride(0), src.stride(1), ptr(dst), dst.stride(0),
+                   dst.stride(1), C, D, self._s())
+
+    # -- diagnostics --------------------------------------------------------------------------------
+    def welford_update(self, mean, m2, theta, n):
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(mean) == ld and _ld(m2) == ld
+        self._call("bk_welford_update", ptr(mean), ptr(m2), ptr(theta), ld, n, C, D, self._s())
+
+    def rhat_partials(self, mean, m2, n, center, out):
+        D, C = mean.shape
+        assert _ld(m2) == _ld(mean)
+        self._call("bk_rhat_partials", ptr(mean), ptr(m2), _ld(mean), n, ptr(center), ptr(out), C, D,
+                   self._s())
+
+    def chain_mean_var(self, x, lengths, mean, var):
+        N, C = x.shape
+        self._call("bk_chain_mean_var", ptr(x), _ld(x), ptr(lengths), N, ptr(mean), ptr(var), C, self._s())
+
+    def ess(self, x, estimator, ess_out, iat_out=None):
+        N, C = x.shape
+        self._call("bk_ess", ptr(x), _ld(x), N, estimator, ptr(ess_out), ptr(iat_out), C, self._s())
+
+
+_default_ops = None
+
+
+def default_ops() -> Ops:
+    """The process-wide HIP ops object (raises without the library or without a GPU)."""
+    global _default_ops
+    if _default_ops is None:
+        _default_ops = Ops()
+    return _default_ops

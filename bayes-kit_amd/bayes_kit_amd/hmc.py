@@ -1,0 +1,127 @@
+"""Many-chain static-trajectory HMC on the GPU: drop-in for ``bayes_kit/hmc.py:8-63``.
+
+Same constructor signature and ``sample() -> (theta, logp)`` / iterator protocol as the
+reference's ``HMCDiag``; the momentum draw, leapfrog integrator, Metropolis accept and the
+per-chain random streams are HIP kernels behind the C ABI of include/bkhip.h.
+
+Per draw and chain (reference lines in brackets):
+  rho ~ N(0, I) from the chain's stream, kin0 = 1/2 rho.(m*rho)            [hmc.py:56, :37]
+  back half-step + L x (kick, drift, gradient) + forward half-step       [hmc.py:40-53]
+  accept iff log(u) < (lp1 - kin1) - (lp0 - kin0), u always drawn        [hmc.py:57-63]
+and the JOINT log density is returned (hmc.py:62-63).
+
+Model calls.  With a reference-style single-chain model the call pattern of the reference is
+kept exactly (2 ``log_density`` + ``steps+1`` ``log_density_gradient`` per draw,
+test/test_hmc.py:22-35).  With a batched device model the sampler keeps (logp, grad) of the
+current point across draws and uses the logp returned with the last gradient of the
+trajectory: ``steps`` model calls per draw, bitwise the same results for any model whose
+``log_density`` equals the first output of ``log_density_gradient``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._engine import ManyChainSampler
+
+
+class HMCDiag(ManyChainSampler):
+    def __init__(
+        self,
+        model,
+        stepsize: float,
+        steps: int,
+        metric_diag=None,
+        init=None,
+        seed=None,
+        *,
+        chains: Optional[int] = None,
+        chain_id0: int = 0,
+        ops=None,
+    ):
+        self._stepsize = stepsize
+        self._steps = steps
+        self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)
+        D, C, dev = self._dim, self._C, self._ops.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._rho = torch.empty((D, C), **f64)
+        self._theta_p = torch.empty((D, C), **f64)
+        self._grad = torch.empty((D, C), **f64)      # gradient at the current point
+        self._grad_p = torch.empty((D, C), **f64)    # gradient along / at the end of the trajectory
+        self._lp = torch.empty(C, **f64)
+        self._lp_p = torch.empty(C, **f64)
+        self._kin0 = torch.empty(C, **f64)
+        self._kin1 = torch.empty(C, **f64)
+        self._logu = torch.empty(C, **f64)
+        self._ret = torch.empty(C, **f64)
+        self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
+        self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._have_cache = False
+        self._draws = 0
+
+    # -- statistics ---------------------------------------------------------------------------
+    def accept_rate(self) -> float:
+        """Fraction of accepted proposals so far (device counter, ballot/popcount sums)."""
+        n = self._draws * self._C
+        return float(self._accepted.item()) / n if n else float("nan")
+
+    @property
+    def last_accept(self):
+        return self._mask.bool() if self._batched else bool(self._mask[0].item())
+
+    # -- one draw for every chain ------------------------------------------------------------------
+    def sample(self):
+        ops = self._ops
+        eps, L, m = float(self._stepsize), int(self._steps), self._metric_dev
+        half = 0.5 * eps
+        th, thp, rho = self._theta_dc, self._theta_p, self._rho
+        mirror = not self._batched
+
+        # momentum + kinetic energy [hmc.py:56, :37]
+        ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, rho, m, self._kin0)
+
+        if mirror:
+            self._eval_logp(th, self._lp)                  # joint_logp(theta, rho)      [hmc.py:57]
+            g = self._eval_grad(th, self._grad, None)       # leapfrog's first gradient   [hmc.py:45]
+        else:
+            if not self._have_cache:
+                self._materialize(self._eval_grad(th, self._grad, self._lp), self._grad)
+                self._have_cache = True
+            g = self._grad
+
+        if L == 0:
+            # rho_mid = rho - c*t ; rho1 = rho_mid + c*t ; theta unchanged [hmc.py:46,52]
+            ops.kick_drift(th, thp, rho, rho, g, m, 0.0, True, -half, False, 0.0)
+            g_last = g
+            if not mirror:
+                self._lp_p.copy_(self._lp)
+        else:
+            g_last = None
+            for n in range(L):
+                last = n == L - 1
+                if n == 0:
+                    ops.kick_drift(th, thp, rho, rho, g, m, eps, True, -half, True, eps)
+                else:
+                    ops.kick_drift(thp, thp, rho, rho, g_last, m, eps, False, 0.0, True, eps)
+                want_lp = self._lp_p if (last and not mirror) else None
+                g_last = self._eval_grad(thp, self._grad_p, want_lp)
+        # forward half-step + kinetic energy of the proposal [hmc.py:52, :37]
+        ops.leapfrog_finish(rho, None, g_last, m, half, False, self._kin1)
+        if mirror:
+            self._eval_logp(thp, self._lp_p)                # joint_logp(theta_prop, rho_prop) [hmc.py:59]
+        # accept [hmc.py:60-63]
+        ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
+        ops.mh_accept(_lib.ACCEPT_HMC, self._lp, self._kin0, self._lp_p, self._kin1, self._logu,
+                      self._mask, self._ret, self._accepted)
+        if mirror:
+            ops.select_columns(self._mask, th, thp)
+        else:
+            gp = self._materialize(g_last, self._grad_p) if L > 0 else None
+            if gp is not None:
+                ops.select_columns(self._mask, th, thp, self._grad, gp)
+            else:
+                ops.select_columns(self._mask, th, thp)
+        self._draws += 1
+        return self._draw_out(th, self._ret)

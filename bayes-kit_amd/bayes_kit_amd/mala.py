@@ -1,0 +1,69 @@
+"""Many-chain Metropolis-adjusted Langevin on the GPU: drop-in for ``bayes_kit/mala.py:14-79``.
+
+Per draw and chain: theta' = (theta + eps*grad) + sqrt(2 eps) z   [mala.py:41-45];
+one gradient call at theta' [:46-48]; forward / reverse proposal densities [:50-53,68-79];
+Metropolis-Hastings accept with strict ``<`` [metropolis.py:70-76]; (logp, grad) of the
+current point are cached [mala.py:31-32,62-64]; the MODEL log density is returned [:66].
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._engine import ManyChainSampler
+
+
+class MALA(ManyChainSampler):
+    def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
+                 chain_id0: int = 0, ops=None):
+        self._epsilon = epsilon
+        self._setup(model, None, init, seed, chains, chain_id0, ops)
+        D, C, dev = self._dim, self._C, self._ops.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._theta_p = torch.empty((D, C), **f64)
+        self._grad = torch.empty((D, C), **f64)
+        self._grad_p = torch.empty((D, C), **f64)
+        self._lp = torch.empty(C, **f64)
+        self._lp_p = torch.empty(C, **f64)
+        self._fwd = torch.empty(C, **f64)
+        self._rev = torch.empty(C, **f64)
+        self._logu = torch.empty(C, **f64)
+        self._ret = torch.empty(C, **f64)
+        self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
+        self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._draws = 0
+        # mala.py:31-32: (logp, grad) at theta0
+        self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+
+    def accept_rate(self) -> float:
+        n = self._draws * self._C
+        return float(self._accepted.item()) / n if n else float("nan")
+
+    @property
+    def last_accept(self):
+        return self._mask.bool() if self._batched else bool(self._mask[0].item())
+
+    @property
+    def _log_p_theta(self):
+        return self._lp if self._batched else float(self._lp[0].item())
+
+    @property
+    def _log_p_grad_theta(self):
+        return self._grad.t() if self._batched else self._grad[:, 0].cpu().numpy()
+
+    def sample(self):
+        ops = self._ops
+        eps = float(self._epsilon)
+        th, thp = self._theta_dc, self._theta_p
+        ops.mala_propose(self._rng_kind, self._rng_state, th, self._grad, thp, eps, math.sqrt(2 * eps))
+        gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)
+        ops.mala_logq(th, self._grad, thp, gp, eps, self._fwd, self._rev)
+        ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
+        ops.mh_accept(_lib.ACCEPT_MALA, self._lp, self._fwd, self._lp_p, self._rev, self._logu,
+                      self._mask, self._ret, self._accepted)
+        ops.select_columns(self._mask, th, thp, self._grad, gp)
+        self._draws += 1
+        return self._draw_out(th, self._ret)

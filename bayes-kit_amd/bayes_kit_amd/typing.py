@@ -1,0 +1,51 @@
+"""Model protocols and type aliases (counterpart of bayes_kit/typing.py:1-42).
+
+Two forms of the reference's structural Model protocol are accepted by the samplers:
+
+* the reference form itself (single chain, NumPy): ``dims()``, ``log_density(theta)``,
+  ``log_density_gradient(theta) -> (float, array-like)`` on a length-D float64 vector
+  (bayes_kit/typing.py:15-27).  The sampler then runs ONE chain; the integrator, RNG and
+  accept still run on the GPU, the model is called on the host once per gradient.
+* the batched device form (many chains): the same three method names with a leading chain
+  axis, marked by a truthy attribute ``batched``.  ``Theta`` is a float64 device tensor
+  view of shape (C, D) with strides (1, ld) over the engine's chain-contiguous buffer;
+  ``log_density(Theta) -> (C,)``, ``log_density_gradient(Theta) -> ((C,), (C, D))``.
+  Outputs may come back in any strides.
+"""
+from __future__ import annotations
+
+from typing import Protocol, Sequence, Tuple, Union, runtime_checkable
+
+import numpy as np
+from numpy.typing import ArrayLike, NDArray
+
+FloatType = np.float64
+IntType = np.int64
+VectorType = NDArray[FloatType]
+DrawAndLogP = tuple  # (theta, logp)
+Seed = Union[int, np.random.BitGenerator, np.random.Generator]
+ChainType = Union[Sequence[float], VectorType]
+
+
+@runtime_checkable
+class LogDensityModel(Protocol):
+    def dims(self) -> int: ...
+
+    def log_density(self, params_unc): ...
+
+
+@runtime_checkable
+class GradModel(LogDensityModel, Protocol):
+    def log_density_gradient(self, params_unc) -> Tuple[float, ArrayLike]: ...
+
+
+@runtime_checkable
+class HessianModel(GradModel, Protocol):
+    def log_density_hessian(self, params_unc): ...
+
+
+@runtime_checkable
+class LogPriorLikelihoodModel(LogDensityModel, Protocol):
+    def log_prior(self, params_unc): ...
+
+    def log_likelihood(self, params_unc): ...

@@ -1,0 +1,182 @@
+// Convergence diagnostics on the device: streaming per-chain moments for R-hat
+// (bayes_kit/rhat.py:111-171) and per-chain effective sample size (ess.py:52-69,
+// iat.py:7-43,95-135, autocorr.py:6-33).
+#include "bk_common.hpp"
+
+namespace {
+
+constexpr int EL_ROWS = 4;
+constexpr int PC_BLOCK = 64;
+
+// Welford: after the n-th draw, mean = np.mean(draws[:n]) and m2/(n-1) = np.var(ddof=1)
+__global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const double* th, i64 ld,
+                                                 double n, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * EL_ROWS;
+  if (c >= C) return;
+#pragma unroll
+  for (int i = 0; i < EL_ROWS; ++i)
+    if (d0 + i < D) {
+      i64 o = (d0 + i) * ld + c;
+      double x = th[o], mu = mean[o];
+      double delta = x - mu;
+      mu = mu + delta / n;
+      mean[o] = mu;
+      m2[o] = m2[o] + delta * (x - mu);
+    }
+}
+
+// one workgroup per dimension; thread t owns chains t, t+256, ... (fixed order), then a
+// fixed-shape LDS tree: deterministic for a given C.
+__global__ __launch_bounds__(256) void k_rhat_partials(const double* mean, const double* m2, i64 ld,
+                                                       double nm1, const double* center, double* out,
+                                                       i64 C, i64 D) {
+  __shared__ double red[3][256];
+  i64 d = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  double ctr = center ? center[d] : 0.0;
+  for (i64 c = threadIdx.x; c < C; c += 256) {
+    double mu = mean[d * ld + c];
+    s0 = s0 + mu;
+    s1 = s1 + m2[d * ld + c] / nm1;
+    double dv = mu - ctr;
+    s2 = s2 + dv * dv;
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  red[2][threadIdx.x] = s2;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+      red[2][threadIdx.x] += red[2][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0 * D + d] = red[0][0];
+    out[1 * D + d] = red[1][0];
+    if (center) out[2 * D + d] = red[2][0];
+  }
+}
+
+// two-pass mean / variance per chain of a stored series (np.mean, np.var(ddof=1))
+__global__ __launch_bounds__(PC_BLOCK) void k_chain_mean_var(const double* x, i64 ld, const int32_t* len,
+                                                             i64 N, double* mean, double* var, i64 C) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  i64 n = len ? (i64)len[c] : N;
+  double s = 0.0;
+  for (i64 t = 0; t < n; ++t) s = s + x[t * ld + c];
+  double mu = s / (double)n;
+  double q = 0.0;
+  for (i64 t = 0; t < n; ++t) {
+    double dv = x[t * ld + c] - mu;
+    q = q + dv * dv;
+  }
+  mean[c] = mu;
+  if (var) var[c] = q / (double)(n - 1);
+}
+
+// ESS per chain, one lane per chain.  acor[n] = (sum_t xc[t]*xc[t+n]) / var0 / N with
+// xc = x - mean, var0 = np.var(x) (ddof=0): the quantity autocorr.py:23-33 obtains via FFT.
+// Lags are produced two at a time (the even/odd pair the Geyer estimators consume) and the
+// scan stops at the first pair with negative sum (iat.py:38-43), so only the lags that
+// matter are ever computed.
+__global__ __launch_bounds__(PC_BLOCK) void k_ess(const double* x, i64 ld, i64 N, int estimator,
+                                                  double* ess_out, double* iat_out, i64 C) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const double* xc = x + c;
+  double s = 0.0;
+  for (i64 t = 0; t < N; ++t) s = s + xc[t * ld];
+  double mu = s / (double)N;
+  double q = 0.0;
+  for (i64 t = 0; t < N; ++t) {
+    double dv = xc[t * ld] - mu;
+    q = q + dv * dv;
+  }
+  double var0 = q / (double)N;
+  double total = 0.0, prev_min = 0.0;
+  i64 n = 0;
+  bool first = true;
+  while (n + 1 < N) {
+    double a0 = 0.0, a1 = 0.0;
+    i64 t = 0;
+    for (; t + n + 1 < N; ++t) {
+      double u = xc[t * ld] - mu;
+      a0 = a0 + u * (xc[(t + n) * ld] - mu);
+      a1 = a1 + u * (xc[(t + n + 1) * ld] - mu);
+    }
+    a0 = a0 + (xc[t * ld] - mu) * (xc[(t + n) * ld] - mu);  // lag n has one more term
+    double r0 = a0 / var0 / (double)N, r1 = a1 / var0 / (double)N;
+    double pair = r0 + r1;
+    if (first) {
+      // iat.py:127-128: the first pair always enters the IMSE sum, even when negative
+      prev_min = pair;
+      if (estimator == 0) total = pair;
+      first = false;
+      if (pair < 0.0) break;  // n stays 0
+      if (estimator == 1) total = pair;
+    } else {
+      if (pair < 0.0) break;
+      if (estimator == 0) {
+        prev_min = prev_min < pair ? prev_min : pair;  // iat.py:132
+        total = total + prev_min;
+      } else {
+        total = total + pair;
+      }
+    }
+    n += 2;
+  }
+  double iat = 2.0 * total - 1.0;
+  if (iat_out) iat_out[c] = iat;
+  ess_out[c] = (double)N / iat;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n, int64_t C,
+                      int64_t D, void* stream) {
+  if (!mean || !m2 || !theta || n < 1 || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, EL_ROWS));
+  k_welford<<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_rhat_partials(const double* mean, const double* m2, int64_t ld, int64_t n, const double* center,
+                     double* out, int64_t C, int64_t D, void* stream) {
+  if (!mean || !m2 || !out || n < 2 || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (D == 0) return BK_OK;
+  k_rhat_partials<<<dim3((unsigned)D), dim3(256), 0, bk_stream(stream)>>>(mean, m2, ld, (double)(n - 1), center,
+                                                                        out, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N, double* mean,
+                      double* var, int64_t C, void* stream) {
+  if (!x || !mean || N < 0 || C < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_chain_mean_var<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+      x, ld, len, N, mean, var, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_ess(const double* x, int64_t ld, int64_t N, int estimator, double* ess_out, double* iat_out,
+           int64_t C, void* stream) {
+  if (!x || !ess_out || N < 4 || C < 0 || (estimator != 0 && estimator != 1)) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_ess<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, estimator,
+                                                                                     ess_out, iat_out, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

@@ -1,0 +1,407 @@
+// Leapfrog integrator, accept/select and MALA proposal-density kernels.
+//
+// Layout: phase-space arrays are [D][ld] with the chain index contiguous, one chain per
+// lane.  Elementwise kernels (kick+drift, select) tile the (d, c) plane so that every
+// wavefront moves 64 lanes x 16 B = 1 KiB per instruction; per-chain reductions (kinetic
+// energy, proposal densities) run one lane per chain sequentially over d, which keeps the
+// summation order fixed (deterministic, independent of the grid) and needs no cross-lane
+// traffic.  The library is compiled with -ffp-contract=off: no FMA, every product and sum
+// is rounded separately, exactly like the NumPy expressions of the reference.
+#include "bk_common.hpp"
+
+namespace {
+
+// ---- fused kick + drift ---------------------------------------------------------------
+constexpr int KD_ROWS = 4;     // rows (dimensions) per thread: 12 x 16-B loads in flight per lane
+constexpr int KD_BLOCK = 256;  // 4 wavefronts
+
+__device__ __forceinline__ double kd_elem(double th, double rho, double g, double m, bool has_m,
+                                          double eps, int use_pre, double pre, int use_kick,
+                                          double kick, double& rho_new) {
+  double t = has_m ? m * g : g;  // metric NULL == ones: 1.0*g == g exactly
+  double r = rho;
+  if (use_pre) r = r + pre * t;
+  if (use_kick) r = r + kick * t;
+  rho_new = r;
+  return th + eps * r;
+}
+
+// chain-contiguous gradient, two chains (16 B) per lane
+__global__ __launch_bounds__(KD_BLOCK) void k_kick_drift_v2(
+    const double* th_in, double* th_out, const double* rho_in, double* rho_out, i64 ld,
+    const double* grad, i64 ldg, const double* metric, double eps, int use_pre, double pre,
+    int use_kick, double kick, i64 C2, i64 D) {
+  i64 c2 = (i64)blockIdx.x * KD_BLOCK + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * KD_ROWS;
+  if (c2 >= C2) return;
+  double2 t[KD_ROWS], r[KD_ROWS], g[KD_ROWS];
+  double m[KD_ROWS];
+#pragma unroll
+  for (int i = 0; i < KD_ROWS; ++i) {
+    i64 d = d0 + i;
+    if (d < D) {
+      t[i] = *reinterpret_cast<const double2*>(th_in + d * ld + 2 * c2);
+      r[i] = *reinterpret_cast<const double2*>(rho_in + d * ld + 2 * c2);
+      g[i] = *reinterpret_cast<const double2*>(grad + d * ldg + 2 * c2);
+      m[i] = metric ? metric[d] : 1.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KD_ROWS; ++i) {
+    i64 d = d0 + i;
+    if (d < D) {
+      double2 rn, tn;
+      tn.x = kd_elem(t[i].x, r[i].x, g[i].x, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn.x);
+      tn.y = kd_elem(t[i].y, r[i].y, g[i].y, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn.y);
+      *reinterpret_cast<double2*>(rho_out + d * ld + 2 * c2) = rn;
+      *reinterpret_cast<double2*>(th_out + d * ld + 2 * c2) = tn;
+    }
+  }
+}
+
+// any layout of the gradient, one chain per lane (odd C, unaligned views, exotic strides)
+__global__ __launch_bounds__(KD_BLOCK) void k_kick_drift_s(
+    const double* th_in, double* th_out, const double* rho_in, double* rho_out, i64 ld,
+    const double* grad, i64 ldg_d, i64 ldg_c, const double* metric, double eps, int use_pre,
+    double pre, int use_kick, double kick, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * KD_BLOCK + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * KD_ROWS;
+  if (c >= C) return;
+  double t[KD_ROWS], r[KD_ROWS], g[KD_ROWS], m[KD_ROWS];
+#pragma unroll
+  for (int i = 0; i < KD_ROWS; ++i) {
+    i64 d = d0 + i;
+    if (d < D) {
+      t[i] = th_in[d * ld + c];
+      r[i] = rho_in[d * ld + c];
+      g[i] = grad[d * ldg_d + c * ldg_c];
+      m[i] = metric ? metric[d] : 1.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KD_ROWS; ++i) {
+    i64 d = d0 + i;
+    if (d < D) {
+      double rn;
+      double tn = kd_elem(t[i], r[i], g[i], m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn);
+      rho_out[d * ld + c] = rn;
+      th_out[d * ld + c] = tn;
+    }
+  }
+}
+
+// dimension-contiguous gradient (a row-major (C, D) model output): 64 x 64 tiles of the
+// gradient are read coalesced along d, staged in LDS and re-read chain-major.  Row pitch
+// 65 doubles keeps the transposed ds_read_b64 conflict-free within each 32-lane group.
+constexpr int TR_TILE = 64;
+__global__ __launch_bounds__(256) void k_kick_drift_tr(
+    const double* th_in, double* th_out, const double* rho_in, double* rho_out, i64 ld,
+    const double* grad, i64 ldg_c, const double* metric, double eps, int use_pre, double pre,
+    int use_kick, double kick, i64 C, i64 D) {
+  __shared__ double tile[TR_TILE][TR_TILE + 1];
+  i64 c0 = (i64)blockIdx.x * TR_TILE, d0 = (i64)blockIdx.y * TR_TILE;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = 0; i < TR_TILE / 4; ++i) {
+    int cl = ty + 4 * i;
+    i64 c = c0 + cl, d = d0 + tx;
+    tile[cl][tx] = (c < C && d < D) ? grad[c * ldg_c + d] : 0.0;
+  }
+  __syncthreads();
+  i64 c = c0 + tx;
+  if (c >= C) return;
+#pragma unroll 4
+  for (int i = 0; i < TR_TILE / 4; ++i) {
+    int dl = ty + 4 * i;
+    i64 d = d0 + dl;
+    if (d < D) {
+      double rn;
+      double m = metric ? metric[d] : 1.0;
+      double tn = kd_elem(th_in[d * ld + c], rho_in[d * ld + c], tile[tx][dl], m, metric != nullptr, eps,
+                          use_pre, pre, use_kick, kick, rn);
+      rho_out[d * ld + c] = rn;
+      th_out[d * ld + c] = tn;
+    }
+  }
+}
+
+// ---- first step of a delayed-rejection stage with gather of the active chains ---------
+constexpr int PC_BLOCK = 64;  // per-chain kernels: one wavefront per workgroup
+constexpr int PC_UNROLL = 8;
+
+__global__ __launch_bounds__(PC_BLOCK) void k_first_step_gather(
+    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
+    double* th_out, double* rho_out, i64 ld_out, const double* metric, double eps, double pre, i64 n,
+    i64 D) {
+  i64 j = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  i64 src = idx ? (i64)idx[j] : j;
+  for (i64 d0 = 0; d0 < D; d0 += PC_UNROLL) {
+    double t[PC_UNROLL], r[PC_UNROLL], g[PC_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PC_UNROLL; ++u)
+      if (d0 + u < D) {
+        i64 o = (d0 + u) * ld_in + src;
+        t[u] = th_in[o];
+        r[u] = rho_in[o];
+        g[u] = g_in[o];
+      }
+#pragma unroll
+    for (int u = 0; u < PC_UNROLL; ++u)
+      if (d0 + u < D) {
+        double rn;
+        double m = metric ? metric[d0 + u] : 1.0;
+        double tn = kd_elem(t[u], r[u], g[u], m, metric != nullptr, eps, 1, pre, 0, 0.0, rn);
+        i64 o = (d0 + u) * ld_out + j;
+        rho_out[o] = rn;
+        th_out[o] = tn;
+      }
+  }
+}
+
+// ---- final half-kick + kinetic energy ---------------------------------------------------
+__global__ __launch_bounds__(PC_BLOCK) void k_finish(const double* rho_in, double* rho_out, i64 ld,
+                                                     const double* grad, i64 ldg_d, i64 ldg_c,
+                                                     const double* metric, double half, int negate,
+                                                     double* kin_out, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double kin = 0.0;
+  for (i64 d0 = 0; d0 < D; d0 += PC_UNROLL) {
+    double r[PC_UNROLL], g[PC_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PC_UNROLL; ++u)
+      if (d0 + u < D) {
+        r[u] = rho_in[(d0 + u) * ld + c];
+        g[u] = grad[(d0 + u) * ldg_d + c * ldg_c];
+      }
+#pragma unroll
+    for (int u = 0; u < PC_UNROLL; ++u)
+      if (d0 + u < D) {
+        double m = metric ? metric[d0 + u] : 1.0;
+        double t = metric ? m * g[u] : g[u];
+        double v = r[u] + half * t;
+        if (negate) v = -v;
+        if (rho_out) rho_out[(d0 + u) * ld + c] = v;
+        double mv = metric ? m * v : v;
+        kin = kin + v * mv;  // sequential in d
+      }
+  }
+  if (kin_out) kin_out[c] = 0.5 * kin;
+}
+
+// ---- accept ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mh_accept(int mode, double* lp_cur, const double* a_cur,
+                                                   const double* lp_prop, const double* a_prop,
+                                                   const double* log_u, uint8_t* mask, double* ret,
+                                                   uint32_t* count, i64 C) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  bool acc = false;
+  if (c < C) {
+    double l0 = lp_cur[c], l1 = lp_prop[c];
+    double a0 = a_cur ? a_cur[c] : 0.0, a1 = a_prop ? a_prop[c] : 0.0;
+    double r0, r1;
+    if (mode == BK_ACCEPT_HMC) {
+      double h0 = l0 - a0, h1 = l1 - a1;  // hmc.py:36-38
+      acc = log_u[c] < h1 - h0;           // hmc.py:60
+      r0 = h0;
+      r1 = h1;
+    } else {
+      acc = log_u[c] < (l1 - l0) + (a1 - a0);  // metropolis.py:70-76
+      r0 = l0;
+      r1 = l1;
+    }
+    if (mask) mask[c] = acc ? 1 : 0;
+    if (ret) ret[c] = acc ? r1 : r0;
+    if (acc) lp_cur[c] = l1;
+  }
+  if (count) {
+    // wavefront ballot -> one atomic per 64 chains
+    unsigned long long b = __ballot(acc);
+    if ((threadIdx.x & (BK_WAVE - 1)) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+  }
+}
+
+// ---- masked column copy -----------------------------------------------------------------
+constexpr int SEL_ROWS = 4;
+__global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst0, const double* src0,
+                                                double* dst1, const double* src1, i64 ld, i64 C,
+                                                i64 D) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * SEL_ROWS;
+  if (c >= C || !mask[c]) return;
+  double a[SEL_ROWS], b[SEL_ROWS];
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) {
+      a[i] = src0[(d0 + i) * ld + c];
+      if (dst1) b[i] = src1[(d0 + i) * ld + c];
+    }
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) {
+      dst0[(d0 + i) * ld + c] = a[i];
+      if (dst1) dst1[(d0 + i) * ld + c] = b[i];
+    }
+}
+
+// ---- MALA proposal log densities --------------------------------------------------------
+__global__ __launch_bounds__(PC_BLOCK) void k_mala_logq(const double* th, const double* g,
+                                                        const double* thp, const double* gp, i64 ld,
+                                                        double eps, double* fwd, double* rev, i64 C,
+                                                        i64 D) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  double sf = 0.0, sr = 0.0;
+  constexpr int U = 4;
+  for (i64 d0 = 0; d0 < D; d0 += U) {
+    double a[U], b[U], p[U], q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (d0 + u < D) {
+        i64 o = (d0 + u) * ld + c;
+        a[u] = th[o];
+        b[u] = g[o];
+        p[u] = thp[o];
+        q[u] = gp[o];
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (d0 + u < D) {
+        double xf = (p[u] - a[u]) - eps * b[u];  // mala.py:78
+        double xr = (a[u] - p[u]) - eps * q[u];
+        sf = sf + xf * xf;
+        sr = sr + xr * xr;
+      }
+  }
+  double k = -0.25 / eps;  // mala.py:79
+  fwd[c] = k * sf;
+  rev[c] = k * sr;
+}
+
+// ---- layout change through LDS tiles ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_relayout(const double* src, i64 s_d, i64 s_c, double* dst,
+                                                  i64 t_d, i64 t_c, i64 C, i64 D) {
+  __shared__ double tile[TR_TILE][TR_TILE + 1];
+  i64 c0 = (i64)blockIdx.x * TR_TILE, d0 = (i64)blockIdx.y * TR_TILE;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // read with the lane index along whichever source axis is contiguous
+  bool src_d_fast = (s_d == 1);
+#pragma unroll 4
+  for (int i = 0; i < TR_TILE / 4; ++i) {
+    int slow = ty + 4 * i;
+    int cl = src_d_fast ? slow : tx, dl = src_d_fast ? tx : slow;
+    i64 c = c0 + cl, d = d0 + dl;
+    if (c < C && d < D) tile[cl][dl] = src[d * s_d + c * s_c];
+  }
+  __syncthreads();
+  bool dst_d_fast = (t_d == 1);
+#pragma unroll 4
+  for (int i = 0; i < TR_TILE / 4; ++i) {
+    int slow = ty + 4 * i;
+    int cl = dst_d_fast ? slow : tx, dl = dst_d_fast ? tx : slow;
+    i64 c = c0 + cl, d = d0 + dl;
+    if (c < C && d < D) dst[d * t_d + c * t_c] = tile[cl][dl];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_leapfrog_kick_drift(const double* theta_in, double* theta_out, const double* rho_in,
+                           double* rho_out, int64_t ld, const double* grad, int64_t ldg_d,
+                           int64_t ldg_c, const double* metric, double eps, int use_pre, double pre,
+                           int use_kick, double kick, int64_t C, int64_t D, void* stream) {
+  if (!theta_in || !theta_out || !rho_in || !rho_out || !grad || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  if (ldg_c == 1) {
+    bool vec = (C % 2 == 0) && (ld % 2 == 0) && (ldg_d % 2 == 0) && bk_aligned16(theta_in) &&
+               bk_aligned16(theta_out) && bk_aligned16(rho_in) && bk_aligned16(rho_out) &&
+               bk_aligned16(grad);
+    if (vec) {
+      dim3 grid((unsigned)bk_cdiv(C / 2, KD_BLOCK), (unsigned)bk_cdiv(D, KD_ROWS));
+      k_kick_drift_v2<<<grid, dim3(KD_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, grad, ldg_d,
+                                                      metric, eps, use_pre, pre, use_kick, kick, C / 2, D);
+      BK_RETURN_LAUNCH_STATUS();
+    }
+  } else if (ldg_d == 1 && C >= TR_TILE / 2 && D >= TR_TILE / 2) {
+    dim3 grid((unsigned)bk_cdiv(C, TR_TILE), (unsigned)bk_cdiv(D, TR_TILE));
+    k_kick_drift_tr<<<grid, dim3(256), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, grad, ldg_c, metric,
+                                               eps, use_pre, pre, use_kick, kick, C, D);
+    BK_RETURN_LAUNCH_STATUS();
+  }
+  dim3 grid((unsigned)bk_cdiv(C, KD_BLOCK), (unsigned)bk_cdiv(D, KD_ROWS));
+  k_kick_drift_s<<<grid, dim3(KD_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, grad, ldg_d, ldg_c,
+                                                 metric, eps, use_pre, pre, use_kick, kick, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, const double* grad_in,
+                                  int64_t ld_in, const int32_t* src_index, double* theta_out,
+                                  double* rho_out, int64_t ld_out, const double* metric, double eps,
+                                  double pre, int64_t n, int64_t D, void* stream) {
+  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || n < 0 || D < 0) return BK_E_ARG;
+  if (ld_out < n) return BK_E_ALIGN;
+  if (n == 0 || D == 0) return BK_OK;
+  k_first_step_gather<<<dim3((unsigned)bk_cdiv(n, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+      theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, ld_out, metric, eps, pre, n, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld, const double* grad,
+                       int64_t ldg_d, int64_t ldg_c, const double* metric, double half, int negate,
+                       double* kin_out, int64_t C, int64_t D, void* stream) {
+  if (!rho_in || !grad || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_finish<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+      rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp_prop,
+                 const double* a_prop, const double* log_u, uint8_t* accept_mask, double* ret,
+                 uint32_t* accept_count, int64_t C, void* stream) {
+  if (!lp_cur || !lp_prop || !log_u || C < 0) return BK_E_ARG;
+  if (mode != BK_ACCEPT_HMC && mode != BK_ACCEPT_MALA) return BK_E_ARG;
+  if (C == 0) return BK_OK;
+  k_mh_accept<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, bk_stream(stream)>>>(
+      mode, lp_cur, a_cur, lp_prop, a_prop, log_u, accept_mask, ret, accept_count, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0, double* dst1,
+                      const double* src1, int64_t ld, int64_t C, int64_t D, void* stream) {
+  if (!mask || !dst0 || !src0 || (dst1 && !src1) || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
+  k_select<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_mala_logq(const double* theta, const double* grad, const double* theta_prop,
+                 const double* grad_prop, int64_t ld, double eps, double* lp_forward,
+                 double* lp_reverse, int64_t C, int64_t D, void* stream) {
+  if (!theta || !grad || !theta_prop || !grad_prop || !lp_forward || !lp_reverse || C < 0 || D < 0)
+    return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_mala_logq<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+      theta, grad, theta_prop, grad_prop, ld, eps, lp_forward, lp_reverse, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_relayout(const double* src, int64_t lds_d, int64_t lds_c, double* dst, int64_t ldd_d,
+                int64_t ldd_c, int64_t C, int64_t D, void* stream) {
+  if (!src || !dst || C < 0 || D < 0) return BK_E_ARG;
+  if (C == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, TR_TILE), (unsigned)bk_cdiv(D, TR_TILE));
+  k_relayout<<<grid, dim3(256), 0, bk_stream(stream)>>>(src, lds_d, lds_c, dst, ldd_d, ldd_c, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

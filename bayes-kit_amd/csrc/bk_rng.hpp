@@ -1,0 +1,215 @@
+// Per-chain random streams for the many-chain samplers: bit-for-bit the stream that
+// numpy.random.Generator hands the reference samplers (bayes_kit/hmc.py:23,56,60;
+// mala.py:25,44; drghmc.py:71,77,360-364,370,378).
+//
+//   * bit generators: Philox4x64-10 (np.random.Philox(key=[k0,k1])) and PCG64
+//     (np.random.default_rng(int) -> PCG64 XSL-RR 128/64), state held per chain in a
+//     caller-owned SoA table  state[BK_RNG_WORDS][ld]  of u64 (one chain per column);
+//   * double in [0,1): (u64 >> 11) * 2^-53;
+//   * standard normal: NumPy's 256-layer ziggurat with NumPy's own tables
+//     (ziggurat_tables.inc), including the tail branch, which needs glibc's log1p
+//     reproduced exactly (bk_log1p below) for the draws to be bit-identical.
+//
+// Everything here is __host__ __device__ so the exact source the GPU runs can also be
+// exercised on the host by the library's bk_host_* self-test hooks (tests only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#define BK_RNG_WORDS 11  // philox: key[2] ctr[4] buf[4] pos ; pcg64: state_hi state_lo inc_hi inc_lo
+#define BK_RNG_PHILOX 0
+#define BK_RNG_PCG64 1
+
+#define BK_HD __host__ __device__ __forceinline__
+
+namespace bk {
+
+BK_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
+#endif
+}
+
+BK_HD double u64_as_double(uint64_t u) {
+  union { uint64_t u; double d; } x;
+  x.u = u;
+  return x.d;
+}
+BK_HD uint64_t double_as_u64(double d) {
+  union { uint64_t u; double d; } x;
+  x.d = d;
+  return x.u;
+}
+
+// ---- Philox4x64-10 -----------------------------------------------------------------
+struct Philox {
+  uint64_t key0, key1;
+  uint64_t c0, c1, c2, c3;
+  uint64_t b0, b1, b2, b3;
+  uint32_t pos;  // 0..4 ; 4 = buffer empty
+
+  BK_HD void block() {
+    const uint64_t M0 = 0xD2E7470EE14C6C93ULL, M1 = 0xCA5A826395121157ULL;
+    const uint64_t W0 = 0x9E3779B97F4A7C15ULL, W1 = 0xBB67AE8584CAA73BULL;
+    uint64_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, k0 = key0, k1 = key1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      if (r) { k0 += W0; k1 += W1; }
+      uint64_t hi0 = mulhi64(M0, x0), lo0 = M0 * x0;
+      uint64_t hi1 = mulhi64(M1, x2), lo1 = M1 * x2;
+      uint64_t y0 = hi1 ^ x1 ^ k0, y2 = hi0 ^ x3 ^ k1;
+      x0 = y0; x1 = lo1; x2 = y2; x3 = lo0;
+    }
+    b0 = x0; b1 = x1; b2 = x2; b3 = x3;
+  }
+
+  BK_HD uint64_t next() {
+    if (pos < 4) {
+      uint64_t v = pos == 0 ? b0 : pos == 1 ? b1 : pos == 2 ? b2 : b3;
+      ++pos;
+      return v;
+    }
+    // the 256-bit counter is incremented BEFORE the block is generated
+    if (++c0 == 0) { if (++c1 == 0) { if (++c2 == 0) { ++c3; } } }
+    block();
+    pos = 1;
+    return b0;
+  }
+
+  template <typename I>
+  BK_HD void load(const uint64_t* st, I ld, I c) {
+    key0 = st[0 * ld + c]; key1 = st[1 * ld + c];
+    c0 = st[2 * ld + c]; c1 = st[3 * ld + c]; c2 = st[4 * ld + c]; c3 = st[5 * ld + c];
+    b0 = st[6 * ld + c]; b1 = st[7 * ld + c]; b2 = st[8 * ld + c]; b3 = st[9 * ld + c];
+    pos = (uint32_t)st[10 * ld + c];
+  }
+  template <typename I>
+  BK_HD void store(uint64_t* st, I ld, I c) const {
+    st[2 * ld + c] = c0; st[3 * ld + c] = c1; st[4 * ld + c] = c2; st[5 * ld + c] = c3;
+    st[6 * ld + c] = b0; st[7 * ld + c] = b1; st[8 * ld + c] = b2; st[9 * ld + c] = b3;
+    st[10 * ld + c] = pos;
+  }
+};
+
+// ---- PCG64 (XSL-RR 128/64, numpy's default_rng(int)) --------------------------------
+struct Pcg64 {
+  uint64_t s_hi, s_lo, i_hi, i_lo;
+
+  BK_HD uint64_t next() {
+    const uint64_t MH = 0x2360ED051FC65DA4ULL, ML = 0x4385DF649FCCF645ULL;
+    // state = state * MULT + inc  (mod 2^128), then output from the NEW state
+    uint64_t lo = s_lo * ML;
+    uint64_t hi = mulhi64(s_lo, ML) + s_lo * MH + s_hi * ML;
+    uint64_t nlo = lo + i_lo;
+    uint64_t nhi = hi + i_hi + (nlo < lo ? 1ULL : 0ULL);
+    s_lo = nlo; s_hi = nhi;
+    uint64_t x = nhi ^ nlo;
+    uint32_t rot = (uint32_t)(nhi >> 58);
+    return (x >> rot) | (x << ((64u - rot) & 63u));
+  }
+  template <typename I>
+  BK_HD void load(const uint64_t* st, I ld, I c) {
+    s_hi = st[0 * ld + c]; s_lo = st[1 * ld + c]; i_hi = st[2 * ld + c]; i_lo = st[3 * ld + c];
+  }
+  template <typename I>
+  BK_HD void store(uint64_t* st, I ld, I c) const {
+    st[0 * ld + c] = s_hi; st[1 * ld + c] = s_lo;
+  }
+};
+
+// ---- glibc 2.35 log1p (sysdeps/ieee754/dbl-64/s_log1p.c) for finite x > -1 -----------
+// fdlibm argument reduction with glibc's split polynomial; every operation individually
+// rounded (the library is built with -ffp-contract=off).
+BK_HD double bk_log1p(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01,
+               Lp3 = 2.857142874366239149e-01, Lp4 = 2.222219843214978396e-01,
+               Lp5 = 1.818357216161805012e-01, Lp6 = 1.531383769920937332e-01,
+               Lp7 = 1.479819860511658591e-01;
+  int32_t hx = (int32_t)(double_as_u64(x) >> 32);
+  int32_t ax = hx & 0x7fffffff;
+  int32_t k = 1, hu = 0;
+  double f = 0.0, c = 0.0;
+  if (hx < 0x3FDA827A) {
+    if (ax >= 0x3ff00000) return x == -1.0 ? -INFINITY : NAN;
+    if (ax < 0x3e200000) {
+      if (ax < 0x3c900000) return x;
+      return x - x * x * 0.5;
+    }
+    if (hx > 0 || hx <= (int32_t)0xbfd2bec3) { k = 0; f = x; hu = 1; }
+  }
+  if (k != 0) {
+    double u = 1.0 + x;
+    uint64_t ub = double_as_u64(u);
+    hu = (int32_t)(ub >> 32);
+    k = (hu >> 20) - 1023;
+    c = (k > 0) ? 1.0 - (u - x) : x - (u - 1.0);
+    c /= u;
+    hu &= 0x000fffff;
+    if (hu < 0x6a09e) {
+      ub = (ub & 0xffffffffULL) | ((uint64_t)(uint32_t)(hu | 0x3ff00000) << 32);
+    } else {
+      k += 1;
+      ub = (ub & 0xffffffffULL) | ((uint64_t)(uint32_t)(hu | 0x3fe00000) << 32);
+      hu = (0x00100000 - hu) >> 2;
+    }
+    f = u64_as_double(ub) - 1.0;
+  }
+  double hfsq = 0.5 * f * f;
+  if (hu == 0) {
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      c += k * ln2_lo;
+      return k * ln2_hi + c;
+    }
+    double R = hfsq * (1.0 - 0.66666666666666666 * f);
+    if (k == 0) return f - R;
+    return k * ln2_hi - ((R - (k * ln2_lo + c)) - f);
+  }
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double R1 = z * Lp1, z2 = z * z;
+  double R2 = Lp2 + z * Lp3, z4 = z2 * z2;
+  double R3 = Lp4 + z * Lp5, z6 = z4 * z2;
+  double R4 = Lp6 + z * Lp7;
+  double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
+  if (k == 0) return f - (hfsq - s * (hfsq + R));
+  return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+
+// ---- doubles and normals -------------------------------------------------------------
+template <typename G>
+BK_HD double next_double(G& g) {
+  return (double)(g.next() >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// NumPy random_standard_normal.  ki/wi/fi point at the three 256-entry tables (LDS on the
+// device, static arrays on the host).
+template <typename G>
+BK_HD double next_normal(G& g, const uint64_t* ki, const double* wi, const double* fi) {
+  const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
+  for (;;) {
+    uint64_t r = g.next();
+    int idx = (int)(r & 0xff);
+    r >>= 8;
+    int sign = (int)(r & 1);
+    uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
+    double x = (double)rabs * wi[idx];
+    if (sign) x = -x;
+    if (rabs < ki[idx]) return x;  // 99.2 %
+    if (idx == 0) {
+      for (;;) {
+        double xx = -zinv * bk_log1p(-next_double(g));
+        double yy = -bk_log1p(-next_double(g));
+        if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+      }
+    } else {
+      if ((fi[idx - 1] - fi[idx]) * next_double(g) + fi[idx] < exp(-0.5 * x * x)) return x;
+    }
+  }
+}
+
+}  // namespace bk

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: leapfrog steps/sec, many-chain HMC on BASELINE.json config 3.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload: ill-conditioned Gaussian, D = 1024, precision
+lam = logspace(0, 4, D); HMC with L = 64 leapfrog steps, eps = 0.006, a streamed
+length-D metric of ones; 65,536 chains PER GPU (weak scaling: chains are independent and
+shard with no data-path collective; Philox key = (20241, global chain id)).  One bench
+"step" = one HMC draw of every chain = 64 leapfrog steps each.  The gradient is supplied
+by a separate device op (the C-ABI built-in target), i.e. the model-opaque path whose
+algorithmic HBM traffic is 56*D bytes per chain-step (40*D integrator + 16*D gradient).
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the fused
+kick+drift, 40*D algorithmic bytes per chain per launch), its duration measured live with
+HIP events on the launch stream over the timed region.  `cpu_baseline` times the oracle
+(NumPy restatement of the reference) on the host cores, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "bayes-kit_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+D_CFG3 = 1024
+L_CFG3 = 64
+EPS_CFG3 = 0.006
+SEED_CFG3 = 20241
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3):
+    """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    lam = torch.logspace(0, 4, D, dtype=torch.float64)
+    model = bk.DiagGaussian(lam)
+    s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
+                   chains=chains, chain_id0=chain_id0)
+    # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
+    # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
+    s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(device)[:, None])
+    return s
+
+
+def cpu_baseline(seconds_hint=12.0):
+    """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler
+    object per chain, chains spread over P processes, config-3 shape, bounded sample."""
+    import subprocess
+
+    P = max(1, min(os.cpu_count() or 1, 32))
+    chains_per_proc, draws = 4, 60  # ~4*60*64 = 15k leapfrog steps per process (~1.5 s each)
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", str(p * chains_per_proc),
+                               str(chains_per_proc), str(draws), str(D_CFG3), str(L_CFG3), str(EPS_CFG3),
+                               str(SEED_CFG3)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+             for p in range(P)]
+    res = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=600)
+        if pr.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed")
+        r = json.loads(out.strip().splitlines()[-1])
+        res.append((r["steps"], r["seconds"]))
+    wall = time.perf_counter() - t0
+    busy = max(r[1] for r in res)  # slowest worker's compute time (excludes process start-up)
+    steps = sum(r[0] for r in res)
+    return {
+        "value": steps / busy,
+        "unit": "leapfrog steps/sec",
+        "cores": P,
+        "kind": "port",
+        "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
+                  f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()  # before the GPU is initialised (worker processes never touch it)
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from bayes_kit_amd import _lib
+
+    C = args.chains
+    D, L = D_CFG3, L_CFG3
+    s = make_cfg3_sampler(C, rank * C, device)
+    ops = s._ops
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        s.sample()
+    if not args.no_kernel_events:
+        ops.timed = {"bk_leapfrog_kick_drift": [], "bk_target_diag_gaussian_grad": []}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.sample()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timed, ops.timed = ops.timed, None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    accept = s.accept_rate()
+
+    total_steps = float(C) * world * L * args.steps
+    value = total_steps / elapsed
+    out = {
+        "metric": "leapfrog steps/sec (whole node), D=1024 x 65,536 chains per GPU",
+        "value": value,
+        "unit": "leapfrog steps/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: ill-conditioned Gaussian D=1024 (lam=logspace(0,4)), HMC L=64 "
+                        "eps=0.006, diag metric of ones, model-opaque gradient op",
+            "chains_per_gpu": C, "dims": D, "leapfrog_steps": L, "parallelism": f"chains sharded x{world}",
+        },
+        "accept_rate": accept,
+        # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
+        "path_hbm_frac": value / world * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
+    }
+    if timed:
+        kd = [a.elapsed_time(b) for a, b in timed["bk_leapfrog_kick_drift"]]
+        gr = [a.elapsed_time(b) for a, b in timed["bk_target_diag_gaussian_grad"]]
+        kd_ms = sum(kd) / len(kd)
+        bytes_per_launch = 40.0 * D * C
+        achieved = bytes_per_launch / (kd_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "kernel": "k_kick_drift_v2 (bk_leapfrog_kick_drift)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "avg_launch_ms": kd_ms,
+            "launches": len(kd),
+            "algorithmic_bytes_per_launch": bytes_per_launch,
+        }
+        if gr:
+            g_ms = sum(gr) / len(gr)
+            out["roofline"]["gradient_kernel"] = {
+                "kernel": "k_gauss_grad_v2 (bk_target_diag_gaussian_grad)",
+                "avg_launch_ms": g_ms,
+                "achieved": 16.0 * D * C / (g_ms * 1e-3) / 1e9,
+                "algorithmic_bytes_per_launch": 16.0 * D * C,
+            }
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

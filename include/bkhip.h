@@ -1,0 +1,214 @@
+/* bkhip.h -- C ABI of libbkhip.so: the MI355X (gfx950) many-chain HMC / MALA / DRGHMC
+ * hot path that stands in for the per-draw arithmetic of flatironinstitute/bayes-kit.
+ *
+ * Conventions (all entry points)
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - Every pointer is a DEVICE pointer owned by the caller (the library never allocates
+ *     persistent memory and never frees caller memory).
+ *   - Phase-space arrays are fp64, chain-major-contiguous ("[D][ld]"): element (d, c) of
+ *     a D-dimensional state of chain c lives at  p[d*ld + c],  ld >= C.  One chain per
+ *     GPU lane, so a wavefront touches 64 consecutive doubles for every d.
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and return.
+ *   - Return value: 0 = ok; < 0 = argument error (BK_E_*); > 0 = hipError_t of the launch.
+ *   - No global mutable state: re-entrant across host threads and one-process-per-GPU.
+ *   - Arithmetic is IEEE fp64 with every * and + individually rounded (the library is
+ *     built with -ffp-contract=off) in the operation order of the cited reference lines,
+ *     so elementwise results are bit-identical to the reference's NumPy expressions.
+ *
+ * Each entry point cites the reference code (flatironinstitute/bayes-kit) it replaces.
+ */
+#ifndef BKHIP_H
+#define BKHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BK_OK 0
+#define BK_E_ARG (-1)      /* null pointer / bad extent / bad enum */
+#define BK_E_ALIGN (-2)    /* ld < C or similar layout violation */
+
+/* ---- per-chain random streams ------------------------------------------------------
+ * state: u64 table [BK_RNG_WORDS][ldr], one chain per column.
+ *   BK_RNG_PHILOX (np.random.Philox(key=[k0,k1])): rows 0-1 key, 2-5 counter,
+ *       6-9 output buffer, 10 buffer_pos (4 = empty) -- the fields of numpy's
+ *       bit_generator.state, so a reference stream can be resumed mid-way.
+ *   BK_RNG_PCG64 (np.random.default_rng(int)): rows 0-1 state (hi, lo), 2-3 inc (hi, lo).
+ */
+#define BK_RNG_WORDS 11
+#define BK_RNG_PHILOX 0
+#define BK_RNG_PCG64 1
+
+int bk_version(void);
+
+/* Philox key = (key0, chain_id0 + c), counter 0, buffer empty: the stream of
+ * np.random.Generator(np.random.Philox(key=[key0, chain_id0 + c])).  Replaces
+ * `self._rng = np.random.default_rng(seed)` (hmc.py:23, mala.py:25, drghmc.py:71) for
+ * chain c when the reference is seeded with that Philox bit generator. */
+int bk_rng_init_philox(uint64_t* state, int64_t ldr, uint64_t key0, uint64_t chain_id0,
+                       int64_t C, void* stream);
+
+/* out[d*ld + c] = loc + scale * z,  z ~ N(0,1) drawn d = 0..D-1 in order from chain c's
+ * stream (NumPy ziggurat; `rng.normal(loc, scale, size=D)`), where
+ *     loc = loc_in ? loc_in[d*ld + c] * loc_mul : 0.0
+ * and, if kin_out != NULL,  kin_out[c] = 0.5 * sum_d out*(metric[d]*out)  (metric NULL = 1).
+ *   HMC momentum draw + kinetic term     hmc.py:56, :37      (loc_in NULL, scale 1)
+ *   initial theta / rho                  hmc.py:24-28, drghmc.py:72-77
+ *   DRGHMC partial refresh               drghmc.py:360-364, :250  (loc_mul = sqrt(1-damping),
+ *                                                                  scale = sqrt(damping))
+ * `active` (NULL = all): u8 mask per chain; inactive chains draw nothing. */
+int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
+                        const double* loc_in, double loc_mul, double scale,
+                        double* out, int64_t ld, const double* metric, double* kin_out,
+                        const uint8_t* active, int64_t C, int64_t D, void* stream);
+
+/* out[c] = log(u), u = next double of chain c's stream: `np.log(self._rng.uniform())`
+ * (hmc.py:60, metropolis.py:74, drghmc.py:370,378).  Inactive chains draw nothing and
+ * keep out[c]. */
+int bk_log_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out,
+                   const uint8_t* active, int64_t C, void* stream);
+
+/* ---- leapfrog integrator -------------------------------------------------------------
+ * One fused kick + drift over all chains and dimensions (the hot loop hmc.py:47-49,
+ * drghmc.py:277-278,282-283):
+ *     t      = metric[d] * grad            (metric NULL = ones, still multiplied by 1.0)
+ *     r      = rho_in
+ *     if use_pre:  r = r + pre  * t        (hmc.py:46 back half-step, pre = -(0.5*eps);
+ *                                           drghmc.py:277 first half-kick, pre = 0.5*h)
+ *     if use_kick: r = r + kick * t        (hmc.py:48 / drghmc.py:282, kick = eps)
+ *     rho_out   = r
+ *     theta_out = theta_in + eps * r       (hmc.py:49 / drghmc.py:278,283)
+ * theta_out may alias theta_in and rho_out may alias rho_in (in-place), or differ (the
+ * first step of a trajectory reads the current point and writes the proposal buffers).
+ * grad may have any strides (ldg_d, ldg_c): element (d,c) at grad[d*ldg_d + c*ldg_c]; the
+ * chain-contiguous case (ldg_c == 1) streams directly, the dimension-contiguous case
+ * (ldg_d == 1, what a row-major (C, D) model output looks like) is transposed through
+ * LDS tiles.  Algorithmic HBM bytes: 40 per element. */
+int bk_leapfrog_kick_drift(const double* theta_in, double* theta_out,
+                           const double* rho_in, double* rho_out, int64_t ld,
+                           const double* grad, int64_t ldg_d, int64_t ldg_c,
+                           const double* metric, double eps,
+                           int use_pre, double pre, int use_kick, double kick,
+                           int64_t C, int64_t D, void* stream);
+
+/* Same step, but chain j of the outputs (compact, leading dimension ld_out) is chain
+ * src_index[j] of the inputs (leading dimension ld_in): gathers the active chains of a
+ * delayed-rejection stage into a dense buffer while taking their first leapfrog step
+ * (drghmc.py:276-278 for the chains that reach proposal k). n = number of gathered chains. */
+int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in,
+                                  const double* grad_in, int64_t ld_in,
+                                  const int32_t* src_index,
+                                  double* theta_out, double* rho_out, int64_t ld_out,
+                                  const double* metric, double eps, double pre,
+                                  int64_t n, int64_t D, void* stream);
+
+/* Final half-kick and kinetic energy of a trajectory:
+ *     r = rho_in + half * (metric[d] * grad)      hmc.py:52, drghmc.py:286
+ *     if negate: r = -r                           drghmc.py:345 (momentum flip)
+ *     if rho_out: rho_out = r
+ *     kin_out[c] = 0.5 * sum_d r*(metric[d]*r)    hmc.py:37, drghmc.py:250
+ * The sum runs d = 0..D-1 sequentially per chain (np.dot uses a different order: results
+ * agree to ~1e-16 relative, see DESIGN.md tolerances). */
+int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld,
+                       const double* grad, int64_t ldg_d, int64_t ldg_c,
+                       const double* metric, double half, int negate,
+                       double* kin_out, int64_t C, int64_t D, void* stream);
+
+/* ---- Metropolis / Metropolis-Hastings accept ------------------------------------------
+ * mode BK_ACCEPT_HMC  (hmc.py:57-63):  h0 = lp_cur - a_cur ; h1 = lp_prop - a_prop ;
+ *        accept = log_u < h1 - h0 ;  ret[c] = accept ? h1 : h0   (joint log density)
+ * mode BK_ACCEPT_MALA (mala.py:50-61, metropolis.py:70-76): a_cur = lp_forward,
+ *        a_prop = lp_reverse ; accept = log_u < (lp_prop - lp_cur) + (a_prop - a_cur) ;
+ *        ret[c] = accept ? lp_prop : lp_cur   (model log density, mala.py:66)
+ * On accept lp_cur[c] <- lp_prop[c].  accept_mask[c] = 0/1.  *accept_count (device u32,
+ * may be NULL) is incremented by the number of accepted chains, one atomic per wavefront
+ * (ballot + popcount).  Strict `<` as in the reference. */
+#define BK_ACCEPT_HMC 0
+#define BK_ACCEPT_MALA 1
+int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp_prop,
+                 const double* a_prop, const double* log_u, uint8_t* accept_mask,
+                 double* ret, uint32_t* accept_count, int64_t C, void* stream);
+
+/* dst[d*ld + c] = mask[c] ? src[d*ld + c] : dst[d*ld + c] for up to two array pairs
+ * (pair 1 may be NULL): `self._theta = theta_prop` (hmc.py:61, mala.py:62-64,
+ * drghmc.py:379) applied to the accepted chains only.  Rejected chains are neither read
+ * nor written. */
+int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
+                      double* dst1, const double* src1, int64_t ld,
+                      int64_t C, int64_t D, void* stream);
+
+/* ---- MALA ---------------------------------------------------------------------------
+ * theta_prop = (theta + eps*grad) + sqrt2eps * z, z from chain c's stream in d order
+ * (mala.py:41-45). */
+int bk_mala_propose(int rng_kind, uint64_t* state, int64_t ldr, const double* theta,
+                    const double* grad, double* theta_prop, int64_t ld, double eps,
+                    double sqrt2eps, int64_t C, int64_t D, void* stream);
+
+/* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
+ * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */
+int bk_mala_logq(const double* theta, const double* grad, const double* theta_prop,
+                 const double* grad_prop, int64_t ld, double eps, double* lp_forward,
+                 double* lp_reverse, int64_t C, int64_t D, void* stream);
+
+/* ---- built-in targets: the "thin C-ABI callback" form of GradModel.log_density_gradient
+ * (typing.py:25-27) batched over chains.  grad and/or logp may be NULL (HMC discards lp
+ * inside the trajectory, hmc.py:45,50).  Operation order = oracle/models.py.
+ *   iso     : logp = -0.5*sum th^2            grad = -th
+ *   diag    : t = lam*th; logp = -0.5*sum th*t; grad = -t
+ *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2
+ *             logp = ((-(v*v)/18) - (0.5*n)*v) - (0.5*ev)*s
+ *             grad0 = ((-v/9) - 0.5*n) + (0.5*ev)*s ; grad_i = -(ev*th_i)
+ */
+int bk_target_iso_gaussian_grad(const double* theta, double* grad, double* logp, int64_t ld,
+                                int64_t C, int64_t D, void* stream);
+int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp, int64_t ld,
+                                 const double* lam, int64_t C, int64_t D, void* stream);
+int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld,
+                          int64_t C, int64_t D, void* stream);
+
+/* ---- layout helper --------------------------------------------------------------------
+ * dst[d*ld + c] = src[c*lds_c + d*lds_d]  (LDS-tiled transpose/copy) -- brings a model's
+ * (C, D) row-major output into the engine's chain-contiguous layout, and back with the
+ * roles of the strides swapped. */
+int bk_relayout(const double* src, int64_t lds_d, int64_t lds_c, double* dst, int64_t ldd_d,
+                int64_t ldd_c, int64_t C, int64_t D, void* stream);
+
+/* ---- streaming diagnostics --------------------------------------------------------------
+ * Welford update with the n-th draw (n >= 1) of every chain and dimension: per-chain mean
+ * and M2 from which rhat.py:163-166 (np.mean, np.var(ddof=1)) follow. */
+int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n,
+                      int64_t C, int64_t D, void* stream);
+
+/* Per-dimension partial sums over this rank's C chains for R-hat (rhat.py:163-171):
+ * out[0*D + d] = sum_c mean ; out[1*D + d] = sum_c var_c (var_c = m2/(n-1)).
+ * With `center` != NULL also out[2*D + d] = sum_c (mean - center[d])^2  (second pass of
+ * np.var(means, ddof=1)).  Deterministic fixed-shape tree per dimension. */
+int bk_rhat_partials(const double* mean, const double* m2, int64_t ld, int64_t n,
+                     const double* center, double* out, int64_t C, int64_t D, void* stream);
+
+/* Per-chain mean and ddof=1 variance of a stored series x[t*ld + c], t < len[c] (len NULL =
+ * all N): the two list comprehensions of rhat.py:165-166 for ragged chains. */
+int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N,
+                      double* mean, double* var, int64_t C, void* stream);
+
+/* ESS of each chain of a stored series (ess.py:52-69 -> iat.py:95-135 -> autocorr.py:6-33):
+ * autocorrelations by direct summation (same quantity the reference gets by FFT), Geyer
+ * initial-positive truncation at the first even lag pair with negative sum, initial
+ * monotone running-min sum, IAT = 2*sum - 1, ESS = N/IAT.  estimator 0 = IMSE (ess /
+ * ess_imse), 1 = IPSE (ess_ipse).  iat_out may be NULL. */
+int bk_ess(const double* x, int64_t ld, int64_t N, int estimator, double* ess_out,
+           double* iat_out, int64_t C, void* stream);
+
+/* ---- host-side self-test hooks (tests only; they run the SAME source as the kernels on
+ * the host so the RNG can be checked against numpy without a GPU).  Host pointers. */
+int bk_host_normals(int rng_kind, uint64_t* state_words /*[BK_RNG_WORDS]*/, double* out,
+                    int64_t n);
+int bk_host_uniforms(int rng_kind, uint64_t* state_words, double* out, int64_t n);
+double bk_host_log1p(double x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BKHIP_H */

@@ -1,0 +1,239 @@
+"""CPU stand-in for ``bayes_kit_amd._lib.Ops`` -- TEST INFRASTRUCTURE ONLY.
+
+It lets the host-side control flow of the samplers (buffer plumbing, model bridge, call
+patterns, the delayed-rejection state machine) run in the build container, which has no GPU.
+Each method restates, with NumPy on CPU tensors, what the corresponding C-ABI entry point
+of include/bkhip.h is specified to compute; random numbers come from numpy Generators
+rebuilt from / written back to the same per-chain state table the device uses.  Nothing in
+the product imports this file; on the GPU box the samplers run on the HIP library.
+"""
+import numpy as np
+import torch
+
+from bayes_kit_amd import _lib
+from bayes_kit_amd._engine import _bitgen_words, numpy_generator_from_words
+
+
+def _np(t):
+    return None if t is None else t.numpy()
+
+
+class FakeOps:
+    name = "fake-cpu"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.calls = {}
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    # -- RNG ------------------------------------------------------------------------------
+    def _gen(self, kind, state, c):
+        return numpy_generator_from_words(kind, state.numpy().view(np.uint64)[:, c])
+
+    def _put(self, kind, state, c, gen):
+        k2, w = _bitgen_words(gen.bit_generator)
+        assert k2 == kind
+        state.numpy().view(np.uint64)[:, c] = w
+
+    def rng_init_philox(self, state, key0, chain_id0):
+        w = state.numpy().view(np.uint64)
+        w[:] = 0
+        w[0, :] = np.uint64(key0)
+        w[1, :] = np.arange(w.shape[1], dtype=np.uint64) + np.uint64(chain_id0)
+        w[10, :] = 4
+
+    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None):
+        self._count("momentum_refresh")
+        D, C = out.shape
+        o, li, m = _np(out), _np(loc_in), _np(metric)
+        for c in range(C):
+            if active is not None and not active[c]:
+                continue
+            g = self._gen(kind, state, c)
+            z = g.standard_normal(D)
+            loc = li[:, c] * loc_mul if li is not None else 0.0
+            v = loc + scale * z
+            o[:, c] = v
+            if kin_out is not None:
+                mv = m * v if m is not None else v
+                kin = 0.0
+                for d in range(D):
+                    kin = kin + v[d] * mv[d]
+                kin_out[c] = 0.5 * kin
+            self._put(kind, state, c, g)
+
+    def log_uniform(self, kind, state, out, active=None):
+        self._count("log_uniform")
+        for c in range(out.shape[0]):
+            if active is not None and not active[c]:
+                continue
+            g = self._gen(kind, state, c)
+            with np.errstate(divide="ignore"):
+                out[c] = float(np.log(g.uniform()))
+            self._put(kind, state, c, g)
+
+    # -- integrator ---------------------------------------------------------------------------
+    @staticmethod
+    def _mt(metric, g):
+        return g if metric is None else metric.numpy()[:, None] * g
+
+    def kick_drift(self, theta_in, theta_out, rho_in, rho_out, grad, metric, eps, use_pre, pre,
+                   use_kick, kick):
+        self._count("kick_drift")
+        t = self._mt(metric, grad.numpy())
+        r = rho_in.numpy().copy()
+        if use_pre:
+            r = r + pre * t
+        if use_kick:
+            r = r + kick * t
+        th = theta_in.numpy() + eps * r
+        rho_out.numpy()[...] = r
+        theta_out.numpy()[...] = th
+
+    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre):
+        self._count("first_step_gather")
+        n = theta_out.shape[1]
+        idx = np.arange(n) if src_index is None else src_index.numpy()[:n]
+        t = self._mt(metric, grad_in.numpy()[:, idx])
+        r = rho_in.numpy()[:, idx] + pre * t
+        rho_out.numpy()[...] = r
+        theta_out.numpy()[...] = theta_in.numpy()[:, idx] + eps * r
+
+    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out):
+        self._count("leapfrog_finish")
+        t = self._mt(metric, grad.numpy())
+        v = rho_in.numpy() + half * t
+        if negate:
+            v = -v
+        if rho_out is not None:
+            rho_out.numpy()[...] = v
+        if kin_out is not None:
+            mv = self._mt(metric, v)
+            kin = np.zeros(v.shape[1])
+            for d in range(v.shape[0]):
+                kin = kin + v[d] * mv[d]
+            kin_out.numpy()[...] = 0.5 * kin
+
+    def mh_accept(self, mode, lp_cur, a_cur, lp_prop, a_prop, log_u, mask, ret, count):
+        self._count("mh_accept")
+        l0, l1 = lp_cur.numpy().copy(), lp_prop.numpy()
+        a0 = a_cur.numpy() if a_cur is not None else 0.0
+        a1 = a_prop.numpy() if a_prop is not None else 0.0
+        with np.errstate(invalid="ignore"):
+            if mode == _lib.ACCEPT_HMC:
+                h0, h1 = l0 - a0, l1 - a1
+                acc = log_u.numpy() < h1 - h0
+                r0, r1 = h0, h1
+            else:
+                acc = log_u.numpy() < (l1 - l0) + (a1 - a0)
+                r0, r1 = l0, l1
+        if mask is not None:
+            mask.numpy()[...] = acc
+        if ret is not None:
+            ret.numpy()[...] = np.where(acc, r1, r0)
+        lp_cur.numpy()[acc] = l1[acc]
+        if count is not None:
+            count += int(acc.sum())
+
+    def select_columns(self, mask, dst0, src0, dst1=None, src1=None):
+        self._count("select_columns")
+        m = mask.numpy().astype(bool)
+        dst0.numpy()[:, m] = src0.numpy()[:, m]
+        if dst1 is not None:
+            dst1.numpy()[:, m] = src1.numpy()[:, m]
+
+    # -- MALA ------------------------------------------------------------------------------------
+    def mala_propose(self, kind, state, theta, grad, theta_prop, eps, sqrt2eps):
+        self._count("mala_propose")
+        D, C = theta.shape
+        for c in range(C):
+            g = self._gen(kind, state, c)
+            z = g.standard_normal(D)
+            theta_prop.numpy()[:, c] = (theta.numpy()[:, c] + eps * grad.numpy()[:, c]) + sqrt2eps * z
+            self._put(kind, state, c, g)
+
+    def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
+        self._count("mala_logq")
+        th, g, thp, gp = theta.numpy(), grad.numpy(), theta_prop.numpy(), grad_prop.numpy()
+        xf = (thp - th) - eps * g
+        xr = (th - thp) - eps * gp
+        sf = np.zeros(th.shape[1])
+        sr = np.zeros(th.shape[1])
+        for d in range(th.shape[0]):
+            sf = sf + xf[d] * xf[d]
+            sr = sr + xr[d] * xr[d]
+        k = -0.25 / eps
+        lp_forward.numpy()[...] = k * sf
+        lp_reverse.numpy()[...] = k * sr
+
+    # -- targets ----------------------------------------------------------------------------------
+    def target_grad(self, kind, params, theta, grad, logp):
+        self._count("target_grad")
+        th = theta.numpy()
+        D, C = th.shape
+        if kind in ("iso_gaussian", "diag_gaussian"):
+            lt = th if kind == "iso_gaussian" else params.numpy()[:, None] * th
+            if grad is not None:
+                grad.numpy()[...] = -lt
+            if logp is not None:
+                s = np.zeros(C)
+                for d in range(D):
+                    s = s + th[d] * lt[d]
+                logp.numpy()[...] = -0.5 * s
+        elif kind == "funnel":
+            v = th[0]
+            s = np.zeros(C)
+            for d in range(1, D):
+                s = s + th[d] * th[d]
+            ev = np.exp(-v)
+            hn = 0.5 * (D - 1)
+            he = 0.5 * ev
+            if logp is not None:
+                logp.numpy()[...] = ((-(v * v) / 18.0) - hn * v) - he * s
+            if grad is not None:
+                grad.numpy()[0] = ((-v / 9.0) - hn) + he * s
+                grad.numpy()[1:] = -(ev[None, :] * th[1:])
+        else:
+            raise KeyError(kind)
+
+    def relayout(self, src, dst):
+        self._count("relayout")
+        dst.copy_(src)
+
+    # -- diagnostics ----------------------------------------------------------------------------------
+    def welford_update(self, mean, m2, theta, n):
+        x, mu = theta.numpy(), mean.numpy()
+        delta = x - mu
+        mu2 = mu + delta / float(n)
+        m2.numpy()[...] = m2.numpy() + delta * (x - mu2)
+        mean.numpy()[...] = mu2
+
+    def rhat_partials(self, mean, m2, n, center, out):
+        mu = mean.numpy()
+        D = mu.shape[0]
+        o = out.numpy().reshape(-1)
+        o[0:D] = mu.sum(axis=1)
+        o[D:2 * D] = (m2.numpy() / float(n - 1)).sum(axis=1)
+        if center is not None:
+            o[2 * D:3 * D] = ((mu - center.numpy()[:, None]) ** 2).sum(axis=1)
+
+    def chain_mean_var(self, x, lengths, mean, var):
+        X = x.numpy()
+        for c in range(X.shape[1]):
+            n = X.shape[0] if lengths is None else int(lengths[c])
+            col = X[:n, c]
+            mean[c] = col.mean()
+            if var is not None:
+                var[c] = col.var(ddof=1)
+
+    def ess(self, x, estimator, ess_out, iat_out=None):
+        from oracle import diagnostics as od
+
+        X = x.numpy()
+        for c in range(X.shape[1]):
+            it = od.iat_imse(X[:, c]) if estimator == 0 else od.iat_ipse(X[:, c])
+            if iat_out is not None:
+                iat_out[c] = it
+            ess_out[c] = X.shape[0] / it

@@ -1,0 +1,92 @@
+"""Parity bodies shared by the CPU (fake ops) and GPU (HIP) sampler tests."""
+import numpy as np
+import torch
+
+import bayes_kit_amd as bk
+from tests.helpers import case_metric, case_seed, load_case, oracle_model
+
+# Tolerances (DESIGN.md "Parity"): theta bit-exact for elementwise-gradient targets; logp and
+# energies are reductions summed in a different order than BLAS ddot -> rel 1e-12; funnel
+# (exp + reduction inside the gradient) theta rel 1e-9.
+LOGP_RTOL = 1e-12
+FUNNEL_RTOL = 1e-9
+
+
+def product_model(spec, ops):
+    kind = spec["kind"]
+    if kind == "std_normal":
+        return bk.IsoGaussian(1, ops=ops)
+    if kind == "iso_gaussian":
+        return bk.IsoGaussian(spec["D"], ops=ops)
+    if kind == "diag_gaussian":
+        return bk.DiagGaussian(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"]), ops=ops)
+    if kind == "funnel":
+        return bk.Funnel(spec["D"], ops=ops)
+    raise KeyError(kind)
+
+
+def build_sampler(case, model, ops, seed, chains=None, chain_id0=0):
+    D = model.dims()
+    init = None if case.get("init") is None else np.asarray(case["init"], dtype=np.float64)
+    kw = dict(init=init, seed=seed, ops=ops)
+    if chains is not None:
+        kw.update(chains=chains, chain_id0=chain_id0)
+    alg = case["alg"]
+    if alg == "hmc":
+        s = bk.HMCDiag(model, case["stepsize"], case["steps"], **kw)
+    elif alg == "mala":
+        s = bk.MALA(model, case["epsilon"], **kw)
+    elif alg == "drghmc":
+        s = bk.DrGhmcDiag(model, case["max_proposals"], case["leapfrog_step_sizes"],
+                          case["leapfrog_step_counts"], case["damping"],
+                          prob_retry=case.get("prob_retry", True), **kw)
+    else:
+        raise KeyError(alg)
+    metric = case_metric(case, D)
+    if metric is not None:
+        s._metric = metric  # same hook the golden generator uses on the reference
+    return s
+
+
+def check_many_chain(name, ops):
+    """All C chains of a golden case in ONE many-chain sampler on a built-in device target."""
+    case, z = load_case(name)
+    N, C, D = z["draws"].shape
+    model = product_model(case["model"], ops)
+    s = build_sampler(case, model, ops, case["seed"], chains=C)
+    exact = case["model"]["kind"] != "funnel"
+    th0 = s._theta.cpu().numpy()
+    np.testing.assert_array_equal(th0, z["theta0"])
+    for n in range(N):
+        th, lp = s.sample()
+        th, lp = th.cpu().numpy(), lp.cpu().numpy()
+        if exact:
+            assert np.array_equal(th, z["draws"][n]), (name, n, np.abs(th - z["draws"][n]).max())
+        else:
+            np.testing.assert_allclose(th, z["draws"][n], rtol=FUNNEL_RTOL, atol=1e-12, err_msg=f"{name} draw {n}")
+        np.testing.assert_allclose(lp, z["logp"][n], rtol=LOGP_RTOL if exact else FUNNEL_RTOL, atol=1e-12,
+                                   err_msg=f"{name} draw {n}")
+    # integer side: the per-chain streams end exactly where numpy's did
+    np.testing.assert_array_equal(s.rng_state().T, z["rng_state"])
+    return s
+
+
+def check_single_chain_host_model(name, ops, chains=None):
+    """Reference-style NumPy model + reference-style seed through the drop-in classes."""
+    case, z = load_case(name)
+    N, C, D = z["draws"].shape
+    exact = case["model"]["kind"] != "funnel"
+    for c in (range(C) if chains is None else chains):
+        s = build_sampler(case, oracle_model(case["model"]), ops, case_seed(case, c))
+        np.testing.assert_array_equal(np.asarray(s._theta, dtype=np.float64), z["theta0"][c])
+        for n in range(N):
+            th, lp = s.sample()
+            assert isinstance(th, np.ndarray) and th.shape == (D,)
+            if exact:
+                assert np.array_equal(th, z["draws"][n, c]), (name, c, n)
+            else:
+                np.testing.assert_allclose(th, z["draws"][n, c], rtol=FUNNEL_RTOL, atol=1e-12)
+            np.testing.assert_allclose(lp, z["logp"][n, c], rtol=LOGP_RTOL if exact else FUNNEL_RTOL, atol=1e-12)
+        got = s.rng_state()[:, 0]
+        want = z["rng_state"][c]
+        np.testing.assert_array_equal(got[: len(want)], want)

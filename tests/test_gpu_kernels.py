@@ -1,0 +1,239 @@
+"""HIP kernels vs the oracle / NumPy on a real MI355X, called through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bayes_kit_amd import _lib
+
+    return _lib.default_ops()
+
+
+def dev(a, ops):
+    return torch.as_tensor(a).to(ops.device)
+
+
+def make_state(seed, C, ops, chain0=0):
+    from bayes_kit_amd._engine import make_streams
+
+    return make_streams(seed, C, chain0, False, ops.device)
+
+
+def test_native_library_is_the_loaded_one(ops):
+    import os
+    from bayes_kit_amd import _lib
+
+    maps = open("/proc/self/maps").read()
+    assert os.path.realpath(_lib.lib_path()) in maps
+
+
+def test_device_rng_matches_numpy_bit_for_bit(ops):
+    from bayes_kit_amd import _lib
+
+    C, D = 192, 3000  # 576k normals: ~140 tail draws, ~8500 wedge draws
+    kind, st = make_state(991, C, ops, chain0=5)
+    out = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    kin = torch.empty(C, dtype=torch.float64, device=ops.device)
+    ops.momentum_refresh(kind, st, None, 0.0, 1.0, out, None, kin)
+    logu = torch.empty(C, dtype=torch.float64, device=ops.device)
+    ops.log_uniform(kind, st, logu)
+    got, kin, logu = out.cpu().numpy(), kin.cpu().numpy(), logu.cpu().numpy()
+    words = st.cpu().numpy().view(np.uint64)
+    for c in range(C):
+        g = np.random.Generator(np.random.Philox(key=[991, 5 + c]))
+        ref = g.normal(size=D)
+        assert np.array_equal(ref.view(np.uint64), got[:, c].view(np.uint64)), c
+        np.testing.assert_allclose(kin[c], 0.5 * np.dot(ref, ref), rtol=1e-13)
+        np.testing.assert_allclose(logu[c], np.log(g.uniform()), rtol=4e-16, atol=0)
+        s = g.bit_generator.state
+        assert [int(v) for v in s["state"]["counter"]] == [int(v) for v in words[2:6, c]]
+        assert [int(v) for v in s["buffer"]] == [int(v) for v in words[6:10, c]]
+        assert s["buffer_pos"] == int(words[10, c])
+
+
+def test_device_rng_pcg64_and_loc_scale(ops):
+    from bayes_kit_amd import _lib
+    from bayes_kit_amd._engine import make_streams
+
+    gens = [np.random.default_rng(100 + c) for c in range(8)]
+    kind, st = make_streams([np.random.default_rng(100 + c) for c in range(8)], 8, 0, False, ops.device)
+    assert kind == _lib.RNG_PCG64
+    D = 257
+    loc = np.random.default_rng(0).normal(size=(D, 8))
+    out = torch.empty((D, 8), dtype=torch.float64, device=ops.device)
+    ops.momentum_refresh(kind, st, dev(loc, ops), math.sqrt(1 - 0.3), math.sqrt(0.3), out, None, None)
+    got = out.cpu().numpy()
+    for c in range(8):
+        ref = gens[c].normal(loc=loc[:, c] * np.sqrt(1 - 0.3), scale=np.sqrt(0.3), size=D)
+        assert np.array_equal(ref, got[:, c])
+    # active mask: inactive chains neither draw nor write
+    act = torch.tensor([1, 0, 1, 0, 0, 1, 1, 0], dtype=torch.uint8, device=ops.device)
+    before = st.clone()
+    out2 = torch.full((D, 8), 7.0, dtype=torch.float64, device=ops.device)
+    ops.momentum_refresh(kind, st, None, 0.0, 1.0, out2, None, None, act)
+    o2 = out2.cpu().numpy()
+    for c in range(8):
+        if act[c]:
+            assert np.array_equal(o2[:, c], gens[c].normal(size=D))
+        else:
+            assert (o2[:, c] == 7.0).all()
+            assert torch.equal(st[:, c], before[:, c])
+
+
+@pytest.mark.parametrize("C,D", [(512, 64), (130, 37), (1, 5), (77, 1), (4096, 128)])
+@pytest.mark.parametrize("layout", ["chain", "dim", "odd"])
+def test_kick_drift_bit_exact(ops, C, D, layout):
+    rng = np.random.default_rng(C * 1000 + D)
+    th, rho, g = (rng.normal(size=(D, C)) for _ in range(3))
+    m = rng.uniform(0.5, 1.5, size=D)
+    eps = 0.0123
+    for (use_pre, pre, use_kick, kick, metric) in [(True, -0.5 * eps, True, eps, m), (False, 0.0, True, eps, m),
+                                                   (True, 0.5 * eps, False, 0.0, None)]:
+        t = (metric[:, None] * g) if metric is not None else g
+        r = rho.copy()
+        if use_pre:
+            r = r + pre * t
+        if use_kick:
+            r = r + kick * t
+        want_th = th + eps * r
+        if layout == "chain":
+            gd = dev(g, ops)
+        elif layout == "dim":  # a row-major (C, D) model output viewed as [D, C]
+            gd = dev(np.ascontiguousarray(g.T), ops).t()
+            assert gd.stride() == (1, D) or D == 1 or C == 1
+        else:  # arbitrary strides
+            big = torch.zeros((D * 2 + 1, C * 3 + 1), dtype=torch.float64, device=ops.device)
+            gd = big[1::2, 1::3][:D, :C]
+            gd.copy_(dev(g, ops))
+        th_d, rho_d = dev(th, ops), dev(rho, ops)
+        tho, rhoo = torch.empty_like(th_d), torch.empty_like(rho_d)
+        ops.kick_drift(th_d, tho, rho_d, rhoo, gd, None if metric is None else dev(metric, ops), eps, use_pre,
+                       pre, use_kick, kick)
+        assert np.array_equal(tho.cpu().numpy(), want_th)
+        assert np.array_equal(rhoo.cpu().numpy(), r)
+        # in place
+        ops.kick_drift(th_d, th_d, rho_d, rho_d, gd, None if metric is None else dev(metric, ops), eps, use_pre,
+                       pre, use_kick, kick)
+        assert np.array_equal(th_d.cpu().numpy(), want_th) and np.array_equal(rho_d.cpu().numpy(), r)
+
+
+def test_finish_gather_select_accept(ops):
+    from bayes_kit_amd import _lib
+
+    rng = np.random.default_rng(3)
+    D, C = 45, 300
+    rho, g, th = (rng.normal(size=(D, C)) for _ in range(3))
+    m = rng.uniform(0.5, 1.5, size=D)
+    half = 0.021
+    for negate in (False, True):
+        v = rho + half * (m[:, None] * g)
+        if negate:
+            v = -v
+        kin = 0.5 * np.einsum("dc,dc->c", v, m[:, None] * v)
+        out = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+        k = torch.empty(C, dtype=torch.float64, device=ops.device)
+        ops.leapfrog_finish(dev(rho, ops), out, dev(g, ops), dev(m, ops), half, negate, k)
+        assert np.array_equal(out.cpu().numpy(), v)
+        np.testing.assert_allclose(k.cpu().numpy(), kin, rtol=1e-13)
+    # gather first step
+    idx = rng.permutation(C)[:97].astype(np.int32)
+    tho = torch.empty((D, 128), dtype=torch.float64, device=ops.device)[:, :97]
+    rhoo = torch.empty((D, 128), dtype=torch.float64, device=ops.device)[:, :97]
+    ops.first_step_gather(dev(th, ops), dev(rho, ops), dev(g, ops), dev(idx, ops), tho, rhoo, dev(m, ops), 0.1, 0.05)
+    r = rho[:, idx] + 0.05 * (m[:, None] * g[:, idx])
+    assert np.array_equal(rhoo.cpu().numpy(), r)
+    assert np.array_equal(tho.cpu().numpy(), th[:, idx] + 0.1 * r)
+    # accept (both modes) + ballot popcount + select
+    lp0, lp1, a0, a1 = (rng.normal(size=C) for _ in range(4))
+    logu = np.log(rng.uniform(size=C))
+    for mode in (_lib.ACCEPT_HMC, _lib.ACCEPT_MALA):
+        if mode == _lib.ACCEPT_HMC:
+            h0, h1 = lp0 - a0, lp1 - a1
+            acc = logu < h1 - h0
+            ret = np.where(acc, h1, h0)
+        else:
+            acc = logu < (lp1 - lp0) + (a1 - a0)
+            ret = np.where(acc, lp1, lp0)
+        lpc = dev(lp0.copy(), ops)
+        mask = torch.empty(C, dtype=torch.uint8, device=ops.device)
+        r_d = torch.empty(C, dtype=torch.float64, device=ops.device)
+        cnt = torch.zeros(1, dtype=torch.int32, device=ops.device)
+        ops.mh_accept(mode, lpc, dev(a0, ops), dev(lp1, ops), dev(a1, ops), dev(logu, ops), mask, r_d, cnt)
+        assert np.array_equal(mask.cpu().numpy().astype(bool), acc)
+        assert np.array_equal(r_d.cpu().numpy(), ret)
+        assert int(cnt.item()) == int(acc.sum())
+        assert np.array_equal(lpc.cpu().numpy(), np.where(acc, lp1, lp0))
+        dst0, dst1 = dev(th.copy(), ops), dev(rho.copy(), ops)
+        ops.select_columns(mask, dst0, dev(g, ops), dst1, dev(th, ops))
+        assert np.array_equal(dst0.cpu().numpy(), np.where(acc[None, :], g, th))
+        assert np.array_equal(dst1.cpu().numpy(), np.where(acc[None, :], th, rho))
+
+
+def test_targets_vs_oracle_models(ops):
+    from oracle import models as om
+
+    rng = np.random.default_rng(11)
+    for D, C in [(1, 3), (16, 130), (101, 64)]:
+        th = rng.normal(size=(D, C))
+        lam = np.logspace(0, 2, D)
+        cases = [("iso_gaussian", None, om.IsoGaussian(D), True), ("diag_gaussian", lam, om.DiagGaussian(lam), True)]
+        if D > 1:
+            cases.append(("funnel", None, om.Funnel(D), False))
+        for kind, params, omodel, exact in cases:
+            g = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+            lp = torch.empty(C, dtype=torch.float64, device=ops.device)
+            p = None if params is None else dev(params, ops)
+            ops.target_grad(kind, p, dev(th, ops), g, lp)
+            g2 = torch.empty_like(g)
+            ops.target_grad(kind, p, dev(th, ops), g2, None)  # gradient-only (streaming) form
+            lp2 = torch.empty_like(lp)
+            ops.target_grad(kind, p, dev(th, ops), None, lp2)
+            assert torch.equal(g, g2) and torch.equal(lp, lp2)
+            for c in range(C):
+                olp, og = omodel.log_density_gradient(th[:, c])
+                if exact:
+                    assert np.array_equal(g[:, c].cpu().numpy(), og)
+                    np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-13)
+                else:
+                    np.testing.assert_allclose(g[:, c].cpu().numpy(), og, rtol=1e-13, atol=1e-300)
+                    np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-13)
+
+
+def test_mala_kernels(ops):
+    rng = np.random.default_rng(8)
+    D, C = 33, 70
+    th, g, gp = (rng.normal(size=(D, C)) for _ in range(3))
+    eps = 0.07
+    kind, st = make_state(55, C, ops)
+    thp = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    ops.mala_propose(kind, st, dev(th, ops), dev(g, ops), thp, eps, math.sqrt(2 * eps))
+    got = thp.cpu().numpy()
+    for c in range(C):
+        z = np.random.Generator(np.random.Philox(key=[55, c])).normal(size=D)
+        assert np.array_equal(got[:, c], th[:, c] + eps * g[:, c] + np.sqrt(2 * eps) * z)
+    f = torch.empty(C, dtype=torch.float64, device=ops.device)
+    r = torch.empty(C, dtype=torch.float64, device=ops.device)
+    ops.mala_logq(dev(th, ops), dev(g, ops), thp, dev(gp, ops), eps, f, r)
+    xf = got - th - eps * g
+    xr = th - got - eps * gp
+    np.testing.assert_allclose(f.cpu().numpy(), (-0.25 / eps) * (xf * xf).sum(0), rtol=1e-13)
+    np.testing.assert_allclose(r.cpu().numpy(), (-0.25 / eps) * (xr * xr).sum(0), rtol=1e-13)
+
+
+def test_relayout(ops):
+    rng = np.random.default_rng(1)
+    for D, C in [(64, 64), (37, 130), (1, 9), (200, 3)]:
+        a = rng.normal(size=(C, D))
+        src = dev(a, ops).t()  # logical [D, C], dimension-contiguous
+        dst = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+        ops.relayout(src, dst)
+        assert np.array_equal(dst.cpu().numpy(), a.T)
+        back = torch.empty((C, D), dtype=torch.float64, device=ops.device)
+        ops.relayout(dst, back.t())
+        assert np.array_equal(back.cpu().numpy(), a)
