@@ -56,7 +56,7 @@ def cpu_baseline(seconds_hint=12.0):
     import subprocess
 
     P = max(1, min(os.cpu_count() or 1, 32))
-    chains_per_proc, draws = 4, 60  # ~4*60*64 = 15k leapfrog steps per process (~1.5 s each)
+    chains_per_proc, draws = 8, 400  # 8*400*64 = 205k leapfrog steps per process (~1.5 s each)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     t0 = time.perf_counter()
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", str(p * chains_per_proc),
