@@ -20,3 +20,7 @@ static inline hipStream_t bk_stream(void* s) { return reinterpret_cast<hipStream
 static inline i64 bk_cdiv(i64 a, i64 b) { return (a + b - 1) / b; }
 
 static inline bool bk_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Whether a kernel touching `elems` doubles streams well past the 256 MiB Infinity Cache
+// (then non-temporal accesses pay) or can be served from it (then they hurt).
+static inline bool bk_streams_past_llc(i64 elems) { return elems * 8 > ((i64)192 << 20); }

@@ -8,6 +8,7 @@
 // traffic.  The library is compiled with -ffp-contract=off: no FMA, every product and sum
 // is rounded separately, exactly like the NumPy expressions of the reference.
 #include "bk_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,34 +28,56 @@ __device__ __forceinline__ double kd_elem(double th, double rho, double g, doubl
 }
 
 // chain-contiguous gradient, two chains (16 B) per lane
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+template <int ROWS, bool NT>
 __global__ __launch_bounds__(KD_BLOCK) void k_kick_drift_v2(
     const double* th_in, double* th_out, const double* rho_in, double* rho_out, i64 ld,
     const double* grad, i64 ldg, const double* metric, double eps, int use_pre, double pre,
     int use_kick, double kick, i64 C2, i64 D) {
   i64 c2 = (i64)blockIdx.x * KD_BLOCK + threadIdx.x;
-  i64 d0 = (i64)blockIdx.y * KD_ROWS;
+  i64 d0 = (i64)blockIdx.y * ROWS;
   if (c2 >= C2) return;
-  double2 t[KD_ROWS], r[KD_ROWS], g[KD_ROWS];
-  double m[KD_ROWS];
+  dvec2 t[ROWS], r[ROWS], g[ROWS];
+  double m[ROWS];
 #pragma unroll
-  for (int i = 0; i < KD_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     i64 d = d0 + i;
     if (d < D) {
-      t[i] = *reinterpret_cast<const double2*>(th_in + d * ld + 2 * c2);
-      r[i] = *reinterpret_cast<const double2*>(rho_in + d * ld + 2 * c2);
-      g[i] = *reinterpret_cast<const double2*>(grad + d * ldg + 2 * c2);
+      const dvec2* pt = reinterpret_cast<const dvec2*>(th_in + d * ld + 2 * c2);
+      const dvec2* pr = reinterpret_cast<const dvec2*>(rho_in + d * ld + 2 * c2);
+      const dvec2* pg = reinterpret_cast<const dvec2*>(grad + d * ldg + 2 * c2);
+      if (NT) {
+        t[i] = __builtin_nontemporal_load(pt);
+        r[i] = __builtin_nontemporal_load(pr);
+        g[i] = __builtin_nontemporal_load(pg);
+      } else {
+        t[i] = *pt;
+        r[i] = *pr;
+        g[i] = *pg;
+      }
       m[i] = metric ? metric[d] : 1.0;
     }
   }
 #pragma unroll
-  for (int i = 0; i < KD_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     i64 d = d0 + i;
     if (d < D) {
-      double2 rn, tn;
-      tn.x = kd_elem(t[i].x, r[i].x, g[i].x, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn.x);
-      tn.y = kd_elem(t[i].y, r[i].y, g[i].y, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn.y);
-      *reinterpret_cast<double2*>(rho_out + d * ld + 2 * c2) = rn;
-      *reinterpret_cast<double2*>(th_out + d * ld + 2 * c2) = tn;
+      dvec2 rn, tn;
+      double rx, ry;
+      tn.x = kd_elem(t[i].x, r[i].x, g[i].x, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, rx);
+      tn.y = kd_elem(t[i].y, r[i].y, g[i].y, m[i], metric != nullptr, eps, use_pre, pre, use_kick, kick, ry);
+      rn.x = rx;
+      rn.y = ry;
+      dvec2* qr = reinterpret_cast<dvec2*>(rho_out + d * ld + 2 * c2);
+      dvec2* qt = reinterpret_cast<dvec2*>(th_out + d * ld + 2 * c2);
+      if (NT) {
+        __builtin_nontemporal_store(rn, qr);
+        __builtin_nontemporal_store(tn, qt);
+      } else {
+        *qr = rn;
+        *qt = tn;
+      }
     }
   }
 }
@@ -322,9 +345,28 @@ int bk_leapfrog_kick_drift(const double* theta_in, double* theta_out, const doub
                bk_aligned16(theta_out) && bk_aligned16(rho_in) && bk_aligned16(rho_out) &&
                bk_aligned16(grad);
     if (vec) {
-      dim3 grid((unsigned)bk_cdiv(C / 2, KD_BLOCK), (unsigned)bk_cdiv(D, KD_ROWS));
-      k_kick_drift_v2<<<grid, dim3(KD_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, grad, ldg_d,
-                                                      metric, eps, use_pre, pre, use_kick, kick, C / 2, D);
+      // Streams much larger than the 256 MiB Infinity Cache use non-temporal loads/stores
+      // (measured +8 % on MI355X: 6.49 vs 6.0 TB/s); cache-resident tiles use plain
+      // accesses (7.1 TB/s out of the Infinity Cache).  BK_KD_VARIANT overrides (tuning).
+      static const int forced = []() { const char* e = getenv("BK_KD_VARIANT"); return e ? atoi(e) : -1; }();
+      int v = forced >= 0 ? forced : (bk_streams_past_llc(5 * C * D) ? 4 : 5);
+#define BK_KD_LAUNCH(ROWS, NT)                                                                          \
+  do {                                                                                                  \
+    dim3 grid((unsigned)bk_cdiv(C / 2, KD_BLOCK), (unsigned)bk_cdiv(D, ROWS));                          \
+    k_kick_drift_v2<ROWS, NT><<<grid, dim3(KD_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, \
+                                                              grad, ldg_d, metric, eps, use_pre, pre,   \
+                                                              use_kick, kick, C / 2, D);                \
+  } while (0)
+      switch (v) {
+        case 1: BK_KD_LAUNCH(2, false); break;
+        case 2: BK_KD_LAUNCH(8, false); break;
+        case 3: BK_KD_LAUNCH(4, true); break;
+        case 4: BK_KD_LAUNCH(2, true); break;
+        case 5: BK_KD_LAUNCH(1, false); break;
+        case 6: BK_KD_LAUNCH(1, true); break;
+        default: BK_KD_LAUNCH(4, false); break;
+      }
+#undef BK_KD_LAUNCH
       BK_RETURN_LAUNCH_STATUS();
     }
   } else if (ldg_d == 1 && C >= TR_TILE / 2 && D >= TR_TILE / 2) {

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
   g.load(st, ldr, c);
   double kin = 0.0;
   for (i64 d = 0; d < D; ++d) {
+    bk::top_up(g);
     double z = bk::next_normal(g, tab.ki, tab.wi, tab.fi);
     double loc = loc_in ? loc_in[d * ld + c] * loc_mul : 0.0;
     double v = loc + scale * z;  // numpy random_normal: loc + scale * z
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_mala_propose(uint64_t* st, i64 ld
   G g;
   g.load(st, ldr, c);
   for (i64 d = 0; d < D; ++d) {
+    bk::top_up(g);
     double z = bk::next_normal(g, tab.ki, tab.wi, tab.fi);
     i64 o = d * ld + c;
     prop[o] = (theta[o] + eps * grad[o]) + s * z;  // mala.py:41-45, left to right

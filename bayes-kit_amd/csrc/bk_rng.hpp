@@ -45,16 +45,28 @@ BK_HD uint64_t double_as_u64(double d) {
 }
 
 // ---- Philox4x64-10 -----------------------------------------------------------------
+// Stored state (numpy's): key, counter `c` of the block held in `b`, read position `pos`.
+// Device-side lookahead: up to two further blocks (n1 = counter c+1, n2 = c+2) generated
+// AHEAD of need.  A Philox block costs ~20 full 64x64->128 multiplies; lanes of a wavefront
+// consume their streams at slightly different rates (ziggurat rejections), so without
+// lookahead every call would make the whole wave wait for the few lanes that need a new
+// block.  Kernels call top_up() at a wave-uniform point: when ANY lane is short, ALL lanes
+// with room generate together.  The lookahead is a cache only: it is never stored, and
+// store() writes exactly the (counter, buffer, pos) numpy would hold.
 struct Philox {
   uint64_t key0, key1;
-  uint64_t c0, c1, c2, c3;
-  uint64_t b0, b1, b2, b3;
-  uint32_t pos;  // 0..4 ; 4 = buffer empty
+  uint64_t c0, c1, c2, c3;   // counter of the block in b (numpy's counter)
+  uint64_t b0, b1, b2, b3;   // that block, complete (numpy's buffer)
+  uint64_t q0, q1, q2, q3;   // its unread words, q0 next (a shift queue: no dynamic indexing,
+  uint32_t rem;              //   which the compiler would otherwise spill to scratch); numpy pos = 4 - rem
+  uint64_t n10, n11, n12, n13, n20, n21, n22, n23;
+  uint32_t cnt;              // lookahead blocks held (0..2)
 
-  BK_HD void block() {
+  BK_HD void block_at(uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3, uint64_t& o0, uint64_t& o1,
+                      uint64_t& o2, uint64_t& o3) const {
     const uint64_t M0 = 0xD2E7470EE14C6C93ULL, M1 = 0xCA5A826395121157ULL;
     const uint64_t W0 = 0x9E3779B97F4A7C15ULL, W1 = 0xBB67AE8584CAA73BULL;
-    uint64_t x0 = c0, x1 = c1, x2 = c2, x3 = c3, k0 = key0, k1 = key1;
+    uint64_t k0 = key0, k1 = key1;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
       if (r) { k0 += W0; k1 += W1; }
@@ -63,20 +75,45 @@ struct Philox {
       uint64_t y0 = hi1 ^ x1 ^ k0, y2 = hi0 ^ x3 ^ k1;
       x0 = y0; x1 = lo1; x2 = y2; x3 = lo0;
     }
-    b0 = x0; b1 = x1; b2 = x2; b3 = x3;
+    o0 = x0; o1 = x1; o2 = x2; o3 = x3;
   }
 
   BK_HD uint64_t next() {
-    if (pos < 4) {
-      uint64_t v = pos == 0 ? b0 : pos == 1 ? b1 : pos == 2 ? b2 : b3;
-      ++pos;
-      return v;
+    if (rem == 0) {
+      // the 256-bit counter is incremented BEFORE the block is generated
+      if (++c0 == 0) { if (++c1 == 0) { if (++c2 == 0) { ++c3; } } }
+      if (cnt > 0) {
+        b0 = n10; b1 = n11; b2 = n12; b3 = n13;
+        n10 = n20; n11 = n21; n12 = n22; n13 = n23;
+        --cnt;
+      } else {
+        block_at(c0, c1, c2, c3, b0, b1, b2, b3);
+      }
+      q0 = b0; q1 = b1; q2 = b2; q3 = b3;
+      rem = 4;
     }
-    // the 256-bit counter is incremented BEFORE the block is generated
-    if (++c0 == 0) { if (++c1 == 0) { if (++c2 == 0) { ++c3; } } }
-    block();
-    pos = 1;
-    return b0;
+    uint64_t v = q0;
+    q0 = q1; q1 = q2; q2 = q3;
+    --rem;
+    return v;
+  }
+
+  // words available without generating a block
+  BK_HD int avail() const { return (int)rem + 4 * (int)cnt; }
+
+  // generate the next lookahead block (caller guarantees cnt < 2)
+  BK_HD void prefetch() {
+    uint64_t k = (uint64_t)cnt + 1;  // counter of the new block = c + cnt + 1 (with carry)
+    uint64_t a0 = c0 + k;
+    uint64_t a1 = c1 + (a0 < k ? 1ULL : 0ULL);
+    uint64_t a2 = c2 + ((a1 == 0 && a0 < k) ? 1ULL : 0ULL);
+    uint64_t a3 = c3 + ((a2 == 0 && a1 == 0 && a0 < k) ? 1ULL : 0ULL);
+    uint64_t t0, t1, t2, t3;
+    block_at(a0, a1, a2, a3, t0, t1, t2, t3);
+    bool first = (cnt == 0);
+    n10 = first ? t0 : n10; n11 = first ? t1 : n11; n12 = first ? t2 : n12; n13 = first ? t3 : n13;
+    n20 = first ? n20 : t0; n21 = first ? n21 : t1; n22 = first ? n22 : t2; n23 = first ? n23 : t3;
+    ++cnt;
   }
 
   template <typename I>
@@ -84,13 +121,20 @@ struct Philox {
     key0 = st[0 * ld + c]; key1 = st[1 * ld + c];
     c0 = st[2 * ld + c]; c1 = st[3 * ld + c]; c2 = st[4 * ld + c]; c3 = st[5 * ld + c];
     b0 = st[6 * ld + c]; b1 = st[7 * ld + c]; b2 = st[8 * ld + c]; b3 = st[9 * ld + c];
-    pos = (uint32_t)st[10 * ld + c];
+    uint32_t pos = (uint32_t)st[10 * ld + c];
+    rem = pos >= 4 ? 0u : 4u - pos;
+    q0 = b0; q1 = b1; q2 = b2; q3 = b3;
+#pragma unroll
+    for (uint32_t k = 0; k < 3; ++k)
+      if (pos > k) { q0 = q1; q1 = q2; q2 = q3; }
+    cnt = 0;
+    n10 = n11 = n12 = n13 = n20 = n21 = n22 = n23 = 0;
   }
   template <typename I>
   BK_HD void store(uint64_t* st, I ld, I c) const {
     st[2 * ld + c] = c0; st[3 * ld + c] = c1; st[4 * ld + c] = c2; st[5 * ld + c] = c3;
     st[6 * ld + c] = b0; st[7 * ld + c] = b1; st[8 * ld + c] = b2; st[9 * ld + c] = b3;
-    st[10 * ld + c] = pos;
+    st[10 * ld + c] = 4u - rem;
   }
 };
 
@@ -110,6 +154,9 @@ struct Pcg64 {
     uint32_t rot = (uint32_t)(nhi >> 58);
     return (x >> rot) | (x << ((64u - rot) & 63u));
   }
+  BK_HD int avail() const { return 1 << 20; }  // one multiply per output: nothing to prefetch
+  BK_HD void prefetch() {}
+  static constexpr uint32_t cnt = 2;
   template <typename I>
   BK_HD void load(const uint64_t* st, I ld, I c) {
     s_hi = st[0 * ld + c]; s_lo = st[1 * ld + c]; i_hi = st[2 * ld + c]; i_lo = st[3 * ld + c];
@@ -178,6 +225,18 @@ BK_HD double bk_log1p(double x) {
   double R = R1 + z2 * R2 + z4 * R3 + z6 * R4;
   if (k == 0) return f - (hfsq - s * (hfsq + R));
   return k * ln2_hi - ((hfsq - (s * (hfsq + R) + (k * ln2_lo + c))) - f);
+}
+
+// Wave-synchronous top-up of the lookahead (device only; call where the whole wavefront
+// is converged).  When any lane could run dry within one normal draw, every lane that has
+// room generates one block at the same time.
+template <typename G>
+__device__ __forceinline__ void top_up(G& g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (__any(g.avail() < 4)) {
+    if (g.cnt < 2) g.prefetch();
+  }
+#endif
 }
 
 // ---- doubles and normals -------------------------------------------------------------

@@ -17,26 +17,32 @@ constexpr int PC_BLOCK = 64;
 constexpr int PC_UNROLL = 8;
 
 // grad = -(lam*theta)  (lam NULL -> grad = -theta), two chains per lane
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+
+template <int ROWS, bool NT>
 __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_v2(const double* th, double* g, i64 ld,
                                                             const double* lam, i64 C2, i64 D) {
   i64 c2 = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
-  i64 d0 = (i64)blockIdx.y * TG_ROWS;
+  i64 d0 = (i64)blockIdx.y * ROWS;
   if (c2 >= C2) return;
-  double2 t[TG_ROWS];
-  double l[TG_ROWS];
+  dvec2 t[ROWS];
+  double l[ROWS];
 #pragma unroll
-  for (int i = 0; i < TG_ROWS; ++i)
+  for (int i = 0; i < ROWS; ++i)
     if (d0 + i < D) {
-      t[i] = *reinterpret_cast<const double2*>(th + (d0 + i) * ld + 2 * c2);
+      const dvec2* p = reinterpret_cast<const dvec2*>(th + (d0 + i) * ld + 2 * c2);
+      t[i] = NT ? __builtin_nontemporal_load(p) : *p;
       l[i] = lam ? lam[d0 + i] : 1.0;
     }
 #pragma unroll
-  for (int i = 0; i < TG_ROWS; ++i)
+  for (int i = 0; i < ROWS; ++i)
     if (d0 + i < D) {
-      double2 o;
+      dvec2 o;
       o.x = lam ? -(l[i] * t[i].x) : -t[i].x;
       o.y = lam ? -(l[i] * t[i].y) : -t[i].y;
-      *reinterpret_cast<double2*>(g + (d0 + i) * ld + 2 * c2) = o;
+      dvec2* q = reinterpret_cast<dvec2*>(g + (d0 + i) * ld + 2 * c2);
+      if (NT) __builtin_nontemporal_store(o, q);
+      else *q = o;
     }
 }
 
@@ -121,8 +127,13 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
   }
   if (D == 0) return BK_OK;
   if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(theta) && bk_aligned16(grad)) {
-    dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)bk_cdiv(D, TG_ROWS));
-    k_gauss_grad_v2<<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C / 2, D);
+    if (bk_streams_past_llc(2 * C * D)) {
+      dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)bk_cdiv(D, 4));
+      k_gauss_grad_v2<4, true><<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C / 2, D);
+    } else {
+      dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)bk_cdiv(D, 2));
+      k_gauss_grad_v2<2, false><<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C / 2, D);
+    }
   } else {
     dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), (unsigned)bk_cdiv(D, TG_ROWS));
     k_gauss_grad_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C, D);
