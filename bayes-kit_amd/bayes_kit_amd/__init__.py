@@ -7,11 +7,13 @@ signatures, while the arithmetic runs in hand-written HIP kernels for gfx950
 (``libbkhip.so``, C ABI in ``include/bkhip.h``).  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
+from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
 from .targets import DiagGaussian, Funnel, IsoGaussian, TorchModel
 
 __all__ = [
+    "DrGhmcDiag",
     "HMCDiag",
     "MALA",
     "IsoGaussian",

@@ -37,6 +37,14 @@ SIGNATURES = {
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
     "bk_select_columns": [P, P, P, P, P, I, I, I, P],
+    "bk_compact_indices": [P, I, P, P, P],
+    "bk_dr_begin": [P, P, P, P, P, P, I, P],
+    "bk_dr_retry_test": [c_int, P, I, P, F, P, I, P],
+    "bk_dr_level_begin": [P, P, P, P, P, I, P],
+    "bk_dr_ghost_update": [P, P, I, P, P, P, P],
+    "bk_dr_accept_prob": [P, P, P, P, P, F, P, P, I, P],
+    "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P],
+    "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
@@ -204,6 +212,41 @@ class Ops:
         ld = _ld(dst0)
         assert _ld(src0) == ld and (dst1 is None or (_ld(dst1) == ld and _ld(src1) == ld))
         self._call("bk_select_columns", ptr(mask), ptr(dst0), ptr(src0), ptr(dst1), ptr(src1), ld, C, D,
+                   self._s())
+
+    # -- delayed rejection ---------------------------------------------------------------------
+    def compact_indices(self, mask, n, idx_out, count_out):
+        self._call("bk_compact_indices", ptr(mask), n, ptr(idx_out), ptr(count_out), self._s())
+
+    def dr_begin(self, logp, kin, cur_H, cur_h, rej, alive):
+        self._call("bk_dr_begin", ptr(logp), ptr(kin), ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive),
+                   logp.shape[0], self._s())
+
+    def dr_retry_test(self, kind, state, rej, prob_retry, alive):
+        self._call("bk_dr_retry_test", kind, ptr(state), state.stride(0), ptr(rej), float(prob_retry),
+                   ptr(alive), alive.shape[0], self._s())
+
+    def dr_level_begin(self, logp, kin, H, h, live, n):
+        self._call("bk_dr_level_begin", ptr(logp), ptr(kin), ptr(H), ptr(h), ptr(live), n, self._s())
+
+    def dr_ghost_update(self, ga, sub_index, m, h, live, a):
+        self._call("bk_dr_ghost_update", ptr(ga), ptr(sub_index), m, ptr(h), ptr(live), ptr(a), self._s())
+
+    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n):
+        self._call("bk_dr_accept_prob", ptr(H), ptr(cur_H), ptr(h), ptr(cur_h), ptr(cur_index),
+                   float(prob_retry), ptr(live), ptr(a), n, self._s())
+
+    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted):
+        self._call("bk_dr_accept_test", kind, ptr(state), state.stride(0), ptr(chain_index), ptr(a), ptr(H),
+                   n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), ptr(accepted), self._s())
+
+    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None):
+        """dsts/srcs: up to three [D, *] tensors each (same ld within each list)."""
+        d = list(dsts) + [None] * (3 - len(dsts))
+        s_ = list(srcs) + [None] * (3 - len(srcs))
+        D = dsts[0].shape[0]
+        self._call("bk_scatter_columns", ptr(mask), ptr(index), n, D, ptr(d[0]), ptr(s_[0]), ptr(d[1]),
+                   ptr(s_[1]), ptr(d[2]), ptr(s_[2]), _ld(dsts[0]), _ld(srcs[0]), ptr(sdst), ptr(ssrc),
                    self._s())
 
     # -- MALA --------------------------------------------------------------------------------

@@ -1,0 +1,244 @@
+"""Many-chain delayed-rejection generalized HMC on the GPU: drop-in for
+``bayes_kit/drghmc.py:10-446`` (Modi, Barnett & Carpenter 2023).
+
+Same constructor, validation (error types and texts), ``sample()`` and iterator protocol
+as the reference's ``DrGhmcDiag``.  The reference evaluates the acceptance probability of
+proposal k recursively, making "ghost" proposals from the proposal itself and keeping
+gradients on a stack (drghmc.py:82, 391-446).  Here every phase-space point carries its
+own (logp, grad) and the recursion runs in lockstep over SETS of chains:
+
+* level 0 holds the proposals P_k of the chains still inside the stage loop, level 1 the
+  ghosts G_i(P_k), level 2 the ghosts of ghosts, ... (at most max_proposals levels);
+* before each trajectory the chains that need it are compacted into a dense [D, n]
+  buffer (``bk_compact_indices`` + the gathering first leapfrog step), so a rarely needed
+  160-step stage costs bandwidth only for the few chains that reach it;
+* per-chain scalars (joint log density H, Hastings term h, log acceptance a) are updated
+  by the ``bk_dr_*`` kernels; uniforms come from each chain's own stream in the reference's
+  order (retry uniform, then accept uniform, per attempted stage; drghmc.py:370,378).
+
+The momentum flip at the end of a draw (drghmc.py:388) is folded into the next partial
+refresh: ``(-rho)*sqrt(1-damping)`` and ``rho*(-sqrt(1-damping))`` are the same double.
+"""
+from __future__ import annotations
+
+import math
+from collections.abc import Sequence
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._engine import ManyChainSampler
+
+
+class _Level:
+    """Dense buffers of one recursion level."""
+
+    def __init__(self, D, C, dev):
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.theta = torch.empty((D, C), **f64)
+        self.rho = torch.empty((D, C), **f64)
+        self.grad = torch.empty((D, C), **f64)
+        self.logp = torch.empty(C, **f64)
+        self.kin = torch.empty(C, **f64)
+        self.H = torch.empty(C, **f64)
+        self.h = torch.empty(C, **f64)
+        self.a = torch.empty(C, **f64)
+        self.live = torch.empty(C, dtype=torch.uint8, device=dev)
+        self.idx = torch.empty(C, dtype=torch.int32, device=dev)
+        self.count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.accepted = torch.empty(C, dtype=torch.uint8, device=dev)
+
+
+class DrGhmcDiag(ManyChainSampler):
+    def __init__(
+        self,
+        model,
+        max_proposals: int,
+        leapfrog_step_sizes: Sequence[float],
+        leapfrog_step_counts: Sequence[int],
+        damping: float,
+        metric_diag=None,
+        init=None,
+        seed=None,
+        prob_retry: bool = True,
+        *,
+        chains: Optional[int] = None,
+        chain_id0: int = 0,
+        ops=None,
+    ):
+        self._max_proposals = max_proposals
+        self._leapfrog_step_sizes = leapfrog_step_sizes
+        self._leapfrog_step_counts = leapfrog_step_counts
+        self._damping = damping
+        self._prob_retry = prob_retry
+        # the reference validates after building its state (drghmc.py:83); nothing of that
+        # state is observable when validation fails, so validate first and allocate after
+        self._validate_arguments()
+        self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)
+        D, C, dev = self._dim, self._C, self._ops.device
+        f64 = dict(dtype=torch.float64, device=dev)
+        # rho0 = rng.normal(size=D) AFTER theta0 (drghmc.py:77)
+        self._rho_dc = torch.empty((D, C), **f64)
+        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_dc, None, None)
+        self._rho_sign = 1.0  # stored momentum is sign * (reference's _rho)
+        self._grad = torch.empty((D, C), **f64)
+        self._lp = torch.empty(C, **f64)
+        self._kin = torch.empty(C, **f64)
+        self._cur_H = torch.empty(C, **f64)
+        self._cur_h = torch.empty(C, **f64)
+        self._rej = torch.empty(C, **f64)
+        self._alive = torch.empty(C, dtype=torch.uint8, device=dev)
+        self._levels = [_Level(D, C, dev) for _ in range(int(max_proposals))]
+        self._have_cache = False
+        self._draws = 0
+        self.last_grad_evals = 0        # model calls in the last draw (each over a lane set)
+        self.last_lane_steps = 0        # sum over trajectories of lanes x steps (useful work)
+        self.last_stage_lanes = []      # (tag, lanes) of every trajectory run in the last draw
+
+    # -- validation: same checks, error types and texts as drghmc.py:85-207 -----------------------
+    def _validate_arguments(self) -> None:
+        K = self._max_proposals
+        if not isinstance(K, int):
+            raise TypeError(f"max_proposals must be an int, not {type(K)}")
+        if not (K >= 1):
+            raise ValueError(f"max_proposals must be greater than or equal to 1, not {K}")
+        sizes = self._leapfrog_step_sizes
+        if not isinstance(sizes, Sequence):
+            raise TypeError(
+                f"leapfrog_step_sizes must be an instance of type sequence, but found type {type(sizes)}")
+        if len(sizes) != K:
+            raise ValueError(
+                f"leapfrog_step_sizes must be a sequence of length {K}, so that each proposal has its own "
+                f"specified leapfrog step size, but instead found length of {len(sizes)}")
+        for idx, step_size in enumerate(sizes):
+            if not isinstance(step_size, float):
+                raise TypeError(
+                    f"each step size in leapfrog_step_sizes must be of type float, but found step size of "
+                    f"type {type(step_size)} at index {idx}")
+            if not step_size > 0:
+                raise ValueError(
+                    f"each step size in leapfrog_step_sizes must be positive, but found step size of "
+                    f"{step_size} at index {idx}")
+        counts = self._leapfrog_step_counts
+        if not isinstance(counts, Sequence):
+            raise TypeError(
+                f"leapfrog_step_counts must be an instance of type sequence, but found type {type(counts)}")
+        if len(counts) != K:
+            raise ValueError(
+                f"leapfrog_step_counts must be a sequence of length {K}, so that each proposal has its own "
+                f"specified number of leapfrog steps, but instead found length of {len(counts)}")
+        for idx, step_count in enumerate(counts):
+            if not isinstance(step_count, int):
+                raise TypeError(
+                    f"each step count in leapfrog_step_counts must be of type int, but found step count of "
+                    f"type {type(step_count)} at index {idx}")
+            if not step_count > 0:
+                raise ValueError(
+                    f"each step count in leapfrog_step_counts must be positive, but found step count of "
+                    f"{step_count} at index {idx}")
+        damping = self._damping
+        if not isinstance(damping, float):
+            raise TypeError(f"damping must be of type float, but found type {type(damping)}")
+        if not 0 < damping <= 1:
+            raise ValueError(f"damping must be within (0, 1], but found damping of {damping}")
+
+    # -- views ----------------------------------------------------------------------------------------
+    @property
+    def _rho(self):
+        r = self._rho_dc * self._rho_sign
+        return r.t() if self._batched else np.array(r[:, 0].cpu().numpy())
+
+    # -- lane-set helpers --------------------------------------------------------------------------------
+    def _compact(self, mask, n, lvl):
+        """Indices of the nonzero entries of mask[:n] in level lvl's idx buffer.
+        Returns (count, idx or None when every lane is set)."""
+        L = self._levels[lvl]
+        self._ops.compact_indices(mask, n, L.idx, L.count)
+        m = int(L.count.item())  # host needs the lane count to size the next launches
+        return m, (None if m == n else L.idx)
+
+    def _proposal_map(self, src, idx, n, k, lvl, tag):
+        """Leapfrog (eps_k, L_k) + momentum flip from lanes idx of `src` into level lvl
+        (drghmc.py:319-346, 253-289)."""
+        ops, m = self._ops, self._metric_dev
+        h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
+        dst = self._levels[lvl]
+        th, rho, gbuf = dst.theta[:, :n], dst.rho[:, :n], dst.grad[:, :n]
+        ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h)
+        for _ in range(steps - 1):
+            g = self._eval_grad(th, gbuf, None)
+            ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h)
+        g = self._materialize(self._eval_grad(th, gbuf, dst.logp[:n]), gbuf)
+        ops.leapfrog_finish(rho, rho, g, m, 0.5 * h, True, dst.kin[:n])
+        self.last_grad_evals += steps
+        self.last_lane_steps += steps * n
+        self.last_stage_lanes.append((tag, n))
+
+    def _accept(self, lvl, n, k, cur_h, cur_H, cur_idx, tag):
+        """log acceptance probability of the level-lvl lanes against their parents
+        (drghmc.py:391-446).  Returns level.a (valid for the first n lanes)."""
+        ops = self._ops
+        P = self._levels[lvl]
+        ops.dr_level_begin(P.logp, P.kin, P.H, P.h, P.live, n)
+        for i in range(k):
+            m, sub = self._compact(P.live, n, lvl + 1)
+            if m == 0:
+                break
+            gtag = "G%d(%s)" % (i, tag)
+            self._proposal_map(_View(P, n), sub, m, i, lvl + 1, gtag)
+            ga = self._accept(lvl + 1, m, i, P.h, P.H, sub, gtag)
+            ops.dr_ghost_update(ga, sub, m, P.h, P.live, P.a)
+        ops.dr_accept_prob(P.H, cur_H, P.h, cur_h, cur_idx, 1.0 if self._prob_retry else 0.0, P.live, P.a, n)
+        return P.a
+
+    # -- one draw for every chain -----------------------------------------------------------------------------
+    def sample(self):
+        ops = self._ops
+        C, m = self._C, self._metric_dev
+        self.last_grad_evals, self.last_lane_steps, self.last_stage_lanes = 0, 0, []
+        damping = self._damping
+        # partial momentum refresh (drghmc.py:360-364); the stored momentum may still carry the
+        # previous draw's pending flip (drghmc.py:388), applied here through the sign of loc_mul
+        ops.momentum_refresh(self._rng_kind, self._rng_state, self._rho_dc,
+                             self._rho_sign * math.sqrt(1 - damping), math.sqrt(damping), self._rho_dc, m,
+                             self._kin)
+        self._rho_sign = 1.0
+        if not self._have_cache:  # drghmc.py:243-245 (first draw only)
+            self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+            self._have_cache = True
+            self.last_grad_evals += 1
+        ops.dr_begin(self._lp, self._kin, self._cur_H, self._cur_h, self._rej, self._alive)
+        cur = _Cur(self)
+        pr = 1.0 if self._prob_retry else 0.0
+        P0 = self._levels[0]
+        for k in range(int(self._max_proposals)):
+            ops.dr_retry_test(self._rng_kind, self._rng_state, self._rej, pr, self._alive)  # :369-371
+            n, idx = self._compact(self._alive, C, 0)
+            if n == 0:
+                break
+            tag = "P%d" % k
+            self._proposal_map(cur, idx, n, k, 0, tag)                                    # :373
+            a = self._accept(0, n, k, self._cur_h, self._cur_H, idx, tag)                 # :374-376
+            ops.dr_accept_test(self._rng_kind, self._rng_state, idx, a, P0.H, n, self._cur_H, self._cur_h,
+                               self._rej, self._alive, P0.accepted)                        # :378-385
+            ops.scatter_columns(P0.accepted, idx, n,
+                                [self._theta_dc, self._rho_dc, self._grad],
+                                [P0.theta[:, :n], P0.rho[:, :n], P0.grad[:, :n]], self._lp, P0.logp)
+        self._rho_sign = -1.0  # drghmc.py:388, applied lazily
+        self._draws += 1
+        return self._draw_out(self._theta_dc, self._cur_H)
+
+
+class _View:
+    """First n lanes of a level, as a source of phase-space points."""
+
+    def __init__(self, level, n):
+        self.theta, self.rho, self.grad = level.theta[:, :n], level.rho[:, :n], level.grad[:, :n]
+
+
+class _Cur:
+    """The chains' current points as a source of phase-space points."""
+
+    def __init__(self, s):
+        self.theta, self.rho, self.grad = s._theta_dc, s._rho_dc, s._grad

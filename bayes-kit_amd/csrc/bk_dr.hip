@@ -1,0 +1,237 @@
+// Delayed-rejection (DRGHMC) stage helpers: per-chain scalar bookkeeping of the
+// reference's recursive accept (bayes_kit/drghmc.py:348-446) as flat kernels over lane
+// sets, plus the compaction / scatter that keep only the active chains in flight.
+#include "bk_common.hpp"
+#include "bk_rng.hpp"
+
+namespace {
+
+constexpr int SC_BLOCK = 256;
+
+// ---- stable compaction: one workgroup, 16 wavefronts, chunked scan ------------------------
+constexpr int CP_BLOCK = 1024;
+__global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n, int32_t* idx,
+                                                      uint32_t* count) {
+  __shared__ uint32_t wave_cnt[CP_BLOCK / BK_WAVE];
+  __shared__ uint32_t base;
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = threadIdx.x / BK_WAVE;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (i64 start = 0; start < n; start += CP_BLOCK) {
+    i64 i = start + threadIdx.x;
+    bool f = (i < n) && mask[i] != 0;
+    unsigned long long b = __ballot(f);
+    uint32_t before = (uint32_t)__popcll(b & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    uint32_t off = base;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (f) idx[off + before] = (int32_t)i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t t = 0;
+      for (int w = 0; w < CP_BLOCK / BK_WAVE; ++w) t += wave_cnt[w];
+      base += t;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = base;
+}
+
+__device__ __forceinline__ double joint(double logp, double kin) {
+  double potential = -logp;  // drghmc.py:249-251
+  return -(potential + kin);
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_dr_begin(const double* logp, const double* kin, double* H,
+                                                       double* h, double* rej, uint8_t* alive, i64 C) {
+  i64 c = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  H[c] = joint(logp[c], kin[c]);
+  h[c] = 0.0;
+  if (rej) rej[c] = 0.0;
+  alive[c] = 1;
+}
+
+template <typename G>
+__global__ __launch_bounds__(64) void k_dr_retry(uint64_t* st, i64 ldr, const double* rej, double pr,
+                                                 uint8_t* alive, i64 C) {
+  i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (c >= C || !alive[c]) return;
+  G g;
+  g.load(st, ldr, c);
+  double lu = log(bk::next_double(g));
+  g.store(st, ldr, c);
+  double retry = pr * rej[c];  // drghmc.py:317 (bool * float)
+  if (!(lu < retry)) alive[c] = 0;  // drghmc.py:370-371
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const int32_t* sub, i64 m,
+                                                       double* h, uint8_t* live, double* a) {
+  i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
+  if (j >= m) return;
+  i64 p = sub ? (i64)sub[j] : j;
+  double g = ga[j];
+  if (g == 0.0) {  // drghmc.py:430-432
+    a[p] = -INFINITY;
+    live[p] = 0;
+  } else {
+    h[p] = h[p] + log1p(-exp(g));  // drghmc.py:434-435
+  }
+}
+
+__global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, const double* cur_H,
+                                                             const double* h, const double* cur_h,
+                                                             const int32_t* cidx, double pr,
+                                                             const uint8_t* live, double* a, i64 n) {
+  i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
+  if (j >= n || !live[j]) return;
+  i64 p = cidx ? (i64)cidx[j] : j;
+  double ph = h[j], ch = cur_h[p];
+  double frac = ((H[j] - cur_H[p]) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
+  a[j] = frac < 0.0 ? frac : 0.0;                                          // min(0, frac), :446
+}
+
+template <typename G>
+__global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, const int32_t* cidx,
+                                                       const double* a, const double* H, i64 n,
+                                                       double* cur_H, double* cur_h, double* rej,
+                                                       uint8_t* alive, uint8_t* accepted) {
+  i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (j >= n) return;
+  i64 c = cidx ? (i64)cidx[j] : j;
+  G g;
+  g.load(st, ldr, c);
+  double lu = log(bk::next_double(g));
+  g.store(st, ldr, c);
+  double aj = a[j];
+  if (lu < aj) {  // drghmc.py:378-381
+    accepted[j] = 1;
+    cur_H[c] = H[j];
+    alive[c] = 0;
+  } else {  // drghmc.py:383-384
+    accepted[j] = 0;
+    double r = log1p(-exp(aj));
+    rej[c] = r;
+    cur_h[c] = cur_h[c] + r;
+  }
+}
+
+constexpr int SCT_UNROLL = 4;
+__global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32_t* idx, i64 n, i64 D,
+                                                double* d0, const double* s0, double* d1, const double* s1,
+                                                double* d2, const double* s2, i64 ldd, i64 lds, double* sd,
+                                                const double* ss) {
+  i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (j >= n || !mask[j]) return;
+  i64 g = idx ? (i64)idx[j] : j;
+  if (sd) sd[g] = ss[j];
+  for (i64 b = 0; b < D; b += SCT_UNROLL) {
+    double x0[SCT_UNROLL], x1[SCT_UNROLL], x2[SCT_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SCT_UNROLL; ++u)
+      if (b + u < D) {
+        x0[u] = s0[(b + u) * lds + j];
+        if (d1) x1[u] = s1[(b + u) * lds + j];
+        if (d2) x2[u] = s2[(b + u) * lds + j];
+      }
+#pragma unroll
+    for (int u = 0; u < SCT_UNROLL; ++u)
+      if (b + u < D) {
+        d0[(b + u) * ldd + g] = x0[u];
+        if (d1) d1[(b + u) * ldd + g] = x1[u];
+        if (d2) d2[(b + u) * ldd + g] = x2[u];
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_compact_indices(const uint8_t* mask, int64_t n, int32_t* idx_out, uint32_t* count_out, void* stream) {
+  if (!mask || !idx_out || !count_out || n < 0 || n > 0x7fffffff) return BK_E_ARG;
+  k_compact<<<dim3(1), dim3(CP_BLOCK), 0, bk_stream(stream)>>>(mask, n, idx_out, count_out);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_begin(const double* logp, const double* kin, double* cur_H, double* cur_h, double* rej,
+                uint8_t* alive, int64_t C, void* stream) {
+  if (!logp || !kin || !cur_H || !cur_h || !rej || !alive || C < 0) return BK_E_ARG;
+  if (C == 0) return BK_OK;
+  k_dr_begin<<<dim3((unsigned)bk_cdiv(C, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(logp, kin, cur_H, cur_h,
+                                                                                           rej, alive, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_level_begin(const double* logp, const double* kin, double* H, double* h, uint8_t* live, int64_t n,
+                      void* stream) {
+  if (!logp || !kin || !H || !h || !live || n < 0) return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_dr_begin<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(logp, kin, H, h, nullptr,
+                                                                                           live, n);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_retry_test(int rng_kind, uint64_t* state, int64_t ldr, const double* rej, double prob_retry,
+                     uint8_t* alive, int64_t C, void* stream) {
+  if (!state || !rej || !alive || C < 0 || ldr < C) return BK_E_ARG;
+  if (C == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, 64)), block(64);
+  if (rng_kind == BK_RNG_PHILOX)
+    k_dr_retry<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, rej, prob_retry, alive, C);
+  else if (rng_kind == BK_RNG_PCG64)
+    k_dr_retry<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, rej, prob_retry, alive, C);
+  else
+    return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_ghost_update(const double* ga, const int32_t* sub_index, int64_t m, double* h, uint8_t* live,
+                       double* a, void* stream) {
+  if (!ga || !h || !live || !a || m < 0) return BK_E_ARG;
+  if (m == 0) return BK_OK;
+  k_dr_ghost<<<dim3((unsigned)bk_cdiv(m, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(ga, sub_index, m, h, live,
+                                                                                           a);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, const double* cur_h,
+                      const int32_t* cur_index, double prob_retry, const uint8_t* live, double* a, int64_t n,
+                      void* stream) {
+  if (!H || !cur_H || !h || !cur_h || !live || !a || n < 0) return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_dr_accept_prob<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(
+      H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* a,
+                      const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
+                      uint8_t* accepted, void* stream) {
+  if (!state || !a || !H || !cur_H || !cur_h || !rej || !alive || !accepted || n < 0) return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(n, 64)), block(64);
+  if (rng_kind == BK_RNG_PHILOX)
+    k_dr_accept_test<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
+                                                                       cur_h, rej, alive, accepted);
+  else if (rng_kind == BK_RNG_PCG64)
+    k_dr_accept_test<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
+                                                                      cur_h, rej, alive, accepted);
+  else
+    return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int64_t D, double* dst0,
+                       const double* src0, double* dst1, const double* src1, double* dst2, const double* src2,
+                       int64_t ld_dst, int64_t ld_src, double* sdst, const double* ssrc, void* stream) {
+  if (!mask || !dst0 || !src0 || (dst1 && !src1) || (dst2 && !src2) || (sdst && !ssrc) || n < 0 || D < 0)
+    return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_scatter<<<dim3((unsigned)bk_cdiv(n, 64)), dim3(64), 0, bk_stream(stream)>>>(
+      mask, index, n, D, dst0, src0, dst1, src1, dst2, src2, ld_dst, ld_src, sdst, ssrc);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"

@@ -139,6 +139,65 @@ int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
                       double* dst1, const double* src1, int64_t ld,
                       int64_t C, int64_t D, void* stream);
 
+/* ---- delayed rejection (DRGHMC) stage helpers -------------------------------------------
+ * The reference's recursive accept() with its gradient-cache stack (drghmc.py:82,391-446)
+ * is run as a lockstep state machine over lane sets: the chains still inside the stage
+ * loop are compacted into dense buffers per recursion level, so a trajectory only costs
+ * bandwidth for the chains that actually take it.  Per-chain scalars of a level: H (joint
+ * log density), h (log of the probability of rejecting all earlier proposals, the
+ * "hastings" term), a (log acceptance probability), live (not yet early-exited).
+ */
+
+/* Stable compaction: idx_out[k] = position of the k-th nonzero entry of mask[0..n),
+ * *count_out = number of nonzero entries (ballot/popcount prefix sums per wavefront). */
+int bk_compact_indices(const uint8_t* mask, int64_t n, int32_t* idx_out, uint32_t* count_out,
+                       void* stream);
+
+/* Start of a draw (drghmc.py:365-366): cur_H = -((-logp) + kin) (joint_logp, :249-251),
+ * cur_h = 0, rej = 0, alive = 1. */
+int bk_dr_begin(const double* logp, const double* kin, double* cur_H, double* cur_h, double* rej,
+                uint8_t* alive, int64_t C, void* stream);
+
+/* Retry test (drghmc.py:369-371) for the alive chains: u from the chain's stream, chain
+ * leaves the stage loop unless log(u) < prob_retry * rej  (prob_retry is 1.0 or 0.0; the
+ * product reproduces False * -inf = nan -> break). */
+int bk_dr_retry_test(int rng_kind, uint64_t* state, int64_t ldr, const double* rej,
+                     double prob_retry, uint8_t* alive, int64_t C, void* stream);
+
+/* Level set-up for accept(): H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0,
+ * live = 1 for the n lanes of a level. */
+int bk_dr_level_begin(const double* logp, const double* kin, double* H, double* h, uint8_t* live,
+                      int64_t n, void* stream);
+
+/* After the recursive accept of ghost proposals (drghmc.py:426-436): ghost lane j belongs
+ * to parent lane p = sub_index ? sub_index[j] : j.  If ga[j] == 0 the parent's result is
+ * a = -inf and it stops (early-out, :430-432); otherwise h[p] += log1p(-exp(ga[j])). */
+int bk_dr_ghost_update(const double* ga, const int32_t* sub_index, int64_t m, double* h,
+                       uint8_t* live, double* a, void* stream);
+
+/* Final acceptance probability of the still-live lanes (drghmc.py:438-446):
+ * a = min(0, (H - cur_H) + (h - cur_h) + (pr*h - pr*cur_h)), with cur_* read at
+ * cur_index ? cur_index[j] : j. */
+int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, const double* cur_h,
+                      const int32_t* cur_index, double prob_retry, const uint8_t* live, double* a,
+                      int64_t n, void* stream);
+
+/* Top-level accept test of a stage (drghmc.py:378-385) for the n compacted lanes; lane j is
+ * chain g = chain_index ? chain_index[j] : j.  u from chain g's stream; if log(u) < a[j]:
+ * accepted[j] = 1, cur_H[g] = H[j], alive[g] = 0; else accepted[j] = 0,
+ * rej[g] = log1p(-exp(a[j])), cur_h[g] += rej[g]. */
+int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index,
+                      const double* a, const double* H, int64_t n, double* cur_H, double* cur_h,
+                      double* rej, uint8_t* alive, uint8_t* accepted, void* stream);
+
+/* Accepted lanes replace their chain's current point (drghmc.py:379): for up to three
+ * array pairs dst[d*ld_dst + g] = src[d*ld_src + j] and one per-chain vector
+ * sdst[g] = ssrc[j], where g = index ? index[j] : j and mask[j] != 0. */
+int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int64_t D,
+                       double* dst0, const double* src0, double* dst1, const double* src1,
+                       double* dst2, const double* src2, int64_t ld_dst, int64_t ld_src,
+                       double* sdst, const double* ssrc, void* stream);
+
 /* ---- MALA ---------------------------------------------------------------------------
  * theta_prop = (theta + eps*grad) + sqrt2eps * z, z from chain c's stream in d order
  * (mala.py:41-45). */

@@ -237,3 +237,85 @@ class FakeOps:
             if iat_out is not None:
                 iat_out[c] = it
             ess_out[c] = X.shape[0] / it
+
+    # -- delayed rejection --------------------------------------------------------------------------
+    def compact_indices(self, mask, n, idx_out, count_out):
+        nz = np.nonzero(mask.numpy()[:n])[0]
+        idx_out.numpy()[: len(nz)] = nz
+        count_out.numpy()[0] = len(nz)
+
+    @staticmethod
+    def _joint(logp, kin):
+        return -((-logp) + kin)
+
+    def dr_begin(self, logp, kin, cur_H, cur_h, rej, alive):
+        cur_H.numpy()[...] = self._joint(logp.numpy(), kin.numpy())
+        cur_h.zero_()
+        rej.zero_()
+        alive.fill_(1)
+
+    def dr_retry_test(self, kind, state, rej, prob_retry, alive):
+        for c in range(alive.shape[0]):
+            if not alive[c]:
+                continue
+            g = self._gen(kind, state, c)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                lu = np.log(g.uniform())
+                retry = prob_retry * rej.numpy()[c]
+                if not lu < retry:
+                    alive[c] = 0
+            self._put(kind, state, c, g)
+
+    def dr_level_begin(self, logp, kin, H, h, live, n):
+        H.numpy()[:n] = self._joint(logp.numpy()[:n], kin.numpy()[:n])
+        h.numpy()[:n] = 0.0
+        live.numpy()[:n] = 1
+
+    def dr_ghost_update(self, ga, sub_index, m, h, live, a):
+        for j in range(m):
+            p = j if sub_index is None else int(sub_index[j])
+            g = ga.numpy()[j]
+            if g == 0:
+                a[p] = -np.inf
+                live[p] = 0
+            else:
+                h.numpy()[p] = h.numpy()[p] + np.log1p(-np.exp(g))
+
+    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n):
+        for j in range(n):
+            if not live[j]:
+                continue
+            p = j if cur_index is None else int(cur_index[j])
+            ph, ch = h.numpy()[j], cur_h.numpy()[p]
+            with np.errstate(invalid="ignore"):
+                frac = ((H.numpy()[j] - cur_H.numpy()[p]) + (ph - ch)) + (prob_retry * ph - prob_retry * ch)
+            a[j] = frac if frac < 0 else 0.0
+
+    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted):
+        for j in range(n):
+            c = j if chain_index is None else int(chain_index[j])
+            g = self._gen(kind, state, c)
+            with np.errstate(divide="ignore"):
+                lu = np.log(g.uniform())
+            self._put(kind, state, c, g)
+            aj = a.numpy()[j]
+            if lu < aj:
+                accepted[j] = 1
+                cur_H[c] = H[j]
+                alive[c] = 0
+            else:
+                accepted[j] = 0
+                with np.errstate(divide="ignore"):
+                    r = np.log1p(-np.exp(aj))
+                rej.numpy()[c] = r
+                cur_h.numpy()[c] = cur_h.numpy()[c] + r
+
+    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None):
+        for j in range(n):
+            if not mask[j]:
+                continue
+            g = j if index is None else int(index[j])
+            for d, s in zip(dsts, srcs):
+                d.numpy()[:, g] = s.numpy()[:, j]
+            if sdst is not None:
+                sdst[g] = ssrc[j]

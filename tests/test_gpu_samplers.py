@@ -9,7 +9,9 @@ from tests.sampler_parity import check_many_chain, check_single_chain_host_model
 pytestmark = pytest.mark.gpu
 
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric", "hmc_diag1024_cfg3",
-        "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init"]
+        "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init",
+        "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
+        "drghmc_funnel101_cfg4", "drghmc_diag16_metric"]
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +24,8 @@ def test_many_chain_vs_reference_golden(name, ops):
     check_many_chain(name, ops)
 
 
-@pytest.mark.parametrize("name", ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init"])
+@pytest.mark.parametrize("name", ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init",
+                                  "drghmc_stdnormal_k3", "drghmc_k1"])
 def test_single_chain_drop_in_vs_reference_golden(name, ops):
     check_single_chain_host_model(name, ops, chains=[0, 1])
 
@@ -96,3 +99,43 @@ def test_full_size_cfg3_properties(ops):
     rate = s.accept_rate()
     assert 0.6 < rate < 0.99, rate
     assert torch.isfinite(tb).all() and torch.isfinite(lb).all()
+
+
+def test_drghmc_many_chains_match_oracle_per_chain(ops):
+    """2,048 funnel chains in lockstep (compaction, ghost levels) vs the oracle chain by chain
+    on a scattered subset: decisions, theta and the RNG position all agree."""
+    from oracle import models as om
+    from oracle import samplers as osamp
+
+    D, C, seed, N = 11, 2048, 909, 12
+    args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
+    s = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=C, seed=seed)
+    draws = []
+    stages = set()
+    for _ in range(N):
+        th, lp = s.sample()
+        draws.append((th.cpu().numpy(), lp.cpu().numpy()))
+        stages.update(t for t, _ in s.last_stage_lanes)
+    assert {"P0", "P1", "G0(P1)"} <= stages
+    st = s.rng_state()
+    for c in list(range(0, C, 97)) + [C - 1]:
+        o = osamp.DrGhmcDiag(om.Funnel(D), *args, seed=np.random.Philox(key=[seed, c]))
+        for n in range(N):
+            oth, olp = o.sample()
+            np.testing.assert_allclose(draws[n][0][c], oth, rtol=1e-7, atol=1e-9)
+            np.testing.assert_allclose(draws[n][1][c], olp, rtol=1e-7, atol=1e-9)
+        from tests.helpers import rng_state_words
+
+        np.testing.assert_array_equal(st[:, c], rng_state_words(o._rng))
+
+
+def test_drghmc_moments_std_normal(ops):
+    # distributional check in the spirit of test/test_drghmc.py:97-117, many chains at once
+    s = bk.DrGhmcDiag(bk.IsoGaussian(1), 3, [0.9, 0.45, 0.225], [2, 4, 8], 0.2, chains=4096, seed=1)
+    acc = []
+    for n in range(60):
+        th, _ = s.sample()
+        if n >= 20:
+            acc.append(th[:, 0].clone())
+    x = torch.stack(acc).cpu().numpy()
+    assert abs(x.mean()) < 0.02 and abs(x.var() - 1.0) < 0.03

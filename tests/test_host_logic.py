@@ -14,8 +14,9 @@ from tests.fake_ops import FakeOps
 from tests.sampler_parity import check_many_chain, check_single_chain_host_model
 
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_diag16_metric", "mala_stdnormal", "mala_iso8",
-        "mala_diag16", "mala_init"]
-SINGLE = ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init"]
+        "mala_diag16", "mala_init", "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1",
+        "drghmc_funnel11_k3", "drghmc_funnel101_cfg4", "drghmc_diag16_metric"]
+SINGLE = ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init", "drghmc_stdnormal_k3", "drghmc_k1"]
 
 
 @pytest.mark.parametrize("name", MANY)
@@ -132,3 +133,106 @@ def test_no_gpu_no_fallback():
 
     with pytest.raises(bk._lib.BkHipError):
         bk.HMCDiag(StdNormal(), 0.1, 3)
+
+
+# ---- DRGHMC specifics ------------------------------------------------------------------------------
+def _drghmc(**over):
+    from oracle.models import StdNormal
+
+    kw = dict(model=StdNormal(), max_proposals=2, leapfrog_step_sizes=[0.25, 0.25],
+              leapfrog_step_counts=[1, 1], damping=0.2, ops=FakeOps())
+    kw.update(over)
+    return bk.DrGhmcDiag(**kw)
+
+
+def test_drghmc_validation_messages():
+    # error types AND texts of drghmc.py:85-207, pinned by test/test_drghmc.py:179-347
+    import re
+
+    for bad in [[1], 1.0]:
+        with pytest.raises(TypeError, match=re.escape(f"max_proposals must be an int, not {type(bad)}")):
+            _drghmc(max_proposals=bad)
+    for bad in [0, -1]:
+        with pytest.raises(ValueError, match=f"max_proposals must be greater than or equal to 1, not {bad}"):
+            _drghmc(max_proposals=bad)
+    for bad in [1, 0.25]:
+        msg = f"leapfrog_step_sizes must be an instance of type sequence, but found type {type(bad)}"
+        with pytest.raises(TypeError, match=re.escape(msg)):
+            _drghmc(leapfrog_step_sizes=bad)
+        msg = f"leapfrog_step_counts must be an instance of type sequence, but found type {type(bad)}"
+        with pytest.raises(TypeError, match=re.escape(msg)):
+            _drghmc(leapfrog_step_counts=bad)
+    for bad in [[0.25], [0.25, 0.25, 0.25]]:
+        msg = (f"leapfrog_step_sizes must be a sequence of length 2, so that each proposal has its own "
+               f"specified leapfrog step size, but instead found length of {len(bad)}")
+        with pytest.raises(ValueError, match=msg):
+            _drghmc(leapfrog_step_sizes=bad)
+    for bad in [[1], [1, 1, 1]]:
+        msg = (f"leapfrog_step_counts must be a sequence of length 2, so that each proposal has its own "
+               f"specified number of leapfrog steps, but instead found length of {len(bad)}")
+        with pytest.raises(ValueError, match=msg):
+            _drghmc(leapfrog_step_counts=bad)
+    with pytest.raises(TypeError, match=re.escape(
+            f"each step size in leapfrog_step_sizes must be of type float, but found step size of type {int} "
+            f"at index 1")):
+        _drghmc(leapfrog_step_sizes=[0.25, 1])
+    for bad in [[-0.25, 0.25], [0.0, 0.25]]:
+        with pytest.raises(ValueError, match=re.escape(
+                f"each step size in leapfrog_step_sizes must be positive, but found step size of {bad[0]} at index 0")):
+            _drghmc(leapfrog_step_sizes=bad)
+    with pytest.raises(TypeError, match=re.escape(
+            f"each step count in leapfrog_step_counts must be of type int, but found step count of type {float} "
+            f"at index 1")):
+        _drghmc(leapfrog_step_counts=[1, 1.0])
+    for bad in [[-2, 1], [0, 1]]:
+        with pytest.raises(ValueError, match=re.escape(
+                f"each step count in leapfrog_step_counts must be positive, but found step count of {bad[0]} at index 0")):
+            _drghmc(leapfrog_step_counts=bad)
+    for bad in [[0.5], int(1)]:
+        with pytest.raises(TypeError, match=re.escape(f"damping must be of type float, but found type {type(bad)}")):
+            _drghmc(damping=bad)
+    for bad in [float(0), float(-1)]:
+        with pytest.raises(ValueError, match=re.escape(f"damping must be within (0, 1], but found damping of {bad}")):
+            _drghmc(damping=bad)
+
+
+def test_drghmc_gradient_call_bound_and_attrs():
+    # test/test_drghmc.py:52-94: at most 1 + sum_k L_k 2^(K-1-k) gradient calls per draw
+    from oracle.models import StdNormal
+
+    model = StdNormal()
+    model.log_density_gradient = _counter(model.log_density_gradient)
+    counts = [2, 4, 8]
+    s = bk.DrGhmcDiag(model, 3, [0.9, 0.45, 0.225], counts, 0.2, seed=5, ops=FakeOps())
+    assert s._leapfrog_step_counts == counts and iter(s) is s
+    bound = 1 + sum(c * 2 ** (3 - 1 - k) for k, c in enumerate(counts))
+    for _ in range(60):
+        before = model.log_density_gradient.calls
+        next(s)
+        assert model.log_density_gradient.calls - before <= bound
+
+
+def test_drghmc_lane_sets_follow_the_reference_schedule():
+    """Which chains run which trajectory = the union of the oracle's per-chain schedules."""
+    from tests.helpers import load_case, oracle_sampler
+    from tests.sampler_parity import build_sampler, product_model
+
+    case, z = load_case("drghmc_funnel11_k3")
+    C = z["draws"].shape[1]
+    ops = FakeOps()
+    s = build_sampler(case, product_model(case["model"], ops), ops, case["seed"], chains=C)
+    oracles = [oracle_sampler(case, c) for c in range(C)]
+    multi = 0
+    for n in range(25):
+        s.sample()
+        want = {}
+        for o in oracles:
+            o.sample()
+            for t in o.last_schedule:
+                want[t] = want.get(t, 0) + 1
+        got = {}
+        for t, lanes in s.last_stage_lanes:
+            got[t] = got.get(t, 0) + lanes
+        assert got == want, (n, got, want)
+        multi += len(got) > 1
+    assert multi > 0
