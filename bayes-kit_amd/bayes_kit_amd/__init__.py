@@ -7,6 +7,10 @@ signatures, while the arithmetic runs in hand-written HIP kernels for gfx950
 (``libbkhip.so``, C ABI in ``include/bkhip.h``).  There is no CPU fallback.
 """
 from . import _lib  # noqa: F401
+from . import dist  # noqa: F401
+from .diagnostics import (RunningMoments, autocorr, ess, ess_imse, ess_ipse, iat, iat_imse, iat_ipse, rhat,
+                          rhat_from_moments, split_rhat)
+from .ensemble import Stretcher
 from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
@@ -16,6 +20,18 @@ __all__ = [
     "DrGhmcDiag",
     "HMCDiag",
     "MALA",
+    "Stretcher",
+    "ess",
+    "ess_imse",
+    "ess_ipse",
+    "iat",
+    "iat_imse",
+    "iat_ipse",
+    "rhat",
+    "split_rhat",
+    "autocorr",
+    "RunningMoments",
+    "rhat_from_moments",
     "IsoGaussian",
     "DiagGaussian",
     "Funnel",

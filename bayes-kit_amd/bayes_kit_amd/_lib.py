@@ -55,6 +55,7 @@ SIGNATURES = {
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
     "bk_ess": [P, I, I, c_int, P, P, I, P],
+    "bk_autocorr": [P, I, I, P, I, I, P],
     "bk_host_normals": [c_int, P, P, I],
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
@@ -302,6 +303,10 @@ class Ops:
     def chain_mean_var(self, x, lengths, mean, var):
         N, C = x.shape
         self._call("bk_chain_mean_var", ptr(x), _ld(x), ptr(lengths), N, ptr(mean), ptr(var), C, self._s())
+
+    def autocorr(self, x, out):
+        N, C = x.shape
+        self._call("bk_autocorr", ptr(x), _ld(x), N, ptr(out), _ld(out), C, self._s())
 
     def ess(self, x, estimator, ess_out, iat_out=None):
         N, C = x.shape

@@ -1,0 +1,268 @@
+"""Convergence diagnostics on the GPU: drop-ins for ``bayes_kit/rhat.py``, ``ess.py``,
+``iat.py`` and ``autocorr.py``, plus the streaming / multi-GPU forms the many-chain engine
+uses.
+
+Inputs.  Every function accepts what the reference accepts (a 1-D chain, or a sequence of
+1-D chains for the R-hat family) and, additionally, a 2-D float64 device tensor ``[N, C]``
+(draw-major: N draws of C chains, one chain per GPU lane).  For a 2-D input the per-chain
+functions (ess, iat, autocorr) return one value (or column) per chain.
+
+Across GPUs.  Chains are sharded; the only cross-rank traffic is the per-dimension partial
+sums of R-hat (a few doubles per dimension).  They are exchanged with ONE small
+``all_gather`` per pass (RCCL when the tensors live on the GPU, gloo in the CPU tests) and
+combined in rank order, so the result does not depend on the reduction order.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+def _ops(ops):
+    return ops if ops is not None else _lib.default_ops()
+
+
+# ---------------------------------------------------------------------------------------------
+# cross-rank combine
+# ---------------------------------------------------------------------------------------------
+def _gather_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of `t` over the ranks of `group`, accumulated in rank order (deterministic).
+    No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out += p
+    return out
+
+
+def rhat_from_moments(mean_dc, m2_dc, n: int, ops=None, group=None) -> np.ndarray:
+    """Per-dimension R-hat (bayes_kit/rhat.py:163-171) from per-chain Welford moments
+    ``mean, M2`` ([D, C_local] each, n draws per chain), over ALL ranks' chains.
+
+    Two passes, like ``np.var(means, ddof=1)``: first sum(mean) and sum(var) -> grand mean;
+    then sum((mean - grand mean)^2).  Each pass is one kernel + one tiny all_gather.
+    """
+    ops = _ops(ops)
+    D, C = mean_dc.shape
+    dev = mean_dc.device
+    if n < 2:
+        raise ValueError("rhat requires len(chain) >= 2 for every chain in chains")
+    part = torch.zeros(3 * D + 1, dtype=torch.float64, device=dev)
+    ops.rhat_partials(mean_dc, m2_dc, n, None, part)
+    part[3 * D] = float(C)
+    tot = _gather_sum(part, group)
+    M = float(tot[3 * D].item())
+    if M < 2:
+        raise ValueError(f"rhat requires len(chains) >= 2, but len(chains) = {int(M)}")
+    centre = (tot[0:D] / M).contiguous()
+    mean_var = tot[D:2 * D] / M
+    part2 = torch.zeros(3 * D + 1, dtype=torch.float64, device=dev)
+    ops.rhat_partials(mean_dc, m2_dc, n, centre, part2)
+    tot2 = _gather_sum(part2, group)
+    var_means = tot2[2 * D:3 * D] / (M - 1.0)
+    nf = float(n)
+    return torch.sqrt((nf - 1.0) / nf + var_means / mean_var).cpu().numpy()
+
+
+class RunningMoments:
+    """Streaming per-chain mean / M2 of every dimension (Welford), fed one draw at a time."""
+
+    def __init__(self, D: int, C: int, ops=None):
+        self._ops = _ops(ops)
+        dev = self._ops.device
+        self.mean = torch.zeros((D, C), dtype=torch.float64, device=dev)
+        self.m2 = torch.zeros((D, C), dtype=torch.float64, device=dev)
+        self.n = 0
+
+    def update(self, theta) -> None:
+        """theta: the sampler's draw, either the engine's [D, C] buffer or the (C, D) view
+        returned by ``sample()``."""
+        t = theta if theta.shape == self.mean.shape else theta.t()
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        self.n += 1
+        self._ops.welford_update(self.mean, self.m2, t, self.n)
+
+    def rhat(self, group=None) -> np.ndarray:
+        return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers for the reference-style inputs
+# ---------------------------------------------------------------------------------------------
+def _is_matrix(x) -> bool:
+    return isinstance(x, torch.Tensor) and x.dim() == 2
+
+
+def _pack_chains(chains: Sequence, ops):
+    """Sequence of (possibly ragged) 1-D chains -> ([Nmax, M] device tensor, lengths)."""
+    arrs = [np.asarray(c, dtype=np.float64).reshape(-1) for c in chains]
+    lens = np.array([a.shape[0] for a in arrs], dtype=np.int32)
+    nmax = int(lens.max()) if len(arrs) else 0
+    host = np.zeros((max(nmax, 1), len(arrs)), dtype=np.float64)
+    for j, a in enumerate(arrs):
+        host[: a.shape[0], j] = a
+    return torch.from_numpy(host).to(ops.device), lens
+
+
+def _rhat_of_columns(x, lens, ops, group=None):
+    """R-hat of the chains stored as columns of x (lens None = all rows)."""
+    N, M = x.shape
+    dev = x.device
+    mean = torch.empty((1, M), dtype=torch.float64, device=dev)
+    var = torch.empty((1, M), dtype=torch.float64, device=dev)
+    lt = None if lens is None else torch.from_numpy(np.asarray(lens, dtype=np.int32)).to(dev)
+    ops.chain_mean_var(x, lt, mean[0], var[0])
+    # reuse the per-dimension partial-sum kernel with D = 1 (n = 2 makes M2/(n-1) = var)
+    part = torch.zeros(4, dtype=torch.float64, device=dev)
+    ops.rhat_partials(mean, var, 2, None, part)
+    part[3] = float(M)
+    len_sum = torch.tensor([float(N * M) if lens is None else float(np.sum(lens))], dtype=torch.float64, device=dev)
+    tot = _gather_sum(torch.cat([part, len_sum]), group)
+    Mt = float(tot[3].item())
+    centre = (tot[0:1] / Mt).contiguous()
+    part2 = torch.zeros(4, dtype=torch.float64, device=dev)
+    ops.rhat_partials(mean, var, 2, centre, part2)
+    tot2 = _gather_sum(part2, group)
+    nbar = float(tot[4].item()) / Mt
+    var_means = float(tot2[2].item()) / (Mt - 1.0)
+    mean_vars = float(tot[1].item()) / Mt
+    return np.float64(np.sqrt((nbar - 1.0) / nbar + var_means / mean_vars))
+
+
+# ---------------------------------------------------------------------------------------------
+# rhat.py
+# ---------------------------------------------------------------------------------------------
+def rhat(chains, *, ops=None, group=None):
+    """Potential scale reduction factor, bayes_kit/rhat.py:111-171.
+
+    ``chains``: a sequence of 1-D chains (ragged allowed) or a device tensor [N, C].  With a
+    process group, ``chains`` is this rank's shard and the statistic is over all ranks.
+    """
+    ops = _ops(ops)
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if _is_matrix(chains):
+        N, M = chains.shape
+        if world == 1 and M < 2:
+            raise ValueError(f"rhat requires len(chains) >= 2, but len(chains) = {M}")
+        if N < 2:
+            raise ValueError("rhat requires len(chain) >= 2 for every chain in chains")
+        x = chains if chains.stride(1) == 1 else chains.contiguous()
+        return _rhat_of_columns(x, None, ops, group)
+    if world == 1 and len(chains) < 2:
+        raise ValueError(f"rhat requires len(chains) >= 2, but {len(chains) = }")
+    if not all(len(chain) >= 2 for chain in chains):
+        raise ValueError("rhat requires len(chain) >= 2 for every chain in chains")
+    x, lens = _pack_chains(chains, ops)
+    return _rhat_of_columns(x, lens, ops, group)
+
+
+def split_chains(chains):
+    """bayes_kit/rhat.py:9-24 (host-side index arithmetic only: no numerics involved)."""
+    return [arr for chain in chains for arr in np.array_split(chain, 2)]
+
+
+def split_rhat(chains, *, ops=None, group=None):
+    """bayes_kit/rhat.py:174-202: R-hat of the chains split in half (first half one longer
+    for odd lengths)."""
+    ops = _ops(ops)
+    if _is_matrix(chains):
+        N, M = chains.shape
+        x = chains if chains.stride(1) == 1 else chains.contiguous()
+        h = (N + 1) // 2
+        if N - h < 2:
+            raise ValueError("rhat requires len(chain) >= 2 for every chain in chains")
+        halves = torch.zeros((h, 2 * M), dtype=torch.float64, device=x.device)
+        halves[:, :M] = x[:h]
+        halves[: N - h, M:] = x[h:]
+        lens = np.concatenate([np.full(M, h), np.full(M, N - h)]).astype(np.int32)
+        return _rhat_of_columns(halves, lens, ops, group)
+    return rhat(split_chains(chains), ops=ops, group=group)
+
+
+# ---------------------------------------------------------------------------------------------
+# autocorr.py / iat.py / ess.py
+# ---------------------------------------------------------------------------------------------
+def _series(chain, ops):
+    """-> ([N, C] device tensor, was_1d)."""
+    if _is_matrix(chain):
+        return (chain if chain.stride(1) == 1 else chain.contiguous()), False
+    a = np.asarray(chain, dtype=np.float64).reshape(-1)
+    return torch.from_numpy(a.copy()).to(ops.device).reshape(-1, 1), True
+
+
+def _len(chain) -> int:
+    return chain.shape[0] if _is_matrix(chain) else len(chain)
+
+
+def autocorr(chain, *, ops=None):
+    """Autocorrelation at all lags, bayes_kit/autocorr.py:6-33 (direct sums on the device)."""
+    if _len(chain) < 2:
+        raise ValueError(f"autocorr requires len(chain) >= 2, but {len(chain)=}")
+    ops = _ops(ops)
+    x, one = _series(chain, ops)
+    out = torch.empty_like(x)
+    ops.autocorr(x, out)
+    return out[:, 0].cpu().numpy() if one else out
+
+
+def _iat_ess(chain, estimator, want, ops):
+    ops = _ops(ops)
+    x, one = _series(chain, ops)
+    N, C = x.shape
+    ess_out = torch.empty(C, dtype=torch.float64, device=x.device)
+    iat_out = torch.empty(C, dtype=torch.float64, device=x.device)
+    ops.ess(x, estimator, ess_out, iat_out)
+    r = ess_out if want == "ess" else iat_out
+    return np.float64(r[0].item()) if one else r
+
+
+def iat_ipse(chain, *, ops=None):
+    """bayes_kit/iat.py:46-92."""
+    if _len(chain) < 4:
+        raise ValueError(f"ess requires len(chains) >= 4, but {len(chain)=}")
+    return _iat_ess(chain, 1, "iat", ops)
+
+
+def iat_imse(chain, *, ops=None):
+    """bayes_kit/iat.py:95-135."""
+    if _len(chain) < 4:
+        raise ValueError(f"iat requires len(chains) >=4, but {len(chain) = }")
+    return _iat_ess(chain, 0, "iat", ops)
+
+
+def iat(chain, *, ops=None):
+    """bayes_kit/iat.py:138-156."""
+    return iat_imse(chain, ops=ops)
+
+
+def ess_ipse(chain, *, ops=None):
+    """bayes_kit/ess.py:5-21."""
+    if _len(chain) < 4:
+        raise ValueError(f"ess_ipse(chain) requires len(chain) >= 4, but {len(chain)=}")
+    return _iat_ess(chain, 1, "ess", ops)
+
+
+def ess_imse(chain, *, ops=None):
+    """bayes_kit/ess.py:24-49."""
+    if _len(chain) < 4:
+        raise ValueError(f"ess_imse(chain) requires len(chain) >=4, but {len(chain) = }")
+    return _iat_ess(chain, 0, "ess", ops)
+
+
+def ess(chain, *, ops=None):
+    """bayes_kit/ess.py:52-69."""
+    if _len(chain) < 4:
+        raise ValueError(f"ess(chain) requires len(chain) >=4, but {len(chain) = }")
+    return _iat_ess(chain, 0, "ess", ops)

@@ -135,6 +135,28 @@ __global__ __launch_bounds__(PC_BLOCK) void k_ess(const double* x, i64 ld, i64 N
   ess_out[c] = (double)N / iat;
 }
 
+// all-lag autocorrelation (autocorr.py:6-33), one lane per chain, direct summation
+__global__ __launch_bounds__(PC_BLOCK) void k_autocorr(const double* x, i64 ld, i64 N, double* out, i64 ldo,
+                                                       i64 C) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  const double* xc = x + c;
+  double s = 0.0;
+  for (i64 t = 0; t < N; ++t) s = s + xc[t * ld];
+  double mu = s / (double)N;
+  double q = 0.0;
+  for (i64 t = 0; t < N; ++t) {
+    double dv = xc[t * ld] - mu;
+    q = q + dv * dv;
+  }
+  double var0 = q / (double)N;
+  for (i64 n = 0; n < N; ++n) {
+    double a = 0.0;
+    for (i64 t = 0; t + n < N; ++t) a = a + (xc[t * ld] - mu) * (xc[(t + n) * ld] - mu);
+    out[n * ldo + c] = a / var0 / (double)N;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -166,6 +188,14 @@ int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N
   if (C == 0) return BK_OK;
   k_chain_mean_var<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
       x, ld, len, N, mean, var, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C, void* stream) {
+  if (!x || !out || N < 2 || C < 0) return BK_E_ARG;
+  if (ld < C || ldo < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_autocorr<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, out, ldo, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -252,6 +252,11 @@ int bk_rhat_partials(const double* mean, const double* m2, int64_t ld, int64_t n
 int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N,
                       double* mean, double* var, int64_t C, void* stream);
 
+/* Autocorrelation at all lags 0..N-1 of each chain of a stored series, out[n*ldo + c]
+ * (autocorr.py:6-33; same normalisation: / np.var(x) / N).  Direct summation. */
+int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C,
+                void* stream);
+
 /* ESS of each chain of a stored series (ess.py:52-69 -> iat.py:95-135 -> autocorr.py:6-33):
  * autocorrelations by direct summation (same quantity the reference gets by FFT), Geyer
  * initial-positive truncation at the first even lag pair with negative sum, initial

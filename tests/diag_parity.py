@@ -1,0 +1,65 @@
+"""Diagnostics parity bodies shared by the CPU (fake ops) and GPU (HIP) tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bayes_kit_amd as bk
+from tests.helpers import GOLDEN
+
+
+def check_diagnostics(ops, ess_rtol):
+    z = np.load(os.path.join(GOLDEN, "diagnostics.npz"))
+    chains = list(z["rhat_chains"])
+    # reference-style inputs (list of 1-D chains)
+    np.testing.assert_allclose(bk.rhat(chains, ops=ops), z["rhat"], rtol=1e-12)
+    np.testing.assert_allclose(bk.split_rhat(chains, ops=ops), z["split_rhat"], rtol=1e-12)
+    # device matrix [N, C]
+    x = torch.from_numpy(np.ascontiguousarray(z["rhat_chains"].T)).to(ops.device)
+    np.testing.assert_allclose(bk.rhat(x, ops=ops), z["rhat"], rtol=1e-12)
+    np.testing.assert_allclose(bk.split_rhat(x, ops=ops), z["split_rhat"], rtol=1e-12)
+    # ragged (rhat.py:163-171 allows it)
+    ragged = np.split(z["ragged_flat"], np.cumsum(z["ragged_lens"])[:-1])
+    np.testing.assert_allclose(bk.rhat(ragged, ops=ops), z["ragged_rhat"], rtol=1e-12)
+    np.testing.assert_allclose(bk.split_rhat(ragged, ops=ops), z["ragged_split_rhat"], rtol=1e-12)
+    # streaming moments == two-pass mean / var
+    D, C, N = 3, 16, 50
+    rng = np.random.default_rng(0)
+    draws = rng.normal(size=(N, C, D)) + rng.normal(size=(1, C, 1)) * 0.2
+    mom = bk.RunningMoments(D, C, ops=ops)
+    for n in range(N):
+        mom.update(torch.from_numpy(draws[n]).to(ops.device))
+    from oracle import diagnostics as od
+
+    want = [od.rhat([draws[:, c, d] for c in range(C)]) for d in range(D)]
+    np.testing.assert_allclose(mom.rhat(), want, rtol=1e-10)
+    # ESS / IAT / autocorr (ess.py, iat.py, autocorr.py): direct sums vs the reference's FFT
+    ar = z["ar_chains"]
+    xm = torch.from_numpy(np.ascontiguousarray(ar.T)).to(ops.device)
+    np.testing.assert_allclose(bk.ess(xm, ops=ops).cpu().numpy(), z["ar_ess"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.ess_imse(xm, ops=ops).cpu().numpy(), z["ar_ess_imse"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.ess_ipse(xm, ops=ops).cpu().numpy(), z["ar_ess_ipse"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.iat(xm, ops=ops).cpu().numpy(), z["ar_iat"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.iat_ipse(xm, ops=ops).cpu().numpy(), z["ar_iat_ipse"], rtol=ess_rtol)
+    ac = bk.autocorr(xm, ops=ops).cpu().numpy()
+    np.testing.assert_allclose(ac.T, z["ar_autocorr"], rtol=0, atol=1e-12)
+    for i in (0, 7, 15):  # 1-D host inputs, as the reference is called
+        np.testing.assert_allclose(bk.ess(ar[i], ops=ops), z["ar_ess"][i], rtol=ess_rtol)
+        np.testing.assert_allclose(bk.autocorr(ar[i], ops=ops), z["ar_autocorr"][i], rtol=0, atol=1e-12)
+    short = np.split(z["short_flat"], np.cumsum(z["short_lens"])[:-1])
+    np.testing.assert_allclose([bk.ess(c, ops=ops) for c in short], z["short_ess"], rtol=ess_rtol)
+    np.testing.assert_allclose(np.concatenate([bk.autocorr(c, ops=ops) for c in short]), z["short_autocorr_flat"],
+                               rtol=0, atol=1e-12)
+    # known answer held by the reference's test (test/test_autocorr.py:10-14)
+    np.testing.assert_allclose(bk.autocorr([1, 0, 0, 0], ops=ops), [1.0, -0.083, -0.167, -0.25], atol=0.001)
+    # error behaviour (rhat.py:159-162, ess.py:67-68, iat.py, autocorr.py:23-24)
+    with pytest.raises(ValueError):
+        bk.rhat([[1.0, 2.0]], ops=ops)
+    with pytest.raises(ValueError):
+        bk.rhat([[1.0, 2.0], [1.0]], ops=ops)
+    for f in (bk.ess, bk.ess_imse, bk.ess_ipse, bk.iat, bk.iat_imse, bk.iat_ipse):
+        with pytest.raises(ValueError):
+            f([1.0, 2.0, 3.0], ops=ops)
+    with pytest.raises(ValueError):
+        bk.autocorr([1.0], ops=ops)

@@ -228,6 +228,12 @@ class FakeOps:
             if var is not None:
                 var[c] = col.var(ddof=1)
 
+    def autocorr(self, x, out):
+        from oracle import diagnostics as od
+
+        for c in range(x.shape[1]):
+            out.numpy()[:, c] = od.autocorr(x.numpy()[:, c])
+
     def ess(self, x, estimator, ess_out, iat_out=None):
         from oracle import diagnostics as od
 

@@ -236,3 +236,9 @@ def test_drghmc_lane_sets_follow_the_reference_schedule():
         assert got == want, (n, got, want)
         multi += len(got) > 1
     assert multi > 0
+
+
+def test_diagnostics_api_vs_reference_golden():
+    from tests.diag_parity import check_diagnostics
+
+    check_diagnostics(FakeOps(), ess_rtol=1e-12)
