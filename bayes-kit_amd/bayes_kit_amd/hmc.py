@@ -39,11 +39,13 @@ class HMCDiag(ManyChainSampler):
         *,
         chains: Optional[int] = None,
         chain_id0: int = 0,
+        chain_tile: Optional[int] = None,
         ops=None,
     ):
         self._stepsize = stepsize
         self._steps = steps
         self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)
+        self._chain_tile = self._pick_tile(chain_tile)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._rho = torch.empty((D, C), **f64)
@@ -60,6 +62,19 @@ class HMCDiag(ManyChainSampler):
         self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
         self._have_cache = False
         self._draws = 0
+
+    # -- optional cache blocking ----------------------------------------------------------------
+    # chain_tile=T runs the L steps tile by tile over blocks of T chains (chains are
+    # independent, so this is only a schedule).  The idea: keep a tile's three arrays inside
+    # the 256 MiB Infinity Cache.  Measured on MI355X (config 3, T = 8192): the kernels gain
+    # ~5 % from the cache but 8x more, 8x smaller launches lose more than that
+    # (8.1e7 vs 9.8e7 steps/s), so the default is NO tiling; the knob stays for experiments.
+    def _pick_tile(self, chain_tile):
+        C = self._C
+        if chain_tile is None:
+            return C
+        t = int(chain_tile)
+        return C if t <= 0 or t >= C else max(2, t - t % 2)
 
     # -- statistics ---------------------------------------------------------------------------
     def accept_rate(self) -> float:
@@ -99,14 +114,27 @@ class HMCDiag(ManyChainSampler):
                 self._lp_p.copy_(self._lp)
         else:
             g_last = None
-            for n in range(L):
-                last = n == L - 1
-                if n == 0:
-                    ops.kick_drift(th, thp, rho, rho, g, m, eps, True, -half, True, eps)
+            T = self._chain_tile
+            for c0 in range(0, self._C, T):
+                c1 = min(self._C, c0 + T)
+                tile = (c0, c1) != (0, self._C)
+                v = (lambda a: a[:, c0:c1]) if tile else (lambda a: a)
+                th_t, thp_t, rho_t, gp_t, g_t = v(th), v(thp), v(rho), v(self._grad_p), v(g)
+                lp_t = self._lp_p[c0:c1] if tile else self._lp_p
+                gl = None
+                for n in range(L):
+                    last = n == L - 1
+                    if n == 0:
+                        ops.kick_drift(th_t, thp_t, rho_t, rho_t, g_t, m, eps, True, -half, True, eps)
+                    else:
+                        ops.kick_drift(thp_t, thp_t, rho_t, rho_t, gl, m, eps, False, 0.0, True, eps)
+                    want_lp = lp_t if (last and not mirror) else None
+                    gl = self._eval_grad(thp_t, gp_t, want_lp)
+                if tile:
+                    self._materialize(gl, gp_t)
+                    g_last = self._grad_p
                 else:
-                    ops.kick_drift(thp, thp, rho, rho, g_last, m, eps, False, 0.0, True, eps)
-                want_lp = self._lp_p if (last and not mirror) else None
-                g_last = self._eval_grad(thp, self._grad_p, want_lp)
+                    g_last = gl
         # forward half-step + kinetic energy of the proposal [hmc.py:52, :37]
         ops.leapfrog_finish(rho, None, g_last, m, half, False, self._kin1)
         if mirror:

@@ -34,7 +34,7 @@ SEED_CFG3 = 20241
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3):
+def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None):
     """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
     import torch
 
@@ -43,7 +43,7 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     lam = torch.logspace(0, 4, D, dtype=torch.float64)
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
-                   chains=chains, chain_id0=chain_id0)
+                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
     s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(device)[:, None])
@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--chain-tile", type=int, default=None,
+                    help="chains per Infinity-Cache tile (default: no tiling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -118,7 +120,8 @@ def main():
 
     C = args.chains
     D, L = D_CFG3, L_CFG3
-    s = make_cfg3_sampler(C, rank * C, device)
+    s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile)
+    Ct = s._chain_tile
     ops = s._ops
 
     def barrier():
@@ -163,6 +166,7 @@ def main():
             "workload": "BASELINE.json configs[2]: ill-conditioned Gaussian D=1024 (lam=logspace(0,4)), HMC L=64 "
                         "eps=0.006, diag metric of ones, model-opaque gradient op",
             "chains_per_gpu": C, "dims": D, "leapfrog_steps": L, "parallelism": f"chains sharded x{world}",
+            "chain_tile": Ct,
         },
         "accept_rate": accept,
         # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
@@ -172,7 +176,7 @@ def main():
         kd = [a.elapsed_time(b) for a, b in timed["bk_leapfrog_kick_drift"]]
         gr = [a.elapsed_time(b) for a, b in timed["bk_target_diag_gaussian_grad"]]
         kd_ms = sum(kd) / len(kd)
-        bytes_per_launch = 40.0 * D * C
+        bytes_per_launch = 40.0 * D * Ct  # one launch advances one tile of Ct chains by one step
         achieved = bytes_per_launch / (kd_ms * 1e-3) / 1e9
         out["roofline"] = {
             "kernel": "k_kick_drift_v2 (bk_leapfrog_kick_drift)",
@@ -191,8 +195,8 @@ def main():
             out["roofline"]["gradient_kernel"] = {
                 "kernel": "k_gauss_grad_v2 (bk_target_diag_gaussian_grad)",
                 "avg_launch_ms": g_ms,
-                "achieved": 16.0 * D * C / (g_ms * 1e-3) / 1e9,
-                "algorithmic_bytes_per_launch": 16.0 * D * C,
+                "achieved": 16.0 * D * Ct / (g_ms * 1e-3) / 1e9,
+                "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
     if cpu is not None:
         out["cpu_baseline"] = cpu

@@ -148,3 +148,14 @@ def test_diagnostics_vs_reference_golden(ops):
     from tests.diag_parity import check_diagnostics
 
     check_diagnostics(ops, ess_rtol=1e-9)
+
+
+def test_cache_tiling_does_not_change_results(ops):
+    lam = np.logspace(0, 2, 48)
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 7, chains=1000, seed=5, chain_tile=0)
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 7, chains=1000, seed=5, chain_tile=128)
+    assert a._chain_tile == 1000 and b._chain_tile == 128
+    for _ in range(4):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb)

@@ -242,3 +242,15 @@ def test_diagnostics_api_vs_reference_golden():
     from tests.diag_parity import check_diagnostics
 
     check_diagnostics(FakeOps(), ess_rtol=1e-12)
+
+
+def test_cache_tiling_is_only_a_schedule():
+    ops = FakeOps()
+    lam = np.logspace(0, 1, 6)
+    a = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 5, chains=10, seed=5, chain_tile=0, ops=ops)
+    b = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 5, chains=10, seed=5, chain_tile=4, ops=ops)
+    for _ in range(5):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert np.array_equal(ta.numpy(), tb.numpy()) and np.array_equal(la.numpy(), lb.numpy())
+    assert a._chain_tile == 10 and b._chain_tile == 4
