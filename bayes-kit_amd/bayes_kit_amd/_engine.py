@@ -216,6 +216,36 @@ class ManyChainSampler:
     def __iter__(self):
         return self
 
+    # -- hipGraph replay of a whole draw ----------------------------------------------------------
+    # Small problems (e.g. 4096 chains x D=128: 4 MiB arrays) are launch-bound: ~2 L tiny
+    # kernels per draw, each costing more host time than device time.  With graph=True the
+    # launch sequence of one draw is captured once (after an eager warm-up draw) and replayed
+    # as one hipGraph; all per-draw state (RNG table, theta, caches, counters) lives in device
+    # memory, so a replay IS the next draw.  Only for samplers whose draw has no host
+    # synchronisation (batched models; not the single-chain host-model mode, not DRGHMC).
+    def _init_graph(self, graph: bool):
+        self._use_graph = bool(graph)
+        self._graph = None
+        self._graph_warm = 0
+        if self._use_graph and not self._batched:
+            raise ValueError("graph=True needs a batched device model (the host-model mode synchronises)")
+
+    def _run_draw(self, draw_fn):
+        if not self._use_graph:
+            draw_fn()
+            return
+        if self._graph is None:
+            if self._graph_warm < 1:
+                draw_fn()  # eager: first-use initialisation, lazy parameter uploads
+                self._graph_warm += 1
+                return
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                draw_fn()
+            self._graph = g
+        self._graph.replay()
+
     def __next__(self):
         return self.sample()
 

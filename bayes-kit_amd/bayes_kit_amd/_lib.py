@@ -50,6 +50,7 @@ SIGNATURES = {
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
+    "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
@@ -201,8 +202,9 @@ class Ops:
         D, C = rho_in.shape
         if rho_out is not None:
             assert _ld(rho_out) == _ld(rho_in)
-        self._call("bk_leapfrog_finish", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), grad.stride(0),
-                   grad.stride(1), ptr(metric), half, int(negate), ptr(kin_out), C, D, self._s())
+        gs = (0, 0) if grad is None else grad.stride()
+        self._call("bk_leapfrog_finish", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), gs[0], gs[1],
+                   ptr(metric), half, int(negate), ptr(kin_out), C, D, self._s())
 
     def mh_accept(self, mode, lp_cur, a_cur, lp_prop, a_prop, log_u, mask, ret, count):
         self._call("bk_mh_accept", mode, ptr(lp_cur), ptr(a_cur), ptr(lp_prop), ptr(a_prop), ptr(log_u),
@@ -280,6 +282,13 @@ class Ops:
             self._call("bk_target_funnel_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
         else:
             raise BkHipError(f"unknown built-in target {kind!r}")
+
+    def hmc_trajectory_gaussian(self, theta_in, theta_out, rho_in, rho_out, lam, metric, eps, steps):
+        D, C = theta_in.shape
+        ld = _ld(theta_in)
+        assert _ld(theta_out) == ld and _ld(rho_in) == ld and _ld(rho_out) == ld
+        self._call("bk_hmc_trajectory_gaussian", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
+                   ptr(lam), ptr(metric), eps, steps, C, D, self._s())
 
     def relayout(self, src, dst):
         """dst[d, c] = src[d, c] for logical [D, C] tensors of any strides (LDS-tiled)."""

@@ -40,12 +40,18 @@ class HMCDiag(ManyChainSampler):
         chains: Optional[int] = None,
         chain_id0: int = 0,
         chain_tile: Optional[int] = None,
+        graph: bool = False,
+        fuse_builtin: bool = True,
         ops=None,
     ):
         self._stepsize = stepsize
         self._steps = steps
         self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)
         self._chain_tile = self._pick_tile(chain_tile)
+        self._init_graph(graph)
+        # built-in separable targets can run the whole trajectory in registers
+        # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
+        self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._rho = torch.empty((D, C), **f64)
@@ -88,6 +94,11 @@ class HMCDiag(ManyChainSampler):
 
     # -- one draw for every chain ------------------------------------------------------------------
     def sample(self):
+        self._run_draw(self._draw)
+        self._draws += 1
+        return self._draw_out(self._theta_dc, self._ret)
+
+    def _draw(self):
         ops = self._ops
         eps, L, m = float(self._stepsize), int(self._steps), self._metric_dev
         half = 0.5 * eps
@@ -96,6 +107,19 @@ class HMCDiag(ManyChainSampler):
 
         # momentum + kinetic energy [hmc.py:56, :37]
         ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, rho, m, self._kin0)
+
+        if self._fused:
+            if not self._have_cache:
+                self._eval_logp(th, self._lp)
+                self._have_cache = True
+            self._model.bk_hmc_trajectory(th, thp, rho, rho, m, eps, L)        # [hmc.py:40-53]
+            ops.leapfrog_finish(rho, None, None, m, 0.0, False, self._kin1)    # kinetic term [hmc.py:37]
+            self._eval_logp(thp, self._lp_p)
+            ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
+            ops.mh_accept(_lib.ACCEPT_HMC, self._lp, self._kin0, self._lp_p, self._kin1, self._logu,
+                          self._mask, self._ret, self._accepted)
+            ops.select_columns(self._mask, th, thp)
+            return
 
         if mirror:
             self._eval_logp(th, self._lp)                  # joint_logp(theta, rho)      [hmc.py:57]
@@ -151,5 +175,3 @@ class HMCDiag(ManyChainSampler):
                 ops.select_columns(self._mask, th, thp, self._grad, gp)
             else:
                 ops.select_columns(self._mask, th, thp)
-        self._draws += 1
-        return self._draw_out(th, self._ret)

@@ -18,9 +18,10 @@ from ._engine import ManyChainSampler
 
 class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
-                 chain_id0: int = 0, ops=None):
+                 chain_id0: int = 0, graph: bool = False, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
+        self._init_graph(graph)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_p = torch.empty((D, C), **f64)
@@ -55,6 +56,11 @@ class MALA(ManyChainSampler):
         return self._grad.t() if self._batched else self._grad[:, 0].cpu().numpy()
 
     def sample(self):
+        self._run_draw(self._draw)
+        self._draws += 1
+        return self._draw_out(self._theta_dc, self._ret)
+
+    def _draw(self):
         ops = self._ops
         eps = float(self._epsilon)
         th, thp = self._theta_dc, self._theta_p
@@ -65,5 +71,3 @@ class MALA(ManyChainSampler):
         ops.mh_accept(_lib.ACCEPT_MALA, self._lp, self._fwd, self._lp_p, self._rev, self._logu,
                       self._mask, self._ret, self._accepted)
         ops.select_columns(self._mask, th, thp, self._grad, gp)
-        self._draws += 1
-        return self._draw_out(th, self._ret)

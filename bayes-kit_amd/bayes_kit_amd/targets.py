@@ -64,6 +64,10 @@ class IsoGaussian(_BuiltinTarget):
 
     _kind = "iso_gaussian"
 
+    def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
+        """Whole leapfrog trajectory with the gradient inlined (register-resident)."""
+        self._get_ops().hmc_trajectory_gaussian(theta_in, theta_out, rho_in, rho_out, None, metric, eps, steps)
+
 
 class DiagGaussian(_BuiltinTarget):
     """logp = -1/2 sum_i lam_i theta_i^2 (BASELINE.json config 3)."""
@@ -75,10 +79,19 @@ class DiagGaussian(_BuiltinTarget):
         super().__init__(lam_t.shape[0], ops)
         self._lam_host = lam_t
 
+    def _lam(self, device):
+        if self._params is None or self._params.device != device:
+            self._params = self._lam_host.to(device).contiguous()
+        return self._params
+
     def bk_eval(self, theta_dc, grad_out, logp_out):
-        if self._params is None or self._params.device != theta_dc.device:
-            self._params = self._lam_host.to(theta_dc.device).contiguous()
+        self._lam(theta_dc.device)
         super().bk_eval(theta_dc, grad_out, logp_out)
+
+    def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
+        """Whole leapfrog trajectory with the gradient inlined (register-resident)."""
+        self._get_ops().hmc_trajectory_gaussian(theta_in, theta_out, rho_in, rho_out, self._lam(theta_in.device),
+                                                metric, eps, steps)
 
 
 class Funnel(_BuiltinTarget):

@@ -196,14 +196,14 @@ __global__ __launch_bounds__(PC_BLOCK) void k_finish(const double* rho_in, doubl
     for (int u = 0; u < PC_UNROLL; ++u)
       if (d0 + u < D) {
         r[u] = rho_in[(d0 + u) * ld + c];
-        g[u] = grad[(d0 + u) * ldg_d + c * ldg_c];
+        g[u] = grad ? grad[(d0 + u) * ldg_d + c * ldg_c] : 0.0;
       }
 #pragma unroll
     for (int u = 0; u < PC_UNROLL; ++u)
       if (d0 + u < D) {
         double m = metric ? metric[d0 + u] : 1.0;
         double t = metric ? m * g[u] : g[u];
-        double v = r[u] + half * t;
+        double v = grad ? r[u] + half * t : r[u];  // grad NULL: kinetic energy of rho_in as is
         if (negate) v = -v;
         if (rho_out) rho_out[(d0 + u) * ld + c] = v;
         double mv = metric ? m * v : v;
@@ -396,7 +396,7 @@ int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, 
 int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld, const double* grad,
                        int64_t ldg_d, int64_t ldg_c, const double* metric, double half, int negate,
                        double* kin_out, int64_t C, int64_t D, void* stream) {
-  if (!rho_in || !grad || C < 0 || D < 0) return BK_E_ARG;
+  if (!rho_in || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   k_finish<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(

@@ -115,6 +115,74 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
   }
 }
 
+// Whole HMC trajectory of the separable Gaussians in registers (hmc.py:40-53 with
+// grad = -(lam*theta) inlined): every (d, c) element is independent of all others through
+// the L steps, so theta and rho are read once and written once (32 B per element per
+// TRAJECTORY instead of 56 B per element per STEP) and the kernel is bound by the fp64
+// vector units, not by HBM.  The per-element operation sequence is exactly the one the
+// step-by-step kernels execute, so the results are bit-identical.
+template <int ROWS>
+__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss(const double* th_in, double* th_out,
+                                                         const double* rho_in, double* rho_out, i64 ld,
+                                                         const double* lam, const double* metric, double eps,
+                                                         int steps, i64 C2, i64 D) {
+  i64 c2 = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * ROWS;
+  if (c2 >= C2) return;
+  const double half = 0.5 * eps;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    i64 d = d0 + i;
+    if (d >= D) break;
+    dvec2 th = *reinterpret_cast<const dvec2*>(th_in + d * ld + 2 * c2);
+    dvec2 r = *reinterpret_cast<const dvec2*>(rho_in + d * ld + 2 * c2);
+    const double l = lam ? lam[d] : 1.0, m = metric ? metric[d] : 1.0;
+    const bool hl = lam != nullptr, hm = metric != nullptr;
+    double gx = hl ? -(l * th.x) : -th.x, gy = hl ? -(l * th.y) : -th.y;
+    double tx = hm ? m * gx : gx, ty = hm ? m * gy : gy;
+    r.x = r.x + (-half) * tx;  // hmc.py:46
+    r.y = r.y + (-half) * ty;
+    for (int n = 0; n < steps; ++n) {
+      r.x = r.x + eps * tx;  // hmc.py:48
+      r.y = r.y + eps * ty;
+      th.x = th.x + eps * r.x;  // hmc.py:49
+      th.y = th.y + eps * r.y;
+      gx = hl ? -(l * th.x) : -th.x;  // hmc.py:50
+      gy = hl ? -(l * th.y) : -th.y;
+      tx = hm ? m * gx : gx;
+      ty = hm ? m * gy : gy;
+    }
+    r.x = r.x + half * tx;  // hmc.py:52
+    r.y = r.y + half * ty;
+    *reinterpret_cast<dvec2*>(th_out + d * ld + 2 * c2) = th;
+    *reinterpret_cast<dvec2*>(rho_out + d * ld + 2 * c2) = r;
+  }
+}
+
+__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_s(const double* th_in, double* th_out,
+                                                           const double* rho_in, double* rho_out, i64 ld,
+                                                           const double* lam, const double* metric, double eps,
+                                                           int steps, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
+  i64 d = blockIdx.y;
+  if (c >= C) return;
+  const double half = 0.5 * eps;
+  double th = th_in[d * ld + c], r = rho_in[d * ld + c];
+  const double l = lam ? lam[d] : 1.0, m = metric ? metric[d] : 1.0;
+  double g = lam ? -(l * th) : -th;
+  double t = metric ? m * g : g;
+  r = r + (-half) * t;
+  for (int n = 0; n < steps; ++n) {
+    r = r + eps * t;
+    th = th + eps * r;
+    g = lam ? -(l * th) : -th;
+    t = metric ? m * g : g;
+  }
+  r = r + half * t;
+  th_out[d * ld + c] = th;
+  rho_out[d * ld + c] = r;
+}
+
 int gauss(const double* theta, double* grad, double* logp, i64 ld, const double* lam, i64 C, i64 D,
           void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 0) return BK_E_ARG;
@@ -154,6 +222,27 @@ int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp
                                  const double* lam, int64_t C, int64_t D, void* stream) {
   if (!lam) return BK_E_ARG;
   return gauss(theta, grad, logp, ld, lam, C, D, stream);
+}
+
+int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const double* rho_in,
+                               double* rho_out, int64_t ld, const double* lam, const double* metric,
+                               double eps, int64_t steps, int64_t C, int64_t D, void* stream) {
+  if (!theta_in || !theta_out || !rho_in || !rho_out || steps < 0 || steps > 0x7fffffff || C < 0 || D < 0)
+    return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(theta_in) && bk_aligned16(theta_out) && bk_aligned16(rho_in) &&
+      bk_aligned16(rho_out)) {
+    dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)bk_cdiv(D, 2));
+    k_traj_gauss<2><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps,
+                                                    (int)steps, C / 2, D);
+  } else {
+    dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), (unsigned)D);
+    k_traj_gauss_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps,
+                                                   (int)steps, C, D);
+  }
+  BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,

@@ -34,7 +34,7 @@ SEED_CFG3 = 20241
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None):
+def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False):
     """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
     import torch
 
@@ -43,7 +43,7 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     lam = torch.logspace(0, 4, D, dtype=torch.float64)
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
-                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile)
+                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
     s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(device)[:, None])
@@ -83,16 +83,93 @@ def cpu_baseline(seconds_hint=12.0):
     }
 
 
+def run_other_config(args, rank, local_rank, world):
+    """Secondary workloads (parity-test configs of BASELINE.json), not the headline line:
+    --config 2: iso-Gaussian D=128, HMC L=32, 4096 chains (cache-resident, launch-bound);
+    --config 4: Neal's funnel D=101, DRGHMC K=3, 32,768 chains per GPU + R-hat / ESS."""
+    import torch
+    import torch.distributed as dist
+
+    import bayes_kit_amd as bk
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        bk.dist.init_from_env()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.config == 2:
+        C, D, L = args.chains or 4096, 128, 32
+        s = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
+                       chains=C, chain_id0=rank * C, graph=not args.no_graph)
+        for _ in range(args.warmup):
+            s.sample()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            s.sample()
+        barrier()
+        el = time.perf_counter() - t0
+        out = {"metric": "leapfrog steps/sec, iso-Gaussian D=128 x 4096 chains per GPU, HMC L=32", "value": C * world * L * args.steps / el,
+               "unit": "leapfrog steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * el / args.steps, "us_per_leapfrog_step": 1e6 * el / args.steps / L,
+               "accept_rate": s.accept_rate(), "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]", "chains_per_gpu": C, "dims": D, "leapfrog_steps": L},
+               "note": "4 MiB arrays: cache-resident and launch-bound; HBM fraction not meaningful"}
+    else:
+        C, D = args.chains or 32768, 101
+        s = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, chain_id0=rank * C,
+                          seed=20242)
+        mom = bk.RunningMoments(D, C)
+        N = args.steps
+        series = torch.empty((4, N, C), dtype=torch.float64, device=device)
+        for _ in range(args.warmup):
+            s.sample()
+        lane_steps = 0
+        barrier()
+        t0 = time.perf_counter()
+        for n in range(N):
+            th, lp = s.sample()
+            lane_steps += s.last_lane_steps
+            mom.update(s._theta_dc)
+            series[0, n], series[1, n], series[2, n], series[3, n] = th[:, 0], th[:, 1], th[:, D - 1], lp
+        barrier()
+        el = time.perf_counter() - t0
+        rh = mom.rhat()
+        ess = torch.stack([bk.ess(series[i]) for i in range(4)]).min(dim=0).values
+        ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), device)
+        lane_total = bk.dist.sum_over_ranks(float(lane_steps), device)
+        out = {"metric": "DRGHMC funnel D=101 K=3: gradient evaluations/sec (chain-steps actually run)",
+               "value": lane_total / el, "unit": "gradient evaluations/sec", "n_gpus": world, "steps": N,
+               "warmup": args.warmup, "ms_per_step": 1e3 * el / N, "draws_per_sec": C * world * N / el,
+               "mean_grad_evals_per_draw": lane_total / (C * world * N), "rhat_max": float(rh.max()),
+               "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[3]", "chains_per_gpu": C, "dims": D, "max_proposals": 3}}
+    out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None})
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=65536, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the config's)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
+                    help="3 = headline (default); 2 and 4 = secondary workloads")
     ap.add_argument("--chain-tile", type=int, default=None,
                     help="chains per Infinity-Cache tile (default: no tiling)")
+    ap.add_argument("--no-graph", action="store_true", help="config 2: eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-fused-extra", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,6 +179,10 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
+
+    if args.config != 3:
+        return run_other_config(args, rank, local_rank, world)
+    args.chains = args.chains or 65536
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -198,6 +279,36 @@ def main():
                 "achieved": 16.0 * D * Ct / (g_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
+    if not args.no_fused_extra:
+        # Separately reported (never priced on the 56*D model): the same workload through the
+        # built-in target's register-resident trajectory kernel (bk_hmc_trajectory_gaussian).
+        # Same results bit for bit; bound by the fp64 vector rate and by the per-draw RNG.
+        del s
+        torch.cuda.empty_cache()
+        f = make_cfg3_sampler(C, rank * C, device, fused=True)
+        ops.timed = {"bk_hmc_trajectory_gaussian": []}
+        for _ in range(2):
+            f.sample()
+        ops.timed = {"bk_hmc_trajectory_gaussian": []}
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            f.sample()
+        barrier()
+        fel = time.perf_counter() - t0
+        tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_trajectory_gaussian"]]
+        ops.timed = None
+        tj_ms = sum(tj) / len(tj)
+        flop = 6.0 * D * C * L  # 4 mul + 2 add per element-step, individually rounded (no FMA)
+        out["fused_builtin"] = {
+            "what": "built-in DiagGaussian, whole trajectory in registers; NOT the model-opaque path, reported "
+                    "separately from `value`",
+            "value": float(C) * L * args.steps / fel, "unit": "leapfrog steps/sec (this rank)",
+            "ms_per_step": 1e3 * fel / args.steps,
+            "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,
+            "fp64_vector_peak_tflops_spec": 78.6,
+            "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3",
+        }
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:

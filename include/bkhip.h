@@ -109,6 +109,7 @@ int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in,
  *     if negate: r = -r                           drghmc.py:345 (momentum flip)
  *     if rho_out: rho_out = r
  *     kin_out[c] = 0.5 * sum_d r*(metric[d]*r)    hmc.py:37, drghmc.py:250
+ * grad NULL: no kick (r = rho_in), i.e. just the kinetic energy of a finished trajectory.
  * The sum runs d = 0..D-1 sequentially per chain (np.dot uses a different order: results
  * agree to ~1e-16 relative, see DESIGN.md tolerances). */
 int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld,
@@ -226,6 +227,16 @@ int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp
                                  const double* lam, int64_t C, int64_t D, void* stream);
 int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld,
                           int64_t C, int64_t D, void* stream);
+
+/* Whole HMC trajectory (hmc.py:40-53) for the separable Gaussian targets with the gradient
+ * callback inlined: back half-step, `steps` x (kick, drift, grad = -(lam*theta)), forward
+ * half-step, all in registers.  lam NULL = iso Gaussian; metric NULL = ones.  Outputs may
+ * alias inputs.  Bit-identical to `steps` calls of bk_leapfrog_kick_drift +
+ * bk_target_*_gaussian_grad followed by bk_leapfrog_finish's half-kick; HBM traffic 32 B per
+ * element per trajectory; bound by the fp64 vector rate (6 flop per element-step). */
+int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const double* rho_in,
+                               double* rho_out, int64_t ld, const double* lam, const double* metric,
+                               double eps, int64_t steps, int64_t C, int64_t D, void* stream);
 
 /* ---- layout helper --------------------------------------------------------------------
  * dst[d*ld + c] = src[c*lds_c + d*lds_d]  (LDS-tiled transpose/copy) -- brings a model's

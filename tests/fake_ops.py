@@ -103,8 +103,10 @@ class FakeOps:
 
     def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out):
         self._count("leapfrog_finish")
-        t = self._mt(metric, grad.numpy())
-        v = rho_in.numpy() + half * t
+        if grad is None:
+            v = rho_in.numpy().copy()
+        else:
+            v = rho_in.numpy() + half * self._mt(metric, grad.numpy())
         if negate:
             v = -v
         if rho_out is not None:
@@ -197,6 +199,21 @@ class FakeOps:
                 grad.numpy()[1:] = -(ev[None, :] * th[1:])
         else:
             raise KeyError(kind)
+
+    def hmc_trajectory_gaussian(self, theta_in, theta_out, rho_in, rho_out, lam, metric, eps, steps):
+        th, r = theta_in.numpy().copy(), rho_in.numpy().copy()
+        lamv = None if lam is None else lam.numpy()[:, None]
+        grad = lambda x: -x if lamv is None else -(lamv * x)
+        half = 0.5 * eps
+        t = self._mt(metric, grad(th))
+        r = r + (-half) * t
+        for _ in range(steps):
+            r = r + eps * t
+            th = th + eps * r
+            t = self._mt(metric, grad(th))
+        r = r + half * t
+        theta_out.numpy()[...] = th
+        rho_out.numpy()[...] = r
 
     def relayout(self, src, dst):
         self._count("relayout")

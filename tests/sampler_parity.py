@@ -32,10 +32,10 @@ def product_model(spec, ops):
     raise KeyError(kind)
 
 
-def build_sampler(case, model, ops, seed, chains=None, chain_id0=0):
+def build_sampler(case, model, ops, seed, chains=None, chain_id0=0, **extra):
     D = model.dims()
     init = None if case.get("init") is None else np.asarray(case["init"], dtype=np.float64)
-    kw = dict(init=init, seed=seed, ops=ops)
+    kw = dict(init=init, seed=seed, ops=ops, **extra)
     if chains is not None:
         kw.update(chains=chains, chain_id0=chain_id0)
     alg = case["alg"]
@@ -55,12 +55,12 @@ def build_sampler(case, model, ops, seed, chains=None, chain_id0=0):
     return s
 
 
-def check_many_chain(name, ops):
+def check_many_chain(name, ops, **extra):
     """All C chains of a golden case in ONE many-chain sampler on a built-in device target."""
     case, z = load_case(name)
     N, C, D = z["draws"].shape
     model = product_model(case["model"], ops)
-    s = build_sampler(case, model, ops, case["seed"], chains=C)
+    s = build_sampler(case, model, ops, case["seed"], chains=C, **extra)
     exact = case["model"]["kind"] != "funnel"
     th0 = s._theta.cpu().numpy()
     np.testing.assert_array_equal(th0, z["theta0"])

@@ -24,6 +24,14 @@ def test_many_chain_vs_reference_golden(name, ops):
     check_many_chain(name, ops)
 
 
+@pytest.mark.parametrize("name", [n for n in MANY if n.startswith("hmc")])
+def test_hmc_step_by_step_path_vs_reference_golden(name, ops):
+    """The model-opaque path (one kick+drift launch and one gradient op per leapfrog step),
+    which is what bench.py measures; the default for built-in Gaussians is the fused one."""
+    s = check_many_chain(name, ops, fuse_builtin=False)
+    assert not s._fused
+
+
 @pytest.mark.parametrize("name", ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init",
                                   "drghmc_stdnormal_k3", "drghmc_k1"])
 def test_single_chain_drop_in_vs_reference_golden(name, ops):
@@ -159,3 +167,38 @@ def test_cache_tiling_does_not_change_results(ops):
         ta, la = a.sample()
         tb, lb = b.sample()
         assert torch.equal(ta, tb) and torch.equal(la, lb)
+
+
+def test_full_size_cfg4_properties(ops):
+    """BASELINE.json config 4 at per-GPU size (32,768 funnel chains, D=101, K=3): a scattered
+    block of chains reproduces a small run exactly (sharding invariance through compaction,
+    ghost levels and scatter), lane accounting is consistent, everything stays finite."""
+    args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
+    big = bk.DrGhmcDiag(bk.Funnel(101), *args, chains=32768, seed=20242)
+    small = bk.DrGhmcDiag(bk.Funnel(101), *args, chains=96, seed=20242, chain_id0=20000)
+    for _ in range(3):
+        tb, lb = big.sample()
+        ts, ls = small.sample()
+        assert torch.equal(tb[20000:20096], ts)
+        assert torch.equal(lb[20000:20096], ls)
+        assert big.last_stage_lanes[0] == ("P0", 32768)
+        assert sum(n * [10, 40, 160][int(t[1])] for t, n in big.last_stage_lanes) == big.last_lane_steps
+    assert torch.isfinite(tb).all() and torch.isfinite(lb).all()
+    assert torch.equal(big._rho[20000:20096], small._rho)
+    np.testing.assert_array_equal(big.rng_state()[:, 20000:20096], small.rng_state())
+
+
+def test_hipgraph_replay_equals_eager(ops):
+    """graph=True replays one captured draw; results identical to eager launches."""
+    for make in (lambda g: bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=20240, graph=g),
+                 lambda g: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 16)), 0.02, chains=512, seed=3, graph=g),
+                 lambda g: bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(dim=1), 8), 0.2, 6,
+                                      chains=256, seed=4, graph=g)):
+        a, b = make(False), make(True)
+        for _ in range(6):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb)
+        assert b._graph is not None
+        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        assert a.accept_rate() == b.accept_rate()

@@ -21,7 +21,15 @@ SINGLE = ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init", "drghmc_std
 
 @pytest.mark.parametrize("name", MANY)
 def test_many_chain_driver_vs_golden(name):
-    check_many_chain(name, FakeOps())
+    s = check_many_chain(name, FakeOps())
+    if name.startswith("hmc"):
+        assert s._fused  # built-in Gaussians take the register-resident trajectory by default
+
+
+@pytest.mark.parametrize("name", [n for n in MANY if n.startswith("hmc")])
+def test_many_chain_driver_vs_golden_step_by_step(name):
+    s = check_many_chain(name, FakeOps(), fuse_builtin=False)
+    assert not s._fused
 
 
 @pytest.mark.parametrize("name", SINGLE)
