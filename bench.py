@@ -50,6 +50,19 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     return s
 
 
+def _pmc_traffic(C, D):
+    """HBM bytes per kick+drift launch from the committed PMC passes (rocprofv3 cannot run
+    inside this process); None if the profile is for another shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_cfg3_traffic.json")) as f:
+            t = json.load(f)
+        if t["chains"] == C and t["dims"] == D:
+            return t["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(seconds_hint=12.0):
     """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler
     object per chain, chains spread over P processes, config-3 shape, bounded sample."""
@@ -266,7 +279,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": _pmc_traffic(C, D),
             "avg_launch_ms": kd_ms,
             "launches": len(kd),
             "algorithmic_bytes_per_launch": bytes_per_launch,

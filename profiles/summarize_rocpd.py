@@ -5,9 +5,16 @@
 
 The first database is a `--kernel-trace --stats` capture (per-kernel time table); any
 further ones are `--pmc <COUNTER> --kernel-trace` captures (per-kernel mean counter value
-per launch).  FETCH_SIZE / WRITE_SIZE are reported in bytes (rocprofv3 unit: KiB); for the
-16-B-per-lane coalesced streaming kernels the gfx950 correction of MI355X_MICROARCH.md
-(FETCH_SIZE reads exactly half of the real bytes) is applied in the `corrected` column.
+per launch, collected in SEPARATE passes).  FETCH_SIZE / WRITE_SIZE are reported in bytes
+(rocprofv3 unit: KiB).  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
+reads exactly half of the bytes of a coalesced streaming read, so the `corrected` column
+doubles it.  Calibration in this repo's own access patterns: k_finish reads two [D][C]
+arrays = 1.0737e9 B and FETCH_SIZE reports 5.369e8 B (8 B/lane); k_kick_drift_v2 reads three
+= 1.6106e9 B and FETCH_SIZE reports 8.054e8 B (16 B/lane) -- exactly 1/2 in both.
+WRITE_SIZE matches the written bytes 1:1 (k_kick_drift_v2 writes two arrays = 1.0737e9 B).
+
+With --json <file> the first PMC rows of k_kick_drift_v2 are also written as the per-launch
+HBM traffic that bench.py reports in roofline.traffic.
 """
 import sqlite3
 import sys
@@ -18,7 +25,15 @@ def short(name):
     return name.split("(")[0][:60]
 
 
+TRAFFIC = {}
+
+
 def main():
+    json_out = None
+    if "--json" in sys.argv:
+        i = sys.argv.index("--json")
+        json_out = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     trace = sqlite3.connect(sys.argv[1])
     print("## kernel time (rocprofv3 --kernel-trace --stats)\n")
     print("| kernel | calls | total ms | avg us | % |")
@@ -33,12 +48,23 @@ def main():
         if not rows:
             continue
         print(f"\n## PMC pass: {rows[0][1]} ({path})\n")
-        print("| kernel | launches | mean value/launch (KiB) | bytes/launch | corrected bytes (x2 for 16-B/lane reads) | avg us |")
+        print("| kernel | launches | mean value/launch (KiB) | bytes/launch | corrected bytes (FETCH x2, gfx950) | avg us |")
         print("|---|---:|---:|---:|---:|---:|")
         for name, ctr, n, val, dur in rows[:8]:
             b = val * 1024
-            corr = b * 2 if ctr == "FETCH_SIZE" and ("_v2" in name) else b
+            corr = b * 2 if ctr == "FETCH_SIZE" else b
+            if "k_kick_drift_v2" in name:
+                TRAFFIC[ctr] = corr
             print(f"| {short(name)} | {n} | {val:.1f} | {b:.4g} | {corr:.4g} | {dur / 1e3:.1f} |")
+    if json_out and "FETCH_SIZE" in TRAFFIC and "WRITE_SIZE" in TRAFFIC:
+        import json
+
+        with open(json_out, "w") as f:
+            json.dump({"kernel": "k_kick_drift_v2", "chains": 65536, "dims": 1024,
+                       "fetch_bytes_corrected": TRAFFIC["FETCH_SIZE"], "write_bytes": TRAFFIC["WRITE_SIZE"],
+                       "traffic_bytes_per_launch": TRAFFIC["FETCH_SIZE"] + TRAFFIC["WRITE_SIZE"],
+                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"},
+                      f, indent=1)
 
 
 if __name__ == "__main__":
