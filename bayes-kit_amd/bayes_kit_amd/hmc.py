@@ -21,6 +21,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -42,6 +43,7 @@ class HMCDiag(ManyChainSampler):
         chain_tile: Optional[int] = None,
         graph: bool = False,
         fuse_builtin: bool = True,
+        prefetch_rng: Optional[bool] = None,
         ops=None,
     ):
         self._stepsize = stepsize
@@ -54,20 +56,37 @@ class HMCDiag(ManyChainSampler):
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
-        self._rho = torch.empty((D, C), **f64)
+        self._rho_bufs = [torch.empty((D, C), **f64)]
         self._theta_p = torch.empty((D, C), **f64)
         self._grad = torch.empty((D, C), **f64)      # gradient at the current point
         self._grad_p = torch.empty((D, C), **f64)    # gradient along / at the end of the trajectory
         self._lp = torch.empty(C, **f64)
         self._lp_p = torch.empty(C, **f64)
-        self._kin0 = torch.empty(C, **f64)
+        self._kin0_bufs = [torch.empty(C, **f64)]
         self._kin1 = torch.empty(C, **f64)
-        self._logu = torch.empty(C, **f64)
+        self._logu_bufs = [torch.empty(C, **f64)]
         self._ret = torch.empty(C, **f64)
         self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
         self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
         self._have_cache = False
         self._draws = 0
+        # Randomness of draw n+1 (momentum, its kinetic energy, the accept uniform) does not
+        # depend on draw n, and the reference consumes it in a fixed order (D normals, then one
+        # uniform: hmc.py:56,60).  With prefetch_rng it is generated on a second HIP stream
+        # while draw n's trajectory streams through HBM on the main one: the RNG kernel is
+        # latency/integer bound (one wavefront per SIMD) and hides under the HBM-bound kernels.
+        if prefetch_rng is None:
+            prefetch_rng = self._batched and not self._use_graph and self._ops.device.type == "cuda"
+        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
+        self._pf_slot = 0
+        self._pf_event = None
+        self._pf_kin_stale = False
+        if self._prefetch:
+            self._rho_bufs.append(torch.empty((D, C), **f64))
+            self._kin0_bufs.append(torch.empty(C, **f64))
+            self._logu_bufs.append(torch.empty(C, **f64))
+            self._side = torch.cuda.Stream(device=dev)
+            self._rng_logical = self._rng_state.clone()  # stream position after the last finished draw
 
     # -- optional cache blocking ----------------------------------------------------------------
     # chain_tile=T runs the L steps tile by tile over blocks of T chains (chains are
@@ -92,6 +111,51 @@ class HMCDiag(ManyChainSampler):
     def last_accept(self):
         return self._mask.bool() if self._batched else bool(self._mask[0].item())
 
+    def _set_metric(self, m):
+        super()._set_metric(m)
+        self._pf_kin_stale = True  # a prefetched kinetic energy was computed with the old metric
+
+    def rng_state(self):
+        if getattr(self, "_prefetch", False) and self._pf_event is not None:
+            self._pf_event.synchronize()
+            return self._rng_logical.cpu().numpy().view(np.uint64)
+        return super().rng_state()
+
+    def _randomness(self, slot):
+        """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
+        ops = self._ops
+        ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
+                             self._metric_dev, self._kin0_bufs[slot])
+        ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])
+
+    def _take_randomness(self):
+        """Buffers holding this draw's randomness; with prefetch also starts the next draw's."""
+        if not self._prefetch:
+            self._randomness(0)
+            return self._rho_bufs[0], self._kin0_bufs[0], self._logu_bufs[0]
+        main = torch.cuda.current_stream()
+        if self._pf_event is None:
+            self._randomness(self._pf_slot)  # very first draw: nothing prefetched yet
+        else:
+            main.wait_event(self._pf_event)
+            if self._pf_kin_stale:
+                self._ops.leapfrog_finish(self._rho_bufs[self._pf_slot], None, None, self._metric_dev, 0.0,
+                                          False, self._kin0_bufs[self._pf_slot])
+        self._pf_kin_stale = False
+        cur = self._pf_slot
+        nxt = 1 - cur
+        # the other slot was last read by the previous draw's kernels, already queued on `main`
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._rng_logical.copy_(self._rng_state)
+            self._randomness(nxt)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pf_event, self._pf_slot = ev, nxt
+        return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
+
     # -- one draw for every chain ------------------------------------------------------------------
     def sample(self):
         self._run_draw(self._draw)
@@ -102,11 +166,13 @@ class HMCDiag(ManyChainSampler):
         ops = self._ops
         eps, L, m = float(self._stepsize), int(self._steps), self._metric_dev
         half = 0.5 * eps
-        th, thp, rho = self._theta_dc, self._theta_p, self._rho
+        th, thp = self._theta_dc, self._theta_p
         mirror = not self._batched
 
-        # momentum + kinetic energy [hmc.py:56, :37]
-        ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, rho, m, self._kin0)
+        # momentum + kinetic energy + accept uniform [hmc.py:56, :37, :60]; the uniform is drawn
+        # right after the D normals -- the same stream order as the reference, whose uniform is
+        # the next value of the stream whatever happens in between
+        rho, kin0, logu = self._take_randomness()
 
         if self._fused:
             if not self._have_cache:
@@ -115,8 +181,7 @@ class HMCDiag(ManyChainSampler):
             self._model.bk_hmc_trajectory(th, thp, rho, rho, m, eps, L)        # [hmc.py:40-53]
             ops.leapfrog_finish(rho, None, None, m, 0.0, False, self._kin1)    # kinetic term [hmc.py:37]
             self._eval_logp(thp, self._lp_p)
-            ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
-            ops.mh_accept(_lib.ACCEPT_HMC, self._lp, self._kin0, self._lp_p, self._kin1, self._logu,
+            ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                           self._mask, self._ret, self._accepted)
             ops.select_columns(self._mask, th, thp)
             return
@@ -164,8 +229,7 @@ class HMCDiag(ManyChainSampler):
         if mirror:
             self._eval_logp(thp, self._lp_p)                # joint_logp(theta_prop, rho_prop) [hmc.py:59]
         # accept [hmc.py:60-63]
-        ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
-        ops.mh_accept(_lib.ACCEPT_HMC, self._lp, self._kin0, self._lp_p, self._kin1, self._logu,
+        ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                       self._mask, self._ret, self._accepted)
         if mirror:
             ops.select_columns(self._mask, th, thp)

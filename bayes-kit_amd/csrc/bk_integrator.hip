@@ -183,10 +183,12 @@ __global__ __launch_bounds__(PC_BLOCK) void k_first_step_gather(
 }
 
 // ---- final half-kick + kinetic energy ---------------------------------------------------
+constexpr int FIN_UNROLL = 16;  // 32 loads in flight per lane: the kernel has only C/64 wavefronts
 __global__ __launch_bounds__(PC_BLOCK) void k_finish(const double* rho_in, double* rho_out, i64 ld,
                                                      const double* grad, i64 ldg_d, i64 ldg_c,
                                                      const double* metric, double half, int negate,
                                                      double* kin_out, i64 C, i64 D) {
+  constexpr int PC_UNROLL = FIN_UNROLL;
   i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
   if (c >= C) return;
   double kin = 0.0;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void k_mh_accept(int mode, double* lp_cur, con
 }
 
 // ---- masked column copy -----------------------------------------------------------------
-constexpr int SEL_ROWS = 4;
+constexpr int SEL_ROWS = 8;
 __global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst0, const double* src0,
                                                 double* dst1, const double* src1, i64 ld, i64 C,
                                                 i64 D) {
@@ -266,6 +268,40 @@ __global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst
       dst0[(d0 + i) * ld + c] = a[i];
       if (dst1) dst1[(d0 + i) * ld + c] = b[i];
     }
+}
+
+// two chains (16 B) per lane; a pair is copied only where needed (per-chain mask kept exact)
+__global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* dst0, const double* src0,
+                                                   double* dst1, const double* src1, i64 ld, i64 C2,
+                                                   i64 D) {
+  i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * SEL_ROWS;
+  if (c2 >= C2) return;
+  const bool m0 = mask[2 * c2] != 0, m1 = mask[2 * c2 + 1] != 0;
+  if (!m0 && !m1) return;
+  dvec2 a[SEL_ROWS], b[SEL_ROWS];
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) {
+      a[i] = *reinterpret_cast<const dvec2*>(src0 + (d0 + i) * ld + 2 * c2);
+      if (dst1) b[i] = *reinterpret_cast<const dvec2*>(src1 + (d0 + i) * ld + 2 * c2);
+    }
+  if (m0 && m1) {
+#pragma unroll
+    for (int i = 0; i < SEL_ROWS; ++i)
+      if (d0 + i < D) {
+        *reinterpret_cast<dvec2*>(dst0 + (d0 + i) * ld + 2 * c2) = a[i];
+        if (dst1) *reinterpret_cast<dvec2*>(dst1 + (d0 + i) * ld + 2 * c2) = b[i];
+      }
+  } else {
+    const int o = m0 ? 0 : 1;
+#pragma unroll
+    for (int i = 0; i < SEL_ROWS; ++i)
+      if (d0 + i < D) {
+        dst0[(d0 + i) * ld + 2 * c2 + o] = m0 ? a[i].x : a[i].y;
+        if (dst1) dst1[(d0 + i) * ld + 2 * c2 + o] = m0 ? b[i].x : b[i].y;
+      }
+  }
 }
 
 // ---- MALA proposal log densities --------------------------------------------------------
@@ -420,8 +456,13 @@ int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0, dou
   if (!mask || !dst0 || !src0 || (dst1 && !src1) || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
-  k_select<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C, D);
+  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(dst0) && bk_aligned16(src0) && (!dst1 || (bk_aligned16(dst1) && bk_aligned16(src1)))) {
+    dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
+    k_select_v2<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C / 2, D);
+  } else {
+    dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
+    k_select<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C, D);
+  }
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_s(const double* th, dou
 // logp (and optionally grad) of the separable Gaussians, one lane per chain
 __global__ __launch_bounds__(PC_BLOCK) void k_gauss_logp(const double* th, double* g, double* logp, i64 ld,
                                                          const double* lam, i64 C, i64 D) {
+  constexpr int PC_UNROLL = 32;  // loads in flight per lane: the kernel has only C/64 wavefronts
   i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
   if (c >= C) return;
   double s = 0.0;

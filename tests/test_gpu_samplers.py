@@ -202,3 +202,22 @@ def test_hipgraph_replay_equals_eager(ops):
         assert b._graph is not None
         np.testing.assert_array_equal(a.rng_state(), b.rng_state())
         assert a.accept_rate() == b.accept_rate()
+
+
+def test_rng_prefetch_stream_is_only_a_schedule(ops):
+    """Generating draw n+1's randomness on a side stream during draw n changes nothing."""
+    lam = np.logspace(0, 2, 64)
+    for fused in (False, True):
+        a = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=False, fuse_builtin=fused)
+        b = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=True, fuse_builtin=fused)
+        assert b._prefetch and not a._prefetch
+        for n in range(8):
+            if n == 4:  # a metric assigned between draws must reach the prefetched kinetic energy
+                m = np.linspace(0.9, 1.1, 64)
+                a._metric = m
+                b._metric = m
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (fused, n)
+            np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        assert a.accept_rate() == b.accept_rate()
