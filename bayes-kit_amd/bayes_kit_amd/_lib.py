@@ -51,6 +51,7 @@ SIGNATURES = {
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
+    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
@@ -289,6 +290,17 @@ class Ops:
         assert _ld(theta_out) == ld and _ld(rho_in) == ld and _ld(rho_out) == ld
         self._call("bk_hmc_trajectory_gaussian", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
                    ptr(lam), ptr(metric), eps, steps, C, D, self._s())
+
+    def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                           kin_out, metric, h, steps):
+        D, n = theta_out.shape
+        ld_in = _ld(theta_in)
+        assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
+        ld_out = _ld(theta_out)
+        assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
+        self._call("bk_dr_proposal_funnel", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
+                   ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
+                   h, steps, n, D, self._s())
 
     def relayout(self, src, dst):
         """dst[d, c] = src[d, c] for logical [D, C] tensors of any strides (LDS-tiled)."""

@@ -65,6 +65,7 @@ class DrGhmcDiag(ManyChainSampler):
         *,
         chains: Optional[int] = None,
         chain_id0: int = 0,
+        fuse_builtin: bool = True,
         ops=None,
     ):
         self._max_proposals = max_proposals
@@ -92,6 +93,9 @@ class DrGhmcDiag(ManyChainSampler):
         self._levels = [_Level(D, C, dev) for _ in range(int(max_proposals))]
         self._have_cache = False
         self._draws = 0
+        # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
+        # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
+        self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
         self.last_grad_evals = 0        # model calls in the last draw (each over a lane set)
         self.last_lane_steps = 0        # sum over trajectories of lanes x steps (useful work)
         self.last_stage_lanes = []      # (tag, lanes) of every trajectory run in the last draw
@@ -165,15 +169,18 @@ class DrGhmcDiag(ManyChainSampler):
         h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
         dst = self._levels[lvl]
         th, rho, gbuf = dst.theta[:, :n], dst.rho[:, :n], dst.grad[:, :n]
+        self.last_grad_evals += steps
+        self.last_lane_steps += steps * n
+        self.last_stage_lanes.append((tag, n))
+        if self._fused and self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, th, rho, gbuf,
+                                                      dst.logp[:n], dst.kin[:n], m, h, steps):
+            return
         ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h)
         for _ in range(steps - 1):
             g = self._eval_grad(th, gbuf, None)
             ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h)
         g = self._materialize(self._eval_grad(th, gbuf, dst.logp[:n]), gbuf)
         ops.leapfrog_finish(rho, rho, g, m, 0.5 * h, True, dst.kin[:n])
-        self.last_grad_evals += steps
-        self.last_lane_steps += steps * n
-        self.last_stage_lanes.append((tag, n))
 
     def _accept(self, lvl, n, k, cur_h, cur_H, cur_idx, tag):
         """log acceptance probability of the level-lvl lanes against their parents

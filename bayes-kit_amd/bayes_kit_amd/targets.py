@@ -98,6 +98,16 @@ class Funnel(_BuiltinTarget):
     """Neal's funnel: v = theta_0 ~ N(0, 9), theta_i ~ N(0, e^v) (BASELINE.json config 4)."""
 
     _kind = "funnel"
+    _FUSED_MAX_D = 129  # bk_dr_proposal_funnel keeps a chain's coordinates in one workgroup's registers
+
+    def bk_dr_proposal(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                       kin_out, metric, h, steps):
+        """Whole delayed-rejection proposal in one launch; False if the shape is unsupported."""
+        if self._D > self._FUSED_MAX_D:
+            return False
+        self._get_ops().dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
+                                           logp_out, kin_out, metric, h, steps)
+        return True
 
 
 class TorchModel:

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(PC_BLOCK) void k_gauss_logp(const double* th, doubl
   logp[c] = -0.5 * s;
 }
 
-// Neal's funnel
+// Neal's funnel, any D: one lane per chain, sequential in d
 __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g, double* logp, i64 ld,
                                                      i64 C, i64 D) {
   i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
@@ -113,6 +113,169 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
       for (int u = 0; u < PC_UNROLL; ++u)
         if (d0 + u < D) g[(d0 + u) * ld + c] = -(ev * t[u]);
     }
+  }
+}
+
+// Neal's funnel.  The only coupling between the coordinates of a chain is s = sum_{i>=1}
+// theta_i^2, so a workgroup of 16 wavefronts serves 64 chains: lane = chain, wavefront w owns
+// the rows d = 1 + w + 16 i (kept in registers), and s is reduced through LDS in a FIXED
+// order (each wavefront's rows in increasing d, then wavefronts 0..15), so the result does
+// not depend on how many chains are in flight.  Every wavefront integrates v = theta_0
+// redundantly (it needs exp(-v) for its own rows); wavefront 0 writes it.
+constexpr int FN_WAVES = 16;
+constexpr int FN_ROWS = 8;  // rows per wavefront held in registers: D - 1 <= 128
+constexpr int FN_BLOCK = FN_WAVES * BK_WAVE;
+
+struct FunnelLds {
+  double part[2][FN_WAVES][BK_WAVE];
+};
+
+// sum over the 16 wavefronts' partials for this lane's chain, fixed order; buf alternates per call
+__device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, int lane, double partial) {
+  lds.part[buf][w][lane] = partial;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < FN_WAVES; ++k) s = s + lds.part[buf][k][lane];
+  return s;
+}
+
+// gradient / log density for n chains (chain j in column j)
+__global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
+                                                          i64 n, i64 D) {
+  __shared__ FunnelLds lds;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
+  const bool on = j < n;
+  double x[FN_ROWS];
+  double p = 0.0;
+#pragma unroll
+  for (int i = 0; i < FN_ROWS; ++i) {
+    i64 d = 1 + w + (i64)FN_WAVES * i;
+    x[i] = (on && d < D) ? th[d * ld + j] : 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < FN_ROWS; ++i) {
+    i64 d = 1 + w + (i64)FN_WAVES * i;
+    if (d < D) p = p + x[i] * x[i];
+  }
+  double v = on ? th[j] : 0.0;
+  double s = funnel_reduce(lds, 0, w, lane, p);
+  if (!on) return;
+  double ev = exp(-v);
+  double hn = 0.5 * (double)(D - 1);
+  double he = 0.5 * ev;
+  if (w == 0) {
+    if (logp) logp[j] = ((-(v * v) / 18.0) - hn * v) - he * s;
+    if (g) g[j] = ((-v / 9.0) - hn) + he * s;
+  }
+  if (g) {
+#pragma unroll
+    for (int i = 0; i < FN_ROWS; ++i) {
+      i64 d = 1 + w + (i64)FN_WAVES * i;
+      if (d < D) g[d * ld + j] = -(ev * x[i]);
+    }
+  }
+}
+
+// One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE
+// launch: gather chain idx[j] of the source point, first half-kick with the source's cached
+// gradient + drift, (steps-1) x {gradient, kick, drift}, final gradient + log density,
+// last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers.
+__global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
+    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
+    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
+    const double* metric, double h, int steps, i64 n, i64 D) {
+  __shared__ FunnelLds lds;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
+  const bool on = j < n;
+  const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
+  const double half = 0.5 * h;
+  const double hn = 0.5 * (double)(D - 1);
+  const bool hm = metric != nullptr;
+  double x[FN_ROWS], r[FN_ROWS], m[FN_ROWS];
+  // gather + first half-kick + drift (drghmc.py:276-278)
+#pragma unroll
+  for (int i = 0; i < FN_ROWS; ++i) {
+    i64 d = 1 + w + (i64)FN_WAVES * i;
+    bool ok = on && d < D;
+    x[i] = ok ? th_in[d * ld_in + src] : 0.0;
+    r[i] = ok ? rho_in[d * ld_in + src] : 0.0;
+    double g0 = ok ? g_in[d * ld_in + src] : 0.0;
+    m[i] = (hm && d < D) ? metric[d] : 1.0;
+    double t = hm ? m[i] * g0 : g0;
+    r[i] = r[i] + half * t;
+    x[i] = x[i] + h * r[i];
+  }
+  double v = on ? th_in[src] : 0.0, rv = on ? rho_in[src] : 0.0;
+  const double mv = hm ? metric[0] : 1.0;
+  {
+    double g0 = on ? g_in[src] : 0.0;
+    double t = hm ? mv * g0 : g0;
+    rv = rv + half * t;
+    v = v + h * rv;
+  }
+  int buf = 0;
+  double ev = 0.0, he = 0.0, s = 0.0;
+  for (int step = 0; step < steps; ++step) {
+    // gradient at the current theta (drghmc.py:281 / :285)
+    double p = 0.0;
+#pragma unroll
+    for (int i = 0; i < FN_ROWS; ++i) {
+      i64 d = 1 + w + (i64)FN_WAVES * i;
+      if (d < D) p = p + x[i] * x[i];
+    }
+    s = funnel_reduce(lds, buf, w, lane, p);
+    buf ^= 1;
+    ev = exp(-v);
+    he = 0.5 * ev;
+    double gv = ((-v / 9.0) - hn) + he * s;
+    const bool last = step == steps - 1;
+    const double kick = last ? half : h;  // drghmc.py:286 vs :282
+    {
+      double t = hm ? mv * gv : gv;
+      rv = rv + kick * t;
+      if (!last) v = v + h * rv;  // drghmc.py:283
+    }
+#pragma unroll
+    for (int i = 0; i < FN_ROWS; ++i) {
+      i64 d = 1 + w + (i64)FN_WAVES * i;
+      if (d < D) {
+        double gi = -(ev * x[i]);
+        double t = hm ? m[i] * gi : gi;
+        r[i] = r[i] + kick * t;
+        if (!last) x[i] = x[i] + h * r[i];
+        else if (on) g_out[d * ld_out + j] = gi;
+      }
+    }
+    if (last && on && w == 0) {
+      g_out[j] = gv;
+      logp_out[j] = ((-(v * v) / 18.0) - hn * v) - he * s;
+    }
+  }
+  // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250), outputs
+  double kp = 0.0;
+#pragma unroll
+  for (int i = 0; i < FN_ROWS; ++i) {
+    i64 d = 1 + w + (i64)FN_WAVES * i;
+    if (d < D) {
+      double rr = -r[i];
+      double mr = hm ? m[i] * rr : rr;
+      kp = kp + rr * mr;
+      if (on) {
+        rho_out[d * ld_out + j] = rr;
+        th_out[d * ld_out + j] = x[i];
+      }
+    }
+  }
+  double ksum = funnel_reduce(lds, buf, w, lane, kp);
+  if (on && w == 0) {
+    double rr = -rv;
+    double mr = hm ? mv * rr : rr;
+    rho_out[j] = rr;
+    th_out[j] = v;
+    kin_out[j] = 0.5 * (rr * mr + ksum);
   }
 }
 
@@ -251,8 +414,28 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
   if (!theta || (!grad && !logp) || C < 0 || D < 1) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_funnel<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
-                                                                                         ld, C, D);
+  if (D - 1 <= FN_WAVES * FN_ROWS)
+    k_funnel_coop<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(FN_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
+                                                                                               ld, C, D);
+  else
+    k_funnel<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
+                                                                                           ld, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                          const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                          double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                          int64_t steps, int64_t n, int64_t D, void* stream) {
+  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
+      steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
+    return BK_E_ARG;
+  if (D - 1 > FN_WAVES * FN_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
+  if (ld_out < n) return BK_E_ALIGN;
+  if (n == 0) return BK_OK;
+  k_funnel_traj<<<dim3((unsigned)bk_cdiv(n, BK_WAVE)), dim3(FN_BLOCK), 0, bk_stream(stream)>>>(
+      theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out, ld_out, metric,
+      h, (int)steps, n, D);
   BK_RETURN_LAUNCH_STATUS();
 }
 

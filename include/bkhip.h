@@ -217,7 +217,9 @@ int bk_mala_logq(const double* theta, const double* grad, const double* theta_pr
  * inside the trajectory, hmc.py:45,50).  Operation order = oracle/models.py.
  *   iso     : logp = -0.5*sum th^2            grad = -th
  *   diag    : t = lam*th; logp = -0.5*sum th*t; grad = -t
- *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2
+ *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2 (for D-1 <= 128 summed
+ *             as 16 interleaved partial sums -- rows 1+w, 17+w, ... for w = 0..15 -- then
+ *             over w; sequentially in d otherwise)
  *             logp = ((-(v*v)/18) - (0.5*n)*v) - (0.5*ev)*s
  *             grad0 = ((-v/9) - 0.5*n) + (0.5*ev)*s ; grad_i = -(ev*th_i)
  */
@@ -237,6 +239,21 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
 int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const double* rho_in,
                                double* rho_out, int64_t ld, const double* lam, const double* metric,
                                double eps, int64_t steps, int64_t C, int64_t D, void* stream);
+
+/* One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) on Neal's funnel in a
+ * single launch, gradient callback inlined: chain j of the outputs starts from chain
+ * src_index[j] (NULL = j) of the source point (theta_in, rho_in and the source's cached
+ * gradient grad_in); first half-kick + drift, (steps-1) x {gradient, kick, drift}, final
+ * gradient and log density, last half-kick, momentum flip.  Outputs (compact, ld_out):
+ * theta, -rho, gradient and log density at the proposal, kin = 0.5 sum rho*(metric*rho).
+ * Requires D - 1 <= 128 (returns BK_E_ARG otherwise: use the step-by-step entry points).
+ * The sum over coordinates uses the same fixed order as bk_target_funnel_grad, so the
+ * proposal is bit-identical to the step-by-step path. */
+int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in,
+                          int64_t ld_in, const int32_t* src_index, double* theta_out,
+                          double* rho_out, double* grad_out, double* logp_out, double* kin_out,
+                          int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
+                          int64_t D, void* stream);
 
 /* ---- layout helper --------------------------------------------------------------------
  * dst[d*ld + c] = src[c*lds_c + d*lds_d]  (LDS-tiled transpose/copy) -- brings a model's

@@ -215,6 +215,15 @@ class FakeOps:
         theta_out.numpy()[...] = th
         rho_out.numpy()[...] = r
 
+    def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                           kin_out, metric, h, steps):
+        self.first_step_gather(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, h, 0.5 * h)
+        for _ in range(steps - 1):
+            self.target_grad("funnel", None, theta_out, grad_out, None)
+            self.kick_drift(theta_out, theta_out, rho_out, rho_out, grad_out, metric, h, False, 0.0, True, h)
+        self.target_grad("funnel", None, theta_out, grad_out, logp_out)
+        self.leapfrog_finish(rho_out, rho_out, grad_out, metric, 0.5 * h, True, kin_out)
+
     def relayout(self, src, dst):
         self._count("relayout")
         dst.copy_(src)

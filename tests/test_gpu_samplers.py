@@ -221,3 +221,27 @@ def test_rng_prefetch_stream_is_only_a_schedule(ops):
             assert torch.equal(ta, tb) and torch.equal(la, lb), (fused, n)
             np.testing.assert_array_equal(a.rng_state(), b.rng_state())
         assert a.accept_rate() == b.accept_rate()
+
+
+def test_drghmc_fused_proposal_equals_step_by_step(ops):
+    """bk_dr_proposal_funnel (one launch per proposal) vs kick+drift / gradient launches: the
+    coordinate sums use the same fixed order, so theta and rho agree bit for bit; energies
+    differ only through the kinetic-energy sum order."""
+    args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
+    for D, metric in ((11, None), (101, np.linspace(0.9, 1.1, 101)), (129, None)):
+        a = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, fuse_builtin=False)
+        b = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, fuse_builtin=True)
+        assert b._fused and not a._fused
+        if metric is not None:
+            a._metric = metric
+            b._metric = metric
+        for n in range(6):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert a.last_stage_lanes == b.last_stage_lanes, (D, n)
+            assert torch.equal(ta, tb), (D, n)
+            np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-12, atol=1e-12)
+        assert torch.equal(a._rho, b._rho)
+        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    big = bk.DrGhmcDiag(bk.Funnel(200), *args, chains=64, seed=1)  # falls back to the step path
+    big.sample()
