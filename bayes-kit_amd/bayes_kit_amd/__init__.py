@@ -8,8 +8,14 @@ signatures, while the arithmetic runs in hand-written HIP kernels for gfx950
 """
 from . import _lib  # noqa: F401
 from . import dist  # noqa: F401
-from .diagnostics import (RunningMoments, autocorr, ess, ess_imse, ess_ipse, iat, iat_imse, iat_ipse, rhat,
-                          rhat_from_moments, split_rhat)
+from .diagnostics import RunningMoments, rhat_from_moments
+# like the reference (bayes_kit/__init__.py:2-13) the function names shadow the sub-modules of
+# the same name; importing them through the sub-modules keeps `bayes_kit_amd.rhat` a function
+# even after `from bayes_kit_amd.rhat import ...`
+from .autocorr import autocorr
+from .ess import ess, ess_imse, ess_ipse
+from .iat import iat, iat_imse, iat_ipse
+from .rhat import rank_normalized_rhat, rhat, split_rhat
 from .ensemble import Stretcher
 from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
@@ -29,6 +35,7 @@ __all__ = [
     "iat_ipse",
     "rhat",
     "split_rhat",
+    "rank_normalized_rhat",
     "autocorr",
     "RunningMoments",
     "rhat_from_moments",

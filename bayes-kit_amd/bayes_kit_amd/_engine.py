@@ -216,6 +216,51 @@ class ManyChainSampler:
     def __iter__(self):
         return self
 
+    # -- checkpoint / resume -------------------------------------------------------------------
+    # The reference keeps a sampler's whole state in plain attributes (_theta, _rng, for
+    # DRGHMC _rho and the gradient cache, for MALA the cached logp/grad: hmc.py:21-28,
+    # mala.py:31-32, drghmc.py:72-82).  The same here: per-chain tensors plus the RNG table,
+    # small and explicit.  A restored sampler continues bit for bit.
+    def _state_tensors(self):
+        return {"theta": self._theta_dc}
+
+    def _logical_rng(self):
+        return self._rng_state
+
+    def _after_load(self):
+        pass
+
+    def state_dict(self):
+        torch.cuda.synchronize() if self._ops.device.type == "cuda" else None
+        sd = {k: v.detach().cpu().clone() for k, v in self._state_tensors().items()}
+        sd["rng_state"] = self._logical_rng().detach().cpu().clone()
+        sd["meta"] = {"class": type(self).__name__, "chains": self._C, "dims": self._dim,
+                      "rng_kind": self._rng_kind, "chain_id0": self._chain_id0,
+                      "draws": getattr(self, "_draws", 0), "have_cache": getattr(self, "_have_cache", True),
+                      "extra": self._state_extra()}
+        return sd
+
+    def _state_extra(self):
+        return {}
+
+    def load_state_dict(self, sd):
+        meta = sd["meta"]
+        if (meta["class"], meta["chains"], meta["dims"]) != (type(self).__name__, self._C, self._dim):
+            raise ValueError(f"checkpoint is for {meta['class']} with {meta['chains']} chains x {meta['dims']} dims")
+        for k, v in self._state_tensors().items():
+            v.copy_(sd[k].to(v.device))
+        self._rng_kind = meta["rng_kind"]
+        self._rng_state.copy_(sd["rng_state"].to(self._rng_state.device))
+        self._draws = meta["draws"]
+        if hasattr(self, "_have_cache"):
+            self._have_cache = meta["have_cache"]
+        self._load_extra(meta.get("extra", {}))
+        self._graph = None if hasattr(self, "_graph") else None
+        self._after_load()
+
+    def _load_extra(self, extra):
+        pass
+
     # -- hipGraph replay of a whole draw ----------------------------------------------------------
     # Small problems (e.g. 4096 chains x D=128: 4 MiB arrays) are launch-bound: ~2 L tiny
     # kernels per draw, each costing more host time than device time.  With graph=True the

@@ -58,6 +58,7 @@ SIGNATURES = {
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
     "bk_ess": [P, I, I, c_int, P, P, I, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
+    "bk_rank_normalize": [P, F, P, I, P],
     "bk_host_normals": [c_int, P, P, I],
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
@@ -324,6 +325,9 @@ class Ops:
     def chain_mean_var(self, x, lengths, mean, var):
         N, C = x.shape
         self._call("bk_chain_mean_var", ptr(x), _ld(x), ptr(lengths), N, ptr(mean), ptr(var), C, self._s())
+
+    def rank_normalize(self, rank, S, out):
+        self._call("bk_rank_normalize", ptr(rank), float(S), ptr(out), rank.numel(), self._s())
 
     def autocorr(self, x, out):
         N, C = x.shape

@@ -191,6 +191,69 @@ def split_rhat(chains, *, ops=None, group=None):
     return rhat(split_chains(chains), ops=ops, group=group)
 
 
+def _ranks_pooled(flat: torch.Tensor) -> torch.Tensor:
+    """Ascending 1-based ranks of the pooled draws (rhat.py:51-52: argsort().argsort() + 1).
+    Ties get distinct consecutive ranks; numpy leaves their order to its sort, here it is the
+    order of appearance (stable sort)."""
+    order = torch.argsort(flat, stable=True)
+    ranks = torch.empty_like(flat)
+    ranks[order] = torch.arange(1, flat.numel() + 1, dtype=flat.dtype, device=flat.device)
+    return ranks
+
+
+def _pooled(chains, ops):
+    """-> (flat chain-major device vector, list of lengths)."""
+    if _is_matrix(chains):
+        N, M = chains.shape
+        return chains.t().contiguous().reshape(-1), [N] * M
+    arrs = [np.asarray(c, dtype=np.float64).reshape(-1) for c in chains]
+    flat = np.concatenate(arrs) if arrs else np.zeros(0)
+    return torch.from_numpy(flat).to(ops.device), [a.shape[0] for a in arrs]
+
+
+def rank_chains(chains, *, ops=None):
+    """bayes_kit/rhat.py:27-59: chains with every value replaced by its pooled rank."""
+    if len(chains) == 0:
+        return chains
+    ops = _ops(ops)
+    flat, lens = _pooled(chains, ops)
+    ranks = _ranks_pooled(flat)
+    if _is_matrix(chains):
+        return ranks.reshape(len(lens), lens[0]).t()
+    out, pos = [], 0
+    r = ranks.cpu().numpy()
+    for n in lens:
+        out.append(r[pos:pos + n])
+        pos += n
+    return out
+
+
+def rank_normalize_chains(chains, *, ops=None):
+    """bayes_kit/rhat.py:62-108: Phi^-1((rank - 0.325) / (S - 0.25)) (the offset the reference
+    actually uses, not the 3/8 of its docstring)."""
+    ops = _ops(ops)
+    flat, lens = _pooled(chains, ops)
+    S = flat.numel()
+    z = torch.empty_like(flat)
+    ops.rank_normalize(_ranks_pooled(flat), float(S), z)
+    if _is_matrix(chains):
+        return z.reshape(len(lens), lens[0]).t().contiguous()
+    out, pos = [], 0
+    zz = z.cpu().numpy()
+    for n in lens:
+        out.append(zz[pos:pos + n])
+        pos += n
+    return out
+
+
+def rank_normalized_rhat(chains, *, ops=None):
+    """bayes_kit/rhat.py:205-236: split R-hat of the rank-normalised chains.  Single rank: a
+    global rank needs every draw in one place (a cross-GPU sort is future work)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        raise NotImplementedError("rank_normalized_rhat across ranks needs a distributed sort (not built yet)")
+    return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops)
+
+
 # ---------------------------------------------------------------------------------------------
 # autocorr.py / iat.py / ess.py
 # ---------------------------------------------------------------------------------------------

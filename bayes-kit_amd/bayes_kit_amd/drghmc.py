@@ -147,6 +147,15 @@ class DrGhmcDiag(ManyChainSampler):
         if not 0 < damping <= 1:
             raise ValueError(f"damping must be within (0, 1], but found damping of {damping}")
 
+    def _state_tensors(self):
+        return {"theta": self._theta_dc, "rho": self._rho_dc, "grad": self._grad, "lp": self._lp}
+
+    def _state_extra(self):
+        return {"rho_sign": self._rho_sign}
+
+    def _load_extra(self, extra):
+        self._rho_sign = float(extra.get("rho_sign", 1.0))
+
     # -- views ----------------------------------------------------------------------------------------
     @property
     def _rho(self):

@@ -121,6 +121,19 @@ class HMCDiag(ManyChainSampler):
             return self._rng_logical.cpu().numpy().view(np.uint64)
         return super().rng_state()
 
+    def _state_tensors(self):
+        return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
+
+    def _logical_rng(self):
+        if self._prefetch and self._pf_event is not None:
+            self._pf_event.synchronize()
+            return self._rng_logical
+        return self._rng_state
+
+    def _after_load(self):
+        # drop any randomness generated ahead: it is regenerated from the restored stream
+        self._pf_event, self._pf_slot, self._pf_kin_stale = None, 0, False
+
     def _randomness(self, slot):
         """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
         ops = self._ops

@@ -39,6 +39,9 @@ class MALA(ManyChainSampler):
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
+    def _state_tensors(self):
+        return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
+
     def accept_rate(self) -> float:
         n = self._draws * self._C
         return float(self._accepted.item()) / n if n else float("nan")

@@ -157,6 +157,66 @@ __global__ __launch_bounds__(PC_BLOCK) void k_autocorr(const double* x, i64 ld, 
   }
 }
 
+// Inverse standard-normal CDF: Cephes ndtri (what scipy.stats.norm.ppf evaluates; rhat.py:106),
+// same rational approximations and evaluation order, no FMA contraction.
+__device__ __forceinline__ double polevl(double x, const double* c, int n) {
+  double a = c[0];
+  for (int i = 1; i <= n; ++i) a = a * x + c[i];
+  return a;
+}
+__device__ __forceinline__ double p1evl(double x, const double* c, int n) {
+  double a = x + c[0];
+  for (int i = 1; i < n; ++i) a = a * x + c[i];
+  return a;
+}
+__device__ double bk_ndtri(double y0) {
+  const double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
+                        1.39312609387279679503E1, -1.23916583867381258016E0};
+  const double Q0[8] = {1.95448858338141759834E0, 4.67627912898881538453E0,  8.63602421390890590575E1,
+                        -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
+                        1.59056225126211695515E1, -1.18331621121330003142E0};
+  const double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1, 5.71628192246421288162E1,
+                        4.40805073893200834700E1, 1.46849561928858024014E1, 2.18663306850790267539E0,
+                        -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
+  const double Q1[8] = {1.57799883256466749731E1, 4.53907635128879210584E1, 4.13172038254672030440E1,
+                        1.50425385692907503408E1, 2.50464946208309415979E0, -1.42182922854787788574E-1,
+                        -3.80806407691578277194E-2, -9.33259480895457427372E-4};
+  const double P2[9] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
+                        1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
+                        3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
+  const double Q2[8] = {6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
+                        2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
+                        2.89247864745380683936E-6, 6.79019408009981274425E-9};
+  const double expm2 = 0.13533528323661269189, s2pi = 2.50662827463100050242E0;
+  if (y0 <= 0.0) return -INFINITY;
+  if (y0 >= 1.0) return INFINITY;
+  bool neg = true;
+  double y = y0;
+  if (y > 1.0 - expm2) {
+    y = 1.0 - y;
+    neg = false;
+  }
+  if (y > expm2) {
+    y = y - 0.5;
+    double y2 = y * y;
+    double x = y + y * (y2 * polevl(y2, P0, 4) / p1evl(y2, Q0, 8));
+    return x * s2pi;
+  }
+  double x = sqrt(-2.0 * log(y));
+  double x0 = x - log(x) / x;
+  double z = 1.0 / x;
+  double x1 = x < 8.0 ? z * polevl(z, P1, 8) / p1evl(z, Q1, 8) : z * polevl(z, P2, 8) / p1evl(z, Q2, 8);
+  x = x0 - x1;
+  return neg ? -x : x;
+}
+
+// out[i] = ndtri((rank[i] - 0.325) / (S - 0.25))   (rhat.py:104-107; 0.325 as implemented there)
+__global__ __launch_bounds__(256) void k_rank_normalize(const double* rank, double S, double* out, i64 n) {
+  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = bk_ndtri((rank[i] - 0.325) / (S - 0.25));
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +248,13 @@ int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N
   if (C == 0) return BK_OK;
   k_chain_mean_var<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
       x, ld, len, N, mean, var, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void* stream) {
+  if (!rank || !out || n < 0) return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_rank_normalize<<<dim3((unsigned)bk_cdiv(n, 256)), dim3(256), 0, bk_stream(stream)>>>(rank, S, out, n);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -293,35 +293,38 @@ def main():
                 "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
     if not args.no_fused_extra:
-        # Separately reported (never priced on the 56*D model): the same workload through the
-        # built-in target's register-resident trajectory kernel (bk_hmc_trajectory_gaussian).
-        # Same results bit for bit; bound by the fp64 vector rate and by the per-draw RNG.
-        del s
-        torch.cuda.empty_cache()
-        f = make_cfg3_sampler(C, rank * C, device, fused=True)
-        ops.timed = {"bk_hmc_trajectory_gaussian": []}
-        for _ in range(2):
-            f.sample()
-        ops.timed = {"bk_hmc_trajectory_gaussian": []}
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            f.sample()
-        barrier()
-        fel = time.perf_counter() - t0
-        tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_trajectory_gaussian"]]
-        ops.timed = None
-        tj_ms = sum(tj) / len(tj)
-        flop = 6.0 * D * C * L  # 4 mul + 2 add per element-step, individually rounded (no FMA)
-        out["fused_builtin"] = {
-            "what": "built-in DiagGaussian, whole trajectory in registers; NOT the model-opaque path, reported "
-                    "separately from `value`",
-            "value": float(C) * L * args.steps / fel, "unit": "leapfrog steps/sec (this rank)",
-            "ms_per_step": 1e3 * fel / args.steps,
-            "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,
-            "fp64_vector_peak_tflops_spec": 78.6,
-            "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3",
-        }
+        try:
+            # Separately reported (never priced on the 56*D model): the same workload through the
+            # built-in target's register-resident trajectory kernel (bk_hmc_trajectory_gaussian).
+            # Same results bit for bit; bound by the fp64 vector rate and by the per-draw RNG.
+            del s
+            torch.cuda.empty_cache()
+            f = make_cfg3_sampler(C, rank * C, device, fused=True)
+            ops.timed = {"bk_hmc_trajectory_gaussian": []}
+            for _ in range(2):
+                f.sample()
+            ops.timed = {"bk_hmc_trajectory_gaussian": []}
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                f.sample()
+            barrier()
+            fel = time.perf_counter() - t0
+            tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_trajectory_gaussian"]]
+            ops.timed = None
+            tj_ms = sum(tj) / len(tj)
+            flop = 6.0 * D * C * L  # 4 mul + 2 add per element-step, individually rounded (no FMA)
+            out["fused_builtin"] = {
+                "what": "built-in DiagGaussian, whole trajectory in registers; NOT the model-opaque path, reported "
+                        "separately from `value`",
+                "value": float(C) * L * args.steps / fel, "unit": "leapfrog steps/sec (this rank)",
+                "ms_per_step": 1e3 * fel / args.steps,
+                "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,
+                "fp64_vector_peak_tflops_spec": 78.6,
+                "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3",
+            }
+        except Exception as e:  # the extra must never cost the headline line
+            out["fused_builtin"] = {"error": repr(e)}
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:

@@ -280,6 +280,11 @@ int bk_rhat_partials(const double* mean, const double* m2, int64_t ld, int64_t n
 int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N,
                       double* mean, double* var, int64_t C, void* stream);
 
+/* Rank normalisation (rhat.py:62-108): out[i] = Phi^-1((rank[i] - 0.325) / (S - 0.25)), ranks as
+ * doubles (1-based), S = total number of draws; Phi^-1 is Cephes ndtri, the function behind
+ * scipy.stats.norm.ppf, evaluated in the same order. */
+int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void* stream);
+
 /* Autocorrelation at all lags 0..N-1 of each chain of a stored series, out[n*ldo + c]
  * (autocorr.py:6-33; same normalisation: / np.var(x) / N).  Direct summation. */
 int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C,

@@ -23,6 +23,22 @@ def check_diagnostics(ops, ess_rtol):
     ragged = np.split(z["ragged_flat"], np.cumsum(z["ragged_lens"])[:-1])
     np.testing.assert_allclose(bk.rhat(ragged, ops=ops), z["ragged_rhat"], rtol=1e-12)
     np.testing.assert_allclose(bk.split_rhat(ragged, ops=ops), z["ragged_split_rhat"], rtol=1e-12)
+    # rank-normalised R-hat (rhat.py:205-236) incl. the known answers of test/test_rhat.py:113-156
+    rk = list(z["rank_chains"])
+    np.testing.assert_allclose(bk.rank_normalized_rhat(rk, ops=ops), z["rank_normalized_rhat"], rtol=1e-12)
+    xr = torch.from_numpy(np.ascontiguousarray(z["rank_chains"].T)).to(ops.device)
+    np.testing.assert_allclose(bk.rank_normalized_rhat(xr, ops=ops), z["rank_normalized_rhat"], rtol=1e-12)
+    from bayes_kit_amd.rhat import rank_chains, rank_normalize_chains
+
+    got = rank_normalize_chains(rk, ops=ops)
+    np.testing.assert_allclose(np.asarray(got), z["rank_normalized"], rtol=1e-13, atol=0)
+    assert [list(r) for r in rank_chains([[4.2, 5.7], [7.2, 6.1], [-12.9, 107]], ops=ops)] == [[2, 3], [5, 4], [1, 6]]
+    got = rank_normalize_chains([[4.2, 5.7], [7.2, 6.1], [-12.9, 107]], ops=ops)
+    np.testing.assert_allclose(got, [[-0.550, -0.087], [0.889, 0.356], [-1.188, 2.225]], atol=2e-2)
+    import scipy.stats as st
+
+    want = [[st.norm.ppf((r - 0.325) / (6 - 0.25)) for r in row] for row in [[2, 3], [5, 4], [1, 6]]]
+    np.testing.assert_allclose(got, want, rtol=1e-14)
     # streaming moments == two-pass mean / var
     D, C, N = 3, 16, 50
     rng = np.random.default_rng(0)

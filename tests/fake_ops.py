@@ -254,6 +254,11 @@ class FakeOps:
             if var is not None:
                 var[c] = col.var(ddof=1)
 
+    def rank_normalize(self, rank, S, out):
+        import scipy.stats
+
+        out.numpy().reshape(-1)[...] = scipy.stats.norm.ppf((rank.numpy().reshape(-1) - 0.325) / (S - 0.25))
+
     def autocorr(self, x, out):
         from oracle import diagnostics as od
 

@@ -104,3 +104,25 @@ def check_single_chain_host_model(name, ops, chains=None):
         got = s.rng_state()[:, 0]
         want = z["rng_state"][c]
         np.testing.assert_array_equal(got[: len(want)], want)
+
+
+def check_checkpoint_resume(ops, make):
+    """5 draws, checkpoint, 5 more == fresh sampler restored from the checkpoint, 5 draws."""
+    import io
+
+    import torch
+
+    a = make()
+    for _ in range(5):
+        a.sample()
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)
+    more = [a.sample() for _ in range(5)]
+    b = make()
+    buf.seek(0)
+    b.load_state_dict(torch.load(buf, weights_only=False))
+    for th_a, lp_a in more:
+        th_b, lp_b = b.sample()
+        assert np.array_equal(np.asarray(th_a.cpu()), np.asarray(th_b.cpu()))
+        assert np.array_equal(np.asarray(lp_a.cpu()), np.asarray(lp_b.cpu()))
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())

@@ -245,3 +245,15 @@ def test_drghmc_fused_proposal_equals_step_by_step(ops):
         np.testing.assert_array_equal(a.rng_state(), b.rng_state())
     big = bk.DrGhmcDiag(bk.Funnel(200), *args, chains=64, seed=1)  # falls back to the step path
     big.sample()
+
+
+def test_checkpoint_resume(ops):
+    from tests.sampler_parity import check_checkpoint_resume
+
+    lam = np.logspace(0, 1, 24)
+    check_checkpoint_resume(ops, lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.1, 4, chains=700, seed=2))
+    check_checkpoint_resume(ops, lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.1, 4, chains=700, seed=2,
+                                                    fuse_builtin=False, prefetch_rng=False))
+    check_checkpoint_resume(ops, lambda: bk.MALA(bk.DiagGaussian(lam), 0.05, chains=700, seed=2))
+    check_checkpoint_resume(ops, lambda: bk.DrGhmcDiag(bk.Funnel(21), 3, [0.3, 0.1, 0.03], [3, 9, 27], 0.3,
+                                                       chains=700, seed=2))

@@ -262,3 +262,14 @@ def test_cache_tiling_is_only_a_schedule():
         tb, lb = b.sample()
         assert np.array_equal(ta.numpy(), tb.numpy()) and np.array_equal(la.numpy(), lb.numpy())
     assert a._chain_tile == 10 and b._chain_tile == 4
+
+
+def test_checkpoint_resume():
+    from tests.sampler_parity import check_checkpoint_resume
+
+    ops = FakeOps()
+    lam = np.logspace(0, 1, 5)
+    check_checkpoint_resume(ops, lambda: bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.1, 4, chains=6, seed=2, ops=ops))
+    check_checkpoint_resume(ops, lambda: bk.MALA(bk.DiagGaussian(lam, ops=ops), 0.05, chains=6, seed=2, ops=ops))
+    check_checkpoint_resume(ops, lambda: bk.DrGhmcDiag(bk.Funnel(5, ops=ops), 2, [0.3, 0.1], [3, 9], 0.3, chains=6,
+                                                       seed=2, ops=ops))
