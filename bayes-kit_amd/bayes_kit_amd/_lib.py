@@ -52,6 +52,8 @@ SIGNATURES = {
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
+    "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
+    "bk_dot_columns": [P, P, I, F, P, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
@@ -302,6 +304,16 @@ class Ops:
         self._call("bk_dr_proposal_funnel", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                    ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                    h, steps, n, D, self._s())
+
+    def dense_metric_apply(self, M, X, Y):
+        D, C = X.shape
+        assert _ld(Y) == _ld(X) and M.stride(1) == 1
+        self._call("bk_dense_metric_apply", ptr(M), M.stride(0), ptr(X), ptr(Y), _ld(X), C, D, self._s())
+
+    def dot_columns(self, x, y, scale, out):
+        D, C = x.shape
+        assert _ld(y) == _ld(x)
+        self._call("bk_dot_columns", ptr(x), ptr(y), _ld(x), scale, ptr(out), C, D, self._s())
 
     def relayout(self, src, dst):
         """dst[d, c] = src[d, c] for logical [D, C] tensors of any strides (LDS-tiled)."""

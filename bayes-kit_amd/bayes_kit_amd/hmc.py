@@ -44,12 +44,39 @@ class HMCDiag(ManyChainSampler):
         graph: bool = False,
         fuse_builtin: bool = True,
         prefetch_rng: Optional[bool] = None,
+        metric_dense=None,
         ops=None,
     ):
         self._stepsize = stepsize
         self._steps = steps
         self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)
         self._chain_tile = self._pick_tile(chain_tile)
+        # Dense metric (extension; the reference only has metric_diag, and its literal
+        # semantics -- rho ~ N(0, I), kick with m*grad, kinetic rho.(m*rho) -- leave the target
+        # invariant only for m = 1).  The dense form is the proper
+        # preconditioned HMC in the same (theta, velocity) variables: M = velocity covariance
+        # (the inverse mass matrix; ideally ~ the posterior covariance),
+        #     rho = chol(M) @ z,  z ~ N(0, I) from the chain's stream
+        #     kick  rho += eps * (M @ grad),  drift  theta += eps * rho   [hmc.py:46-52 shape]
+        #     kinetic energy 1/2 rho . (M^-1 @ rho)
+        # and it reduces to the reference path exactly for M = I.  Every `matrix @ all chains`
+        # is one fp64 MFMA GEMM (bk_dense_metric_apply).
+        self._M = None
+        if metric_dense is not None:
+            if metric_diag is not None:
+                raise ValueError("give metric_diag or metric_dense, not both")
+            if not self._batched:
+                raise ValueError("metric_dense needs a batched device model")
+            Mt = torch.as_tensor(metric_dense, dtype=torch.float64)
+            if tuple(Mt.shape) != (self._dim, self._dim):
+                raise ValueError(f"metric_dense must be ({self._dim}, {self._dim})")
+            Mt = 0.5 * (Mt + Mt.t())
+            dev_ = self._ops.device
+            self._M = Mt.to(dev_).contiguous()
+            self._M_chol = torch.linalg.cholesky(Mt).to(dev_).contiguous()   # host-side set-up
+            self._M_inv = torch.linalg.inv(Mt)
+            self._M_inv = (0.5 * (self._M_inv + self._M_inv.t())).to(dev_).contiguous()
+            fuse_builtin = False
         self._init_graph(graph)
         # built-in separable targets can run the whole trajectory in registers
         # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
@@ -68,6 +95,9 @@ class HMCDiag(ManyChainSampler):
         self._ret = torch.empty(C, **f64)
         self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
         self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self._M is not None:
+            self._mv = torch.empty((D, C), **f64)      # M @ grad along the trajectory
+            self._mv_rng = torch.empty((D, C), **f64)  # M @ rho of the (possibly prefetched) momentum
         self._have_cache = False
         self._draws = 0
         # Randomness of draw n+1 (momentum, its kinetic energy, the accept uniform) does not
@@ -137,9 +167,32 @@ class HMCDiag(ManyChainSampler):
     def _randomness(self, slot):
         """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
         ops = self._ops
-        ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
-                             self._metric_dev, self._kin0_bufs[slot])
+        if self._M is None:
+            ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
+                                 self._metric_dev, self._kin0_bufs[slot])
+        else:
+            ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._mv_rng, None, None)
+            ops.dense_metric_apply(self._M_chol, self._mv_rng, self._rho_bufs[slot])  # rho = chol(M) @ z
+            self._dense_kinetic(self._rho_bufs[slot], self._kin0_bufs[slot], self._mv_rng)
         ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])
+
+    def _dense_kinetic(self, rho, kin_out, scratch):
+        """kin = 1/2 rho . (M^-1 @ rho)"""
+        self._ops.dense_metric_apply(self._M_inv, rho, scratch)
+        self._ops.dot_columns(rho, scratch, 0.5, kin_out)
+
+    def _mg(self, g):
+        """Gradient as the kick sees it: M @ grad with a dense metric, grad itself otherwise."""
+        if self._M is None:
+            return g
+        self._ops.dense_metric_apply(self._M, self._materialize_dense(g), self._mv)
+        return self._mv
+
+    def _materialize_dense(self, g):
+        if g.dim() == 2 and g.stride(1) == 1:
+            return g
+        self._ops.relayout(g, self._grad_p)
+        return self._grad_p
 
     def _take_randomness(self):
         """Buffers holding this draw's randomness; with prefetch also starts the next draw's."""
@@ -208,9 +261,11 @@ class HMCDiag(ManyChainSampler):
                 self._have_cache = True
             g = self._grad
 
+        if self._M is not None:
+            m = None  # the metric is applied by _mg()
         if L == 0:
             # rho_mid = rho - c*t ; rho1 = rho_mid + c*t ; theta unchanged [hmc.py:46,52]
-            ops.kick_drift(th, thp, rho, rho, g, m, 0.0, True, -half, False, 0.0)
+            ops.kick_drift(th, thp, rho, rho, self._mg(g), m, 0.0, True, -half, False, 0.0)
             g_last = g
             if not mirror:
                 self._lp_p.copy_(self._lp)
@@ -227,9 +282,9 @@ class HMCDiag(ManyChainSampler):
                 for n in range(L):
                     last = n == L - 1
                     if n == 0:
-                        ops.kick_drift(th_t, thp_t, rho_t, rho_t, g_t, m, eps, True, -half, True, eps)
+                        ops.kick_drift(th_t, thp_t, rho_t, rho_t, self._mg(g_t), m, eps, True, -half, True, eps)
                     else:
-                        ops.kick_drift(thp_t, thp_t, rho_t, rho_t, gl, m, eps, False, 0.0, True, eps)
+                        ops.kick_drift(thp_t, thp_t, rho_t, rho_t, self._mg(gl), m, eps, False, 0.0, True, eps)
                     want_lp = lp_t if (last and not mirror) else None
                     gl = self._eval_grad(thp_t, gp_t, want_lp)
                 if tile:
@@ -238,7 +293,11 @@ class HMCDiag(ManyChainSampler):
                 else:
                     g_last = gl
         # forward half-step + kinetic energy of the proposal [hmc.py:52, :37]
-        ops.leapfrog_finish(rho, None, g_last, m, half, False, self._kin1)
+        if self._M is None:
+            ops.leapfrog_finish(rho, None, g_last, m, half, False, self._kin1)
+        else:
+            ops.leapfrog_finish(rho, rho, self._mg(g_last), None, half, False, None)
+            self._dense_kinetic(rho, self._kin1, self._mv)
         if mirror:
             self._eval_logp(thp, self._lp_p)                # joint_logp(theta_prop, rho_prop) [hmc.py:59]
         # accept [hmc.py:60-63]

@@ -255,6 +255,19 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
                           int64_t D, void* stream);
 
+/* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
+ * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix
+ * cores (v_mfma_f64_16x16x4_f64), 128 x 128 workgroup tiles, XCD-aware placement.  Used for
+ * rho = chol(M) @ z, the kick's M @ grad and the kinetic energy's M^-1 @ rho, where the
+ * reference has the elementwise `metric * grad` / `metric * rho` (hmc.py:37,46-52).
+ * 2*D*D*C flop. */
+int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double* Y, int64_t ld,
+                          int64_t C, int64_t D, void* stream);
+
+/* out[c] = scale * sum_d x[d*ld + c] * y[d*ld + c]  (kinetic energy 0.5 * rho . (M rho)). */
+int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, double* out,
+                   int64_t C, int64_t D, void* stream);
+
 /* ---- layout helper --------------------------------------------------------------------
  * dst[d*ld + c] = src[c*lds_c + d*lds_d]  (LDS-tiled transpose/copy) -- brings a model's
  * (C, D) row-major output into the engine's chain-contiguous layout, and back with the

@@ -74,6 +74,44 @@ class HMCDiag:
         return self._theta, h0
 
 
+class HMCDense(HMCDiag):
+    """HMC with a dense metric: NO reference counterpart (parity unpinned).  Specification of
+    the product's MFMA path, in the reference's (theta, velocity) variables (hmc.py:40-63 shape):
+    M = velocity covariance;  rho = chol(M) @ z, z = rng.normal(size=D);  kick rho += eps*(M @ grad);
+    drift theta += eps*rho;  kinetic energy 1/2 rho.(M^-1 @ rho).  Equals HMCDiag for M = I."""
+
+    def __init__(self, model, stepsize, steps, metric_dense, init=None, seed=None):
+        super().__init__(model, stepsize, steps, metric_diag=None, init=init, seed=seed)
+        M = np.asarray(metric_dense, dtype=np.float64)
+        self._M = 0.5 * (M + M.T)
+        self._L = np.linalg.cholesky(self._M)
+        Mi = np.linalg.inv(self._M)
+        self._Minv = 0.5 * (Mi + Mi.T)
+
+    def _joint(self, theta, rho):
+        return self._model.log_density(theta) - 0.5 * np.dot(rho, self._Minv @ rho)
+
+    def sample(self):
+        eps, M = self._stepsize, self._M
+        rho = self._L @ self._rng.normal(size=self._dim)
+        h0 = self._joint(self._theta, rho)
+        theta = self._theta
+        _, g = self._model.log_density_gradient(theta)
+        half = 0.5 * eps
+        r = rho - half * (M @ g)
+        for _ in range(self._steps):
+            r = r + eps * (M @ g)
+            theta = theta + eps * r
+            _, g = self._model.log_density_gradient(theta)
+        rho1 = r + half * (M @ g)
+        h1 = self._joint(theta, rho1)
+        self.last_accept = bool(np.log(self._rng.uniform()) < h1 - h0)
+        if self.last_accept:
+            self._theta = theta
+            return self._theta, h1
+        return self._theta, h0
+
+
 class MALA:
     """bayes_kit/mala.py:14-79 with the accept rule of metropolis.py:41-76."""
 

@@ -224,6 +224,12 @@ class FakeOps:
         self.target_grad("funnel", None, theta_out, grad_out, logp_out)
         self.leapfrog_finish(rho_out, rho_out, grad_out, metric, 0.5 * h, True, kin_out)
 
+    def dense_metric_apply(self, M, X, Y):
+        Y.numpy()[...] = M.numpy() @ X.numpy()
+
+    def dot_columns(self, x, y, scale, out):
+        out.numpy()[...] = scale * np.einsum("dc,dc->c", x.numpy(), y.numpy())
+
     def relayout(self, src, dst):
         self._count("relayout")
         dst.copy_(src)

@@ -126,3 +126,35 @@ def check_checkpoint_resume(ops, make):
         assert np.array_equal(np.asarray(th_a.cpu()), np.asarray(th_b.cpu()))
         assert np.array_equal(np.asarray(lp_a.cpu()), np.asarray(lp_b.cpu()))
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+
+
+def check_dense_metric_hmc(ops, C=40, D=24, draws=6, rtol=1e-10):
+    """HMC with a dense mass matrix vs the oracle's HMCDense (no reference counterpart:
+    parity unpinned; tolerance because M @ v is summed in a different order)."""
+    from oracle import models as om
+    from oracle import samplers as osamp
+
+    rng = np.random.default_rng(42)
+    lam = np.logspace(0, 1, D)
+    A = rng.normal(size=(D, D)) * 0.05
+    M = np.diag(1.0 / lam) + A @ A.T / lam.max()  # near the posterior covariance: a useful metric
+    s = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, metric_dense=M, ops=ops)
+    outs = []
+    for _ in range(draws):
+        th, lp = s.sample()
+        outs.append((np.asarray(th.cpu()), np.asarray(lp.cpu())))
+    for c in range(0, C, max(1, C // 8)):
+        o = osamp.HMCDense(om.DiagGaussian(lam), 0.05, 7, M, seed=np.random.Philox(key=[31, c]))
+        for n in range(draws):
+            oth, olp = o.sample()
+            np.testing.assert_allclose(outs[n][0][c], oth, rtol=rtol, atol=1e-13)
+            np.testing.assert_allclose(outs[n][1][c], olp, rtol=rtol, atol=1e-12)
+    assert 0.3 < s.accept_rate() <= 1.0
+    # M = I: the dense path IS the reference path (multiplying by 1 and adding zeros is exact)
+    a = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, metric_dense=np.eye(D), ops=ops)
+    b = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, fuse_builtin=False, ops=ops)
+    for _ in range(3):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert np.array_equal(np.asarray(ta.cpu()), np.asarray(tb.cpu()))
+        np.testing.assert_allclose(np.asarray(la.cpu()), np.asarray(lb.cpu()), rtol=1e-12)

@@ -341,3 +341,23 @@ def test_dr_scalar_kernels_vs_fake(ops):
         res[name] += [h.cpu().numpy(), live.cpu().numpy()]
     for a_, b_ in zip(res["hip"], res["fake"]):
         np.testing.assert_allclose(a_, b_, rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("D,C", [(16, 16), (128, 128), (130, 200), (64, 1000), (512, 4096), (37, 65), (3, 5)])
+def test_dense_metric_apply_mfma(ops, D, C):
+    """Y = M @ X on the fp64 matrix cores vs NumPy; asymmetric M and X catch any row/column or
+    fragment-layout mix-up."""
+    rng = np.random.default_rng(D * 7 + C)
+    M = rng.normal(size=(D, D))
+    X = rng.normal(size=(D, C))
+    Y = torch.full((D, C), 7.0, dtype=torch.float64, device=ops.device)
+    ops.dense_metric_apply(dev(M, ops), dev(X, ops), Y)
+    want = M @ X
+    np.testing.assert_allclose(Y.cpu().numpy(), want, rtol=1e-12, atol=1e-12 * np.sqrt(D))
+    # identity and a permutation matrix must reproduce X exactly
+    P = np.eye(D)[rng.permutation(D)]
+    ops.dense_metric_apply(dev(P, ops), dev(X, ops), Y)
+    assert np.array_equal(Y.cpu().numpy(), P @ X)
+    out = torch.empty(C, dtype=torch.float64, device=ops.device)
+    ops.dot_columns(dev(X, ops), dev(want, ops), 0.5, out)
+    np.testing.assert_allclose(out.cpu().numpy(), 0.5 * np.einsum("dc,dc->c", X, want), rtol=1e-13)

@@ -257,3 +257,10 @@ def test_checkpoint_resume(ops):
     check_checkpoint_resume(ops, lambda: bk.MALA(bk.DiagGaussian(lam), 0.05, chains=700, seed=2))
     check_checkpoint_resume(ops, lambda: bk.DrGhmcDiag(bk.Funnel(21), 3, [0.3, 0.1, 0.03], [3, 9, 27], 0.3,
                                                        chains=700, seed=2))
+
+
+def test_dense_metric_hmc_vs_oracle(ops):
+    from tests.sampler_parity import check_dense_metric_hmc
+
+    check_dense_metric_hmc(ops, C=300, D=48)
+    check_dense_metric_hmc(ops, C=130, D=130, draws=3)

@@ -273,3 +273,9 @@ def test_checkpoint_resume():
     check_checkpoint_resume(ops, lambda: bk.MALA(bk.DiagGaussian(lam, ops=ops), 0.05, chains=6, seed=2, ops=ops))
     check_checkpoint_resume(ops, lambda: bk.DrGhmcDiag(bk.Funnel(5, ops=ops), 2, [0.3, 0.1], [3, 9], 0.3, chains=6,
                                                        seed=2, ops=ops))
+
+
+def test_dense_metric_driver():
+    from tests.sampler_parity import check_dense_metric_hmc
+
+    check_dense_metric_hmc(FakeOps(), C=8, D=6)
