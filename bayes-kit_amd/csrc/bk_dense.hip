@@ -31,9 +31,23 @@ struct DenseLds {
   double b[2][BK][LDP];  // [k][chain]
 };
 
+template <bool FULL>
 __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const double* X, i64 ld, i64 r0,
                                             i64 c0, i64 k0, i64 D, i64 C, double (&ra)[8], double (&rb)[8]) {
   const int t = threadIdx.x;
+  if (FULL) {  // whole tiles, 16-B aligned rows: four 16-B loads per panel, no bounds checks
+    const dvec2* pa = reinterpret_cast<const dvec2*>(M + (r0 + (t >> 1)) * ldm + k0 + (t & 1) * 8);
+    const dvec2* pb = reinterpret_cast<const dvec2*>(X + (k0 + (t >> 4)) * ld + c0 + (t & 15) * 8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dvec2 va = pa[i], vb = pb[i];
+      ra[2 * i] = va.x;
+      ra[2 * i + 1] = va.y;
+      rb[2 * i] = vb.x;
+      rb[2 * i + 1] = vb.y;
+    }
+    return;
+  }
   // A panel: 128 rows x 16 k, row-major in global (k contiguous): thread -> (row, 8 consecutive k)
   {
     int row = t >> 1, kk = (t & 1) * 8;
@@ -70,8 +84,9 @@ __device__ __forceinline__ void store_panels(DenseLds& lds, int buf, const doubl
   }
 }
 
-__global__ __launch_bounds__(256) void k_dense_apply(const double* M, i64 ldm, const double* X, double* Y,
-                                                     i64 ld, i64 C, i64 D, int row_blocks, int chain_blocks) {
+template <bool FULL>
+__global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm, const double* X, double* Y,
+                                                        i64 ld, i64 C, i64 D, int row_blocks, int chain_blocks) {
   __shared__ DenseLds lds;
   // XCD-aware placement: consecutive slots of one XCD walk the row blocks of one chain block
   const int nblk = row_blocks * chain_blocks;
@@ -99,13 +114,13 @@ __global__ __launch_bounds__(256) void k_dense_apply(const double* M, i64 ldm, c
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
   double ra[8], rb[8];
-  load_panels(M, ldm, X, ld, r0, c0, 0, D, C, ra, rb);
+  load_panels<FULL>(M, ldm, X, ld, r0, c0, 0, D, C, ra, rb);
   store_panels(lds, 0, ra, rb);
   __syncthreads();
   const i64 nk = (D + BK - 1) / BK;
   for (i64 kb = 0; kb < nk; ++kb) {
     const int buf = (int)(kb & 1);
-    if (kb + 1 < nk) load_panels(M, ldm, X, ld, r0, c0, (kb + 1) * BK, D, C, ra, rb);  // in flight under the MFMAs
+    if (kb + 1 < nk) load_panels<FULL>(M, ldm, X, ld, r0, c0, (kb + 1) * BK, D, C, ra, rb);  // in flight under the MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
       double a[4], b[4];
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(256) void k_dense_apply(const double* M, i64 ldm, c
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         i64 r = r0 + wr + 16 * i + l4 + 4 * v;
-        if (r < D && c < C) Y[r * ld + c] = acc[i][j][v];
+        if (FULL || (r < D && c < C)) Y[r * ld + c] = acc[i][j][v];
       }
     }
 }
@@ -172,7 +187,13 @@ int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double*
   int row_blocks = (int)bk_cdiv(D, BM), chain_blocks = (int)bk_cdiv(C, BN);
   int per = (chain_blocks + 7) / 8;
   unsigned grid = (unsigned)(per * 8 * row_blocks);
-  k_dense_apply<<<dim3(grid), dim3(256), 0, bk_stream(stream)>>>(M, ldm, X, Y, ld, C, D, row_blocks, chain_blocks);
+  bool full = (D % BM == 0) && (C % BN == 0) && (ldm % 2 == 0) && (ld % 2 == 0) && bk_aligned16(M) && bk_aligned16(X);
+  if (full)
+    k_dense_apply<true><<<dim3(grid), dim3(256), 0, bk_stream(stream)>>>(M, ldm, X, Y, ld, C, D, row_blocks,
+                                                                        chain_blocks);
+  else
+    k_dense_apply<false><<<dim3(grid), dim3(256), 0, bk_stream(stream)>>>(M, ldm, X, Y, ld, C, D, row_blocks,
+                                                                         chain_blocks);
   BK_RETURN_LAUNCH_STATUS();
 }
 
