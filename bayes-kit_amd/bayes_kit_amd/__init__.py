@@ -20,12 +20,14 @@ from .ensemble import Stretcher
 from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
+from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, mala_kernel, metropolis_kernel
 from .targets import DiagGaussian, Funnel, IsoGaussian, TorchModel
 
 __all__ = [
     "DrGhmcDiag",
     "HMCDiag",
     "MALA",
+    "TemperedLikelihoodSMC",
     "Stretcher",
     "ess",
     "ess_imse",

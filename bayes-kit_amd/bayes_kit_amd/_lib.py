@@ -32,6 +32,7 @@ SIGNATURES = {
     "bk_rng_init_philox": [P, I, c_uint64, c_uint64, I, P],
     "bk_momentum_refresh": [c_int, P, I, P, F, F, P, I, P, P, P, I, I, P],
     "bk_log_uniform": [c_int, P, I, P, P, I, P],
+    "bk_uniform": [c_int, P, I, P, P, I, P],
     "bk_leapfrog_kick_drift": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P],
     "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P],
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
@@ -54,6 +55,8 @@ SIGNATURES = {
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_dot_columns": [P, P, I, F, P, I, I, P],
+    "bk_resample_indices": [P, I, P, I, P, P, P],
+    "bk_gather_columns": [P, P, I, P, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
@@ -183,6 +186,10 @@ class Ops:
     def log_uniform(self, kind, state, out, active=None):
         self._call("bk_log_uniform", kind, ptr(state), state.stride(0), ptr(out), ptr(active),
                    out.shape[0], self._s())
+
+    def uniform(self, kind, state, out, active=None):
+        self._call("bk_uniform", kind, ptr(state), state.stride(0), ptr(out), ptr(active), out.shape[0],
+                   self._s())
 
     # -- integrator -----------------------------------------------------------------------
     def kick_drift(self, theta_in, theta_out, rho_in, rho_out, grad, metric, eps,
@@ -314,6 +321,14 @@ class Ops:
         D, C = x.shape
         assert _ld(y) == _ld(x)
         self._call("bk_dot_columns", ptr(x), ptr(y), _ld(x), scale, ptr(out), C, D, self._s())
+
+    def resample_indices(self, weights, u, cdf_work, idx_out):
+        self._call("bk_resample_indices", ptr(weights), weights.shape[0], ptr(u), u.shape[0], ptr(cdf_work),
+                   ptr(idx_out), self._s())
+
+    def gather_columns(self, index, src, dst):
+        D, m = dst.shape
+        self._call("bk_gather_columns", ptr(index), ptr(src), _ld(src), ptr(dst), _ld(dst), m, D, self._s())
 
     def relayout(self, src, dst):
         """dst[d, c] = src[d, c] for logical [D, C] tensors of any strides (LDS-tiled)."""

@@ -1,0 +1,188 @@
+"""Likelihood-tempered sequential Monte Carlo on the GPU: many-particle counterpart of
+``bayes_kit/smc.py:12-89`` (``TemperedLikelihoodSMC``, ``importance_resample``,
+``metropolis_kernel``).
+
+Same constructor shape ``(model, M, N, sample_initial, kernel)``, ``run()``,
+``transition(n)``, ``time(n)``, ``thetas`` and iteration protocol.  The M particles live in
+one chain-contiguous ``[D, M]`` buffer (one particle per GPU lane); a temperature step is
+
+1. the move kernel applied to every particle at temperature (n-1)/N       [smc.py:53-57]
+2. weights exp(lp_n - lp_{n-1}), multinomial resampling                   [smc.py:60, 64-75]
+
+The reference draws its random numbers from the process-global ``np.random`` (smc.py:73,
+81, 85), which cannot be seeded through its API, so parity is distributional (the moment
+test of test/test_tempered_smc.py).  Here every particle slot owns a Philox stream
+(key = (seed, slot)): proposal normals, the accept uniform and one resampling uniform per
+slot, which makes runs reproducible.
+
+Model: the batched form of ``LogPriorLikelihoodModel`` (typing.py:37-42):
+``log_prior(Theta) -> (M,)``, ``log_likelihood(Theta) -> (M,)`` on a (M, D) device view; for
+the gradient-based move kernel also ``log_density_gradient_tempered(Theta, t)``.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._engine import make_streams
+
+
+class _RWMKernel:
+    """Random-walk Metropolis move, the reference's ``metropolis_kernel(scale)`` (smc.py:79-89)."""
+
+    def __init__(self, scale: float):
+        self.scale = float(scale)
+
+    def move(self, smc, t: float) -> None:
+        ops = smc._ops
+        th, prop = smc._theta_dc, smc._prop_dc
+        lp_cur = smc._tempered(th, t)
+        # theta* = normal(loc=theta, scale) [smc.py:81]
+        ops.momentum_refresh(smc._rng_kind, smc._rng_state, th, 1.0, self.scale, prop, None, None)
+        lp_prop = smc._tempered(prop, t)
+        ops.log_uniform(smc._rng_kind, smc._rng_state, smc._logu)
+        # accept iff log u < lp(theta*) - lp(theta) [smc.py:85]
+        ops.mh_accept(_lib.ACCEPT_MALA, lp_cur, None, lp_prop, None, smc._logu, smc._mask, None, smc._accepted)
+        ops.select_columns(smc._mask, th, prop)
+
+
+class _MALAKernel:
+    """Langevin move (mala.py:40-66 arithmetic) on the tempered density, `steps` times."""
+
+    def __init__(self, epsilon: float, steps: int = 1):
+        self.epsilon, self.steps = float(epsilon), int(steps)
+
+    def move(self, smc, t: float) -> None:
+        ops, eps = smc._ops, self.epsilon
+        th, prop = smc._theta_dc, smc._prop_dc
+        f64 = dict(dtype=torch.float64, device=th.device)
+        lp, g = smc._model.log_density_gradient_tempered(th.t(), t)
+        grad = torch.empty_like(th)
+        ops.relayout(g.t(), grad)
+        lp = lp.clone()
+        grad_p = torch.empty_like(th)
+        fwd, rev = torch.empty(smc.M, **f64), torch.empty(smc.M, **f64)
+        for _ in range(self.steps):
+            ops.mala_propose(smc._rng_kind, smc._rng_state, th, grad, prop, eps, math.sqrt(2 * eps))
+            lp_p, g_p = smc._model.log_density_gradient_tempered(prop.t(), t)
+            ops.relayout(g_p.t(), grad_p)
+            ops.mala_logq(th, grad, prop, grad_p, eps, fwd, rev)
+            ops.log_uniform(smc._rng_kind, smc._rng_state, smc._logu)
+            ops.mh_accept(_lib.ACCEPT_MALA, lp, fwd, lp_p.contiguous(), rev, smc._logu, smc._mask, None,
+                          smc._accepted)
+            ops.select_columns(smc._mask, th, prop, grad, grad_p)
+
+
+def metropolis_kernel(scale: float) -> _RWMKernel:
+    return _RWMKernel(scale)
+
+
+def mala_kernel(epsilon: float, steps: int = 1) -> _MALAKernel:
+    return _MALAKernel(epsilon, steps)
+
+
+class TemperedLikelihoodSMC:
+    def __init__(self, model, M: int, N: int, sample_initial, kernel, *, seed=None, ops=None):
+        self.M, self.N = int(M), int(N)
+        self._model = model
+        self.kernel = kernel
+        self._ops = ops if ops is not None else _lib.default_ops()
+        dev = self._ops.device
+        # initial particles: a callable i -> array-like (smc.py:24) or an (M, D) array / tensor
+        if callable(sample_initial):
+            init = np.array([np.asarray(sample_initial(i), dtype=np.float64).reshape(-1) for i in range(self.M)])
+        else:
+            init = sample_initial
+        init_t = torch.as_tensor(init, dtype=torch.float64)
+        if init_t.dim() != 2 or init_t.shape[0] != self.M:
+            raise ValueError(f"initial particles must have shape ({self.M}, D)")
+        self.D = int(init_t.shape[1])
+        f64 = dict(dtype=torch.float64, device=dev)
+        self._theta_dc = init_t.t().contiguous().to(dev)
+        self._prop_dc = torch.empty_like(self._theta_dc)
+        self._rng_kind, self._rng_state = make_streams(seed, self.M, 0, False, dev)
+        self._logu = torch.empty(self.M, **f64)
+        self._u = torch.empty(self.M, **f64)
+        self._cdf = torch.empty(self.M, **f64)
+        self._idx = torch.empty(self.M, dtype=torch.int32, device=dev)
+        self._mask = torch.empty(self.M, dtype=torch.uint8, device=dev)
+        self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.last_ess = float("nan")
+
+    # -- reference API ------------------------------------------------------------------------
+    @property
+    def thetas(self):
+        """(M, D) view of the particles."""
+        return self._theta_dc.t()
+
+    def log_prior(self, Theta):
+        return self._model.log_prior(Theta)
+
+    def log_likelihood(self, Theta):
+        return self._model.log_likelihood(Theta)
+
+    def time(self, n: int) -> float:
+        return n / self.N
+
+    def run(self) -> None:
+        for n in range(1, self.N + 1):
+            self.transition(n)
+
+    def __iter__(self):
+        self.run()
+        return iter(self.thetas)
+
+    # -- one temperature step ---------------------------------------------------------------------
+    def _tempered(self, theta_dc, t: float):
+        """log_likelihood * t + log_prior for every particle [smc.py:47-51]."""
+        Th = theta_dc.t()
+        return (self.log_likelihood(Th) * t + self.log_prior(Th)).contiguous()
+
+    def transition(self, n: int) -> None:
+        ops = self._ops
+        self.kernel.move(self, self.time(n - 1))                      # smc.py:53-57
+        th = self._theta_dc
+        lpm1 = self._tempered(th, self.time(n - 1))
+        lp = self._tempered(th, self.time(n))
+        w = torch.exp(lp - lpm1).contiguous()                        # smc.py:67-70
+        self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
+        ops.uniform(self._rng_kind, self._rng_state, self._u)
+        ops.resample_indices(w, self._u, self._cdf, self._idx)       # smc.py:73
+        ops.gather_columns(self._idx, th, self._prop_dc)             # thetas[idxs], smc.py:75
+        self._theta_dc, self._prop_dc = self._prop_dc, self._theta_dc
+
+
+class TorchPriorLikelihoodModel:
+    """Batched ``LogPriorLikelihoodModel`` from two PyTorch functions of a (M, D) tensor."""
+
+    batched = True
+
+    def __init__(self, log_prior, log_likelihood, dims: int):
+        self._lp, self._ll, self._D = log_prior, log_likelihood, int(dims)
+
+    def dims(self) -> int:
+        return self._D
+
+    def log_prior(self, Theta):
+        with torch.no_grad():
+            return self._lp(Theta)
+
+    def log_likelihood(self, Theta):
+        with torch.no_grad():
+            return self._ll(Theta)
+
+    def log_density(self, Theta):
+        return self.log_prior(Theta) + self.log_likelihood(Theta)
+
+    def log_density_gradient_tempered(self, Theta, t: float):
+        x = Theta.detach().requires_grad_(True)
+        with torch.enable_grad():
+            lp = self._ll(x) * t + self._lp(x)
+            (g,) = torch.autograd.grad(lp.sum(), x)
+        return lp.detach(), g
+
+    def log_density_gradient(self, Theta):
+        return self.log_density_gradient_tempered(Theta, 1.0)

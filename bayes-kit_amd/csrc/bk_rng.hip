@@ -72,7 +72,7 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
   if (kin_out) kin_out[c] = 0.5 * kin;
 }
 
-template <typename G>
+template <typename G, bool LOG>
 __global__ __launch_bounds__(RNG_BLOCK) void k_log_uniform(uint64_t* st, i64 ldr, double* out,
                                                            const uint8_t* active, i64 C) {
   i64 c = (i64)blockIdx.x * RNG_BLOCK + threadIdx.x;
@@ -80,7 +80,8 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_log_uniform(uint64_t* st, i64 ldr
   if (active && !active[c]) return;
   G g;
   g.load(st, ldr, c);
-  out[c] = log(bk::next_double(g));
+  double u = bk::next_double(g);
+  out[c] = LOG ? log(u) : u;
   g.store(st, ldr, c);
 }
 
@@ -141,9 +142,23 @@ int bk_log_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out, cons
   if (C == 0) return BK_OK;
   dim3 grid((unsigned)bk_cdiv(C, RNG_BLOCK)), block(RNG_BLOCK);
   if (rng_kind == BK_RNG_PHILOX)
-    k_log_uniform<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
+    k_log_uniform<bk::Philox, true><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
   else if (rng_kind == BK_RNG_PCG64)
-    k_log_uniform<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
+    k_log_uniform<bk::Pcg64, true><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
+  else
+    return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out, const uint8_t* active, int64_t C,
+               void* stream) {
+  if (!state || !out || C < 0 || ldr < C) return BK_E_ARG;
+  if (C == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, RNG_BLOCK)), block(RNG_BLOCK);
+  if (rng_kind == BK_RNG_PHILOX)
+    k_log_uniform<bk::Philox, false><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
+  else if (rng_kind == BK_RNG_PCG64)
+    k_log_uniform<bk::Pcg64, false><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, out, active, C);
   else
     return BK_E_ARG;
   BK_RETURN_LAUNCH_STATUS();

@@ -70,6 +70,10 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
 int bk_log_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out,
                    const uint8_t* active, int64_t C, void* stream);
 
+/* out[c] = u itself (`rng.uniform()`): the resampling uniforms of smc.py:73. */
+int bk_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out, const uint8_t* active,
+               int64_t C, void* stream);
+
 /* ---- leapfrog integrator -------------------------------------------------------------
  * One fused kick + drift over all chains and dimensions (the hot loop hmc.py:47-49,
  * drghmc.py:277-278,282-283):
@@ -267,6 +271,16 @@ int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double*
 /* out[c] = scale * sum_d x[d*ld + c] * y[d*ld + c]  (kinetic energy 0.5 * rho . (M rho)). */
 int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, double* out,
                    int64_t C, int64_t D, void* stream);
+
+/* ---- sequential Monte Carlo resampling (smc.py:64-75) ---------------------------------------
+ * Multinomial resampling as numpy's choice(M, size=m, p=w/sum(w)): cdf = cumsum(w) (written
+ * to cdf_work[n]), idx_out[j] = searchsorted(cdf / cdf[n-1], u[j], side="right"). */
+int bk_resample_indices(const double* weights, int64_t n, const double* u, int64_t m,
+                        double* cdf_work, int32_t* idx_out, void* stream);
+
+/* dst[d*ld_dst + j] = src[d*ld_src + index[j]]: the resampled particles (thetas[idxs]). */
+int bk_gather_columns(const int32_t* index, const double* src, int64_t ld_src, double* dst,
+                      int64_t ld_dst, int64_t m, int64_t D, void* stream);
 
 /* ---- layout helper --------------------------------------------------------------------
  * dst[d*ld + c] = src[c*lds_c + d*lds_d]  (LDS-tiled transpose/copy) -- brings a model's

@@ -74,6 +74,14 @@ class FakeOps:
                 out[c] = float(np.log(g.uniform()))
             self._put(kind, state, c, g)
 
+    def uniform(self, kind, state, out, active=None):
+        for c in range(out.shape[0]):
+            if active is not None and not active[c]:
+                continue
+            g = self._gen(kind, state, c)
+            out[c] = float(g.uniform())
+            self._put(kind, state, c, g)
+
     # -- integrator ---------------------------------------------------------------------------
     @staticmethod
     def _mt(metric, g):
@@ -229,6 +237,15 @@ class FakeOps:
 
     def dot_columns(self, x, y, scale, out):
         out.numpy()[...] = scale * np.einsum("dc,dc->c", x.numpy(), y.numpy())
+
+    def resample_indices(self, weights, u, cdf_work, idx_out):
+        cdf = np.cumsum(weights.numpy())
+        cdf_work.numpy()[...] = cdf
+        idx = np.searchsorted(cdf / cdf[-1], u.numpy(), side="right")
+        idx_out.numpy()[...] = np.minimum(idx, len(cdf) - 1)
+
+    def gather_columns(self, index, src, dst):
+        dst.numpy()[...] = src.numpy()[:, index.numpy()[: dst.shape[1]]]
 
     def relayout(self, src, dst):
         self._count("relayout")

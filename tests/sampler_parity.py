@@ -158,3 +158,38 @@ def check_dense_metric_hmc(ops, C=40, D=24, draws=6, rtol=1e-10):
         tb, lb = b.sample()
         assert np.array_equal(np.asarray(ta.cpu()), np.asarray(tb.cpu()))
         np.testing.assert_allclose(np.asarray(la.cpu()), np.asarray(lb.cpu()), rtol=1e-12)
+
+
+def check_smc_binomial(ops, M, N, kernel, mean_atol, var_atol, seed=11):
+    """Likelihood-tempered SMC on the conjugate beta-binomial model of the reference's
+    test/test_tempered_smc.py:8-30 (logit scale, posterior Beta(alpha+x, beta+N-x))."""
+    import math
+
+    import torch
+
+    alpha, beta, x, Nobs = 2.0, 3.0, 5.0, 15.0
+    logB = math.lgamma(alpha) + math.lgamma(beta) - math.lgamma(alpha + beta)
+    logC = math.lgamma(Nobs + 1) - math.lgamma(x + 1) - math.lgamma(Nobs - x + 1)
+
+    def log_prior(Th):
+        lp, l1p = torch.nn.functional.logsigmoid(Th[:, 0]), torch.nn.functional.logsigmoid(-Th[:, 0])
+        return (alpha - 1) * lp + (beta - 1) * l1p - logB + lp + l1p  # beta prior + logit Jacobian
+
+    def log_lik(Th):
+        lp, l1p = torch.nn.functional.logsigmoid(Th[:, 0]), torch.nn.functional.logsigmoid(-Th[:, 0])
+        return x * lp + (Nobs - x) * l1p + logC
+
+    model = bk.TorchPriorLikelihoodModel(log_prior, log_lik, 1)
+    rng = np.random.default_rng(seed)
+    p0 = rng.beta(alpha, beta, size=M)
+    init = np.log(p0 / (1 - p0)).reshape(M, 1)  # model.initial_state: logit of a prior draw
+    smc = bk.TemperedLikelihoodSMC(model, M, N, init, kernel, seed=seed, ops=ops)
+    assert smc.time(3) == 3 / N and smc.D == 1
+    smc.run()
+    th = np.asarray(smc.thetas.cpu())
+    assert th.shape == (M, 1)
+    draws = 1.0 / (1.0 + np.exp(-th[:, 0]))
+    a, b = alpha + x, beta + Nobs - x
+    np.testing.assert_allclose(draws.mean(), a / (a + b), atol=mean_atol)
+    np.testing.assert_allclose(draws.var(ddof=1), a * b / ((a + b) ** 2 * (a + b + 1)), atol=var_atol)
+    return smc

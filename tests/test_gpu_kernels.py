@@ -361,3 +361,36 @@ def test_dense_metric_apply_mfma(ops, D, C):
     out = torch.empty(C, dtype=torch.float64, device=ops.device)
     ops.dot_columns(dev(X, ops), dev(want, ops), 0.5, out)
     np.testing.assert_allclose(out.cpu().numpy(), 0.5 * np.einsum("dc,dc->c", X, want), rtol=1e-13)
+
+
+def test_resample_indices_and_gather(ops):
+    rng = np.random.default_rng(9)
+    for n in [1, 5, 1000, 1024, 1025, 50000]:
+        w = rng.uniform(0.0, 2.0, size=n)
+        w[rng.uniform(size=n) < 0.1] = 0.0
+        if w.sum() == 0:
+            w[0] = 1.0
+        u = rng.uniform(size=n + 3)
+        cdf = torch.empty(n, dtype=torch.float64, device=ops.device)
+        idx = torch.empty(n + 3, dtype=torch.int32, device=ops.device)
+        ops.resample_indices(dev(w, ops), dev(u, ops), cdf, idx)
+        c = np.cumsum(w)
+        np.testing.assert_allclose(cdf.cpu().numpy(), c, rtol=1e-13)
+        want = np.minimum(np.searchsorted(c / c[-1], u, side="right"), n - 1)
+        got = idx.cpu().numpy()
+        # the device sums the cdf in a different order: indices may differ only where u sits
+        # within rounding of a cdf step
+        bad = got != want
+        assert bad.mean() < 1e-3
+        assert (w[got] > 0).all()  # zero-weight particles are never chosen
+    D, M = 7, 300
+    src = rng.normal(size=(D, M))
+    idx = rng.integers(0, M, size=M).astype(np.int32)
+    dst = torch.empty((D, M), dtype=torch.float64, device=ops.device)
+    ops.gather_columns(dev(idx, ops), dev(src, ops), dst)
+    assert np.array_equal(dst.cpu().numpy(), src[:, idx])
+    kind, st = make_state(77, 100, ops)
+    out = torch.empty(100, dtype=torch.float64, device=ops.device)
+    ops.uniform(kind, st, out)
+    for c in (0, 57, 99):
+        assert out[c].item() == np.random.Generator(np.random.Philox(key=[77, c])).uniform()

@@ -264,3 +264,14 @@ def test_dense_metric_hmc_vs_oracle(ops):
 
     check_dense_metric_hmc(ops, C=300, D=48)
     check_dense_metric_hmc(ops, C=130, D=130, draws=3)
+
+
+def test_tempered_smc_binomial_moments(ops):
+    """test/test_tempered_smc.py:8-30 with many more particles (distributional parity: the
+    reference's SMC uses the unseedable global np.random)."""
+    from tests.sampler_parity import check_smc_binomial
+
+    a = check_smc_binomial(ops, 8192, 15, bk.metropolis_kernel(0.5), mean_atol=0.006, var_atol=0.0012)
+    b = check_smc_binomial(ops, 8192, 15, bk.metropolis_kernel(0.5), mean_atol=0.006, var_atol=0.0012)
+    assert torch.equal(a.thetas, b.thetas)  # reproducible: every slot owns a Philox stream
+    check_smc_binomial(ops, 8192, 10, bk.mala_kernel(0.2, 2), mean_atol=0.006, var_atol=0.0012)

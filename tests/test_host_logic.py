@@ -279,3 +279,10 @@ def test_dense_metric_driver():
     from tests.sampler_parity import check_dense_metric_hmc
 
     check_dense_metric_hmc(FakeOps(), C=8, D=6)
+
+
+def test_tempered_smc_driver():
+    from tests.sampler_parity import check_smc_binomial
+
+    check_smc_binomial(FakeOps(), 400, 8, bk.metropolis_kernel(0.5), mean_atol=0.03, var_atol=0.004)
+    check_smc_binomial(FakeOps(), 300, 6, bk.mala_kernel(0.15, 2), mean_atol=0.04, var_atol=0.005)
