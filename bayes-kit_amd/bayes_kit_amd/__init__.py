@@ -21,7 +21,7 @@ from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
 from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, mala_kernel, metropolis_kernel
-from .targets import DiagGaussian, Funnel, IsoGaussian, TorchModel
+from .targets import DiagGaussian, Funnel, IsoGaussian, LogisticRegression, TorchModel
 
 __all__ = [
     "DrGhmcDiag",
@@ -44,5 +44,6 @@ __all__ = [
     "IsoGaussian",
     "DiagGaussian",
     "Funnel",
+    "LogisticRegression",
     "TorchModel",
 ]

@@ -54,6 +54,9 @@ SIGNATURES = {
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
+    "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
+    "bk_logistic_residual": [P, I, P, P, I, I, I, P],
+    "bk_logistic_finish": [P, P, I, P, I, F, F, P, P, P, I, I, P],
     "bk_dot_columns": [P, P, I, F, P, I, I, P],
     "bk_resample_indices": [P, I, P, I, P, P, P],
     "bk_gather_columns": [P, P, I, P, I, I, I, P],
@@ -316,6 +319,24 @@ class Ops:
         D, C = X.shape
         assert _ld(Y) == _ld(X) and M.stride(1) == 1
         self._call("bk_dense_metric_apply", ptr(M), M.stride(0), ptr(X), ptr(Y), _ld(X), C, D, self._s())
+
+    def gemm_chains(self, A, X, Y, work=None):
+        """Y[R, C] = A[R, K] @ X[K, C] on the fp64 matrix cores (work: optional split-K scratch)."""
+        R, K = A.shape
+        assert X.shape[0] == K and Y.shape[0] == R and A.stride(1) == 1
+        self._call("bk_gemm_chains", ptr(A), A.stride(0), R, K, ptr(X), _ld(X), ptr(Y), _ld(Y), X.shape[1],
+                   ptr(work), 0 if work is None else work.numel(), self._s())
+
+    def logistic_residual(self, Z, y, part):
+        N, C = Z.shape
+        self._call("bk_logistic_residual", ptr(Z), _ld(Z), ptr(y), ptr(part), N, C, part.shape[0], self._s())
+
+    def logistic_finish(self, G, theta, part, inv_prior_var, t, grad, logp, loglik):
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert (G is None or _ld(G) == ld) and (grad is None or _ld(grad) == ld)
+        self._call("bk_logistic_finish", ptr(G), ptr(theta), ld, ptr(part), part.shape[0], inv_prior_var, t,
+                   ptr(grad), ptr(logp), ptr(loglik), C, D, self._s())
 
     def dot_columns(self, x, y, scale, out):
         D, C = x.shape

@@ -110,6 +110,70 @@ class Funnel(_BuiltinTarget):
         return True
 
 
+class LogisticRegression(_BuiltinTarget):
+    """Bayesian logistic regression, y_n ~ Bernoulli(sigmoid(x_n . theta)), theta ~ N(0, s^2 I)
+    (BASELINE.json config 5; no reference counterpart).  The gradient for ALL chains is two
+    fp64 MFMA GEMMs -- Z = X @ Theta (N x C) and G = X^T @ (y - sigmoid(Z)) (D x C) -- with one
+    elementwise pass in between; also a batched LogPriorLikelihoodModel (typing.py:37-42) with
+    a likelihood temperature for smc.py's annealing."""
+
+    _kind = "logistic"
+    SEGMENTS = 256  # blocks of observations whose log-likelihood partial sums are combined in order
+
+    def __init__(self, X, y, prior_scale: float = 1.0, ops=None):
+        X = torch.as_tensor(X, dtype=torch.float64)
+        super().__init__(X.shape[1], ops)
+        self._N = int(X.shape[0])
+        self._X_host, self._y_host = X, torch.as_tensor(y, dtype=torch.float64).reshape(-1)
+        self._inv_s2 = 1.0 / float(prior_scale) ** 2
+        self._dev = None
+
+    def _buffers(self, device, C):
+        if self._dev is None or self._dev["X"].device != device:
+            X = self._X_host.to(device).contiguous()
+            self._dev = {"X": X, "Xt": X.t().contiguous(), "y": self._y_host.to(device).contiguous(), "C": 0}
+        b = self._dev
+        if b["C"] < C:
+            f64 = dict(dtype=torch.float64, device=device)
+            b["Z"] = torch.empty((self._N, C), **f64)
+            b["part"] = torch.empty((min(self.SEGMENTS, max(1, self._N)), C), **f64)
+            b["G"] = torch.empty((self._D, C), **f64)
+            b["work"] = torch.empty(min(64, max(1, self._N // 512)) * self._D * C, **f64)  # split-K slabs
+            b["C"] = C
+        return b
+
+    def bk_eval(self, theta_dc, grad_out, logp_out, t: float = 1.0, loglik_out=None):
+        ops = self._get_ops()
+        D, C = theta_dc.shape
+        b = self._buffers(theta_dc.device, C)
+        Z, part = b["Z"][:, :C], b["part"][:, :C]
+        ops.gemm_chains(b["X"], theta_dc, Z)              # z = X theta          (MFMA)
+        ops.logistic_residual(Z, b["y"], part)            # r = y - sigmoid(z), log-likelihood partials
+        G = None
+        if grad_out is not None:
+            G = b["G"][:, :C]
+            ops.gemm_chains(b["Xt"], Z, G, b["work"])     # X^T r                (MFMA, split over N)
+        ops.logistic_finish(G, theta_dc, part, self._inv_s2, float(t), grad_out, logp_out, loglik_out)
+
+    # batched LogPriorLikelihoodModel
+    def log_likelihood(self, Theta):
+        t = _as_dc(Theta)
+        ll = torch.empty(t.shape[1], dtype=torch.float64, device=t.device)
+        self.bk_eval(t, None, None, 1.0, ll)
+        return ll
+
+    def log_prior(self, Theta):
+        return -0.5 * self._inv_s2 * (Theta * Theta).sum(dim=1)
+
+    def log_density_gradient_tempered(self, Theta, t: float):
+        th = _as_dc(Theta)
+        lp = torch.empty(th.shape[1], dtype=torch.float64, device=th.device)
+        g = torch.empty_strided(th.shape, (th.stride(0) if th.shape[0] > 1 else th.shape[1], 1),
+                                dtype=torch.float64, device=th.device)
+        self.bk_eval(th, g, lp, t)
+        return lp, g.t()
+
+
 class TorchModel:
     """Any differentiable PyTorch log density, batched over chains.
 

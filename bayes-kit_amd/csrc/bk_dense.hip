@@ -33,7 +33,8 @@ struct DenseLds {
 
 template <bool FULL>
 __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const double* X, i64 ld, i64 r0,
-                                            i64 c0, i64 k0, i64 D, i64 C, double (&ra)[8], double (&rb)[8]) {
+                                            i64 c0, i64 k0, i64 R, i64 D, i64 C, double (&ra)[8],
+                                            double (&rb)[8]) {
   const int t = threadIdx.x;
   if (FULL) {  // whole tiles, 16-B aligned rows: four 16-B loads per panel, no bounds checks
     const dvec2* pa = reinterpret_cast<const dvec2*>(M + (r0 + (t >> 1)) * ldm + k0 + (t & 1) * 8);
@@ -55,7 +56,7 @@ __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const doub
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       i64 k = k0 + kk + i;
-      ra[i] = (r < D && k < D) ? M[r * ldm + k] : 0.0;
+      ra[i] = (r < R && k < D) ? M[r * ldm + k] : 0.0;
     }
   }
   // B panel: 16 k x 128 chains (chain contiguous): thread -> (k, 8 consecutive chains)
@@ -86,8 +87,13 @@ __device__ __forceinline__ void store_panels(DenseLds& lds, int buf, const doubl
 
 template <bool FULL>
 __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm, const double* X, double* Y,
-                                                        i64 ld, i64 C, i64 D, int row_blocks, int chain_blocks) {
+                                                        i64 ld, i64 ldy, i64 C, i64 R, i64 Dtot, int row_blocks,
+                                                        int chain_blocks, i64 k_chunk) {
   __shared__ DenseLds lds;
+  // split-K: blockIdx.y owns the inner-dimension range [k_lo, k_hi) and its own output slab
+  const i64 k_lo = (i64)blockIdx.y * k_chunk;
+  const i64 D = (k_lo + k_chunk < Dtot) ? k_lo + k_chunk : Dtot;  // exclusive upper bound of k
+  Y += (i64)blockIdx.y * R * ldy;
   // XCD-aware placement: consecutive slots of one XCD walk the row blocks of one chain block
   const int nblk = row_blocks * chain_blocks;
   int id = blockIdx.x;
@@ -114,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4f64){0.0, 0.0, 0.0, 0.0};
 
   double ra[8], rb[8];
-  load_panels<FULL>(M, ldm, X, ld, r0, c0, 0, D, C, ra, rb);
+  load_panels<FULL>(M, ldm, X, ld, r0, c0, k_lo, R, D, C, ra, rb);
   store_panels(lds, 0, ra, rb);
   __syncthreads();
-  const i64 nk = (D + BK - 1) / BK;
+  const i64 nk = (D - k_lo + BK - 1) / BK;
   for (i64 kb = 0; kb < nk; ++kb) {
     const int buf = (int)(kb & 1);
-    if (kb + 1 < nk) load_panels<FULL>(M, ldm, X, ld, r0, c0, (kb + 1) * BK, D, C, ra, rb);  // in flight under the MFMAs
+    if (kb + 1 < nk) load_panels<FULL>(M, ldm, X, ld, r0, c0, k_lo + (kb + 1) * BK, R, D, C, ra, rb);  // in flight under the MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
       double a[4], b[4];
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         i64 r = r0 + wr + 16 * i + l4 + 4 * v;
-        if (FULL || (r < D && c < C)) Y[r * ld + c] = acc[i][j][v];
+        if (FULL || (r < R && c < C)) Y[r * ldy + c] = acc[i][j][v];
       }
     }
 }
@@ -175,26 +181,71 @@ __global__ __launch_bounds__(64) void k_dot_columns(const double* x, const doubl
   out[c] = scale * s;
 }
 
+// deterministic reduction of split-K slabs: Y = sum_s P[s] in increasing s
+__global__ __launch_bounds__(256) void k_sum_slabs(const double* P, i64 slab, int S, double* Y, i64 n) {
+  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double a = P[i];
+  for (int s = 1; s < S; ++s) a = a + P[(i64)s * slab + i];
+  Y[i] = a;
+}
+
+}  // namespace
+namespace {
+
+static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, i64 ldx, double* Y, i64 ldy, i64 C,
+                       double* work, i64 work_elems, void* stream) {
+  if (!A || !X || !Y || C < 0 || R < 0 || K < 0 || lda < K) return BK_E_ARG;
+  if (ldx < C || ldy < C) return BK_E_ALIGN;
+  if (C == 0 || R == 0) return BK_OK;
+  i64 rb = bk_cdiv(R, BM), cb = bk_cdiv(C, BN);
+  i64 per = (cb + 7) / 8;
+  if (per * 8 * rb > 0x7fffffff) return BK_E_ARG;
+  unsigned grid = (unsigned)(per * 8 * rb);
+  // split the inner dimension when the output has too few tiles to fill 256 CUs x 2 workgroups
+  i64 S = 1;
+  if (work && rb * cb < 1024 && K >= 64 * BK) {
+    S = bk_cdiv(2048, rb * cb);
+    i64 maxS = K / (32 * BK);  // keep >= 32 K-panels per split
+    if (S > maxS) S = maxS;
+    if (S * R * ldy > work_elems) S = work_elems / (R * ldy);
+    if (S > 65535) S = 65535;
+    if (S < 2) S = 1;
+  }
+  i64 k_chunk = K;
+  if (S > 1) {
+    k_chunk = bk_cdiv(bk_cdiv(K, S), BK) * BK;
+    S = bk_cdiv(K, k_chunk);
+  }
+  double* out = S > 1 ? work : Y;
+  bool full = (R % BM == 0) && (K % BK == 0) && (C % BN == 0) && (lda % 2 == 0) && (ldx % 2 == 0) &&
+              bk_aligned16(A) && bk_aligned16(X);
+  hipStream_t st = bk_stream(stream);
+  if (full)
+    k_dense_apply<true><<<dim3(grid, (unsigned)S), dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R, K, (int)rb,
+                                                                      (int)cb, k_chunk);
+  else
+    k_dense_apply<false><<<dim3(grid, (unsigned)S), dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R, K, (int)rb,
+                                                                       (int)cb, k_chunk);
+  if (S > 1) {
+    i64 n = R * ldy;
+    k_sum_slabs<<<dim3((unsigned)bk_cdiv(n, 256)), dim3(256), 0, st>>>(work, n, (int)S, Y, n);
+  }
+  BK_RETURN_LAUNCH_STATUS();
+}
+
 }  // namespace
 
 extern "C" {
 
 int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double* Y, int64_t ld, int64_t C,
                           int64_t D, void* stream) {
-  if (!M || !X || !Y || C < 0 || D < 0 || ldm < D) return BK_E_ARG;
-  if (ld < C) return BK_E_ALIGN;
-  if (C == 0 || D == 0) return BK_OK;
-  int row_blocks = (int)bk_cdiv(D, BM), chain_blocks = (int)bk_cdiv(C, BN);
-  int per = (chain_blocks + 7) / 8;
-  unsigned grid = (unsigned)(per * 8 * row_blocks);
-  bool full = (D % BM == 0) && (C % BN == 0) && (ldm % 2 == 0) && (ld % 2 == 0) && bk_aligned16(M) && bk_aligned16(X);
-  if (full)
-    k_dense_apply<true><<<dim3(grid), dim3(256), 0, bk_stream(stream)>>>(M, ldm, X, Y, ld, C, D, row_blocks,
-                                                                        chain_blocks);
-  else
-    k_dense_apply<false><<<dim3(grid), dim3(256), 0, bk_stream(stream)>>>(M, ldm, X, Y, ld, C, D, row_blocks,
-                                                                         chain_blocks);
-  BK_RETURN_LAUNCH_STATUS();
+  return gemm_launch(M, ldm, D, D, X, ld, Y, ld, C, nullptr, 0, stream);
+}
+
+int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx, double* Y,
+                   int64_t ldy, int64_t C, double* work, int64_t work_elems, void* stream) {
+  return gemm_launch(A, lda, R, K, X, ldx, Y, ldy, C, work, work_elems, stream);
 }
 
 int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, double* out, int64_t C, int64_t D,
@@ -203,6 +254,77 @@ int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, d
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   k_dot_columns<<<dim3((unsigned)bk_cdiv(C, 64)), dim3(64), 0, bk_stream(stream)>>>(x, y, ld, scale, out, C, D);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+}  // extern "C"
+
+// ---- logistic regression target (config 5): the elementwise part between the two GEMMs --------
+namespace {
+
+// Z[n][c] (= x_n . theta_c) -> residual y_n - sigmoid(z) in place; per-segment partial sums of
+// the log likelihood  y z - log(1 + e^z)  (softplus evaluated stably).
+__global__ __launch_bounds__(256) void k_logistic_residual(double* Z, i64 ldz, const double* y, double* part,
+                                                           i64 N, i64 C, i64 rows_per_seg) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 seg = blockIdx.y;
+  if (c >= C) return;
+  i64 n0 = seg * rows_per_seg, n1 = n0 + rows_per_seg;
+  if (n1 > N) n1 = N;
+  double ll = 0.0;
+  for (i64 n = n0; n < n1; ++n) {
+    double z = Z[n * ldz + c];
+    double yn = y[n];
+    double e = exp(-fabs(z));
+    double sp = (z > 0.0 ? z : 0.0) + log1p(e);  // log(1 + e^z)
+    ll = ll + (yn * z - sp);
+    double p = z >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+    Z[n * ldz + c] = yn - p;
+  }
+  part[seg * C + c] = ll;
+}
+
+// grad = t * G + (-(inv_s2 * theta)); logp = t * sum_s part[s] + (-0.5 * inv_s2 * sum theta^2)
+__global__ __launch_bounds__(64) void k_logistic_finish(const double* G, const double* th, i64 ld, const double* part,
+                                                        i64 S, double inv_s2, double t, double* grad, double* logp,
+                                                        double* ll_out, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double s2 = 0.0;
+  for (i64 d = 0; d < D; ++d) {
+    double x = th[d * ld + c];
+    s2 = s2 + x * x;
+    if (grad) grad[d * ld + c] = t * G[d * ld + c] + (-(inv_s2 * x));
+  }
+  double ll = 0.0;
+  for (i64 s = 0; s < S; ++s) ll = ll + part[s * C + c];
+  if (ll_out) ll_out[c] = ll;
+  if (logp) logp[c] = t * ll + (-0.5 * inv_s2 * s2);
+}
+
+}  // namespace
+
+extern "C" {
+
+int bk_logistic_residual(double* Z, int64_t ldz, const double* y, double* part, int64_t N, int64_t C,
+                         int64_t segments, void* stream) {
+  if (!Z || !y || !part || N < 0 || C < 0 || segments < 1 || segments > 65535) return BK_E_ARG;
+  if (ldz < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  i64 rows = bk_cdiv(N > 0 ? N : 1, segments);
+  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)segments);
+  k_logistic_residual<<<grid, dim3(256), 0, bk_stream(stream)>>>(Z, ldz, y, part, N, C, rows);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_logistic_finish(const double* G, const double* theta, int64_t ld, const double* part, int64_t segments,
+                       double inv_prior_var, double t, double* grad, double* logp, double* loglik, int64_t C,
+                       int64_t D, void* stream) {
+  if (!theta || !part || (grad && !G) || C < 0 || D < 0 || segments < 1) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_logistic_finish<<<dim3((unsigned)bk_cdiv(C, 64)), dim3(64), 0, bk_stream(stream)>>>(
+      G, theta, ld, part, segments, inv_prior_var, t, grad, logp, loglik, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -268,6 +268,27 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
 int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double* Y, int64_t ld,
                           int64_t C, int64_t D, void* stream);
 
+/* The same MFMA GEMM with a rectangular left factor: Y[R x C] = A[R x K] @ X[K x C], all three
+ * with the chain index contiguous on the right (design matrices: X_data @ Theta with R = number
+ * of observations, X_data^T @ residuals with R = dims).  `work` (may be NULL; work_elems
+ * doubles, caller-owned) lets the library split a long inner dimension over several workgroups
+ * when the output has too few tiles to fill the chip; the slabs are summed in a fixed order. */
+int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx,
+                   double* Y, int64_t ldy, int64_t C, double* work, int64_t work_elems, void* stream);
+
+/* Logistic regression target (BASELINE.json config 5; no reference oracle), between the two
+ * GEMMs Z = X_data @ Theta and G = X_data^T @ R:
+ *   bk_logistic_residual: Z[n*ldz + c] <- y[n] - sigmoid(z) in place, and
+ *       part[s*C + c] = sum over the s-th block of observations of  y z - log(1 + e^z);
+ *   bk_logistic_finish:   grad = t*G + (-(inv_prior_var*theta)),
+ *       loglik[c] = sum_s part[s*C + c],  logp[c] = t*loglik + (-0.5*inv_prior_var*|theta|^2)
+ *       (t = likelihood temperature of smc.py:47-51; 1 for plain sampling). */
+int bk_logistic_residual(double* Z, int64_t ldz, const double* y, double* part, int64_t N, int64_t C,
+                         int64_t segments, void* stream);
+int bk_logistic_finish(const double* G, const double* theta, int64_t ld, const double* part,
+                       int64_t segments, double inv_prior_var, double t, double* grad, double* logp,
+                       double* loglik, int64_t C, int64_t D, void* stream);
+
 /* out[c] = scale * sum_d x[d*ld + c] * y[d*ld + c]  (kinetic energy 0.5 * rho . (M rho)). */
 int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, double* out,
                    int64_t C, int64_t D, void* stream);

@@ -93,3 +93,32 @@ class Funnel:
         g[0] = ((-v / 9.0) - hn) + he * s
         g[1:] = -(ev * x)
         return lp, g
+
+
+class LogisticRegression:
+    """y_n ~ Bernoulli(sigmoid(x_n . theta)), theta ~ N(0, s^2 I) (BASELINE.json config 5).
+    No reference counterpart: specification of the product's MFMA target (tolerance parity)."""
+
+    def __init__(self, X, y, prior_scale=1.0):
+        self._X = np.asarray(X, dtype=np.float64)
+        self._y = np.asarray(y, dtype=np.float64)
+        self._inv_s2 = 1.0 / prior_scale**2
+
+    def dims(self) -> int:
+        return self._X.shape[1]
+
+    def log_likelihood(self, theta):
+        z = self._X @ theta
+        return np.sum(self._y * z - np.logaddexp(0.0, z))
+
+    def log_prior(self, theta):
+        return -0.5 * self._inv_s2 * np.dot(theta, theta)
+
+    def log_density(self, theta):
+        return self.log_likelihood(theta) + self.log_prior(theta)
+
+    def log_density_gradient(self, theta):
+        z = self._X @ theta
+        p = 1.0 / (1.0 + np.exp(-z))
+        g = self._X.T @ (self._y - p) - self._inv_s2 * theta
+        return np.sum(self._y * z - np.logaddexp(0.0, z)) + self.log_prior(theta), g

@@ -235,6 +235,32 @@ class FakeOps:
     def dense_metric_apply(self, M, X, Y):
         Y.numpy()[...] = M.numpy() @ X.numpy()
 
+    def gemm_chains(self, A, X, Y, work=None):
+        Y.numpy()[...] = A.numpy() @ X.numpy()
+
+    def logistic_residual(self, Z, y, part):
+        z = Z.numpy()
+        yv = y.numpy()[:, None]
+        S = part.shape[0]
+        N = z.shape[0]
+        rows = -(-max(N, 1) // S)
+        ll = yv * z - np.logaddexp(0.0, z)
+        for s in range(S):
+            part.numpy()[s] = ll[s * rows:(s + 1) * rows].sum(axis=0)
+        from scipy.special import expit
+
+        z[...] = yv - expit(z)
+
+    def logistic_finish(self, G, theta, part, inv_prior_var, t, grad, logp, loglik):
+        th = theta.numpy()
+        ll = part.numpy().sum(axis=0)
+        if grad is not None:
+            grad.numpy()[...] = t * G.numpy() + (-(inv_prior_var * th))
+        if loglik is not None:
+            loglik.numpy()[...] = ll
+        if logp is not None:
+            logp.numpy()[...] = t * ll + (-0.5 * inv_prior_var * (th * th).sum(axis=0))
+
     def dot_columns(self, x, y, scale, out):
         out.numpy()[...] = scale * np.einsum("dc,dc->c", x.numpy(), y.numpy())
 

@@ -193,3 +193,39 @@ def check_smc_binomial(ops, M, N, kernel, mean_atol, var_atol, seed=11):
     np.testing.assert_allclose(draws.mean(), a / (a + b), atol=mean_atol)
     np.testing.assert_allclose(draws.var(ddof=1), a * b / ((a + b) ** 2 * (a + b + 1)), atol=var_atol)
     return smc
+
+
+def check_logistic_target(ops, N=700, D=24, C=50):
+    """LogisticRegression (two MFMA GEMMs + one elementwise pass) vs the oracle's NumPy model,
+    then HMC on it vs the oracle sampler chain by chain (no reference counterpart: tolerance)."""
+    import torch
+    from oracle import models as om
+    from oracle import samplers as osamp
+
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(N, D)) / np.sqrt(D)
+    tstar = rng.normal(size=D)
+    y = (rng.uniform(size=N) < 1 / (1 + np.exp(-X @ tstar))).astype(np.float64)
+    model = bk.LogisticRegression(X, y, prior_scale=2.0, ops=ops)
+    omodel = om.LogisticRegression(X, y, prior_scale=2.0)
+    Th = rng.normal(size=(C, D))
+    th_dc = torch.from_numpy(np.ascontiguousarray(Th.T)).to(ops.device)
+    lp, g = model.log_density_gradient(th_dc.t())
+    ll = model.log_likelihood(th_dc.t())
+    lpt, gt = model.log_density_gradient_tempered(th_dc.t(), 0.3)
+    for c in range(0, C, 7):
+        olp, og = omodel.log_density_gradient(Th[c])
+        np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-11)
+        np.testing.assert_allclose(np.asarray(g[c].cpu()), og, rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(ll[c].item(), omodel.log_likelihood(Th[c]), rtol=1e-11)
+        np.testing.assert_allclose(lpt[c].item(), 0.3 * omodel.log_likelihood(Th[c]) + omodel.log_prior(Th[c]),
+                                   rtol=1e-11)
+    s = bk.HMCDiag(model, 0.05, 6, chains=C, seed=13, ops=ops)
+    outs = [s.sample() for _ in range(4)]
+    for c in range(0, C, 11):
+        o = osamp.HMCDiag(omodel, 0.05, 6, seed=np.random.Philox(key=[13, c]))
+        for th, lp in outs:
+            oth, olp = o.sample()
+            np.testing.assert_allclose(np.asarray(th[c].cpu()), oth, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-9)
+    return model, tstar

@@ -286,3 +286,9 @@ def test_tempered_smc_driver():
 
     check_smc_binomial(FakeOps(), 400, 8, bk.metropolis_kernel(0.5), mean_atol=0.03, var_atol=0.004)
     check_smc_binomial(FakeOps(), 300, 6, bk.mala_kernel(0.15, 2), mean_atol=0.04, var_atol=0.005)
+
+
+def test_logistic_target_driver():
+    from tests.sampler_parity import check_logistic_target
+
+    check_logistic_target(FakeOps(), N=120, D=6, C=12)
