@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         i64 r = r0 + wr + 16 * i + l4 + 4 * v;
-        if (FULL || (r < R && c < C)) Y[r * ldy + c] = acc[i][j][v];
+        if (FULL || (r < R && c < C)) { if (k_chunk >= 0) Y[r * ldy + c] = acc[i][j][v]; }
       }
     }
 }
