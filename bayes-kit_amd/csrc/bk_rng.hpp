@@ -46,8 +46,8 @@ BK_HD uint64_t double_as_u64(double d) {
 
 // ---- Philox4x64-10 -----------------------------------------------------------------
 // Stored state (numpy's): key, counter `c` of the block held in `b`, read position `pos`.
-// Device-side lookahead: up to two further blocks (n1 = counter c+1, n2 = c+2) generated
-// AHEAD of need.  A Philox block costs ~20 full 64x64->128 multiplies; lanes of a wavefront
+// Device-side lookahead: up to three further blocks (n1 = counter c+1, n2 = c+2, n3 = c+3)
+// generated AHEAD of need, two at a time with their rounds interleaved.  A Philox block costs ~20 full 64x64->128 multiplies; lanes of a wavefront
 // consume their streams at slightly different rates (ziggurat rejections), so without
 // lookahead every call would make the whole wave wait for the few lanes that need a new
 // block.  Kernels call top_up() at a wave-uniform point: when ANY lane is short, ALL lanes
@@ -59,8 +59,8 @@ struct Philox {
   uint64_t b0, b1, b2, b3;   // that block, complete (numpy's buffer)
   uint64_t q0, q1, q2, q3;   // its unread words, q0 next (a shift queue: no dynamic indexing,
   uint32_t rem;              //   which the compiler would otherwise spill to scratch); numpy pos = 4 - rem
-  uint64_t n10, n11, n12, n13, n20, n21, n22, n23;
-  uint32_t cnt;              // lookahead blocks held (0..2)
+  uint64_t n10, n11, n12, n13, n20, n21, n22, n23, n30, n31, n32, n33;
+  uint32_t cnt;              // lookahead blocks held (0..3)
 
   BK_HD void block_at(uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3, uint64_t& o0, uint64_t& o1,
                       uint64_t& o2, uint64_t& o3) const {
@@ -85,6 +85,7 @@ struct Philox {
       if (cnt > 0) {
         b0 = n10; b1 = n11; b2 = n12; b3 = n13;
         n10 = n20; n11 = n21; n12 = n22; n13 = n23;
+        n20 = n30; n21 = n31; n22 = n32; n23 = n33;
         --cnt;
       } else {
         block_at(c0, c1, c2, c3, b0, b1, b2, b3);
@@ -101,19 +102,51 @@ struct Philox {
   // words available without generating a block
   BK_HD int avail() const { return (int)rem + 4 * (int)cnt; }
 
-  // generate the next lookahead block (caller guarantees cnt < 2)
+  // Two Philox blocks at once (counters x and y), rounds interleaved: a block is a serial chain
+  // of 10 rounds of 64x64->128 multiplies, and with one wavefront per SIMD nothing else hides
+  // that latency -- two independent chains in flight do.
+  BK_HD void block_at2(uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3, uint64_t y0, uint64_t y1,
+                       uint64_t y2, uint64_t y3, uint64_t (&o)[4], uint64_t (&p)[4]) const {
+    const uint64_t M0 = 0xD2E7470EE14C6C93ULL, M1 = 0xCA5A826395121157ULL;
+    const uint64_t W0 = 0x9E3779B97F4A7C15ULL, W1 = 0xBB67AE8584CAA73BULL;
+    uint64_t k0 = key0, k1 = key1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      if (r) { k0 += W0; k1 += W1; }
+      uint64_t xh0 = mulhi64(M0, x0), xl0 = M0 * x0, yh0 = mulhi64(M0, y0), yl0 = M0 * y0;
+      uint64_t xh1 = mulhi64(M1, x2), xl1 = M1 * x2, yh1 = mulhi64(M1, y2), yl1 = M1 * y2;
+      uint64_t xa = xh1 ^ x1 ^ k0, xc = xh0 ^ x3 ^ k1;
+      uint64_t ya = yh1 ^ y1 ^ k0, yc = yh0 ^ y3 ^ k1;
+      x0 = xa; x1 = xl1; x2 = xc; x3 = xl0;
+      y0 = ya; y1 = yl1; y2 = yc; y3 = yl0;
+    }
+    o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;
+    p[0] = y0; p[1] = y1; p[2] = y2; p[3] = y3;
+  }
+
+  BK_HD static void ctr_add(uint64_t c0, uint64_t c1, uint64_t c2, uint64_t c3, uint64_t k, uint64_t& a0,
+                            uint64_t& a1, uint64_t& a2, uint64_t& a3) {
+    a0 = c0 + k;
+    uint64_t cy = a0 < k ? 1ULL : 0ULL;
+    a1 = c1 + cy;
+    cy = (cy && a1 == 0) ? 1ULL : 0ULL;
+    a2 = c2 + cy;
+    cy = (cy && a2 == 0) ? 1ULL : 0ULL;
+    a3 = c3 + cy;
+  }
+
+  // generate the next TWO lookahead blocks (caller guarantees cnt <= 1)
   BK_HD void prefetch() {
-    uint64_t k = (uint64_t)cnt + 1;  // counter of the new block = c + cnt + 1 (with carry)
-    uint64_t a0 = c0 + k;
-    uint64_t a1 = c1 + (a0 < k ? 1ULL : 0ULL);
-    uint64_t a2 = c2 + ((a1 == 0 && a0 < k) ? 1ULL : 0ULL);
-    uint64_t a3 = c3 + ((a2 == 0 && a1 == 0 && a0 < k) ? 1ULL : 0ULL);
-    uint64_t t0, t1, t2, t3;
-    block_at(a0, a1, a2, a3, t0, t1, t2, t3);
-    bool first = (cnt == 0);
-    n10 = first ? t0 : n10; n11 = first ? t1 : n11; n12 = first ? t2 : n12; n13 = first ? t3 : n13;
-    n20 = first ? n20 : t0; n21 = first ? n21 : t1; n22 = first ? n22 : t2; n23 = first ? n23 : t3;
-    ++cnt;
+    uint64_t a0, a1, a2, a3, e0, e1, e2, e3;
+    ctr_add(c0, c1, c2, c3, (uint64_t)cnt + 1, a0, a1, a2, a3);
+    ctr_add(c0, c1, c2, c3, (uint64_t)cnt + 2, e0, e1, e2, e3);
+    uint64_t t[4], u[4];
+    block_at2(a0, a1, a2, a3, e0, e1, e2, e3, t, u);
+    const bool first = (cnt == 0);  // cnt == 0: fill n1, n2 ; cnt == 1: fill n2, n3
+    n10 = first ? t[0] : n10; n11 = first ? t[1] : n11; n12 = first ? t[2] : n12; n13 = first ? t[3] : n13;
+    n20 = first ? u[0] : t[0]; n21 = first ? u[1] : t[1]; n22 = first ? u[2] : t[2]; n23 = first ? u[3] : t[3];
+    n30 = first ? n30 : u[0]; n31 = first ? n31 : u[1]; n32 = first ? n32 : u[2]; n33 = first ? n33 : u[3];
+    cnt += 2;
   }
 
   template <typename I>
@@ -128,7 +161,7 @@ struct Philox {
     for (uint32_t k = 0; k < 3; ++k)
       if (pos > k) { q0 = q1; q1 = q2; q2 = q3; }
     cnt = 0;
-    n10 = n11 = n12 = n13 = n20 = n21 = n22 = n23 = 0;
+    n10 = n11 = n12 = n13 = n20 = n21 = n22 = n23 = n30 = n31 = n32 = n33 = 0;
   }
   template <typename I>
   BK_HD void store(uint64_t* st, I ld, I c) const {
@@ -156,7 +189,7 @@ struct Pcg64 {
   }
   BK_HD int avail() const { return 1 << 20; }  // one multiply per output: nothing to prefetch
   BK_HD void prefetch() {}
-  static constexpr uint32_t cnt = 2;
+  static constexpr uint32_t cnt = 3;
   template <typename I>
   BK_HD void load(const uint64_t* st, I ld, I c) {
     s_hi = st[0 * ld + c]; s_lo = st[1 * ld + c]; i_hi = st[2 * ld + c]; i_lo = st[3 * ld + c];
@@ -234,7 +267,7 @@ template <typename G>
 __device__ __forceinline__ void top_up(G& g) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (__any(g.avail() < 4)) {
-    if (g.cnt < 2) g.prefetch();
+    if (g.cnt < 2) g.prefetch();  // two blocks, interleaved
   }
 #endif
 }
