@@ -47,6 +47,7 @@ SIGNATURES = {
     "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
+    "bk_mala_propose_from_normals": [P, P, P, P, I, F, F, I, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
@@ -273,6 +274,13 @@ class Ops:
         assert _ld(grad) == ld and _ld(theta_prop) == ld
         self._call("bk_mala_propose", kind, ptr(state), state.stride(0), ptr(theta), ptr(grad),
                    ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
+
+    def mala_propose_from_normals(self, theta, grad, z, theta_prop, eps, sqrt2eps):
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(grad) == ld and _ld(theta_prop) == ld and _ld(z) == ld
+        self._call("bk_mala_propose_from_normals", ptr(theta), ptr(grad), ptr(z), ptr(theta_prop), ld, eps,
+                   sqrt2eps, C, D, self._s())
 
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         D, C = theta.shape

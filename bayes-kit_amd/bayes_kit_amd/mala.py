@@ -18,7 +18,7 @@ from ._engine import ManyChainSampler
 
 class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
-                 chain_id0: int = 0, graph: bool = False, ops=None):
+                 chain_id0: int = 0, graph: bool = False, prefetch_rng: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph)
@@ -36,11 +36,60 @@ class MALA(ManyChainSampler):
         self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
         self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
         self._draws = 0
+        # As in HMCDiag: the D proposal normals and the accept uniform of draw n+1 do not depend
+        # on draw n and are consumed in a fixed order (mala.py:44 then metropolis.py:74), so they
+        # are generated on a second HIP stream under draw n's HBM-bound kernels; the proposal
+        # then is a pure elementwise kernel.  (The RNG kernel is more than half of a MALA draw.)
+        if prefetch_rng is None:
+            prefetch_rng = self._batched and not self._use_graph and dev.type == "cuda"
+        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
+        self._pf_slot, self._pf_event = 0, None
+        if self._prefetch:
+            self._z_bufs = [torch.empty((D, C), **f64) for _ in range(2)]
+            self._logu_bufs = [torch.empty(C, **f64) for _ in range(2)]
+            self._side = torch.cuda.Stream(device=dev)
+            self._rng_logical = self._rng_state.clone()
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
     def _state_tensors(self):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
+
+    def _logical_rng(self):
+        if self._prefetch and self._pf_event is not None:
+            self._pf_event.synchronize()
+            return self._rng_logical
+        return self._rng_state
+
+    def rng_state(self):
+        import numpy as np
+
+        return self._logical_rng().cpu().numpy().view(np.uint64)
+
+    def _after_load(self):
+        self._pf_event, self._pf_slot = None, 0
+
+    def _gen(self, slot):
+        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._z_bufs[slot], None, None)
+        self._ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])
+
+    def _take_randomness(self):
+        main = torch.cuda.current_stream()
+        if self._pf_event is None:
+            self._gen(self._pf_slot)
+        else:
+            main.wait_event(self._pf_event)
+        cur, nxt = self._pf_slot, 1 - self._pf_slot
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._rng_logical.copy_(self._rng_state)
+            self._gen(nxt)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pf_event, self._pf_slot = ev, nxt
+        return self._z_bufs[cur], self._logu_bufs[cur]
 
     def accept_rate(self) -> float:
         n = self._draws * self._C
@@ -67,10 +116,15 @@ class MALA(ManyChainSampler):
         ops = self._ops
         eps = float(self._epsilon)
         th, thp = self._theta_dc, self._theta_p
-        ops.mala_propose(self._rng_kind, self._rng_state, th, self._grad, thp, eps, math.sqrt(2 * eps))
+        if self._prefetch:
+            z, logu = self._take_randomness()
+            ops.mala_propose_from_normals(th, self._grad, z, thp, eps, math.sqrt(2 * eps))
+        else:
+            logu = self._logu
+            ops.mala_propose(self._rng_kind, self._rng_state, th, self._grad, thp, eps, math.sqrt(2 * eps))
+            ops.log_uniform(self._rng_kind, self._rng_state, logu)  # right after the normals: same stream order
         gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)
         ops.mala_logq(th, self._grad, thp, gp, eps, self._fwd, self._rev)
-        ops.log_uniform(self._rng_kind, self._rng_state, self._logu)
-        ops.mh_accept(_lib.ACCEPT_MALA, self._lp, self._fwd, self._lp_p, self._rev, self._logu,
+        ops.mh_accept(_lib.ACCEPT_MALA, self._lp, self._fwd, self._lp_p, self._rev, logu,
                       self._mask, self._ret, self._accepted)
         ops.select_columns(self._mask, th, thp, self._grad, gp)

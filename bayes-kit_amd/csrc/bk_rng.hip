@@ -104,6 +104,26 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_mala_propose(uint64_t* st, i64 ld
   g.store(st, ldr, c);
 }
 
+// theta' = (theta + eps*grad) + s*z with z already drawn (mala.py:41-45), two rows per thread
+__global__ __launch_bounds__(256) void k_mala_propose_z(const double* th, const double* g, const double* z,
+                                                        double* prop, i64 ld, double eps, double s, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * 4;
+  if (c >= C) return;
+  double a[4], b[4], n[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (d0 + i < D) {
+      i64 o = (d0 + i) * ld + c;
+      a[i] = th[o];
+      b[i] = g[o];
+      n[i] = z[o];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (d0 + i < D) prop[(d0 + i) * ld + c] = (a[i] + eps * b[i]) + s * n[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -178,6 +198,16 @@ int bk_mala_propose(int rng_kind, uint64_t* state, int64_t ldr, const double* th
                                                                     ld, eps, sqrt2eps, C, D);
   else
     return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_mala_propose_from_normals(const double* theta, const double* grad, const double* z, double* theta_prop,
+                                 int64_t ld, double eps, double sqrt2eps, int64_t C, int64_t D, void* stream) {
+  if (!theta || !grad || !z || !theta_prop || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, 4));
+  k_mala_propose_z<<<grid, dim3(256), 0, bk_stream(stream)>>>(theta, grad, z, theta_prop, ld, eps, sqrt2eps, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }
 

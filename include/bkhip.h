@@ -210,6 +210,12 @@ int bk_mala_propose(int rng_kind, uint64_t* state, int64_t ldr, const double* th
                     const double* grad, double* theta_prop, int64_t ld, double eps,
                     double sqrt2eps, int64_t C, int64_t D, void* stream);
 
+/* The same proposal with the D normals already drawn into z[d*ld + c] (e.g. generated ahead on
+ * another stream by bk_momentum_refresh): theta_prop = (theta + eps*grad) + sqrt2eps * z. */
+int bk_mala_propose_from_normals(const double* theta, const double* grad, const double* z,
+                                 double* theta_prop, int64_t ld, double eps, double sqrt2eps,
+                                 int64_t C, int64_t D, void* stream);
+
 /* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
  * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */
 int bk_mala_logq(const double* theta, const double* grad, const double* theta_prop,

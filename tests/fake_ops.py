@@ -164,6 +164,9 @@ class FakeOps:
             theta_prop.numpy()[:, c] = (theta.numpy()[:, c] + eps * grad.numpy()[:, c]) + sqrt2eps * z
             self._put(kind, state, c, g)
 
+    def mala_propose_from_normals(self, theta, grad, z, theta_prop, eps, sqrt2eps):
+        theta_prop.numpy()[...] = (theta.numpy() + eps * grad.numpy()) + sqrt2eps * z.numpy()
+
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         self._count("mala_logq")
         th, g, thp, gp = theta.numpy(), grad.numpy(), theta_prop.numpy(), grad_prop.numpy()

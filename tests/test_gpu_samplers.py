@@ -304,3 +304,16 @@ def test_rectangular_mfma_gemm(ops, R, K, C):
     Y2 = torch.empty_like(Y)
     ops.gemm_chains(torch.from_numpy(A).to(ops.device), torch.from_numpy(X).to(ops.device), Y2, work)
     np.testing.assert_allclose(Y2.cpu().numpy(), A @ X, rtol=1e-12, atol=1e-12 * np.sqrt(K))
+
+
+def test_mala_rng_prefetch_is_only_a_schedule(ops):
+    lam = np.logspace(0, 2, 48)
+    a = bk.MALA(bk.DiagGaussian(lam), 0.004, chains=2500, seed=8, prefetch_rng=False)
+    b = bk.MALA(bk.DiagGaussian(lam), 0.004, chains=2500, seed=8, prefetch_rng=True)
+    assert b._prefetch and not a._prefetch
+    for _ in range(8):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb)
+        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    assert 0.2 < a.accept_rate() == b.accept_rate()
