@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true")
+    ap.add_argument("--ess-draws", type=int, default=50, help="extra draws for the ESS/sec figure (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -292,6 +293,36 @@ def main():
                 "achieved": 16.0 * D * Ct / (g_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
+    if args.ess_draws > 0:
+        try:
+            # Second half of BASELINE.json's metric: ESS/sec.  Extra draws (outside the timed region
+            # above), three tracked coordinates + the returned log density, ESS by the reference's
+            # estimator (ess.py:52-69 -> bk_ess), summed over chains of the per-chain minimum.
+            import bayes_kit_amd as bk
+
+            N = args.ess_draws
+            series = torch.empty((4, N, C), dtype=torch.float64, device=device)
+            barrier()
+            t0 = time.perf_counter()
+            for n in range(N):
+                th, lp = s.sample()
+                series[0, n], series[1, n], series[2, n], series[3, n] = th[:, 0], th[:, D // 2], th[:, D - 1], lp
+            barrier()
+            eel = time.perf_counter() - t0
+            ess = torch.stack([bk.ess(series[i]) for i in range(4)])
+            # the reference's estimator returns N/IAT with IAT <= 0 possible for antithetic chains
+            # (iat.py:151-152); for a throughput figure each series counts as at most N draws
+            ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N))
+            ess_min = ess.min(dim=0).values
+            tot = bk.dist.sum_over_ranks(float(ess_min.sum().item()), device)
+            out["ess"] = {"draws": N, "tracked": ["theta[0]", "theta[D/2]", "theta[D-1]", "logp"],
+                          "ess_per_sec": tot / eel, "mean_min_ess_per_chain": tot / (C * world),
+                          "mean_ess_per_tracked": [float(e.mean().item()) for e in ess],
+                          "note": "whole job; per-chain minimum over the tracked series (each clipped to "
+                                  "(0, N]: IAT <= 0 counts as N), summed over chains"}
+            del series
+        except Exception as e:
+            out["ess"] = {"error": repr(e)}
     if not args.no_fused_extra:
         try:
             # Separately reported (never priced on the 56*D model): the same workload through the
