@@ -375,7 +375,7 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
         default: BK_GG(4, true); break;
       }
 #undef BK_GG
-    } else if (bk_streams_past_llc(2 * C * D)) {
+    } else if (bk_streams_past_llc(2 * C * D) && D <= 65535) {
       // one row per thread, non-temporal: 6.5 TB/s vs 6.1 with four rows (MI355X, 1 GiB streams)
       dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)D);
       k_gauss_grad_v2<1, true><<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C / 2, D);
