@@ -246,12 +246,33 @@ def rank_normalize_chains(chains, *, ops=None):
     return out
 
 
-def rank_normalized_rhat(chains, *, ops=None):
-    """bayes_kit/rhat.py:205-236: split R-hat of the rank-normalised chains.  Single rank: a
-    global rank needs every draw in one place (a cross-GPU sort is future work)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        raise NotImplementedError("rank_normalized_rhat across ranks needs a distributed sort (not built yet)")
-    return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops)
+def _all_gather_columns(x: torch.Tensor, group=None):
+    """[N, C_local] on every rank -> ([N, C_total] in rank order, first column of this rank).
+    Equal C_local on every rank (chains shard evenly)."""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(x) for _ in range(world)]
+    dist.all_gather(parts, x.contiguous(), group=group)
+    return torch.cat(parts, dim=1), dist.get_rank(group) * x.shape[1]
+
+
+def rank_normalized_rhat(chains, *, ops=None, group=None):
+    """bayes_kit/rhat.py:205-236: split R-hat of the rank-normalised chains.
+
+    Across ranks (an [N, C_local] shard per rank): ranks are global, so every rank receives all
+    draws (one all_gather of N x C_total doubles over RCCL/xGMI; fine up to a few GB per
+    parameter), ranks the pooled values redundantly, keeps its own chains' normal scores and
+    joins the usual cross-rank split R-hat.  (A distributed sample sort would avoid the
+    replication; not needed at the sizes of BASELINE.json.)"""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not multi:
+        return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops)
+    if not _is_matrix(chains):
+        raise ValueError("across ranks rank_normalized_rhat takes this rank's [N, C_local] device tensor")
+    ops = _ops(ops)
+    full, first = _all_gather_columns(chains, group)
+    z = rank_normalize_chains(full, ops=ops)
+    mine = z[:, first:first + chains.shape[1]].contiguous()
+    return split_rhat(mine, ops=ops, group=group)
 
 
 # ---------------------------------------------------------------------------------------------

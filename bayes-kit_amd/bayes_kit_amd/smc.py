@@ -85,8 +85,15 @@ def mala_kernel(epsilon: float, steps: int = 1) -> _MALAKernel:
 
 
 class TemperedLikelihoodSMC:
-    def __init__(self, model, M: int, N: int, sample_initial, kernel, *, seed=None, ops=None):
+    def __init__(self, model, M: int, N: int, sample_initial, kernel, *, seed=None, slot_id0: int = 0,
+                 group=None, ops=None):
+        """M = particles held by THIS rank.  Across ranks (one process per GPU) pass the rank's
+        first global slot as slot_id0; resampling is then global: weights and particles are
+        all-gathered (RCCL over xGMI), every rank builds the same cumulative weights and draws
+        its own slots' indices into the global population."""
         self.M, self.N = int(M), int(N)
+        self._group = group
+        self._slot0 = int(slot_id0)
         self._model = model
         self.kernel = kernel
         self._ops = ops if ops is not None else _lib.default_ops()
@@ -103,7 +110,7 @@ class TemperedLikelihoodSMC:
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_dc = init_t.t().contiguous().to(dev)
         self._prop_dc = torch.empty_like(self._theta_dc)
-        self._rng_kind, self._rng_state = make_streams(seed, self.M, 0, False, dev)
+        self._rng_kind, self._rng_state = make_streams(seed, self.M, self._slot0, False, dev)
         self._logu = torch.empty(self.M, **f64)
         self._u = torch.empty(self.M, **f64)
         self._cdf = torch.empty(self.M, **f64)
@@ -148,10 +155,25 @@ class TemperedLikelihoodSMC:
         lpm1 = self._tempered(th, self.time(n - 1))
         lp = self._tempered(th, self.time(n))
         w = torch.exp(lp - lpm1).contiguous()                        # smc.py:67-70
-        self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
         ops.uniform(self._rng_kind, self._rng_state, self._u)
-        ops.resample_indices(w, self._u, self._cdf, self._idx)       # smc.py:73
-        ops.gather_columns(self._idx, th, self._prop_dc)             # thetas[idxs], smc.py:75
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            world = dist.get_world_size(self._group)
+            wparts = [torch.empty_like(w) for _ in range(world)]
+            dist.all_gather(wparts, w, group=self._group)
+            w_all = torch.cat(wparts)
+            tparts = [torch.empty_like(th) for _ in range(world)]
+            dist.all_gather(tparts, th.contiguous(), group=self._group)
+            th_all = torch.cat(tparts, dim=1)
+            cdf = torch.empty_like(w_all)
+            self.last_ess = float((w_all.sum() ** 2 / (w_all * w_all).sum()).item())
+            ops.resample_indices(w_all, self._u, cdf, self._idx)
+            ops.gather_columns(self._idx, th_all, self._prop_dc)
+        else:
+            self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
+            ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73
+            ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
         self._theta_dc, self._prop_dc = self._prop_dc, self._theta_dc
 
 

@@ -54,6 +54,30 @@ def main():
         for i in range(30):
             th, _ = ref.sample()
             assert np.array_equal(th.numpy(), full[i])
+    # 4) rank-normalised R-hat across ranks == the reference's value on all chains
+    rk = z["rank_chains"]  # (8 chains, 100 draws)
+    f4, n4 = bk.dist.shard(rk.shape[0])
+    xr = torch.from_numpy(np.ascontiguousarray(rk[f4:f4 + n4].T))
+    np.testing.assert_allclose(bk.rank_normalized_rhat(xr, ops=ops), z["rank_normalized_rhat"], rtol=1e-12)
+    # 5) tempered SMC with global resampling: the two shards == one process holding all particles
+    lp_fn = lambda Th: -0.5 * (Th * Th).sum(dim=1)
+    ll_fn = lambda Th: -2.0 * ((Th - 1.0) ** 2).sum(dim=1)
+    M_total, Dp = 12, 2
+    init = np.random.default_rng(4).normal(size=(M_total, Dp))
+    f5, n5 = bk.dist.shard(M_total)
+    smc = bk.TemperedLikelihoodSMC(bk.TorchPriorLikelihoodModel(lp_fn, ll_fn, Dp), n5, 5, init[f5:f5 + n5],
+                                   bk.metropolis_kernel(0.4), seed=21, slot_id0=f5, ops=ops)
+    smc.run()
+    parts = [None, None]
+    dist.all_gather_object(parts, smc.thetas.numpy().copy())
+    # a single-process reference run must not see the 2-rank group: give it a 1-rank subgroup
+    # (new_group is collective: every rank creates both groups, in the same order)
+    solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
+    solo_group = solo_groups[rank]
+    solo = bk.TemperedLikelihoodSMC(bk.TorchPriorLikelihoodModel(lp_fn, ll_fn, Dp), M_total, 5, init,
+                                    bk.metropolis_kernel(0.4), seed=21, group=solo_group, ops=ops)
+    solo.run()
+    assert np.array_equal(np.concatenate(parts, axis=0), solo.thetas.numpy())
     total = bk.dist.sum_over_ranks(float(n))
     assert total == C
     dist.barrier()
