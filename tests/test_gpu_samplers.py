@@ -317,3 +317,46 @@ def test_mala_rng_prefetch_is_only_a_schedule(ops):
         assert torch.equal(ta, tb) and torch.equal(la, lb)
         np.testing.assert_array_equal(a.rng_state(), b.rng_state())
     assert 0.2 < a.accept_rate() == b.accept_rate()
+
+
+@pytest.mark.parametrize("C,D", [(1, 1), (3, 2), (65, 7), (130, 129), (257, 33), (64, 200)])
+def test_odd_shapes_all_samplers_vs_oracle(ops, C, D):
+    """Ragged shapes (odd chain counts, D not a multiple of any tile, D = 1): every sampler on
+    the device vs the oracle chain by chain, built-in fast paths on and off."""
+    from oracle import models as om
+    from oracle import samplers as osamp
+
+    lam = np.logspace(0, 1, D)
+    seed = 1000 + C + D
+    chains_to_check = sorted({0, C // 2, C - 1})
+
+    def compare(dev_sampler, make_oracle, draws, exact=True):
+        outs = [dev_sampler.sample() for _ in range(draws)]
+        for c in chains_to_check:
+            o = make_oracle(c)
+            for th, lp in outs:
+                oth, olp = o.sample()
+                if exact:
+                    assert np.array_equal(th[c].cpu().numpy(), oth), (type(dev_sampler).__name__, C, D, c)
+                else:
+                    np.testing.assert_allclose(th[c].cpu().numpy(), oth, rtol=1e-7, atol=1e-9)
+                np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-11 if exact else 1e-7, atol=1e-12 if exact else 1e-9)
+
+    key = lambda c: np.random.Philox(key=[seed, c])
+    for fused in (True, False):
+        compare(bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=C, seed=seed, fuse_builtin=fused),
+                lambda c: osamp.HMCDiag(om.DiagGaussian(lam), 0.05, 5, seed=key(c)), 4)
+    compare(bk.MALA(bk.DiagGaussian(lam), 0.01, chains=C, seed=seed),
+            lambda c: osamp.MALA(om.DiagGaussian(lam), 0.01, seed=key(c)), 4)
+    args = (3, [0.3, 0.1, 0.03], [2, 5, 11], 0.4)
+    compare(bk.DrGhmcDiag(bk.DiagGaussian(lam), *args, chains=C, seed=seed),
+            lambda c: osamp.DrGhmcDiag(om.DiagGaussian(lam), *args, seed=key(c)), 6)
+    if D >= 2:
+        for fused in (True, False):
+            compare(bk.DrGhmcDiag(bk.Funnel(D), *args, chains=C, seed=seed, fuse_builtin=fused),
+                    lambda c: osamp.DrGhmcDiag(om.Funnel(D), *args, seed=key(c)), 5, exact=False)
+    # dense metric on a ragged shape (MFMA tiles with bounds checks)
+    if D <= 64:
+        M = np.eye(D) + 0.1 * np.outer(np.ones(D), np.ones(D)) / D
+        compare(bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 4, chains=C, seed=seed, metric_dense=M),
+                lambda c: osamp.HMCDense(om.DiagGaussian(lam), 0.05, 4, M, seed=key(c)), 3, exact=False)
