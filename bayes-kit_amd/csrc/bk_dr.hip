@@ -8,8 +8,9 @@ namespace {
 
 constexpr int SC_BLOCK = 256;
 
-// ---- stable compaction: one workgroup, 16 wavefronts, chunked scan ------------------------
+// ---- stable compaction: one workgroup, 16 wavefronts, 8 flags per thread per pass ---------
 constexpr int CP_BLOCK = 1024;
+constexpr int CP_ITEMS = 8;
 __global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n, int32_t* idx,
                                                       uint32_t* count) {
   __shared__ uint32_t wave_cnt[CP_BLOCK / BK_WAVE];
@@ -17,20 +18,38 @@ __global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = threadIdx.x / BK_WAVE;
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
-  for (i64 start = 0; start < n; start += CP_BLOCK) {
-    i64 i = start + threadIdx.x;
-    bool f = (i < n) && mask[i] != 0;
-    unsigned long long b = __ballot(f);
-    uint32_t before = (uint32_t)__popcll(b & ((1ULL << lane) - 1ULL));
-    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(b);
+  const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;
+  for (i64 start = 0; start < n; start += (i64)CP_BLOCK * CP_ITEMS) {
+    i64 i0 = start + (i64)threadIdx.x * CP_ITEMS;
+    uint32_t bits = 0;  // bit k set <=> mask[i0 + k] != 0
+    if (aligned && i0 + CP_ITEMS <= n) {
+      uint64_t w = *reinterpret_cast<const uint64_t*>(mask + i0);
+#pragma unroll
+      for (int k = 0; k < CP_ITEMS; ++k) bits |= ((w >> (8 * k)) & 0xffu) ? (1u << k) : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < CP_ITEMS; ++k)
+        if (i0 + k < n && mask[i0 + k]) bits |= 1u << k;
+    }
+    uint32_t mine = (uint32_t)__popc(bits);
+    // exclusive prefix of `mine` inside the wavefront
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < BK_WAVE; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == BK_WAVE - 1) wave_cnt[wave] = incl;
     __syncthreads();
-    uint32_t off = base;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (f) idx[off + before] = (int32_t)i;
+    uint32_t off = base + (incl - mine);
+    for (int w2 = 0; w2 < wave; ++w2) off += wave_cnt[w2];
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k)
+      if (bits & (1u << k)) idx[off++] = (int32_t)(i0 + k);
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t t = 0;
-      for (int w = 0; w < CP_BLOCK / BK_WAVE; ++w) t += wave_cnt[w];
+      for (int w2 = 0; w2 < CP_BLOCK / BK_WAVE; ++w2) t += wave_cnt[w2];
       base += t;
     }
     __syncthreads();
