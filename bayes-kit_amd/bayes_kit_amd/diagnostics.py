@@ -98,6 +98,50 @@ class RunningMoments:
         return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
 
 
+class DrawRecorder:
+    """Draw storage for post-processing: the full series of a few tracked
+    coordinates (and the returned log density) as ``[K, N, C]`` -- draw-major, chain-contiguous,
+    the layout ``ess`` / ``rhat`` consume directly -- filled one draw at a time on the device.
+    Storing every coordinate of every draw is rarely wanted at 65,536 chains x 1024 dims
+    (512 MiB per draw); ``RunningMoments`` covers all coordinates in O(1) memory."""
+
+    def __init__(self, dims: Sequence[int], capacity: int, chains: int, with_logp: bool = True, ops=None):
+        self._ops = _ops(ops)
+        self.dims = [int(d) for d in dims]
+        self.with_logp = bool(with_logp)
+        K = len(self.dims) + (1 if with_logp else 0)
+        self.series = torch.empty((K, int(capacity), int(chains)), dtype=torch.float64, device=self._ops.device)
+        self.n = 0
+
+    def record(self, theta, logp=None) -> None:
+        """theta: the (C, D) draw returned by ``sample()``; logp: its (C,) log density."""
+        if self.n >= self.series.shape[1]:
+            raise IndexError("DrawRecorder is full")
+        for k, d in enumerate(self.dims):
+            self.series[k, self.n].copy_(theta[:, d])
+        if self.with_logp:
+            self.series[-1, self.n].copy_(logp)
+        self.n += 1
+
+    def names(self):
+        return [f"theta[{d}]" for d in self.dims] + (["logp"] if self.with_logp else [])
+
+    def view(self, k: int) -> torch.Tensor:
+        """[n, C] series of tracked quantity k."""
+        return self.series[k, : self.n]
+
+    def ess(self) -> torch.Tensor:
+        """[K, C] effective sample sizes (ess.py:52-69) of every tracked series of every chain."""
+        return torch.stack([ess(self.view(k), ops=self._ops) for k in range(self.series.shape[0])])
+
+    def rhat(self, group=None) -> np.ndarray:
+        """R-hat (rhat.py:111-171) of every tracked quantity over all chains (and ranks)."""
+        return np.array([rhat(self.view(k), ops=self._ops, group=group) for k in range(self.series.shape[0])])
+
+    def state_dict(self):
+        return {"series": self.series[:, : self.n].cpu().clone(), "dims": self.dims, "with_logp": self.with_logp}
+
+
 # ---------------------------------------------------------------------------------------------
 # helpers for the reference-style inputs
 # ---------------------------------------------------------------------------------------------

@@ -139,7 +139,7 @@ def run_other_config(args, rank, local_rank, world):
                           seed=20242)
         mom = bk.RunningMoments(D, C)
         N = args.steps
-        series = torch.empty((4, N, C), dtype=torch.float64, device=device)
+        rec = bk.DrawRecorder([0, 1, D - 1], N, C)
         for _ in range(args.warmup):
             s.sample()
         lane_steps = 0
@@ -149,11 +149,12 @@ def run_other_config(args, rank, local_rank, world):
             th, lp = s.sample()
             lane_steps += s.last_lane_steps
             mom.update(s._theta_dc)
-            series[0, n], series[1, n], series[2, n], series[3, n] = th[:, 0], th[:, 1], th[:, D - 1], lp
+            rec.record(th, lp)
         barrier()
         el = time.perf_counter() - t0
         rh = mom.rhat()
-        ess = torch.stack([bk.ess(series[i]) for i in range(4)]).min(dim=0).values
+        ess = rec.ess()
+        ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N)).min(dim=0).values
         ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), device)
         lane_total = bk.dist.sum_over_ranks(float(lane_steps), device)
         out = {"metric": "DRGHMC funnel D=101 K=3: gradient evaluations/sec (chain-steps actually run)",

@@ -50,6 +50,13 @@ def check_diagnostics(ops, ess_rtol):
 
     want = [od.rhat([draws[:, c, d] for c in range(C)]) for d in range(D)]
     np.testing.assert_allclose(mom.rhat(), want, rtol=1e-10)
+    # draw storage: tracked coordinates + logp, consumed by ess / rhat without reshaping
+    rec = bk.DrawRecorder([0, 2], N, C, ops=ops)
+    for n in range(N):
+        rec.record(torch.from_numpy(draws[n]).to(ops.device), torch.from_numpy(draws[n].sum(axis=1)).to(ops.device))
+    assert rec.names() == ["theta[0]", "theta[2]", "logp"] and rec.ess().shape == (3, C)
+    np.testing.assert_allclose(rec.rhat()[:2], [want[0], want[2]], rtol=1e-10)
+    np.testing.assert_allclose(rec.ess()[1].cpu().numpy(), [od.ess(draws[:, c, 2]) for c in range(C)], rtol=ess_rtol)
     # ESS / IAT / autocorr (ess.py, iat.py, autocorr.py): direct sums vs the reference's FFT
     ar = z["ar_chains"]
     xm = torch.from_numpy(np.ascontiguousarray(ar.T)).to(ops.device)
