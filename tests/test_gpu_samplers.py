@@ -360,3 +360,23 @@ def test_odd_shapes_all_samplers_vs_oracle(ops, C, D):
         M = np.eye(D) + 0.1 * np.outer(np.ones(D), np.ones(D)) / D
         compare(bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 4, chains=C, seed=seed, metric_dense=M),
                 lambda c: osamp.HMCDense(om.DiagGaussian(lam), 0.05, 4, M, seed=key(c)), 3, exact=False)
+
+
+def test_moments_many_chains_hmc_and_mala(ops):
+    """Statistical checks in the spirit of test/test_hmc.py:38-51 and test/test_mala.py:9-41,
+    with thousands of chains at once: draws match the target's mean and variance."""
+    lam = np.array([1.0, 4.0, 0.25])
+    for s, burn, keep in (
+        (bk.HMCDiag(bk.DiagGaussian(lam), 0.25, 10, chains=8192, seed=12), 20, 30),
+        (bk.HMCDiag(bk.DiagGaussian(lam), 0.25, 10, chains=8192, seed=12, fuse_builtin=False), 20, 30),
+        (bk.MALA(bk.DiagGaussian(lam), 0.2, chains=8192, seed=13), 150, 50),
+    ):
+        acc = []
+        for n in range(burn + keep):
+            th, _ = s.sample()
+            if n >= burn:
+                acc.append(th.clone())
+        x = torch.stack(acc).reshape(-1, 3).cpu().numpy()
+        np.testing.assert_allclose(x.mean(axis=0), 0.0, atol=0.02)
+        np.testing.assert_allclose(x.var(axis=0), 1.0 / lam, rtol=0.04)
+        assert 0.3 < s.accept_rate() <= 1.0
