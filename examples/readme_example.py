@@ -36,8 +36,8 @@ print(f"65536 chains after 200 draws: mean {theta.mean().item():+.4f}  var {thet
       f"accept {sampler.accept_rate():.2f}")
 
 # 3) HMC on an ill-conditioned Gaussian, R-hat over all chains from streaming moments
-lam = np.logspace(0, 2, 64)
-hmc = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 16, chains=4096, seed=1)
+lam = np.logspace(0, 1, 64)  # (static HMC: keep sqrt(lam)*eps*L away from multiples of pi)
+hmc = bk.HMCDiag(bk.DiagGaussian(lam), 0.08, 10, chains=4096, seed=1)
 mom = bk.RunningMoments(64, 4096)
 for _ in range(100):
     theta, _ = hmc.sample()
