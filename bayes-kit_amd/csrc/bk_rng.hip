@@ -57,9 +57,7 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
   G g;
   g.load(st, ldr, c);
   double kin = 0.0;
-  for (i64 d = 0; d < D; ++d) {
-    bk::top_up(g);
-    double z = bk::next_normal(g, tab.ki, tab.wi, tab.fi);
+  auto emit = [&](i64 d, double z) {
     double loc = loc_in ? loc_in[d * ld + c] * loc_mul : 0.0;
     double v = loc + scale * z;  // numpy random_normal: loc + scale * z
     out[d * ld + c] = v;
@@ -67,6 +65,18 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
       double mv = metric ? metric[d] * v : v;
       kin = kin + v * mv;
     }
+  };
+  i64 d = 0;
+  for (; d + 1 < D; d += 2) {  // two normals per pass (same stream order, more ILP)
+    bk::top_up(g);
+    double z0, z1;
+    bk::next_normal_pair(g, tab.ki, tab.wi, tab.fi, z0, z1);
+    emit(d, z0);
+    emit(d + 1, z1);
+  }
+  if (d < D) {
+    bk::top_up(g);
+    emit(d, bk::next_normal(g, tab.ki, tab.wi, tab.fi));
   }
   g.store(st, ldr, c);
   if (kin_out) kin_out[c] = 0.5 * kin;
@@ -95,11 +105,19 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_mala_propose(uint64_t* st, i64 ld
   if (c >= C) return;
   G g;
   g.load(st, ldr, c);
-  for (i64 d = 0; d < D; ++d) {
+  i64 d = 0;
+  for (; d + 1 < D; d += 2) {
     bk::top_up(g);
-    double z = bk::next_normal(g, tab.ki, tab.wi, tab.fi);
+    double z0, z1;
+    bk::next_normal_pair(g, tab.ki, tab.wi, tab.fi, z0, z1);
     i64 o = d * ld + c;
-    prop[o] = (theta[o] + eps * grad[o]) + s * z;  // mala.py:41-45, left to right
+    prop[o] = (theta[o] + eps * grad[o]) + s * z0;  // mala.py:41-45, left to right
+    prop[o + ld] = (theta[o + ld] + eps * grad[o + ld]) + s * z1;
+  }
+  if (d < D) {
+    bk::top_up(g);
+    i64 o = d * ld + c;
+    prop[o] = (theta[o] + eps * grad[o]) + s * bk::next_normal(g, tab.ki, tab.wi, tab.fi);
   }
   g.store(st, ldr, c);
 }
@@ -233,7 +251,9 @@ int bk_host_normals(int rng_kind, uint64_t* w, double* out, int64_t n) {
   if (rng_kind == BK_RNG_PHILOX) {
     bk::Philox g;
     g.load(w, (i64)1, (i64)0);
-    for (i64 i = 0; i < n; ++i) out[i] = bk::next_normal(g, h_zig_ki, wi, fi);
+    i64 i = 0;
+    for (; i + 1 < n; i += 2) bk::next_normal_pair(g, h_zig_ki, wi, fi, out[i], out[i + 1]);
+    if (i < n) out[i] = bk::next_normal(g, h_zig_ki, wi, fi);
     g.store(w, (i64)1, (i64)0);
   } else if (rng_kind == BK_RNG_PCG64) {
     bk::Pcg64 g;

@@ -99,6 +99,12 @@ struct Philox {
     return v;
   }
 
+  // push the word just returned by next() back (the caller will consume it again)
+  BK_HD void unget(uint64_t v) {
+    q3 = q2; q2 = q1; q1 = q0; q0 = v;
+    ++rem;
+  }
+
   // words available without generating a block
   BK_HD int avail() const { return (int)rem + 4 * (int)cnt; }
 
@@ -279,29 +285,83 @@ BK_HD double next_double(G& g) {
 }
 
 // NumPy random_standard_normal.  ki/wi/fi point at the three 256-entry tables (LDS on the
-// device, static arrays on the host).
+// device, static arrays on the host).  Split into the word-local fast test and the rare
+// continuation so that two normals can be started from two words at once (next_normal_pair).
+BK_HD bool zig_fast(uint64_t r, const uint64_t* ki, const double* wi, double& x, int& idx, uint64_t& rabs) {
+  idx = (int)(r & 0xff);
+  r >>= 8;
+  int sign = (int)(r & 1);
+  rabs = (r >> 1) & 0x000fffffffffffffULL;
+  x = (double)rabs * wi[idx];
+  if (sign) x = -x;
+  return rabs < ki[idx];  // 99.2 %
+}
+
+// the rest of one ziggurat attempt whose first word failed the fast test; false = rejected
 template <typename G>
-BK_HD double next_normal(G& g, const uint64_t* ki, const double* wi, const double* fi) {
+BK_HD bool zig_slow(G& g, int idx, uint64_t rabs, double x, const double* fi, double& out) {
   const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
-  for (;;) {
-    uint64_t r = g.next();
-    int idx = (int)(r & 0xff);
-    r >>= 8;
-    int sign = (int)(r & 1);
-    uint64_t rabs = (r >> 1) & 0x000fffffffffffffULL;
-    double x = (double)rabs * wi[idx];
-    if (sign) x = -x;
-    if (rabs < ki[idx]) return x;  // 99.2 %
-    if (idx == 0) {
-      for (;;) {
-        double xx = -zinv * bk_log1p(-next_double(g));
-        double yy = -bk_log1p(-next_double(g));
-        if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+  if (idx == 0) {
+    for (;;) {
+      double xx = -zinv * bk_log1p(-next_double(g));
+      double yy = -bk_log1p(-next_double(g));
+      if (yy + yy > xx * xx) {
+        out = ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+        return true;
       }
-    } else {
-      if ((fi[idx - 1] - fi[idx]) * next_double(g) + fi[idx] < exp(-0.5 * x * x)) return x;
     }
   }
+  if ((fi[idx - 1] - fi[idx]) * next_double(g) + fi[idx] < exp(-0.5 * x * x)) {
+    out = x;
+    return true;
+  }
+  return false;
+}
+
+template <typename G>
+BK_HD double next_normal(G& g, const uint64_t* ki, const double* wi, const double* fi) {
+  for (;;) {
+    double x, out;
+    int idx;
+    uint64_t rabs;
+    if (zig_fast(g.next(), ki, wi, x, idx, rabs)) return x;
+    if (zig_slow(g, idx, rabs, x, fi, out)) return out;
+  }
+}
+
+// Two consecutive normals.  Generic form: one after the other.
+template <typename G>
+BK_HD void next_normal_pair(G& g, const uint64_t* ki, const double* wi, const double* fi, double& z0, double& z1) {
+  z0 = next_normal(g, ki, wi, fi);
+  z1 = next_normal(g, ki, wi, fi);
+}
+
+// Philox: 98.3 % of the time both normals take one word each and pass the fast test, so the
+// two words are popped and tested together (two independent table look-ups / conversions in
+// flight instead of one -- the loop is latency bound with one wavefront per SIMD).  Otherwise
+// the stream order is restored exactly: if the FIRST normal needs more words, the second word
+// is pushed back and consumed again.
+BK_HD void next_normal_pair(Philox& g, const uint64_t* ki, const double* wi, const double* fi, double& z0,
+                            double& z1) {
+  uint64_t r0 = g.next(), r1 = g.next();
+  double x0, x1, out;
+  int i0, i1;
+  uint64_t a0, a1;
+  bool ok0 = zig_fast(r0, ki, wi, x0, i0, a0);
+  bool ok1 = zig_fast(r1, ki, wi, x1, i1, a1);
+  if (ok0 && ok1) {
+    z0 = x0;
+    z1 = x1;
+    return;
+  }
+  if (ok0) {
+    z0 = x0;
+    z1 = zig_slow(g, i1, a1, x1, fi, out) ? out : next_normal(g, ki, wi, fi);
+    return;
+  }
+  g.unget(r1);
+  z0 = zig_slow(g, i0, a0, x0, fi, out) ? out : next_normal(g, ki, wi, fi);
+  z1 = next_normal(g, ki, wi, fi);
 }
 
 }  // namespace bk
