@@ -38,6 +38,11 @@ def make_model(spec):
         return models.DiagGaussian(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"]))
     if kind == "funnel":
         return models.Funnel(spec["D"])
+    if kind == "ref_binomial":
+        # the reference's OWN test model (test/models/binomial.py), imported from /root/reference
+        from test.models.binomial import Binomial
+
+        return Binomial(alpha=2, beta=3, x=5, N=15)
     raise KeyError(kind)
 
 
@@ -178,6 +183,14 @@ SAMPLER_CASES = [
          chains=8, draws=60, seed=203),
     dict(name="mala_init", alg="mala", model=dict(kind="iso_gaussian", D=3), epsilon=0.15,
          init=[0.2, -1.0, 0.5], chains=3, draws=30, seed=204),
+    # --- the reference's own Binomial test model (scipy densities, finite-difference gradient) ---
+    dict(name="hmc_ref_binomial", alg="hmc", model=dict(kind="ref_binomial"), stepsize=0.08, steps=3,
+         init=[0.1], chains=2, draws=40, seed=401),
+    dict(name="mala_ref_binomial", alg="mala", model=dict(kind="ref_binomial"), epsilon=0.12,
+         init=[0.1], chains=2, draws=40, seed=402),
+    dict(name="drghmc_ref_binomial", alg="drghmc", model=dict(kind="ref_binomial"), max_proposals=2,
+         leapfrog_step_sizes=[0.3, 0.1], leapfrog_step_counts=[2, 6], damping=0.3, init=[0.1],
+         chains=2, draws=40, seed=403),
     # --- DRGHMC (bayes_kit/drghmc.py) ---
     dict(name="drghmc_stdnormal_k3", alg="drghmc", model=dict(kind="std_normal"), max_proposals=3,
          leapfrog_step_sizes=[0.9, 0.45, 0.225], leapfrog_step_counts=[2, 4, 8], damping=0.2,

@@ -15,6 +15,7 @@ SAMPLER_CASES = [
     "mala_readme_cfg1", "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init",
     "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
     "drghmc_funnel101_cfg4", "drghmc_diag16_metric",
+    "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
 ]
 
 
@@ -34,6 +35,10 @@ def oracle_model(spec):
         return omodels.DiagGaussian(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"]))
     if kind == "funnel":
         return omodels.Funnel(spec["D"])
+    if kind == "ref_binomial":
+        from tests.host_models import Binomial
+
+        return Binomial(alpha=2, beta=3, x=5, N=15)
     raise KeyError(kind)
 
 

@@ -33,7 +33,9 @@ def test_hmc_step_by_step_path_vs_reference_golden(name, ops):
 
 
 @pytest.mark.parametrize("name", ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init",
-                                  "drghmc_stdnormal_k3", "drghmc_k1"])
+                                  "drghmc_stdnormal_k3", "drghmc_k1",
+                                  # the reference's own scipy-based test model with its finite-difference gradient
+                                  "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial"])
 def test_single_chain_drop_in_vs_reference_golden(name, ops):
     check_single_chain_host_model(name, ops, chains=[0, 1])
 
