@@ -309,8 +309,13 @@ class ManyChainSampler:
             return grad_out
         if self._batched:
             lp, g = m.log_density_gradient(theta_dc.t())
+            if g.dtype != torch.float64 or g.device != theta_dc.device:
+                g = g.to(device=theta_dc.device, dtype=torch.float64)  # the kernels read raw fp64 pointers
+            if tuple(g.shape) != (theta_dc.shape[1], theta_dc.shape[0]):
+                raise ValueError(f"log_density_gradient must return a ({theta_dc.shape[1]}, {theta_dc.shape[0]}) "
+                                 f"gradient, got {tuple(g.shape)}")
             if logp_out is not None:
-                logp_out.copy_(lp)
+                logp_out.copy_(lp.reshape(-1))
             return g.t()
         th = np.array(theta_dc[:, 0].cpu().numpy())
         lp, g = m.log_density_gradient(th)

@@ -293,3 +293,33 @@ def test_logistic_target_driver():
     from tests.sampler_parity import check_logistic_target
 
     check_logistic_target(FakeOps(), N=120, D=6, C=12)
+
+
+def test_batched_model_output_is_validated():
+    import torch
+
+    class F32:
+        batched = True
+
+        def dims(self):
+            return 4
+
+        def log_density(self, Th):
+            return -0.5 * (Th * Th).sum(dim=1)
+
+        def log_density_gradient(self, Th):
+            return (-0.5 * (Th * Th).sum(dim=1)).reshape(-1, 1), (-Th).to(torch.float32)  # f32 grad, (C,1) logp
+
+    ops = FakeOps()
+    a = bk.HMCDiag(F32(), 0.1, 3, chains=5, seed=1, ops=ops)
+    b = bk.HMCDiag(bk.IsoGaussian(4, ops=ops), 0.1, 3, chains=5, seed=1, fuse_builtin=False, ops=ops)
+    ta, _ = a.sample()
+    tb, _ = b.sample()
+    np.testing.assert_allclose(ta.numpy(), tb.numpy(), rtol=1e-6)  # gradient rounded through f32
+
+    class Bad(F32):
+        def log_density_gradient(self, Th):
+            return -0.5 * (Th * Th).sum(dim=1), -Th[:, :2]
+
+    with pytest.raises(ValueError):
+        bk.HMCDiag(Bad(), 0.1, 3, chains=5, seed=1, ops=ops).sample()
