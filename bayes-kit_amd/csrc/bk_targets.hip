@@ -123,8 +123,8 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
 // order (each wavefront's rows in increasing d, then wavefronts 0..15), so the result does
 // not depend on how many chains are in flight.  Every wavefront integrates v = theta_0
 // redundantly (it needs exp(-v) for its own rows); wavefront 0 writes it.
-constexpr int FN_WAVES = 16;
-constexpr int FN_ROWS = 8;  // rows per wavefront held in registers: D - 1 <= 128
+constexpr int FN_WAVES = 4;
+constexpr int FN_ROWS = 32;  // rows per wavefront held in registers: D - 1 <= 128
 constexpr int FN_BLOCK = FN_WAVES * BK_WAVE;
 
 struct FunnelLds {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   const double half = 0.5 * h;
   const double hn = 0.5 * (double)(D - 1);
   const bool hm = metric != nullptr;
-  double x[FN_ROWS], r[FN_ROWS], m[FN_ROWS];
+  double x[FN_ROWS], r[FN_ROWS];
   // gather + first half-kick + drift (drghmc.py:276-278)
 #pragma unroll
   for (int i = 0; i < FN_ROWS; ++i) {
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     x[i] = ok ? th_in[d * ld_in + src] : 0.0;
     r[i] = ok ? rho_in[d * ld_in + src] : 0.0;
     double g0 = ok ? g_in[d * ld_in + src] : 0.0;
-    m[i] = (hm && d < D) ? metric[d] : 1.0;
-    double t = hm ? m[i] * g0 : g0;
+    const double mi = (hm && d < D) ? metric[d] : 1.0;  // wave-uniform index: scalar load
+    double t = hm ? mi * g0 : g0;
     r[i] = r[i] + half * t;
     x[i] = x[i] + h * r[i];
   }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
       i64 d = 1 + w + (i64)FN_WAVES * i;
       if (d < D) {
         double gi = -(ev * x[i]);
-        double t = hm ? m[i] * gi : gi;
+        double t = hm ? metric[d] * gi : gi;
         r[i] = r[i] + kick * t;
         if (!last) x[i] = x[i] + h * r[i];
         else if (on) g_out[d * ld_out + j] = gi;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     i64 d = 1 + w + (i64)FN_WAVES * i;
     if (d < D) {
       double rr = -r[i];
-      double mr = hm ? m[i] * rr : rr;
+      double mr = hm ? metric[d] * rr : rr;
       kp = kp + rr * mr;
       if (on) {
         rho_out[d * ld_out + j] = rr;

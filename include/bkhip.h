@@ -228,7 +228,7 @@ int bk_mala_logq(const double* theta, const double* grad, const double* theta_pr
  *   iso     : logp = -0.5*sum th^2            grad = -th
  *   diag    : t = lam*th; logp = -0.5*sum th*t; grad = -t
  *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2 (for D-1 <= 128 summed
- *             as 16 interleaved partial sums -- rows 1+w, 17+w, ... for w = 0..15 -- then
+ *             as 4 interleaved partial sums -- rows 1+w, 5+w, ... for w = 0..3 -- then
  *             over w; sequentially in d otherwise)
  *             logp = ((-(v*v)/18) - (0.5*n)*v) - (0.5*ev)*s
  *             grad0 = ((-v/9) - 0.5*n) + (0.5*ev)*s ; grad_i = -(ev*th_i)
