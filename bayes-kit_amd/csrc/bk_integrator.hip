@@ -183,36 +183,59 @@ __global__ __launch_bounds__(PC_BLOCK) void k_first_step_gather(
 }
 
 // ---- final half-kick + kinetic energy ---------------------------------------------------
-constexpr int FIN_UNROLL = 16;  // 32 loads in flight per lane: the kernel has only C/64 wavefronts
-__global__ __launch_bounds__(PC_BLOCK) void k_finish(const double* rho_in, double* rho_out, i64 ld,
-                                                     const double* grad, i64 ldg_d, i64 ldg_c,
-                                                     const double* metric, double half, int negate,
-                                                     double* kin_out, i64 C, i64 D) {
+// Per-chain reductions: a workgroup of RED_WAVES wavefronts serves 64 chains (lane = chain);
+// wavefront w owns the contiguous quarter of the dimensions [w*Dq, (w+1)*Dq) and sums it
+// sequentially, the quarters are combined through LDS in the fixed order ((p0+p1)+p2)+p3.
+// The order depends on D only, never on the number of chains or the grid.
+constexpr int RED_WAVES = 4;
+constexpr int RED_BLOCK = RED_WAVES * BK_WAVE;
+constexpr int FIN_UNROLL = 8;
+
+__device__ __forceinline__ double red_combine(double (&part)[RED_WAVES][BK_WAVE], int w, int lane, double p) {
+  part[w][lane] = p;
+  __syncthreads();
+  double s = part[0][lane];
+#pragma unroll
+  for (int k = 1; k < RED_WAVES; ++k) s = s + part[k][lane];
+  return s;
+}
+
+__global__ __launch_bounds__(RED_BLOCK) void k_finish(const double* rho_in, double* rho_out, i64 ld,
+                                                      const double* grad, i64 ldg_d, i64 ldg_c,
+                                                      const double* metric, double half, int negate,
+                                                      double* kin_out, i64 C, i64 D) {
+  __shared__ double part[RED_WAVES][BK_WAVE];
   constexpr int PC_UNROLL = FIN_UNROLL;
-  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
-  if (c >= C) return;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
   double kin = 0.0;
-  for (i64 d0 = 0; d0 < D; d0 += PC_UNROLL) {
-    double r[PC_UNROLL], g[PC_UNROLL];
+  if (c < C) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += PC_UNROLL) {
+      double r[PC_UNROLL], g[PC_UNROLL];
 #pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) {
-        r[u] = rho_in[(d0 + u) * ld + c];
-        g[u] = grad ? grad[(d0 + u) * ldg_d + c * ldg_c] : 0.0;
-      }
+      for (int u = 0; u < PC_UNROLL; ++u)
+        if (d0 + u < dhi) {
+          r[u] = rho_in[(d0 + u) * ld + c];
+          g[u] = grad ? grad[(d0 + u) * ldg_d + c * ldg_c] : 0.0;
+        }
 #pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) {
-        double m = metric ? metric[d0 + u] : 1.0;
-        double t = metric ? m * g[u] : g[u];
-        double v = grad ? r[u] + half * t : r[u];  // grad NULL: kinetic energy of rho_in as is
-        if (negate) v = -v;
-        if (rho_out) rho_out[(d0 + u) * ld + c] = v;
-        double mv = metric ? m * v : v;
-        kin = kin + v * mv;  // sequential in d
-      }
+      for (int u = 0; u < PC_UNROLL; ++u)
+        if (d0 + u < dhi) {
+          double m = metric ? metric[d0 + u] : 1.0;
+          double t = metric ? m * g[u] : g[u];
+          double v = grad ? r[u] + half * t : r[u];  // grad NULL: kinetic energy of rho_in as is
+          if (negate) v = -v;
+          if (rho_out) rho_out[(d0 + u) * ld + c] = v;
+          double mv = metric ? m * v : v;
+          kin = kin + v * mv;
+        }
+    }
   }
-  if (kin_out) kin_out[c] = 0.5 * kin;
+  if (!kin_out) return;  // uniform: no barrier needed without the reduction
+  double s = red_combine(part, w, lane, kin);
+  if (w == 0 && c < C) kin_out[c] = 0.5 * s;
 }
 
 // ---- accept ---------------------------------------------------------------------------
@@ -305,37 +328,47 @@ __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* 
 }
 
 // ---- MALA proposal log densities --------------------------------------------------------
-__global__ __launch_bounds__(PC_BLOCK) void k_mala_logq(const double* th, const double* g,
-                                                        const double* thp, const double* gp, i64 ld,
-                                                        double eps, double* fwd, double* rev, i64 C,
-                                                        i64 D) {
-  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(RED_BLOCK) void k_mala_logq(const double* th, const double* g,
+                                                         const double* thp, const double* gp, i64 ld,
+                                                         double eps, double* fwd, double* rev, i64 C,
+                                                         i64 D) {
+  __shared__ double part_f[RED_WAVES][BK_WAVE];
+  __shared__ double part_r[RED_WAVES][BK_WAVE];
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
   double sf = 0.0, sr = 0.0;
   constexpr int U = 4;
-  for (i64 d0 = 0; d0 < D; d0 += U) {
-    double a[U], b[U], p[U], q[U];
+  if (c < C) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += U) {
+      double a[U], b[U], p[U], q[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (d0 + u < D) {
-        i64 o = (d0 + u) * ld + c;
-        a[u] = th[o];
-        b[u] = g[o];
-        p[u] = thp[o];
-        q[u] = gp[o];
-      }
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) {
+          i64 o = (d0 + u) * ld + c;
+          a[u] = th[o];
+          b[u] = g[o];
+          p[u] = thp[o];
+          q[u] = gp[o];
+        }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (d0 + u < D) {
-        double xf = (p[u] - a[u]) - eps * b[u];  // mala.py:78
-        double xr = (a[u] - p[u]) - eps * q[u];
-        sf = sf + xf * xf;
-        sr = sr + xr * xr;
-      }
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) {
+          double xf = (p[u] - a[u]) - eps * b[u];  // mala.py:78
+          double xr = (a[u] - p[u]) - eps * q[u];
+          sf = sf + xf * xf;
+          sr = sr + xr * xr;
+        }
+    }
   }
-  double k = -0.25 / eps;  // mala.py:79
-  fwd[c] = k * sf;
-  rev[c] = k * sr;
+  double tf = red_combine(part_f, w, lane, sf);
+  double tr = red_combine(part_r, w, lane, sr);
+  if (w == 0 && c < C) {
+    double k = -0.25 / eps;  // mala.py:79
+    fwd[c] = k * tf;
+    rev[c] = k * tr;
+  }
 }
 
 // ---- layout change through LDS tiles ------------------------------------------------------
@@ -435,7 +468,7 @@ int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld, const 
   if (!rho_in || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_finish<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+  k_finish<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
       rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }
@@ -473,7 +506,7 @@ int bk_mala_logq(const double* theta, const double* grad, const double* theta_pr
     return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_mala_logq<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
+  k_mala_logq<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
       theta, grad, theta_prop, grad_prop, ld, eps, lp_forward, lp_reverse, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }

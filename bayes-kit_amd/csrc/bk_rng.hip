@@ -60,14 +60,22 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
   if (active && !active[c]) return;
   G g;
   g.load(st, ldr, c);
-  double kin = 0.0;
+  // kinetic energy summed in the same order as bk_leapfrog_finish (four contiguous quarters of
+  // the dimensions, each sequential, combined ((p0+p1)+p2)+p3), so the same momentum has the
+  // same energy whichever kernel computes it
+  const i64 Dq = (D + 3) / 4;
+  double k0 = 0.0, k1 = 0.0, k2 = 0.0, k3 = 0.0;
   auto emit = [&](i64 d, double z) {
     double loc = loc_in ? loc_in[d * ld + c] * loc_mul : 0.0;
     double v = loc + scale * z;  // numpy random_normal: loc + scale * z
     out[d * ld + c] = v;
     if (kin_out) {
       double mv = metric ? metric[d] * v : v;
-      kin = kin + v * mv;
+      double t = v * mv;
+      if (d < Dq) k0 = k0 + t;
+      else if (d < 2 * Dq) k1 = k1 + t;
+      else if (d < 3 * Dq) k2 = k2 + t;
+      else k3 = k3 + t;
     }
   };
   i64 d = 0;
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_refresh(uint64_t* st, i64 ldr, co
     emit(d, bk::next_normal(g, tab.ki, tab.wi, tab.fi));
   }
   g.store(st, ldr, c);
-  if (kin_out) kin_out[c] = 0.5 * kin;
+  if (kin_out) kin_out[c] = 0.5 * (((k0 + k1) + k2) + k3);
 }
 
 template <typename G, bool LOG>

@@ -60,27 +60,42 @@ __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_s(const double* th, dou
     }
 }
 
-// logp (and optionally grad) of the separable Gaussians, one lane per chain
-__global__ __launch_bounds__(PC_BLOCK) void k_gauss_logp(const double* th, double* g, double* logp, i64 ld,
-                                                         const double* lam, i64 C, i64 D) {
-  constexpr int PC_UNROLL = 32;  // loads in flight per lane: the kernel has only C/64 wavefronts
-  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
-  if (c >= C) return;
+// logp (and optionally grad) of the separable Gaussians: 4 wavefronts per 64 chains, wavefront w
+// sums its contiguous quarter of the dimensions sequentially, quarters combined in fixed order
+constexpr int RED_WAVES = 4;
+constexpr int RED_BLOCK = RED_WAVES * BK_WAVE;
+__global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp(const double* th, double* g, double* logp, i64 ld,
+                                                          const double* lam, i64 C, i64 D) {
+  __shared__ double part[RED_WAVES][BK_WAVE];
+  constexpr int PC_UNROLL = 8;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
   double s = 0.0;
-  for (i64 d0 = 0; d0 < D; d0 += PC_UNROLL) {
-    double t[PC_UNROLL];
+  if (c < C) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += PC_UNROLL) {
+      double t[PC_UNROLL];
 #pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) t[u] = th[(d0 + u) * ld + c];
+      for (int u = 0; u < PC_UNROLL; ++u)
+        if (d0 + u < dhi) t[u] = th[(d0 + u) * ld + c];
 #pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) {
-        double lt = lam ? lam[d0 + u] * t[u] : t[u];
-        s = s + t[u] * lt;
-        if (g) g[(d0 + u) * ld + c] = -lt;
-      }
+      for (int u = 0; u < PC_UNROLL; ++u)
+        if (d0 + u < dhi) {
+          double lt = lam ? lam[d0 + u] * t[u] : t[u];
+          s = s + t[u] * lt;
+          if (g) g[(d0 + u) * ld + c] = -lt;
+        }
+    }
   }
-  logp[c] = -0.5 * s;
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    double tot = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < RED_WAVES; ++k) tot = tot + part[k][lane];
+    logp[c] = -0.5 * tot;
+  }
 }
 
 // Neal's funnel, any D: one lane per chain, sequential in d
@@ -355,7 +370,7 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
   if (C == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
   if (logp) {
-    k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D);
+    k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D);
     BK_RETURN_LAUNCH_STATUS();
   }
   if (D == 0) return BK_OK;

@@ -114,8 +114,10 @@ int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in,
  *     if rho_out: rho_out = r
  *     kin_out[c] = 0.5 * sum_d r*(metric[d]*r)    hmc.py:37, drghmc.py:250
  * grad NULL: no kick (r = rho_in), i.e. just the kinetic energy of a finished trajectory.
- * The sum runs d = 0..D-1 sequentially per chain (np.dot uses a different order: results
- * agree to ~1e-16 relative, see DESIGN.md tolerances). */
+ * Per-chain sums (here, in bk_momentum_refresh, bk_mala_logq and the Gaussian targets' logp)
+ * run over four contiguous quarters of the dimensions, each sequentially in d, combined as
+ * ((p0+p1)+p2)+p3: a fixed order that depends on D only (np.dot uses yet another order:
+ * results agree to ~1e-16 relative, see DESIGN.md tolerances). */
 int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld,
                        const double* grad, int64_t ldg_d, int64_t ldg_c,
                        const double* metric, double half, int negate,
