@@ -306,15 +306,15 @@ __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* 
 #pragma unroll
   for (int i = 0; i < SEL_ROWS; ++i)
     if (d0 + i < D) {
-      a[i] = *reinterpret_cast<const dvec2*>(src0 + (d0 + i) * ld + 2 * c2);
-      if (dst1) b[i] = *reinterpret_cast<const dvec2*>(src1 + (d0 + i) * ld + 2 * c2);
+      a[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src0 + (d0 + i) * ld + 2 * c2));
+      if (dst1) b[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src1 + (d0 + i) * ld + 2 * c2));
     }
   if (m0 && m1) {
 #pragma unroll
     for (int i = 0; i < SEL_ROWS; ++i)
       if (d0 + i < D) {
-        *reinterpret_cast<dvec2*>(dst0 + (d0 + i) * ld + 2 * c2) = a[i];
-        if (dst1) *reinterpret_cast<dvec2*>(dst1 + (d0 + i) * ld + 2 * c2) = b[i];
+        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(dst0 + (d0 + i) * ld + 2 * c2));
+        if (dst1) __builtin_nontemporal_store(b[i], reinterpret_cast<dvec2*>(dst1 + (d0 + i) * ld + 2 * c2));
       }
   } else {
     const int o = m0 ? 0 : 1;
