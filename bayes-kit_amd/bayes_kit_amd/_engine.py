@@ -179,7 +179,13 @@ class ManyChainSampler:
         mt = torch.as_tensor(m, dtype=torch.float64).reshape(-1)
         if mt.shape[0] != self._dim:
             raise ValueError(f"metric_diag has {mt.shape[0]} entries, model has {self._dim} dims")
-        self._metric_dev = mt.to(self._ops.device).contiguous()
+        new = mt.to(self._ops.device).contiguous()
+        if getattr(self, "_metric_dev", None) is not None:
+            self._metric_dev.copy_(new)  # in place: a captured hipGraph keeps pointing at this buffer
+        else:
+            self._metric_dev = new
+            if getattr(self, "_graph", None) is not None:
+                self._graph = None  # the captured launches had no metric argument: capture again
 
     @property
     def _metric(self):
@@ -268,7 +274,16 @@ class ManyChainSampler:
     # as one hipGraph; all per-draw state (RNG table, theta, caches, counters) lives in device
     # memory, so a replay IS the next draw.  Only for samplers whose draw has no host
     # synchronisation (batched models; not the single-chain host-model mode, not DRGHMC).
-    def _init_graph(self, graph: bool):
+    GRAPH_AUTO_MAX_ELEMS = 1 << 22  # D*C below which a draw is launch-bound (arrays <= 32 MiB)
+
+    def _init_graph(self, graph, prefer_streams: bool = False):
+        if graph is None and prefer_streams:
+            graph = False  # the caller explicitly asked for the side-stream RNG, which is not captured
+        if graph is None:
+            # automatic only where capture is known to be safe (the library's own targets: no host
+            # synchronisation, no allocation patterns of user code) and where it pays
+            graph = (self._batched and hasattr(self._model, "bk_eval") and self._ops.device.type == "cuda"
+                     and self._dim * self._C <= self.GRAPH_AUTO_MAX_ELEMS)
         self._use_graph = bool(graph)
         self._graph = None
         self._graph_warm = 0

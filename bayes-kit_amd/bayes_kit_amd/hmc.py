@@ -41,7 +41,7 @@ class HMCDiag(ManyChainSampler):
         chains: Optional[int] = None,
         chain_id0: int = 0,
         chain_tile: Optional[int] = None,
-        graph: bool = False,
+        graph: Optional[bool] = None,
         fuse_builtin: bool = True,
         prefetch_rng: Optional[bool] = None,
         metric_dense=None,
@@ -77,7 +77,7 @@ class HMCDiag(ManyChainSampler):
             self._M_inv = torch.linalg.inv(Mt)
             self._M_inv = (0.5 * (self._M_inv + self._M_inv.t())).to(dev_).contiguous()
             fuse_builtin = False
-        self._init_graph(graph)
+        self._init_graph(graph, prefer_streams=prefetch_rng is True)
         # built-in separable targets can run the whole trajectory in registers
         # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")

@@ -18,10 +18,10 @@ from ._engine import ManyChainSampler
 
 class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
-                 chain_id0: int = 0, graph: bool = False, prefetch_rng: Optional[bool] = None, ops=None):
+                 chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
-        self._init_graph(graph)
+        self._init_graph(graph, prefer_streams=prefetch_rng is True)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_p = torch.empty((D, C), **f64)

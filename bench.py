@@ -118,7 +118,7 @@ def run_other_config(args, rank, local_rank, world):
     if args.config == 2:
         C, D, L = args.chains or 4096, 128, 32
         s = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
-                       chains=C, chain_id0=rank * C, graph=not args.no_graph)
+                       chains=C, chain_id0=rank * C, graph=False if args.no_graph else None)
         for _ in range(args.warmup):
             s.sample()
         barrier()

@@ -201,7 +201,7 @@ def test_hipgraph_replay_equals_eager(ops):
             ta, la = a.sample()
             tb, lb = b.sample()
             assert torch.equal(ta, tb) and torch.equal(la, lb)
-        assert b._graph is not None
+        assert b._graph is not None and a._graph is None
         np.testing.assert_array_equal(a.rng_state(), b.rng_state())
         assert a.accept_rate() == b.accept_rate()
 
@@ -382,3 +382,33 @@ def test_moments_many_chains_hmc_and_mala(ops):
         np.testing.assert_allclose(x.mean(axis=0), 0.0, atol=0.02)
         np.testing.assert_allclose(x.var(axis=0), 1.0 / lam, rtol=0.04)
         assert 0.3 < s.accept_rate() <= 1.0
+
+
+def test_graph_replay_is_automatic_for_small_builtin_problems(ops):
+    small = bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=1)
+    big = bk.HMCDiag(bk.IsoGaussian(1024), 0.05, 2, chains=8192, seed=1)
+    torchm = bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(dim=1), 8), 0.2, 3, chains=64, seed=1)
+    assert small._use_graph and not small._prefetch
+    assert not big._use_graph and big._prefetch
+    assert not torchm._use_graph
+    for _ in range(3):
+        small.sample()
+    assert small._graph is not None
+
+
+def test_metric_assignment_survives_graph_replay(ops):
+    """_metric assigned after capture must reach the replayed kernels (in-place update, or a
+    re-capture when there was no metric before)."""
+    lam = np.logspace(0, 1, 16)
+    m = np.linspace(0.9, 1.1, 16)
+    for first_metric in (None, np.ones(16)):
+        a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=512, seed=3, graph=True, metric_diag=first_metric)
+        b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=512, seed=3, graph=False, prefetch_rng=False,
+                       metric_diag=first_metric)
+        for n in range(7):
+            if n == 4:
+                a._metric = m
+                b._metric = m
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (first_metric is None, n)
