@@ -230,7 +230,12 @@ class DrGhmcDiag(ManyChainSampler):
         P0 = self._levels[0]
         for k in range(int(self._max_proposals)):
             ops.dr_retry_test(self._rng_kind, self._rng_state, self._rej, pr, self._alive)  # :369-371
-            n, idx = self._compact(self._alive, C, 0)
+            if k == 0:
+                # reject_logp = 0 at the first stage, so log(u) < 0 always holds (drghmc.py:366-371):
+                # every chain proposes; the uniform is still drawn above (stream alignment)
+                n, idx = C, None
+            else:
+                n, idx = self._compact(self._alive, C, 0)
             if n == 0:
                 break
             tag = "P%d" % k
