@@ -20,7 +20,7 @@ from .ensemble import Stretcher
 from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
-from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, mala_kernel, metropolis_kernel
+from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, hmc_kernel, mala_kernel, metropolis_kernel
 from .targets import DiagGaussian, Funnel, IsoGaussian, LogisticRegression, TorchModel
 
 __all__ = [

@@ -76,6 +76,59 @@ class _MALAKernel:
             ops.select_columns(smc._mask, th, prop, grad, grad_p)
 
 
+class _TemperedTarget:
+    """The tempered density log_likelihood * t + log_prior as a batched GradModel."""
+
+    batched = True
+
+    def __init__(self, model):
+        self._model, self.t = model, 1.0
+
+    def dims(self):
+        return self._model.dims()
+
+    def log_density(self, Theta):
+        return self._model.log_likelihood(Theta) * self.t + self._model.log_prior(Theta)
+
+    def log_density_gradient(self, Theta):
+        return self._model.log_density_gradient_tempered(Theta, self.t)
+
+
+class _HMCKernel:
+    """`draws` HMC transitions (bayes_kit/hmc.py:55-63 arithmetic, through HMCDiag) on the tempered
+    density; optionally with a diagonal or a dense metric (dense = fp64 MFMA GEMMs)."""
+
+    def __init__(self, stepsize, steps, draws=1, metric_diag=None, metric_dense=None):
+        self.stepsize, self.steps, self.draws = float(stepsize), int(steps), int(draws)
+        self.metric_diag, self.metric_dense = metric_diag, metric_dense
+        self._hmc = None
+        self._target = None
+
+    def move(self, smc, t: float) -> None:
+        from .hmc import HMCDiag
+
+        if self._hmc is None:
+            self._target = _TemperedTarget(smc._model)
+            seed = [int(w) for w in smc._rng_state[1, :2].tolist()]  # derive a distinct key from slot ids
+            base = int(smc._rng_state[0, 0].item()) & ((1 << 63) - 1)
+            self._hmc = HMCDiag(self._target, self.stepsize, self.steps, metric_diag=self.metric_diag,
+                                init=smc.thetas, seed=base ^ 0x5DEECE66D, chains=smc.M, chain_id0=smc._slot0,
+                                metric_dense=self.metric_dense, graph=False, ops=smc._ops)
+            del seed
+        h = self._hmc
+        self._target.t = float(t)
+        h._theta_dc.copy_(smc._theta_dc)
+        h._have_cache = False  # new temperature, new positions: (logp, grad) must be re-evaluated
+        for _ in range(self.draws):
+            h._run_draw(h._draw)
+            h._draws += 1
+        smc._theta_dc.copy_(h._theta_dc)
+
+
+def hmc_kernel(stepsize: float, steps: int, draws: int = 1, metric_diag=None, metric_dense=None) -> _HMCKernel:
+    return _HMCKernel(stepsize, steps, draws, metric_diag, metric_dense)
+
+
 def metropolis_kernel(scale: float) -> _RWMKernel:
     return _RWMKernel(scale)
 
@@ -154,11 +207,19 @@ class TemperedLikelihoodSMC:
         th = self._theta_dc
         lpm1 = self._tempered(th, self.time(n - 1))
         lp = self._tempered(th, self.time(n))
-        w = torch.exp(lp - lpm1).contiguous()                        # smc.py:67-70
-        ops.uniform(self._rng_kind, self._rng_state, self._u)
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+        # weights exp(lp - lpminus1) [smc.py:67-70], scaled by exp(-max) so that a large data set
+        # (log-likelihood steps of 1e4 and more) cannot underflow every weight to zero; the
+        # reference normalises by the sum (smc.py:73), so the common factor changes nothing
+        logw = lp - lpm1
+        top = logw.max()
+        if multi:
+            dist.all_reduce(top, op=dist.ReduceOp.MAX, group=self._group)
+        w = torch.exp(logw - top).contiguous()
+        ops.uniform(self._rng_kind, self._rng_state, self._u)
+        if multi:
             world = dist.get_world_size(self._group)
             wparts = [torch.empty_like(w) for _ in range(world)]
             dist.all_gather(wparts, w, group=self._group)

@@ -292,6 +292,13 @@ def test_logistic_regression_target_and_annealed_smc(ops):
     smc.run()
     post = smc.thetas.mean(dim=0).cpu().numpy()
     assert np.corrcoef(post, tstar)[0, 1] > 0.9
+    # the same with HMC moves under a dense metric (MFMA GEMMs in the move kernel as well)
+    Md = np.eye(40) * 0.04
+    smc2 = bk.TemperedLikelihoodSMC(model, M, 12, init, bk.hmc_kernel(0.3, 5, metric_dense=Md), seed=3)
+    smc2.run()
+    post2 = smc2.thetas.mean(dim=0).cpu().numpy()
+    assert np.corrcoef(post2, tstar)[0, 1] > 0.9
+    assert np.corrcoef(post2, post)[0, 1] > 0.9  # two move kernels, same posterior (Monte Carlo noise apart)
 
 
 @pytest.mark.parametrize("R,K,C", [(128, 16, 128), (300, 70, 200), (1000, 512, 256), (40, 3000, 130), (128, 8192, 128)])

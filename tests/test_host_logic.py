@@ -287,6 +287,7 @@ def test_tempered_smc_driver():
 
     check_smc_binomial(FakeOps(), 400, 8, bk.metropolis_kernel(0.5), mean_atol=0.03, var_atol=0.004)
     check_smc_binomial(FakeOps(), 300, 6, bk.mala_kernel(0.15, 2), mean_atol=0.04, var_atol=0.005)
+    check_smc_binomial(FakeOps(), 300, 6, bk.hmc_kernel(0.4, 3), mean_atol=0.04, var_atol=0.005)
 
 
 def test_logistic_target_driver():

@@ -43,3 +43,18 @@ if os.environ.get("HMC", "1") == "1":
     out["hmc_dense_steps_per_sec"] = C * 8 * n / el
     out["hmc_dense_accept"] = s.accept_rate()
 print(json.dumps(out))
+
+if os.environ.get("SMC", "1") == "1":
+    # the whole of config 5 on one GPU: likelihood-annealed SMC, HMC moves with a dense metric
+    M, T = C, int(os.environ.get("T", 8))
+    init = torch.randn((M, D), dtype=torch.float64, device=dev, generator=g)  # prior draws
+    Md = torch.eye(D, dtype=torch.float64) * (4.0 * D / N)
+    smc = bk.TemperedLikelihoodSMC(model, M, T, init, bk.hmc_kernel(0.5, 4, metric_dense=Md), seed=20243)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    smc.run()
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    post = smc.thetas.mean(dim=0)
+    corr = torch.corrcoef(torch.stack([post, tstar]))[0, 1].item()
+    print(json.dumps({"annealed_smc": {"particles": M, "temperatures": T, "move": "HMC L=4, dense metric",
+                                       "seconds": el, "corr_posterior_mean_vs_truth": corr,
+                                       "final_step_ess": smc.last_ess}}))
