@@ -261,7 +261,8 @@ class ManyChainSampler:
         if hasattr(self, "_have_cache"):
             self._have_cache = meta["have_cache"]
         self._load_extra(meta.get("extra", {}))
-        self._graph = None if hasattr(self, "_graph") else None
+        if hasattr(self, "_graph"):
+            self._graph = None  # captured launches may refer to superseded state: capture again
         self._after_load()
 
     def _load_extra(self, extra):

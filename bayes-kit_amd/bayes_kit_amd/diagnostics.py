@@ -14,7 +14,7 @@ combined in rank order, so the result does not depend on the reduction order.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence
+from typing import Sequence
 
 import numpy as np
 import torch

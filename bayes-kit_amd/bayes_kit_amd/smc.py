@@ -109,12 +109,10 @@ class _HMCKernel:
 
         if self._hmc is None:
             self._target = _TemperedTarget(smc._model)
-            seed = [int(w) for w in smc._rng_state[1, :2].tolist()]  # derive a distinct key from slot ids
-            base = int(smc._rng_state[0, 0].item()) & ((1 << 63) - 1)
+            base = int(smc._rng_state[0, 0].item()) & ((1 << 63) - 1)  # the SMC's Philox key word
             self._hmc = HMCDiag(self._target, self.stepsize, self.steps, metric_diag=self.metric_diag,
                                 init=smc.thetas, seed=base ^ 0x5DEECE66D, chains=smc.M, chain_id0=smc._slot0,
                                 metric_dense=self.metric_dense, graph=False, ops=smc._ops)
-            del seed
         h = self._hmc
         self._target.t = float(t)
         h._theta_dc.copy_(smc._theta_dc)

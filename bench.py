@@ -212,8 +212,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from bayes_kit_amd import _lib
-
     C = args.chains
     D, L = D_CFG3, L_CFG3
     s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile)
