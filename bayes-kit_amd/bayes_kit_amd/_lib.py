@@ -30,7 +30,8 @@ F = c_double
 SIGNATURES = {
     "bk_version": [],
     "bk_rng_init_philox": [P, I, c_uint64, c_uint64, I, P],
-    "bk_momentum_refresh": [c_int, P, I, P, F, F, P, I, P, P, P, I, I, P],
+    "bk_refresh_work_elems": [I, I],
+    "bk_momentum_refresh": [c_int, P, I, P, F, F, P, I, P, P, P, I, I, P, I, P],
     "bk_log_uniform": [c_int, P, I, P, P, I, P],
     "bk_uniform": [c_int, P, I, P, P, I, P],
     "bk_leapfrog_kick_drift": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P],
@@ -72,7 +73,7 @@ SIGNATURES = {
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
 }
-_RESTYPE = {"bk_host_log1p": c_double}
+_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64}
 
 
 class BkHipError(RuntimeError):
@@ -182,10 +183,15 @@ class Ops:
         self._call("bk_rng_init_philox", ptr(state), state.stride(0), key0 & (2**64 - 1),
                    chain_id0 & (2**64 - 1), state.shape[1], self._s())
 
-    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None):
+    def refresh_work(self, C, D):
+        """Scratch for the wavefront-per-chain momentum refresh (bk_refresh_work_elems doubles)."""
+        return torch.empty(self.lib.bk_refresh_work_elems(C, D), dtype=torch.float64, device=self.device)
+
+    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None, work=None):
         D, C = out.shape
         self._call("bk_momentum_refresh", kind, ptr(state), state.stride(0), ptr(loc_in), loc_mul, scale,
-                   ptr(out), _ld(out), ptr(metric), ptr(kin_out), ptr(active), C, D, self._s())
+                   ptr(out), _ld(out), ptr(metric), ptr(kin_out), ptr(active), C, D, ptr(work),
+                   0 if work is None else work.numel(), self._s())
 
     def log_uniform(self, kind, state, out, active=None):
         self._call("bk_log_uniform", kind, ptr(state), state.stride(0), ptr(out), ptr(active),

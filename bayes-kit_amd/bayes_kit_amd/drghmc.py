@@ -81,7 +81,8 @@ class DrGhmcDiag(ManyChainSampler):
         f64 = dict(dtype=torch.float64, device=dev)
         # rho0 = rng.normal(size=D) AFTER theta0 (drghmc.py:77)
         self._rho_dc = torch.empty((D, C), **f64)
-        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_dc, None, None)
+        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_dc, None, None,
+                                   None, self._rng_work)
         self._rho_sign = 1.0  # stored momentum is sign * (reference's _rho)
         self._grad = torch.empty((D, C), **f64)
         self._lp = torch.empty(C, **f64)
@@ -218,7 +219,7 @@ class DrGhmcDiag(ManyChainSampler):
         # previous draw's pending flip (drghmc.py:388), applied here through the sign of loc_mul
         ops.momentum_refresh(self._rng_kind, self._rng_state, self._rho_dc,
                              self._rho_sign * math.sqrt(1 - damping), math.sqrt(damping), self._rho_dc, m,
-                             self._kin)
+                             self._kin, None, self._rng_work)
         self._rho_sign = 1.0
         if not self._have_cache:  # drghmc.py:243-245 (first draw only)
             self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)

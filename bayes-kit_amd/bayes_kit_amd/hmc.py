@@ -169,9 +169,10 @@ class HMCDiag(ManyChainSampler):
         ops = self._ops
         if self._M is None:
             ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
-                                 self._metric_dev, self._kin0_bufs[slot])
+                                 self._metric_dev, self._kin0_bufs[slot], None, self._rng_work)
         else:
-            ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._mv_rng, None, None)
+            ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._mv_rng, None, None,
+                                 None, self._rng_work)
             ops.dense_metric_apply(self._M_chol, self._mv_rng, self._rho_bufs[slot])  # rho = chol(M) @ z
             self._dense_kinetic(self._rho_bufs[slot], self._kin0_bufs[slot], self._mv_rng)
         ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])

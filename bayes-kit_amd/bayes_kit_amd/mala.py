@@ -70,7 +70,8 @@ class MALA(ManyChainSampler):
         self._pf_event, self._pf_slot = None, 0
 
     def _gen(self, slot):
-        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._z_bufs[slot], None, None)
+        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._z_bufs[slot], None, None,
+                                   None, self._rng_work)
         self._ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])
 
     def _take_randomness(self):

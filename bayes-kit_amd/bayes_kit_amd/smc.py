@@ -41,7 +41,8 @@ class _RWMKernel:
         th, prop = smc._theta_dc, smc._prop_dc
         lp_cur = smc._tempered(th, t)
         # theta* = normal(loc=theta, scale) [smc.py:81]
-        ops.momentum_refresh(smc._rng_kind, smc._rng_state, th, 1.0, self.scale, prop, None, None)
+        ops.momentum_refresh(smc._rng_kind, smc._rng_state, th, 1.0, self.scale, prop, None, None,
+                             None, getattr(smc, "_rng_work", None))
         lp_prop = smc._tempered(prop, t)
         ops.log_uniform(smc._rng_kind, smc._rng_state, smc._logu)
         # accept iff log u < lp(theta*) - lp(theta) [smc.py:85]

@@ -134,6 +134,219 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_mala_propose(uint64_t* st, i64 ld
   g.store(st, ldr, c);
 }
 
+// ---- word-parallel ziggurat: one WAVEFRONT per chain ------------------------------------------
+// The one-lane-per-chain kernel above is latency bound: a chain's stream is consumed
+// sequentially, ~2,200 cycles per normal with one wavefront per SIMD, and with few chains most
+// SIMDs are idle (4096 chains = 64 wavefronts on 1024 SIMDs).  But Philox is counter based --
+// word v of a stream is block(counter0 + v/4)[v%4] -- and 98.5 % of the normals use exactly
+// one word.  So here the 64 lanes of a wavefront evaluate 256 consecutive words of ONE chain
+// at once: every lane generates one block, runs the ziggurat fast test on its 4 words and, for
+// the rare words that fail it, the complete slow path (wedge / tail) with positional access to
+// the following words.  Which words actually START a normal is then resolved exactly in
+// stream order: only the "exception" words can consume extra words, so a short scalar loop over
+// the exceptions (a few per 256 words) tracks the covered range; everything else is ballot /
+// popcount arithmetic.  The result is bit for bit the sequential stream, with C wavefronts of
+// parallelism instead of C/64.  Normals go to a chain-major scratch zt[c][d] (coalesced per
+// wavefront); k_refresh_apply transposes them into the [D][C] layout with loc + scale*z.
+struct SlowRes {
+  double val;
+  int len;   // words consumed by the attempt that starts at this word (>= 2)
+  bool emit; // false: rejected wedge attempt (its words are consumed, no normal is produced)
+};
+
+struct WordWindow {
+  uint64_t w0, w1, w2, w3, w4, w5, w6, w7;  // own block, next lane's block
+  bool has_next;
+  const bk::Philox* ph;  // key
+  uint64_t c0, c1, c2, c3;  // counter of the lane's own block
+  uint64_t e0, e1, e2, e3;  // on-demand block cache
+  int eblk;
+
+  __device__ uint64_t at(int j) {
+    if (j < 4) return j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : w3;
+    if (j < 8 && has_next) return j == 4 ? w4 : j == 5 ? w5 : j == 6 ? w6 : w7;
+    int blk = j >> 2;
+    if (blk != eblk) {
+      uint64_t a0, a1, a2, a3;
+      bk::Philox::ctr_add(c0, c1, c2, c3, (uint64_t)blk, a0, a1, a2, a3);
+      ph->block_at(a0, a1, a2, a3, e0, e1, e2, e3);
+      eblk = blk;
+    }
+    int k = j & 3;
+    return k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
+  }
+  __device__ double dbl(int j) { return (double)(at(j) >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// everything after a failed fast test for the word at offset k of the window (same arithmetic as
+// bk::zig_slow, with positional instead of sequential word access)
+__device__ SlowRes zig_slow_at(WordWindow& win, int k, int idx, uint64_t rabs, double x, const double* fi) {
+  const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
+  SlowRes r;
+  if (idx == 0) {
+    int j = k + 1;
+    for (;;) {
+      double xx = -zinv * bk::bk_log1p(-win.dbl(j));
+      double yy = -bk::bk_log1p(-win.dbl(j + 1));
+      j += 2;
+      if (yy + yy > xx * xx) {
+        r.val = ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+        break;
+      }
+    }
+    r.len = j - k;
+    r.emit = true;
+    return r;
+  }
+  r.len = 2;
+  r.emit = (fi[idx - 1] - fi[idx]) * win.dbl(k + 1) + fi[idx] < exp(-0.5 * x * x);
+  r.val = x;
+  return r;
+}
+
+constexpr int ZP_WAVES = 4;  // chains per workgroup (one wavefront each)
+__global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st, i64 ldr, double* zt, i64 ldz,
+                                                                    i64 C, i64 D) {
+  __shared__ ZigLds tab;
+  load_tables(tab);
+  const int lane = threadIdx.x & (BK_WAVE - 1);
+  const i64 c = (i64)blockIdx.x * ZP_WAVES + (threadIdx.x / BK_WAVE);
+  if (c >= C) return;  // whole wavefront
+  bk::Philox ph;
+  ph.key0 = st[0 * ldr + c];
+  ph.key1 = st[1 * ldr + c];
+  const uint64_t k0 = st[2 * ldr + c], k1 = st[3 * ldr + c], k2 = st[4 * ldr + c], k3 = st[5 * ldr + c];
+  const i64 v0 = (i64)st[10 * ldr + c];  // words of block `counter` already consumed (4 = all)
+  i64 cover_until = v0;                  // words below this position are consumed / not attempt starts
+  i64 d_base = 0, p_end = v0;
+  for (i64 t = 0; d_base < D; ++t) {
+    // 1. one Philox block per lane: block (counter + 64 t + lane), words v = 256 t + 4 lane + k
+    WordWindow win;
+    win.ph = &ph;
+    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)(64 * t + lane), win.c0, win.c1, win.c2, win.c3);
+    ph.block_at(win.c0, win.c1, win.c2, win.c3, win.w0, win.w1, win.w2, win.w3);
+    win.w4 = __shfl_down((unsigned long long)win.w0, 1);
+    win.w5 = __shfl_down((unsigned long long)win.w1, 1);
+    win.w6 = __shfl_down((unsigned long long)win.w2, 1);
+    win.w7 = __shfl_down((unsigned long long)win.w3, 1);
+    win.has_next = lane < BK_WAVE - 1;
+    win.eblk = -1;
+    const i64 vbase = 256 * t + 4 * lane;
+    // 2. fast test on the four words; 3. full slow path where it fails
+    double val[4];
+    int len[4];
+    bool okf[4], emitf[4];
+    const uint64_t wk[4] = {win.w0, win.w1, win.w2, win.w3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double x;
+      int idx;
+      uint64_t rabs;
+      okf[k] = bk::zig_fast(wk[k], tab.ki, tab.wi, x, idx, rabs);
+      val[k] = x;
+      len[k] = 1;
+      emitf[k] = true;
+      if (!okf[k]) {
+        SlowRes r = zig_slow_at(win, k, idx, rabs, x, tab.fi);
+        val[k] = r.val;
+        len[k] = r.len;
+        emitf[k] = r.emit;
+      }
+    }
+    // 4. which words start an attempt: scan the exceptions in stream order
+    unsigned long long ex[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ex[k] = __ballot(!okf[k]);
+    unsigned cov = 0;  // bit k: word k of this lane is consumed by an earlier attempt
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (vbase + k < cover_until) cov |= 1u << k;
+    unsigned long long any = ex[0] | ex[1] | ex[2] | ex[3];
+    while (any) {
+      int L = __ffsll((long long)any) - 1;
+      any &= any - 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((ex[k] >> L) & 1ULL) {
+          i64 pos = 256 * t + 4 * L + k;
+          int ln = __shfl(len[k], L);
+          if (pos >= cover_until) {  // an actual attempt: it consumes words pos .. pos+ln-1
+            cover_until = pos + ln;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              if (vbase + kk > pos && vbase + kk < pos + ln) cov |= 1u << kk;
+          }
+        }
+      }
+    }
+    // 5./6. emitting words, their dimension index, output
+    bool em[4];
+    unsigned long long mk[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      em[k] = !((cov >> k) & 1u) && emitf[k];
+      mk[k] = __ballot(em[k]);
+    }
+    const unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
+    i64 rank = __popcll(mk[0] & below) + __popcll(mk[1] & below) + __popcll(mk[2] & below) + __popcll(mk[3] & below);
+    bool last_here = false;
+    i64 my_end = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (em[k]) {
+        i64 dim = d_base + rank;
+        if (dim < D) zt[c * ldz + dim] = val[k];
+        if (dim == D - 1) {
+          last_here = true;
+          my_end = vbase + k + len[k];
+        }
+        ++rank;
+      }
+    }
+    unsigned long long lb = __ballot(last_here);
+    if (lb) p_end = __shfl(my_end, __ffsll((long long)lb) - 1);
+    d_base += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
+    // an attempt that started in this chunk may reach into the next one: cover_until carries over
+  }
+  // new stream position: p_end words into the block stream that starts at `counter`
+  if (lane == 0 && p_end > v0) {
+    i64 bf = (p_end - 1) / 4;
+    uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
+    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)bf, a0, a1, a2, a3);
+    ph.block_at(a0, a1, a2, a3, b0, b1, b2, b3);
+    st[2 * ldr + c] = a0; st[3 * ldr + c] = a1; st[4 * ldr + c] = a2; st[5 * ldr + c] = a3;
+    st[6 * ldr + c] = b0; st[7 * ldr + c] = b1; st[8 * ldr + c] = b2; st[9 * ldr + c] = b3;
+    st[10 * ldr + c] = (uint64_t)(p_end - 4 * bf);
+  }
+}
+
+// out[d][c] = loc + scale * zt[c][d]  (64 x 64 LDS tiles; zt is chain-major, out chain-contiguous)
+__global__ __launch_bounds__(256) void k_refresh_apply(const double* zt, i64 ldz, const double* loc_in,
+                                                       double loc_mul, double scale, double* out, i64 ld, i64 C,
+                                                       i64 D) {
+  __shared__ double tile[64][65];
+  i64 c0 = (i64)blockIdx.x * 64, d0 = (i64)blockIdx.y * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    int cl = ty + 4 * i;
+    i64 cc = c0 + cl, d = d0 + tx;
+    tile[cl][tx] = (cc < C && d < D) ? zt[cc * ldz + d] : 0.0;
+  }
+  __syncthreads();
+  i64 cc = c0 + tx;
+  if (cc >= C) return;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    int dl = ty + 4 * i;
+    i64 d = d0 + dl;
+    if (d < D) {
+      double loc = loc_in ? loc_in[d * ld + cc] * loc_mul : 0.0;
+      out[d * ld + cc] = loc + scale * tile[tx][dl];
+    }
+  }
+}
+
 // theta' = (theta + eps*grad) + s*z with z already drawn (mala.py:41-45), two rows per thread
 __global__ __launch_bounds__(256) void k_mala_propose_z(const double* th, const double* g, const double* z,
                                                         double* prop, i64 ld, double eps, double s, i64 C, i64 D) {
@@ -169,21 +382,41 @@ int bk_rng_init_philox(uint64_t* state, int64_t ldr, uint64_t key0, uint64_t cha
   BK_RETURN_LAUNCH_STATUS();
 }
 
+int64_t bk_refresh_work_elems(int64_t C, int64_t D) {
+  int64_t dp = (D + 7) / 8 * 8;  // chain-major scratch zt[C][dp]
+  return C * dp;
+}
+
 int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr, const double* loc_in,
                         double loc_mul, double scale, double* out, int64_t ld, const double* metric,
-                        double* kin_out, const uint8_t* active, int64_t C, int64_t D, void* stream) {
+                        double* kin_out, const uint8_t* active, int64_t C, int64_t D, double* work,
+                        int64_t work_elems, void* stream) {
   if (!state || !out || C < 0 || D < 0 || ld < C || ldr < C) return BK_E_ARG;
   if (C == 0) return BK_OK;
   const int rb_ = rng_block(C);
   dim3 grid((unsigned)bk_cdiv(C, rb_)), block(rb_);
-  if (rng_kind == BK_RNG_PHILOX)
-    k_refresh<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, loc_in, loc_mul, scale, out,
-                                                                ld, metric, kin_out, active, C, D);
-  else if (rng_kind == BK_RNG_PCG64)
-    k_refresh<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, loc_in, loc_mul, scale, out,
-                                                               ld, metric, kin_out, active, C, D);
-  else
+  hipStream_t s = bk_stream(stream);
+  if (rng_kind == BK_RNG_PHILOX) {
+    // With scratch, enough dimensions to fill a wavefront's 256-word window, and few enough chains
+    // that one-lane-per-chain would leave SIMDs idle or latency bound: one wavefront per chain.
+    if (work && !active && D >= 32 && work_elems >= bk_refresh_work_elems(C, D)) {
+      i64 dp = (D + 7) / 8 * 8;
+      k_zig_parallel<<<dim3((unsigned)bk_cdiv(C, ZP_WAVES)), dim3(ZP_WAVES * BK_WAVE), 0, s>>>(state, ldr, work, dp, C, D);
+      dim3 g2((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
+      k_refresh_apply<<<g2, dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out, ld, C, D);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return (int)e;
+      if (kin_out) return bk_leapfrog_finish(out, nullptr, ld, nullptr, 0, 0, metric, 0.0, 0, kin_out, C, D, stream);
+      return BK_OK;
+    }
+    k_refresh<bk::Philox><<<grid, block, 0, s>>>(state, ldr, loc_in, loc_mul, scale, out, ld, metric, kin_out, active,
+                                                 C, D);
+  } else if (rng_kind == BK_RNG_PCG64) {
+    k_refresh<bk::Pcg64><<<grid, block, 0, s>>>(state, ldr, loc_in, loc_mul, scale, out, ld, metric, kin_out, active,
+                                                C, D);
+  } else {
     return BK_E_ARG;
+  }
   BK_RETURN_LAUNCH_STATUS();
 }
 

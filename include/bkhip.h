@@ -58,11 +58,19 @@ int bk_rng_init_philox(uint64_t* state, int64_t ldr, uint64_t key0, uint64_t cha
  *   initial theta / rho                  hmc.py:24-28, drghmc.py:72-77
  *   DRGHMC partial refresh               drghmc.py:360-364, :250  (loc_mul = sqrt(1-damping),
  *                                                                  scale = sqrt(damping))
- * `active` (NULL = all): u8 mask per chain; inactive chains draw nothing. */
+ * `active` (NULL = all): u8 mask per chain; inactive chains draw nothing.
+ * `work` (may be NULL): caller-owned scratch of bk_refresh_work_elems(C, D) doubles.  With it
+ * (Philox streams, no mask, D >= 32) the normals are produced by one WAVEFRONT per chain -- 256
+ * stream words evaluated at once, the sequential consumption order resolved exactly -- instead
+ * of one lane per chain: same stream, same values and final state, C wavefronts of parallelism
+ * instead of C/64 (measured: 4.9x faster at 4096 chains x 128 dims, 17x at 1024 x 1024,
+ * 1.3x at 65,536 x 1024 including the transpose into [D][C]). */
+int64_t bk_refresh_work_elems(int64_t C, int64_t D);
 int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
                         const double* loc_in, double loc_mul, double scale,
                         double* out, int64_t ld, const double* metric, double* kin_out,
-                        const uint8_t* active, int64_t C, int64_t D, void* stream);
+                        const uint8_t* active, int64_t C, int64_t D, double* work,
+                        int64_t work_elems, void* stream);
 
 /* out[c] = log(u), u = next double of chain c's stream: `np.log(self._rng.uniform())`
  * (hmc.py:60, metropolis.py:74, drghmc.py:370,378).  Inactive chains draw nothing and

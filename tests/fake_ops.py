@@ -44,7 +44,10 @@ class FakeOps:
         w[1, :] = np.arange(w.shape[1], dtype=np.uint64) + np.uint64(chain_id0)
         w[10, :] = 4
 
-    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None):
+    def refresh_work(self, C, D):
+        return None
+
+    def momentum_refresh(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, active=None, work=None):
         self._count("momentum_refresh")
         D, C = out.shape
         o, li, m = _np(out), _np(loc_in), _np(metric)

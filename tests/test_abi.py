@@ -11,7 +11,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "bkhip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|double)\s+(bk_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|double|int64_t)\s+(bk_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_build_and_symbols():

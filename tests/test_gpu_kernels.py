@@ -33,14 +33,17 @@ def test_native_library_is_the_loaded_one(ops):
     assert os.path.realpath(_lib.lib_path()) in maps
 
 
-def test_device_rng_matches_numpy_bit_for_bit(ops):
+@pytest.mark.parametrize("wave_per_chain", [False, True])
+def test_device_rng_matches_numpy_bit_for_bit(ops, wave_per_chain):
     from bayes_kit_amd import _lib
 
     C, D = 192, 3000  # 576k normals: ~140 tail draws, ~8500 wedge draws
     kind, st = make_state(991, C, ops, chain0=5)
     out = torch.empty((D, C), dtype=torch.float64, device=ops.device)
     kin = torch.empty(C, dtype=torch.float64, device=ops.device)
-    ops.momentum_refresh(kind, st, None, 0.0, 1.0, out, None, kin)
+    # wave_per_chain: k_zig_parallel (256 stream words of one chain per wavefront) + transpose
+    work = ops.refresh_work(C, D) if wave_per_chain else None
+    ops.momentum_refresh(kind, st, None, 0.0, 1.0, out, None, kin, None, work)
     logu = torch.empty(C, dtype=torch.float64, device=ops.device)
     ops.log_uniform(kind, st, logu)
     got, kin, logu = out.cpu().numpy(), kin.cpu().numpy(), logu.cpu().numpy()
@@ -394,3 +397,34 @@ def test_resample_indices_and_gather(ops):
     ops.uniform(kind, st, out)
     for c in (0, 57, 99):
         assert out[c].item() == np.random.Generator(np.random.Philox(key=[77, c])).uniform()
+
+
+@pytest.mark.parametrize("D", [32, 63, 64, 65, 255, 256, 257, 1000])
+def test_wave_per_chain_refresh_resumes_anywhere(ops, D):
+    """k_zig_parallel must continue a stream from any buffer position, over many consecutive
+    calls (state written back each time), with loc/scale and the kinetic energy, exactly like
+    the one-lane-per-chain kernel and like numpy."""
+    C = 67
+    kind, st_a = make_state(31337, C, ops)
+    _, st_b = make_state(31337, C, ops)
+    u = torch.empty(C, dtype=torch.float64, device=ops.device)
+    work = ops.refresh_work(C, D)
+    m = dev(np.linspace(0.5, 1.5, D), ops)
+    loc = dev(np.random.default_rng(D).normal(size=(D, C)), ops)
+    gens = {c: np.random.Generator(np.random.Philox(key=[31337, c])) for c in (0, 33, 66)}
+    for rep in range(5):
+        for _ in range(rep):  # shift the buffer position between calls
+            ops.uniform(kind, st_a, u)
+            ops.uniform(kind, st_b, u)
+            for g in gens.values():
+                g.uniform()
+        a = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+        b = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+        ka = torch.empty(C, dtype=torch.float64, device=ops.device)
+        kb = torch.empty(C, dtype=torch.float64, device=ops.device)
+        ops.momentum_refresh(kind, st_a, loc, 0.7, 0.3, a, m, ka, None, work)
+        ops.momentum_refresh(kind, st_b, loc, 0.7, 0.3, b, m, kb, None, None)
+        assert torch.equal(a, b) and torch.equal(ka, kb) and torch.equal(st_a, st_b), (D, rep)
+        for c, g in gens.items():
+            want = g.normal(loc=loc[:, c].cpu().numpy() * 0.7, scale=0.3, size=D)
+            assert np.array_equal(a[:, c].cpu().numpy(), want), (D, rep, c)
