@@ -367,8 +367,20 @@ class ManyChainSampler:
         self._ops.relayout(g, grad_out)
         return grad_out
 
+    _out = None
+
+    def _select(self, mask, th, thp, g=None, gp=None):
+        """theta (and its cached gradient) <- proposal on the accepted chains; in the same pass
+        the array sample() returns is written (a fresh tensor per draw: the reference rebinds
+        ``_theta`` instead of mutating it, so returned draws must stay valid)."""
+        self._out = None
+        if self._batched and not self._use_graph:
+            self._out = torch.empty_like(th)
+        self._ops.select_columns(mask, th, thp, g, gp, self._out)
+
     def _draw_out(self, theta_dc, logp):
         """What sample() hands back: stable copies, shaped like the reference's return."""
         if self._batched:
-            return theta_dc.t().clone(), logp.clone()
+            out, self._out = self._out, None
+            return (out.t() if out is not None else theta_dc.t().clone()), logp.clone()
         return np.array(theta_dc[:, 0].cpu().numpy()), np.float64(logp[0].item())

@@ -38,7 +38,7 @@ SIGNATURES = {
     "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P],
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
-    "bk_select_columns": [P, P, P, P, P, I, I, I, P],
+    "bk_select_columns": [P, P, P, P, P, P, I, I, I, P],
     "bk_compact_indices": [P, I, P, P, P],
     "bk_dr_begin": [P, P, P, P, P, P, I, P],
     "bk_dr_retry_test": [c_int, P, I, P, F, P, I, P],
@@ -48,7 +48,8 @@ SIGNATURES = {
     "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
-    "bk_mala_propose_from_normals": [P, P, P, P, I, F, F, I, I, P],
+    "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
+    "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
@@ -231,12 +232,13 @@ class Ops:
         self._call("bk_mh_accept", mode, ptr(lp_cur), ptr(a_cur), ptr(lp_prop), ptr(a_prop), ptr(log_u),
                    ptr(mask), ptr(ret), ptr(count), lp_cur.shape[0], self._s())
 
-    def select_columns(self, mask, dst0, src0, dst1=None, src1=None):
+    def select_columns(self, mask, dst0, src0, dst1=None, src1=None, copy0=None):
         D, C = dst0.shape
         ld = _ld(dst0)
         assert _ld(src0) == ld and (dst1 is None or (_ld(dst1) == ld and _ld(src1) == ld))
-        self._call("bk_select_columns", ptr(mask), ptr(dst0), ptr(src0), ptr(dst1), ptr(src1), ld, C, D,
-                   self._s())
+        assert copy0 is None or _ld(copy0) == ld
+        self._call("bk_select_columns", ptr(mask), ptr(dst0), ptr(src0), ptr(dst1), ptr(src1), ptr(copy0), ld,
+                   C, D, self._s())
 
     # -- delayed rejection ---------------------------------------------------------------------
     def compact_indices(self, mask, n, idx_out, count_out):
@@ -282,11 +284,20 @@ class Ops:
                    ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
 
     def mala_propose_from_normals(self, theta, grad, z, theta_prop, eps, sqrt2eps):
+        """z: logical [D, C]; either laid out like theta or the transposed view of chain-major
+        normals (``zt[:, :D].t()`` of a normals_chain_major buffer)."""
         D, C = theta.shape
         ld = _ld(theta)
-        assert _ld(grad) == ld and _ld(theta_prop) == ld and _ld(z) == ld
-        self._call("bk_mala_propose_from_normals", ptr(theta), ptr(grad), ptr(z), ptr(theta_prop), ld, eps,
-                   sqrt2eps, C, D, self._s())
+        assert _ld(grad) == ld and _ld(theta_prop) == ld and tuple(z.shape) == (D, C)
+        self._call("bk_mala_propose_from_normals", ptr(theta), ptr(grad), ptr(z), z.stride(0), z.stride(1),
+                   ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
+
+    def normals_chain_major(self, kind, state, zt, D):
+        """zt[c, :D] = the next D standard normals of chain c (one wavefront per chain)."""
+        C = zt.shape[0]
+        assert zt.stride(1) == 1 and zt.shape[1] >= D
+        self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
+                   self._s())
 
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         D, C = theta.shape

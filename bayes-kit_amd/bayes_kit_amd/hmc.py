@@ -250,7 +250,7 @@ class HMCDiag(ManyChainSampler):
             self._eval_logp(thp, self._lp_p)
             ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                           self._mask, self._ret, self._accepted)
-            ops.select_columns(self._mask, th, thp)
+            self._select(self._mask, th, thp)
             return
 
         if mirror:
@@ -305,10 +305,10 @@ class HMCDiag(ManyChainSampler):
         ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                       self._mask, self._ret, self._accepted)
         if mirror:
-            ops.select_columns(self._mask, th, thp)
+            self._select(self._mask, th, thp)
         else:
             gp = self._materialize(g_last, self._grad_p) if L > 0 else None
             if gp is not None:
-                ops.select_columns(self._mask, th, thp, self._grad, gp)
+                self._select(self._mask, th, thp, self._grad, gp)
             else:
-                ops.select_columns(self._mask, th, thp)
+                self._select(self._mask, th, thp)

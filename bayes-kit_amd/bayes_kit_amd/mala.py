@@ -44,8 +44,18 @@ class MALA(ManyChainSampler):
             prefetch_rng = self._batched and not self._use_graph and dev.type == "cuda"
         self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
         self._pf_slot, self._pf_event = 0, None
-        if self._prefetch:
+        # Philox streams: the normals come from the wavefront-per-chain generator, chain-major
+        # (zt[c, d]); the proposal kernel turns them through LDS.  Otherwise (PCG64 host-seeded
+        # single chains, tiny D): one lane per chain, normals in the state layout.
+        self._chain_major = self._rng_kind == _lib.RNG_PHILOX and D >= 32
+        nbuf = 2 if self._prefetch else 1
+        if self._chain_major:
+            dp = (D + 7) // 8 * 8
+            self._zt_bufs = [torch.empty((C, dp), **f64) for _ in range(nbuf)]
+            self._z_bufs = [zt[:, :D].t() for zt in self._zt_bufs]
+        elif self._prefetch:
             self._z_bufs = [torch.empty((D, C), **f64) for _ in range(2)]
+        if self._prefetch:
             self._logu_bufs = [torch.empty(C, **f64) for _ in range(2)]
             self._side = torch.cuda.Stream(device=dev)
             self._rng_logical = self._rng_state.clone()
@@ -70,8 +80,11 @@ class MALA(ManyChainSampler):
         self._pf_event, self._pf_slot = None, 0
 
     def _gen(self, slot):
-        self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._z_bufs[slot], None, None,
-                                   None, self._rng_work)
+        if self._chain_major:
+            self._ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)
+        else:
+            self._ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._z_bufs[slot],
+                                       None, None)
         self._ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])
 
     def _take_randomness(self):
@@ -120,6 +133,11 @@ class MALA(ManyChainSampler):
         if self._prefetch:
             z, logu = self._take_randomness()
             ops.mala_propose_from_normals(th, self._grad, z, thp, eps, math.sqrt(2 * eps))
+        elif self._chain_major:
+            logu = self._logu
+            ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[0], self._dim)
+            ops.log_uniform(self._rng_kind, self._rng_state, logu)  # right after the normals: same stream order
+            ops.mala_propose_from_normals(th, self._grad, self._z_bufs[0], thp, eps, math.sqrt(2 * eps))
         else:
             logu = self._logu
             ops.mala_propose(self._rng_kind, self._rng_state, th, self._grad, thp, eps, math.sqrt(2 * eps))
@@ -128,4 +146,4 @@ class MALA(ManyChainSampler):
         ops.mala_logq(th, self._grad, thp, gp, eps, self._fwd, self._rev)
         ops.mh_accept(_lib.ACCEPT_MALA, self._lp, self._fwd, self._lp_p, self._rev, logu,
                       self._mask, self._ret, self._accepted)
-        ops.select_columns(self._mask, th, thp, self._grad, gp)
+        self._select(self._mask, th, thp, self._grad, gp)

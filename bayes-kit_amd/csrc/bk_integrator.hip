@@ -272,58 +272,81 @@ __global__ __launch_bounds__(256) void k_mh_accept(int mode, double* lp_cur, con
 
 // ---- masked column copy -----------------------------------------------------------------
 constexpr int SEL_ROWS = 8;
+// copy0 (optional): the selected array as it stands after the select, for every chain -- the
+// stable array sample() hands back -- written in the same pass instead of by a second copy.
 __global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst0, const double* src0,
-                                                double* dst1, const double* src1, i64 ld, i64 C,
-                                                i64 D) {
+                                                double* dst1, const double* src1, double* copy0, i64 ld,
+                                                i64 C, i64 D) {
   i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
   i64 d0 = (i64)blockIdx.y * SEL_ROWS;
-  if (c >= C || !mask[c]) return;
+  if (c >= C) return;
+  const bool m = mask[c] != 0;
+  if (!m && !copy0) return;
   double a[SEL_ROWS], b[SEL_ROWS];
 #pragma unroll
   for (int i = 0; i < SEL_ROWS; ++i)
     if (d0 + i < D) {
-      a[i] = src0[(d0 + i) * ld + c];
-      if (dst1) b[i] = src1[(d0 + i) * ld + c];
+      a[i] = m ? src0[(d0 + i) * ld + c] : dst0[(d0 + i) * ld + c];
+      if (dst1 && m) b[i] = src1[(d0 + i) * ld + c];
     }
 #pragma unroll
   for (int i = 0; i < SEL_ROWS; ++i)
     if (d0 + i < D) {
-      dst0[(d0 + i) * ld + c] = a[i];
-      if (dst1) dst1[(d0 + i) * ld + c] = b[i];
+      if (m) dst0[(d0 + i) * ld + c] = a[i];
+      if (dst1 && m) dst1[(d0 + i) * ld + c] = b[i];
+      if (copy0) copy0[(d0 + i) * ld + c] = a[i];
     }
 }
 
 // two chains (16 B) per lane; a pair is copied only where needed (per-chain mask kept exact)
+template <bool COPY>
 __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* dst0, const double* src0,
-                                                   double* dst1, const double* src1, i64 ld, i64 C2,
-                                                   i64 D) {
+                                                   double* dst1, const double* src1, double* copy0, i64 ld,
+                                                   i64 C2, i64 D) {
   i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
   i64 d0 = (i64)blockIdx.y * SEL_ROWS;
   if (c2 >= C2) return;
   const bool m0 = mask[2 * c2] != 0, m1 = mask[2 * c2 + 1] != 0;
-  if (!m0 && !m1) return;
+  const bool any = m0 || m1, both = m0 && m1;
+  if (!any && !COPY) return;
   dvec2 a[SEL_ROWS], b[SEL_ROWS];
 #pragma unroll
   for (int i = 0; i < SEL_ROWS; ++i)
     if (d0 + i < D) {
-      a[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src0 + (d0 + i) * ld + 2 * c2));
-      if (dst1) b[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src1 + (d0 + i) * ld + 2 * c2));
+      const i64 o = (d0 + i) * ld + 2 * c2;
+      if (any) {
+        a[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src0 + o));
+        if (dst1) b[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src1 + o));
+      }
+      if (COPY && !both) {
+        dvec2 old = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(dst0 + o));
+        if (!m0) a[i].x = old.x;
+        if (!m1) a[i].y = old.y;
+      }
     }
-  if (m0 && m1) {
+  if (both) {
 #pragma unroll
     for (int i = 0; i < SEL_ROWS; ++i)
       if (d0 + i < D) {
-        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(dst0 + (d0 + i) * ld + 2 * c2));
-        if (dst1) __builtin_nontemporal_store(b[i], reinterpret_cast<dvec2*>(dst1 + (d0 + i) * ld + 2 * c2));
+        const i64 o = (d0 + i) * ld + 2 * c2;
+        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(dst0 + o));
+        if (dst1) __builtin_nontemporal_store(b[i], reinterpret_cast<dvec2*>(dst1 + o));
       }
-  } else {
-    const int o = m0 ? 0 : 1;
+  } else if (any) {
+    const int k = m0 ? 0 : 1;
 #pragma unroll
     for (int i = 0; i < SEL_ROWS; ++i)
       if (d0 + i < D) {
-        dst0[(d0 + i) * ld + 2 * c2 + o] = m0 ? a[i].x : a[i].y;
-        if (dst1) dst1[(d0 + i) * ld + 2 * c2 + o] = m0 ? b[i].x : b[i].y;
+        const i64 o = (d0 + i) * ld + 2 * c2 + k;
+        dst0[o] = m0 ? a[i].x : a[i].y;
+        if (dst1) dst1[o] = m0 ? b[i].x : b[i].y;
       }
+  }
+  if (COPY) {
+#pragma unroll
+    for (int i = 0; i < SEL_ROWS; ++i)
+      if (d0 + i < D)
+        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(copy0 + (d0 + i) * ld + 2 * c2));
   }
 }
 
@@ -485,16 +508,21 @@ int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp
 }
 
 int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0, double* dst1,
-                      const double* src1, int64_t ld, int64_t C, int64_t D, void* stream) {
+                      const double* src1, double* copy0, int64_t ld, int64_t C, int64_t D, void* stream) {
   if (!mask || !dst0 || !src0 || (dst1 && !src1) || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(dst0) && bk_aligned16(src0) && (!dst1 || (bk_aligned16(dst1) && bk_aligned16(src1)))) {
+  hipStream_t s = bk_stream(stream);
+  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(dst0) && bk_aligned16(src0) &&
+      (!dst1 || (bk_aligned16(dst1) && bk_aligned16(src1))) && (!copy0 || bk_aligned16(copy0))) {
     dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
-    k_select_v2<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C / 2, D);
+    if (copy0)
+      k_select_v2<true><<<grid, dim3(256), 0, s>>>(mask, dst0, src0, dst1, src1, copy0, ld, C / 2, D);
+    else
+      k_select_v2<false><<<grid, dim3(256), 0, s>>>(mask, dst0, src0, dst1, src1, nullptr, ld, C / 2, D);
   } else {
     dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
-    k_select<<<grid, dim3(256), 0, bk_stream(stream)>>>(mask, dst0, src0, dst1, src1, ld, C, D);
+    k_select<<<grid, dim3(256), 0, s>>>(mask, dst0, src0, dst1, src1, copy0, ld, C, D);
   }
   BK_RETURN_LAUNCH_STATUS();
 }

@@ -367,6 +367,34 @@ __global__ __launch_bounds__(256) void k_mala_propose_z(const double* th, const 
     if (d0 + i < D) prop[(d0 + i) * ld + c] = (a[i] + eps * b[i]) + s * n[i];
 }
 
+// the same with the normals chain-major (zt[c*ldz + d], as k_zig_parallel leaves them): 64x64
+// tiles turned through LDS, so both sides stay coalesced
+__global__ __launch_bounds__(256) void k_mala_propose_zt(const double* th, const double* g, const double* zt,
+                                                         i64 ldz, double* prop, i64 ld, double eps, double s,
+                                                         i64 C, i64 D) {
+  __shared__ double tile[64][65];
+  i64 c0 = (i64)blockIdx.x * 64, d0 = (i64)blockIdx.y * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    int cl = ty + 4 * i;
+    i64 cc = c0 + cl, d = d0 + tx;
+    tile[cl][tx] = (cc < C && d < D) ? zt[cc * ldz + d] : 0.0;
+  }
+  __syncthreads();
+  i64 cc = c0 + tx;
+  if (cc >= C) return;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    int dl = ty + 4 * i;
+    i64 d = d0 + dl;
+    if (d < D) {
+      i64 o = d * ld + cc;
+      prop[o] = (th[o] + eps * g[o]) + s * tile[tx][dl];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -468,13 +496,32 @@ int bk_mala_propose(int rng_kind, uint64_t* state, int64_t ldr, const double* th
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_mala_propose_from_normals(const double* theta, const double* grad, const double* z, double* theta_prop,
-                                 int64_t ld, double eps, double sqrt2eps, int64_t C, int64_t D, void* stream) {
+int bk_mala_propose_from_normals(const double* theta, const double* grad, const double* z, int64_t z_stride_d,
+                                 int64_t z_stride_c, double* theta_prop, int64_t ld, double eps,
+                                 double sqrt2eps, int64_t C, int64_t D, void* stream) {
   if (!theta || !grad || !z || !theta_prop || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, 4));
-  k_mala_propose_z<<<grid, dim3(256), 0, bk_stream(stream)>>>(theta, grad, z, theta_prop, ld, eps, sqrt2eps, C, D);
+  if (z_stride_c == 1 && z_stride_d == ld) {
+    dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, 4));
+    k_mala_propose_z<<<grid, dim3(256), 0, bk_stream(stream)>>>(theta, grad, z, theta_prop, ld, eps, sqrt2eps, C, D);
+  } else if (z_stride_d == 1 && z_stride_c >= D) {
+    dim3 grid((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
+    k_mala_propose_zt<<<grid, dim3(256), 0, bk_stream(stream)>>>(theta, grad, z, z_stride_c, theta_prop, ld, eps,
+                                                                 sqrt2eps, C, D);
+  } else {
+    return BK_E_ALIGN;
+  }
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
+                           int64_t D, void* stream) {
+  if (!state || !zt || C < 0 || D < 0 || ldr < C || ldz < D) return BK_E_ARG;
+  if (rng_kind != BK_RNG_PHILOX) return BK_E_ARG;
+  if (C == 0 || D == 0) return BK_OK;
+  k_zig_parallel<<<dim3((unsigned)bk_cdiv(C, ZP_WAVES)), dim3(ZP_WAVES * BK_WAVE), 0, bk_stream(stream)>>>(
+      state, ldr, zt, ldz, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -149,9 +149,11 @@ int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp
 /* dst[d*ld + c] = mask[c] ? src[d*ld + c] : dst[d*ld + c] for up to two array pairs
  * (pair 1 may be NULL): `self._theta = theta_prop` (hmc.py:61, mala.py:62-64,
  * drghmc.py:379) applied to the accepted chains only.  Rejected chains are neither read
- * nor written. */
+ * nor written -- unless `copy0` (may be NULL) is given: then copy0 additionally receives
+ * array 0 as it stands after the select, for every chain (the stable array that sample()
+ * returns while the sampler keeps mutating its own; same leading dimension). */
 int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
-                      double* dst1, const double* src1, int64_t ld,
+                      double* dst1, const double* src1, double* copy0, int64_t ld,
                       int64_t C, int64_t D, void* stream);
 
 /* ---- delayed rejection (DRGHMC) stage helpers -------------------------------------------
@@ -220,11 +222,20 @@ int bk_mala_propose(int rng_kind, uint64_t* state, int64_t ldr, const double* th
                     const double* grad, double* theta_prop, int64_t ld, double eps,
                     double sqrt2eps, int64_t C, int64_t D, void* stream);
 
-/* The same proposal with the D normals already drawn into z[d*ld + c] (e.g. generated ahead on
- * another stream by bk_momentum_refresh): theta_prop = (theta + eps*grad) + sqrt2eps * z. */
+/* The same proposal with the D normals already drawn (e.g. generated ahead on another stream):
+ * theta_prop = (theta + eps*grad) + sqrt2eps * z, with z[d*z_stride_d + c*z_stride_c] either in
+ * the state layout (strides ld, 1; from bk_momentum_refresh) or chain-major (strides 1, ldz;
+ * from bk_normals_chain_major, turned through LDS tiles here). */
 int bk_mala_propose_from_normals(const double* theta, const double* grad, const double* z,
-                                 double* theta_prop, int64_t ld, double eps, double sqrt2eps,
-                                 int64_t C, int64_t D, void* stream);
+                                 int64_t z_stride_d, int64_t z_stride_c, double* theta_prop,
+                                 int64_t ld, double eps, double sqrt2eps, int64_t C, int64_t D,
+                                 void* stream);
+
+/* zt[c*ldz + d] = d-th next standard normal of chain c's stream, d = 0..D-1 (what
+ * `rng.normal(size=D)` returns, mala.py:44 / hmc.py:56), one wavefront per chain, Philox streams
+ * only; state advanced exactly as by sequential consumption.  ldz >= D. */
+int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz,
+                           int64_t C, int64_t D, void* stream);
 
 /* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
  * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */

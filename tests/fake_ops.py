@@ -150,12 +150,14 @@ class FakeOps:
         if count is not None:
             count += int(acc.sum())
 
-    def select_columns(self, mask, dst0, src0, dst1=None, src1=None):
+    def select_columns(self, mask, dst0, src0, dst1=None, src1=None, copy0=None):
         self._count("select_columns")
         m = mask.numpy().astype(bool)
         dst0.numpy()[:, m] = src0.numpy()[:, m]
         if dst1 is not None:
             dst1.numpy()[:, m] = src1.numpy()[:, m]
+        if copy0 is not None:
+            copy0.numpy()[...] = dst0.numpy()
 
     # -- MALA ------------------------------------------------------------------------------------
     def mala_propose(self, kind, state, theta, grad, theta_prop, eps, sqrt2eps):
@@ -165,6 +167,13 @@ class FakeOps:
             g = self._gen(kind, state, c)
             z = g.standard_normal(D)
             theta_prop.numpy()[:, c] = (theta.numpy()[:, c] + eps * grad.numpy()[:, c]) + sqrt2eps * z
+            self._put(kind, state, c, g)
+
+    def normals_chain_major(self, kind, state, zt, D):
+        self._count("normals_chain_major")
+        for c in range(zt.shape[0]):
+            g = self._gen(kind, state, c)
+            zt.numpy()[c, :D] = g.standard_normal(D)
             self._put(kind, state, c, g)
 
     def mala_propose_from_normals(self, theta, grad, z, theta_prop, eps, sqrt2eps):

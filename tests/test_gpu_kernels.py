@@ -428,3 +428,50 @@ def test_wave_per_chain_refresh_resumes_anywhere(ops, D):
         for c, g in gens.items():
             want = g.normal(loc=loc[:, c].cpu().numpy() * 0.7, scale=0.3, size=D)
             assert np.array_equal(a[:, c].cpu().numpy(), want), (D, rep, c)
+
+
+@pytest.mark.parametrize("C,D", [(1, 1), (64, 9), (129, 17), (130, 8), (1024, 33)])
+def test_select_with_fused_output_copy(ops, C, D):
+    """copy0 = array 0 after the select, for every chain; with and without the second pair; the
+    16-byte path (even C) and the scalar one (odd C); masks mixed inside a lane pair."""
+    rng = np.random.default_rng(C * 100 + D)
+    th, prop, g, gp = (rng.normal(size=(D, C)) for _ in range(4))
+    for acc in (rng.random(C) < 0.5, np.zeros(C, bool), np.ones(C, bool)):
+        mask = torch.as_tensor(acc.astype(np.uint8)).to(ops.device)
+        for two in (False, True):
+            d0, d1 = dev(th.copy(), ops), dev(g.copy(), ops)
+            out = torch.full((D, C), np.nan, dtype=torch.float64, device=ops.device)
+            if two:
+                ops.select_columns(mask, d0, dev(prop, ops), d1, dev(gp, ops), out)
+            else:
+                ops.select_columns(mask, d0, dev(prop, ops), None, None, out)
+            want = np.where(acc[None, :], prop, th)
+            assert np.array_equal(d0.cpu().numpy(), want)
+            assert np.array_equal(out.cpu().numpy(), want)
+            assert np.array_equal(d1.cpu().numpy(), np.where(acc[None, :], gp, g) if two else g)
+
+
+@pytest.mark.parametrize("C,D", [(5, 32), (70, 100), (64, 257)])
+def test_chain_major_normals_and_transposing_proposal(ops, C, D):
+    """bk_normals_chain_major leaves the normals chain-major; the MALA proposal kernel reading them
+    through LDS tiles must equal the one reading the state layout, and numpy."""
+    kind, st_a = make_state(4242, C, ops)
+    _, st_b = make_state(4242, C, ops)
+    dp = (D + 7) // 8 * 8
+    zt = torch.full((C, dp), np.nan, dtype=torch.float64, device=ops.device)
+    z = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    for _ in range(2):
+        ops.normals_chain_major(kind, st_a, zt, D)
+        ops.momentum_refresh(kind, st_b, None, 0.0, 1.0, z, None, None)
+        assert torch.equal(zt[:, :D].t(), z) and torch.equal(st_a, st_b)
+    g = np.random.Generator(np.random.Philox(key=[4242, C - 1]))
+    g.normal(size=D)
+    assert np.array_equal(zt[C - 1, :D].cpu().numpy(), g.normal(size=D))
+    rng = np.random.default_rng(3)
+    th, gr = rng.normal(size=(D, C)), rng.normal(size=(D, C))
+    pa = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    pb = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    ops.mala_propose_from_normals(dev(th, ops), dev(gr, ops), zt[:, :D].t(), pa, 0.03, math.sqrt(0.06))
+    ops.mala_propose_from_normals(dev(th, ops), dev(gr, ops), z, pb, 0.03, math.sqrt(0.06))
+    assert torch.equal(pa, pb)
+    assert np.array_equal(pa.cpu().numpy(), (th + 0.03 * gr) + math.sqrt(0.06) * z.cpu().numpy())

@@ -6,7 +6,8 @@ import torch
 import bayes_kit_amd as bk
 C, D = int(os.environ.get("C", 65536)), int(os.environ.get("D", 1024))
 lam = torch.logspace(0, 4, D, dtype=torch.float64)
-s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, graph=os.environ.get("GRAPH", "0") == "1")
+s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, graph=os.environ.get("GRAPH", "0") == "1",
+            prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None))
 s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(s._theta_dc.device)[:, None])
 for _ in range(3):
     s.sample()
