@@ -20,6 +20,7 @@ from .ensemble import Stretcher
 from .drghmc import DrGhmcDiag
 from .hmc import HMCDiag
 from .mala import MALA
+from .metropolis import ChainRng, Metropolis, MetropolisHastings
 from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, hmc_kernel, mala_kernel, metropolis_kernel
 from .targets import DiagGaussian, Funnel, IsoGaussian, LogisticRegression, TorchModel
 
@@ -27,6 +28,8 @@ __all__ = [
     "DrGhmcDiag",
     "HMCDiag",
     "MALA",
+    "Metropolis",
+    "MetropolisHastings",
     "TemperedLikelihoodSMC",
     "Stretcher",
     "ess",
@@ -47,4 +50,5 @@ __all__ = [
     "Funnel",
     "LogisticRegression",
     "TorchModel",
+    "ChainRng",
 ]

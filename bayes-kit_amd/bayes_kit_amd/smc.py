@@ -219,22 +219,50 @@ class TemperedLikelihoodSMC:
         w = torch.exp(logw - top).contiguous()
         ops.uniform(self._rng_kind, self._rng_state, self._u)
         if multi:
-            world = dist.get_world_size(self._group)
-            wparts = [torch.empty_like(w) for _ in range(world)]
-            dist.all_gather(wparts, w, group=self._group)
-            w_all = torch.cat(wparts)
-            tparts = [torch.empty_like(th) for _ in range(world)]
-            dist.all_gather(tparts, th.contiguous(), group=self._group)
-            th_all = torch.cat(tparts, dim=1)
-            cdf = torch.empty_like(w_all)
-            self.last_ess = float((w_all.sum() ** 2 / (w_all * w_all).sum()).item())
-            ops.resample_indices(w_all, self._u, cdf, self._idx)
-            ops.gather_columns(self._idx, th_all, self._prop_dc)
+            self._resample_across_ranks(w, th)
         else:
             self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
             ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73
             ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
         self._theta_dc, self._prop_dc = self._prop_dc, self._theta_dc
+
+    def _resample_across_ranks(self, w, th):
+        """Multinomial resampling over the particles of ALL ranks (smc.py:64-75 with the particle
+        array sharded): the weights are all-gathered (8 B per particle), every rank draws the
+        global ancestor index of each of its own slots, and the ancestors' columns travel
+        point to point -- one all_to_all of requests (indices) and one of particles, M_local*D*8
+        bytes received per rank instead of the M_total*D*8 an all_gather of particles costs.
+        On a node this is RCCL over the direct xGMI links."""
+        import torch.distributed as dist
+
+        ops, g = self._ops, self._group
+        world, M = dist.get_world_size(g), w.shape[0]
+        wparts = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(wparts, w, group=g)
+        w_all = torch.cat(wparts)
+        self.last_ess = float((w_all.sum() ** 2 / (w_all * w_all).sum()).item())
+        ops.resample_indices(w_all, self._u, torch.empty_like(w_all), self._idx)  # global ancestors
+        idx = self._idx.to(torch.int64)
+        owner = torch.div(idx, M, rounding_mode="floor")
+        order = torch.sort(owner, stable=True).indices       # my slots grouped by the rank that owns their ancestor
+        want = torch.bincount(owner, minlength=world)         # how many columns I need from each rank
+        give = torch.empty_like(want)
+        dist.all_to_all_single(give, want, group=g)           # how many each rank needs from me
+        want_l, give_l = want.tolist(), give.tolist()
+        req_out = (idx[order] - owner[order] * M).contiguous()
+        req_in = torch.empty(sum(give_l), dtype=torch.int64, device=idx.device)
+        dist.all_to_all_single(req_in, req_out, give_l, want_l, group=g)
+        # the requested columns, particle-major so that each destination's block is contiguous
+        D, n_send = th.shape[0], req_in.shape[0]
+        send_pm = torch.empty((n_send, D), dtype=th.dtype, device=th.device)
+        if n_send:
+            cols = torch.empty((D, n_send), dtype=th.dtype, device=th.device)
+            ops.gather_columns(req_in.to(self._idx.dtype), th, cols)
+            ops.relayout(cols, send_pm.t())
+        recv_pm = torch.empty((M, D), dtype=th.dtype, device=th.device)
+        dist.all_to_all_single(recv_pm, send_pm, want_l, give_l, group=g)
+        # arrival k belongs to slot order[k]
+        self._prop_dc[:, order] = recv_pm.t()
 
 
 class TorchPriorLikelihoodModel:

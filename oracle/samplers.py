@@ -152,6 +152,60 @@ class MALA:
         return self._theta, self._lp
 
 
+def metropolis_accept_test(lp_proposal, lp_current, rng):
+    """bayes_kit/metropolis.py:12-38."""
+    return bool(np.log(rng.uniform()) < lp_proposal - lp_current)
+
+
+def metropolis_hastings_accept_test(lp_proposal, lp_current, lp_forward, lp_reverse, rng):
+    """bayes_kit/metropolis.py:41-76."""
+    ratio = (lp_proposal - lp_current) + (lp_reverse - lp_forward)
+    return bool(np.log(rng.uniform()) < ratio)
+
+
+class MetropolisHastings:
+    """bayes_kit/metropolis.py:79-135: user proposal + user transition log density."""
+
+    def __init__(self, model, proposal_fn, transition_lp_fn, *, init=None, seed=None):
+        self._model = model
+        self._dim = model.dims()
+        self._rng = np.random.default_rng(seed)  # metropolis.py:91
+        self._proposal_fn = proposal_fn
+        self._transition_lp_fn = transition_lp_fn
+        self._theta = _init_theta(init, self._rng, self._dim)
+        self._log_p_theta = model.log_density(self._theta)  # metropolis.py:99
+        self.last_accept = False
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.sample()
+
+    def _accepts(self, prop, lp_prop):
+        fwd = self._transition_lp_fn(prop, self._theta)  # metropolis.py:126
+        rev = self._transition_lp_fn(self._theta, prop)  # metropolis.py:127
+        return metropolis_hastings_accept_test(lp_prop, self._log_p_theta, fwd, rev, self._rng)
+
+    def sample(self):
+        prop = np.asanyarray(self._proposal_fn(self._theta), dtype=np.float64)  # metropolis.py:114-116
+        lp_prop = self._model.log_density(prop)
+        self.last_accept = self._accepts(prop, lp_prop)
+        if self.last_accept:
+            self._theta, self._log_p_theta = prop, lp_prop
+        return self._theta, self._log_p_theta
+
+
+class Metropolis(MetropolisHastings):
+    """bayes_kit/metropolis.py:138-155: symmetric proposal, plain Metropolis ratio."""
+
+    def __init__(self, model, proposal_fn, *, init=None, seed=None):
+        super().__init__(model, proposal_fn, None, init=init, seed=seed)
+
+    def _accepts(self, prop, lp_prop):
+        return metropolis_accept_test(lp_prop, self._log_p_theta, self._rng)
+
+
 class _Point(NamedTuple):
     """A phase-space point with the model outputs that belong to it."""
 

@@ -92,6 +92,22 @@ def rng_state(gen):
     )
 
 
+def make_proposal(spec, c):
+    """User-side proposal callbacks (the reference takes them as arguments, metropolis.py:83-84):
+    theta* ~ N(a * theta, scale^2 I) from the proposal's OWN per-chain Philox stream."""
+    prng = np.random.Generator(np.random.Philox(key=[spec["seed"], c]))
+    a, scale = spec.get("a", 1.0), spec["scale"]
+
+    def proposal_fn(theta):
+        return prng.normal(loc=a * theta, scale=scale)
+
+    def transition_lp_fn(to, frm):
+        r = (to - a * frm) / scale
+        return -0.5 * np.sum(r * r)
+
+    return proposal_fn, transition_lp_fn
+
+
 def run_sampler_case(case):
     C, N = case["chains"], case["draws"]
     model0 = make_model(case["model"])
@@ -127,6 +143,12 @@ def run_sampler_case(case):
                 seed=seed,
                 prob_retry=case.get("prob_retry", True),
             )
+        elif alg in ("metropolis", "mh"):
+            proposal_fn, transition_lp_fn = make_proposal(case["proposal"], c)
+            if alg == "metropolis":
+                s = ref.Metropolis(model, proposal_fn, init=init, seed=seed)
+            else:
+                s = ref.MetropolisHastings(model, proposal_fn, transition_lp_fn, init=init, seed=seed)
         else:
             raise KeyError(alg)
         metric = make_metric(case.get("metric"), D)
@@ -207,6 +229,13 @@ SAMPLER_CASES = [
     dict(name="drghmc_funnel101_cfg4", alg="drghmc", model=dict(kind="funnel", D=101),
          max_proposals=3, leapfrog_step_sizes=[0.2, 0.05, 0.0125],
          leapfrog_step_counts=[10, 40, 160], damping=0.1, chains=4, draws=40, seed=20242),
+    # --- Metropolis / Metropolis-Hastings (bayes_kit/metropolis.py) with seeded user proposals ---
+    dict(name="metropolis_rw_iso3", alg="metropolis", model=dict(kind="iso_gaussian", D=3),
+         proposal=dict(kind="normal", scale=0.6, seed=9001), chains=6, draws=80, seed=501),
+    dict(name="mh_ar_iso2", alg="mh", model=dict(kind="iso_gaussian", D=2),
+         proposal=dict(kind="normal", a=0.8, scale=0.5, seed=9002), chains=6, draws=80, seed=502),
+    dict(name="metropolis_pcg_seed", alg="metropolis", model=dict(kind="std_normal"),
+         proposal=dict(kind="normal", scale=1.1, seed=9003), chains=2, draws=60, pcg_seed=77),
     dict(name="drghmc_diag16_metric", alg="drghmc",
          model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), max_proposals=3,
          leapfrog_step_sizes=[0.5, 0.25, 0.1], leapfrog_step_counts=[3, 6, 12], damping=0.3,
@@ -263,12 +292,17 @@ def run_diagnostics():
 
 
 def main():
+    only = set(sys.argv[1:])  # optional: regenerate just the named cases
     for case in SAMPLER_CASES:
+        if only and case["name"] not in only:
+            continue
         res = run_sampler_case(case)
         path = os.path.join(HERE, case["name"] + ".npz")
         np.savez_compressed(path, **res)
         print("%-28s draws %s  mean grad calls/draw %.1f  size %d B"
               % (case["name"], res["draws"].shape, res["grad_calls"].mean(), os.path.getsize(path)))
+    if only and "diagnostics" not in only:
+        return
     d = run_diagnostics()
     path = os.path.join(HERE, "diagnostics.npz")
     np.savez_compressed(path, **d)

@@ -16,6 +16,7 @@ SAMPLER_CASES = [
     "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
     "drghmc_funnel101_cfg4", "drghmc_diag16_metric",
     "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
+    "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed",
 ]
 
 
@@ -57,6 +58,23 @@ def case_seed(case, c):
     return np.random.Philox(key=[case["seed"], c])
 
 
+def host_proposal(spec, c):
+    """The golden cases' user-side proposal callbacks for chain c (NumPy, single chain):
+    theta* ~ N(a*theta, scale^2 I) from the proposal's own Philox(key=[seed, c]) stream, and its
+    log transition density up to a constant."""
+    prng = np.random.Generator(np.random.Philox(key=[spec["seed"], c]))
+    a, scale = spec.get("a", 1.0), spec["scale"]
+
+    def proposal_fn(theta):
+        return prng.normal(loc=a * theta, scale=scale)
+
+    def transition_lp_fn(to, frm):
+        r = (to - a * frm) / scale
+        return -0.5 * np.sum(r * r)
+
+    return proposal_fn, transition_lp_fn
+
+
 def oracle_sampler(case, c, model=None):
     """Oracle sampler for chain c of a golden case."""
     model = model or oracle_model(case["model"])
@@ -73,6 +91,11 @@ def oracle_sampler(case, c, model=None):
         return osamplers.DrGhmcDiag(
             model, case["max_proposals"], case["leapfrog_step_sizes"], case["leapfrog_step_counts"],
             case["damping"], metric_diag=metric, init=init, seed=seed, prob_retry=case.get("prob_retry", True))
+    if alg in ("metropolis", "mh"):
+        proposal_fn, transition_lp_fn = host_proposal(case["proposal"], c)
+        if alg == "metropolis":
+            return osamplers.Metropolis(model, proposal_fn, init=init, seed=seed)
+        return osamplers.MetropolisHastings(model, proposal_fn, transition_lp_fn, init=init, seed=seed)
     raise KeyError(alg)
 
 

@@ -3,7 +3,7 @@ import numpy as np
 import torch
 
 import bayes_kit_amd as bk
-from tests.helpers import case_metric, case_seed, load_case, oracle_model
+from tests.helpers import case_metric, case_seed, host_proposal, load_case, oracle_model
 
 # Tolerances (DESIGN.md "Parity"): theta bit-exact for elementwise-gradient targets; logp and
 # energies are reductions summed in a different order than BLAS ddot -> rel 1e-12.
@@ -47,12 +47,47 @@ def build_sampler(case, model, ops, seed, chains=None, chain_id0=0, **extra):
         s = bk.DrGhmcDiag(model, case["max_proposals"], case["leapfrog_step_sizes"],
                           case["leapfrog_step_counts"], case["damping"],
                           prob_retry=case.get("prob_retry", True), **kw)
+    elif alg in ("metropolis", "mh"):
+        kw.pop("fuse_builtin", None)
+        if chains is not None:  # every chain in one sampler: batched callbacks on device streams
+            proposal_fn, transition_lp_fn = device_proposal(case["proposal"], chains, chain_id0, ops)
+        else:
+            proposal_fn, transition_lp_fn = host_proposal(case["proposal"], extra_chain(seed, case))
+        if alg == "metropolis":
+            s = bk.Metropolis(model, proposal_fn, **kw)
+        else:
+            s = bk.MetropolisHastings(model, proposal_fn, transition_lp_fn, **kw)
     else:
         raise KeyError(alg)
     metric = case_metric(case, D)
     if metric is not None:
         s._metric = metric  # same hook the golden generator uses on the reference
     return s
+
+
+def extra_chain(seed, case):
+    """Chain index a single-chain golden seed belongs to (the proposal stream is keyed by it)."""
+    if "pcg_seed" in case:
+        return int(seed) - case["pcg_seed"]
+    return int(seed.state["state"]["key"][1])
+
+
+def device_proposal(spec, chains, chain_id0, ops):
+    """The many-chain form of tests.helpers.host_proposal: one call proposes for every chain, the
+    normals coming from ChainRng streams keyed like the single-chain proposals' generators."""
+    from bayes_kit_amd.metropolis import ChainRng
+
+    prng = ChainRng(spec["seed"], chains, chain_id0, ops=ops)
+    a, scale = spec.get("a", 1.0), spec["scale"]
+
+    def proposal_fn(Theta):
+        return prng.normal(a * Theta, scale)
+
+    def transition_lp_fn(To, From):
+        r = (To - a * From) / scale
+        return -0.5 * (r * r).sum(dim=1)
+
+    return proposal_fn, transition_lp_fn
 
 
 def check_many_chain(name, ops, **extra):

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric", "hmc_diag1024_cfg3",
         "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init",
         "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
-        "drghmc_funnel101_cfg4", "drghmc_diag16_metric"]
+        "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "metropolis_rw_iso3", "mh_ar_iso2"]
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +35,8 @@ def test_hmc_step_by_step_path_vs_reference_golden(name, ops):
 @pytest.mark.parametrize("name", ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init",
                                   "drghmc_stdnormal_k3", "drghmc_k1",
                                   # the reference's own scipy-based test model with its finite-difference gradient
-                                  "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial"])
+                                  "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
+                                  "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed"])
 def test_single_chain_drop_in_vs_reference_golden(name, ops):
     check_single_chain_host_model(name, ops, chains=[0, 1])
 
@@ -419,3 +420,35 @@ def test_metric_assignment_survives_graph_replay(ops):
             ta, la = a.sample()
             tb, lb = b.sample()
             assert torch.equal(ta, tb) and torch.equal(la, lb), (first_metric is None, n)
+
+
+def test_metropolis_accept_functions_and_moments(ops):
+    """metropolis.py:12-76 on device streams + a many-chain random-walk Metropolis run
+    (moment test in the spirit of test_metropolis.py:106-168)."""
+    from bayes_kit_amd.metropolis import ChainRng, metropolis_accept_test, metropolis_hastings_accept_test
+
+    C = 300
+    rng = ChainRng(31, C, ops=ops)
+    gens = [np.random.Generator(np.random.Philox(key=[31, c])) for c in range(C)]
+    logu = np.array([np.log(g.uniform()) for g in gens])
+    # a few ulp either side of the boundary (the device log is within 1 ulp of the host's, as
+    # different hosts' logs are of each other: DESIGN.md parity table)
+    k = np.arange(C) % 2
+    delta = np.where(k == 0, logu * (1 - 2e-15), logu * (1 + 2e-15))
+    zero = torch.zeros(C, dtype=torch.float64, device=ops.device)
+    got = metropolis_accept_test(torch.from_numpy(delta).to(ops.device), zero, rng)
+    assert got.cpu().tolist() == [int(i) == 0 for i in k]
+    logu2 = np.array([np.log(g.uniform()) for g in gens])
+    fwd, rev, lp_p = np.linspace(-1, 1, C), np.linspace(0.5, -2, C), np.linspace(-3, 0.2, C)
+    got = metropolis_hastings_accept_test(lp_p, zero, fwd, rev, rng)
+    assert got.cpu().tolist() == [bool(l < (p - 0.0) + (r - f)) for l, p, f, r in zip(logu2, lp_p, fwd, rev)]
+
+    C, D = 4096, 3
+    prop = ChainRng(77, C, ops=ops)
+    s = bk.Metropolis(bk.IsoGaussian(D), lambda Th: prop.normal(Th, 1.2), chains=C, seed=5)
+    for _ in range(100):
+        s.sample()
+    draws = torch.stack([s.sample()[0] for _ in range(50)])
+    assert 0.2 < s.accept_rate() < 0.6, s.accept_rate()
+    # 4096 independent chains x 50 (autocorrelated) draws x 3 dims: s.e. ~0.01 on both moments
+    assert abs(float(draws.mean())) < 0.05 and abs(float(draws.var()) - 1.0) < 0.06, (draws.mean(), draws.var())

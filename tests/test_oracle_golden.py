@@ -46,8 +46,10 @@ def test_sampler_matches_reference_bit_for_bit(name):
                 assert calls == z["grad_calls"][n, c], (name, c, n)
             elif case["alg"] == "hmc":
                 assert calls == case["steps"] + 1
-            else:
+            elif case["alg"] == "mala":
                 assert calls == 1
+            else:
+                assert calls == 0  # Metropolis(-Hastings) never asks for a gradient
         np.testing.assert_array_equal(rng_state_words(s._rng), z["rng_state"][c])
         if case["alg"] == "drghmc":
             np.testing.assert_array_equal(s._rho, z["rho_final"][c])
