@@ -1,0 +1,28 @@
+"""DRGHMC in the HBM-bound regime (config-3 target and shape, model-opaque gradient op):
+useful lane-steps/s of the lockstep state machine next to plain HMC's leapfrog steps/s."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
+import torch
+import bayes_kit_amd as bk
+C, D = int(os.environ.get("C", 65536)), int(os.environ.get("D", 1024))
+lam = torch.logspace(0, 4, D, dtype=torch.float64)
+eps = [0.012, 0.006, 0.003]
+L = [32, 64, 128]
+s = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, eps, L, 0.5, chains=C, seed=11, fuse_builtin=False)
+s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(s._theta_dc.device)[:, None])
+s._have_cache = False
+for _ in range(2):
+    s.sample()
+torch.cuda.synchronize()
+n, steps, t0 = 5, 0, time.perf_counter()
+stages = []
+for _ in range(n):
+    s.sample()
+    steps += s.last_lane_steps
+    stages.append(s.last_stage_lanes)
+torch.cuda.synchronize()
+el = time.perf_counter() - t0
+print(json.dumps({"workload": f"DRGHMC K=3 diag Gaussian D={D} x {C} chains, opaque gradient", "ms_per_draw": 1e3 * el / n,
+                  "lane_steps_per_sec": steps / el, "hbm_GBps_56D_model": steps / el * 56 * D / 1e9,
+                  "frac_of_8TBps": steps / el * 56 * D / 8e12, "last_draw_stages": stages[-1]}))
