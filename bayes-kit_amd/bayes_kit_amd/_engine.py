@@ -49,9 +49,6 @@ def _as_bitgen(seed):
     return None
 
 
-WAVE_RNG_MAX_CHAINS = 16384  # up to here momentum refresh runs one wavefront per chain
-
-
 def make_streams(seed, C: int, chain_id0: int, reference_int_seed: bool, device):
     """Build the per-chain RNG table.
 
@@ -157,12 +154,10 @@ class ManyChainSampler:
         C = self._C = int(chains)
         self._chain_id0 = int(chain_id0)
         self._rng_kind, self._rng_state = make_streams(seed, C, chain_id0, not self._batched, dev)
-        # Scratch that lets bk_momentum_refresh put one wavefront (not one lane) on each chain.
-        # Worth it while one lane per chain leaves SIMDs empty (C/64 wavefronts < 1024 SIMDs);
-        # beyond that the lane-per-chain kernel is within 1.3x and, unlike this path, adds no
-        # HBM traffic to compete with the integrator when it runs ahead on the side stream
-        # (measured: MALA 65,536 x 1024 2.08 ms/draw lane-per-chain, 2.45 wave-per-chain).
-        wave_rng = self._rng_kind == _lib.RNG_PHILOX and D >= 32 and C <= WAVE_RNG_MAX_CHAINS
+        # Scratch that lets bk_momentum_refresh put one wavefront (not one lane) on each chain:
+        # 5-17x faster while one lane per chain leaves SIMDs empty (C < 65,536), still 1.3x at
+        # 65,536 x 1024 (config 3 +1.3 %, config 4 +5 % per draw, same box A/B).
+        wave_rng = self._rng_kind == _lib.RNG_PHILOX and D >= 32
         self._rng_work = self._ops.refresh_work(C, D) if wave_rng else None
         self._metric_dev: Optional[torch.Tensor] = None
         if metric_diag is not None:
