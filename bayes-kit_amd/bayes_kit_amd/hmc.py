@@ -103,8 +103,8 @@ class HMCDiag(ManyChainSampler):
         # Randomness of draw n+1 (momentum, its kinetic energy, the accept uniform) does not
         # depend on draw n, and the reference consumes it in a fixed order (D normals, then one
         # uniform: hmc.py:56,60).  With prefetch_rng it is generated on a second HIP stream
-        # while draw n's trajectory streams through HBM on the main one: the RNG kernel is
-        # latency/integer bound (one wavefront per SIMD) and hides under the HBM-bound kernels.
+        # while draw n's trajectory streams through HBM on the main one: the RNG kernels are
+        # integer bound and a small fraction of a draw, so they hide under the HBM-bound kernels.
         if prefetch_rng is None:
             prefetch_rng = self._batched and not self._use_graph and self._ops.device.type == "cuda"
         self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph

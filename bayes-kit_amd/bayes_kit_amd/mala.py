@@ -39,7 +39,8 @@ class MALA(ManyChainSampler):
         # As in HMCDiag: the D proposal normals and the accept uniform of draw n+1 do not depend
         # on draw n and are consumed in a fixed order (mala.py:44 then metropolis.py:74), so they
         # are generated on a second HIP stream under draw n's HBM-bound kernels; the proposal
-        # then is a pure elementwise kernel.  (The RNG kernel is more than half of a MALA draw.)
+        # then is a pure elementwise kernel.  (At a quarter of a MALA draw the generator only
+        # partly hides: DESIGN.md section 3, tools/overlap_probe.py.)
         if prefetch_rng is None:
             prefetch_rng = self._batched and not self._use_graph and dev.type == "cuda"
         self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
