@@ -22,7 +22,7 @@ from .hmc import HMCDiag
 from .mala import MALA
 from .metropolis import ChainRng, Metropolis, MetropolisHastings
 from .smc import TemperedLikelihoodSMC, TorchPriorLikelihoodModel, hmc_kernel, mala_kernel, metropolis_kernel
-from .targets import DiagGaussian, Funnel, IsoGaussian, LogisticRegression, TorchModel
+from .targets import CTarget, DiagGaussian, Funnel, IsoGaussian, LogisticRegression, TorchModel
 
 __all__ = [
     "DrGhmcDiag",
@@ -50,5 +50,6 @@ __all__ = [
     "Funnel",
     "LogisticRegression",
     "TorchModel",
+    "CTarget",
     "ChainRng",
 ]

@@ -3,7 +3,8 @@
 ``IsoGaussian``, ``DiagGaussian`` and ``Funnel`` evaluate their gradient through the
 library's C-ABI target entry points (``bk_target_*_grad``, include/bkhip.h) -- the "thin
 C-ABI callback" provider of GradModel.log_density_gradient (bayes_kit/typing.py:25-27).
-``TorchModel`` adapts any PyTorch-ROCm log-density function through autograd.  All of them
+``CTarget`` loads a user-compiled target with the same calling convention (plugin ABI
+``bk_target_fn``).  ``TorchModel`` adapts any PyTorch-ROCm log-density function through autograd.  All of them
 satisfy the batched form of the Model protocol (see typing.py) and can also be called
 directly by users.
 """
@@ -172,6 +173,53 @@ class LogisticRegression(_BuiltinTarget):
                                 dtype=torch.float64, device=th.device)
         self.bk_eval(th, g, lp, t)
         return lp, g.t()
+
+
+class CTarget(_BuiltinTarget):
+    """A user-compiled device model behind the plugin ABI ``bk_target_fn`` (include/bkhip.h).
+
+    ``library``: path of the user's shared library; ``symbol``: the exported function;
+    ``params``: what the function receives as its opaque ``params`` pointer -- a torch tensor
+    (its data pointer; device or host), a ``ctypes`` structure / array (host memory, kept alive
+    here) or None.  The gradient call goes straight from the sampler to the user's launch: no
+    PyTorch ops, no Python callback per chain.
+    """
+
+    def __init__(self, library: str, symbol: str, dims: int, params=None, ops=None):
+        import ctypes
+
+        super().__init__(dims, ops)
+        self._cdll = ctypes.CDLL(library)
+        try:
+            fn = getattr(self._cdll, symbol)
+        except AttributeError as e:
+            raise _lib.BkHipError(f"{library} does not export {symbol}") from e
+        I = ctypes.c_int64
+        P = ctypes.c_void_p
+        fn.argtypes = [P, P, P, I, P, I, I, P]
+        fn.restype = ctypes.c_int
+        self._fn, self._symbol = fn, symbol
+        self._keep = params
+        if params is None:
+            self._pp = None
+        elif isinstance(params, torch.Tensor):
+            self._pp = params.data_ptr()
+        else:
+            self._pp = ctypes.cast(ctypes.pointer(params), P) if not isinstance(params, ctypes.Array) \
+                else ctypes.cast(params, P)
+
+    def bk_eval(self, theta_dc, grad_out, logp_out):
+        D, C = theta_dc.shape
+        ld = theta_dc.stride(0) if D > 1 else max(C, theta_dc.stride(0))
+        if C > 1 and theta_dc.stride(1) != 1:
+            raise ValueError("CTarget needs chain-contiguous theta")
+        if grad_out is not None and (grad_out.stride(0) if D > 1 else ld) != ld:
+            raise ValueError("theta and grad must share their leading dimension")
+        stream = torch.cuda.current_stream(theta_dc.device).cuda_stream if theta_dc.is_cuda else None
+        rc = self._fn(theta_dc.data_ptr(), None if grad_out is None else grad_out.data_ptr(),
+                      None if logp_out is None else logp_out.data_ptr(), ld, self._pp, C, D, stream)
+        if rc != 0:
+            raise _lib.BkHipError(f"{self._symbol} returned {rc}")
 
 
 class TorchModel:

@@ -63,5 +63,23 @@ def build(force=False, verbose=True):
     return LIB
 
 
+PLUGIN_SRC = os.path.join(HERE, "..", "examples", "plugin_target", "ar1_target.hip")
+PLUGIN_LIB = os.path.join(HERE, "..", "examples", "plugin_target", "libar1_target.so")
+
+
+def build_example_plugin(force=False, verbose=True):
+    """The example USER target (plugin ABI bk_target_fn): its own shared library, not part of
+    libbkhip.so; built here so that the tests can load it on the GPU box."""
+    src, lib = os.path.abspath(PLUGIN_SRC), os.path.abspath(PLUGIN_LIB)
+    if force or _stale(lib, [src]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               src, "-o", lib]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return lib
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    print(build_example_plugin(force="--force" in sys.argv))

@@ -261,6 +261,18 @@ int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp
 int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld,
                           int64_t C, int64_t D, void* stream);
 
+/* ---- user targets (plugin ABI) ------------------------------------------------------------
+ * A model the USER compiles into their own shared library plugs in below the samplers through
+ * one exported function of this type: GradModel.log_density_gradient (typing.py:25-27) for all
+ * chains at once.  theta[d*ld + c] in; grad[d*ld + c] and logp[c] out (either may be NULL);
+ * `params` is an opaque pointer owned by the model (host or device memory, its choice); the
+ * function only enqueues on `stream` and returns 0 or a nonzero status (hipError_t or its own
+ * negative codes).  bayes_kit_amd.CTarget(library, symbol, dims, params) loads it; the samplers
+ * then treat it exactly like the bk_target_* functions above (no torch, no Python in the
+ * gradient call).  examples/plugin_target/ar1_target.hip is a complete one. */
+typedef int (*bk_target_fn)(const double* theta, double* grad, double* logp, int64_t ld,
+                            const void* params, int64_t C, int64_t D, void* stream);
+
 /* Whole HMC trajectory (hmc.py:40-53) for the separable Gaussian targets with the gradient
  * callback inlined: back half-step, `steps` x (kick, drift, grad = -(lam*theta)), forward
  * half-step, all in registers.  lam NULL = iso Gaussian; metric NULL = ones.  Outputs may

@@ -17,7 +17,8 @@ def pytest_sessionstart(session):
     # the in-tree libbkhip.so normally travels with the working tree; if it does not, build it
     # (hipcc cross-compiles without a GPU).  A failed build surfaces in the tests that load it.
     lib = os.path.join(ROOT, "bayes-kit_amd", "bayes_kit_amd", "lib", "libbkhip.so")
-    if not os.path.exists(lib):
+    plugin = os.path.join(ROOT, "examples", "plugin_target", "libar1_target.so")
+    if not (os.path.exists(lib) and os.path.exists(plugin)):
         try:
             import __graft_entry__ as ge
 

@@ -32,3 +32,33 @@ class Binomial:
 
     def posterior_mean(self):
         return stats.beta(self.alpha + self.x, self.beta + self.N - self.x).mean()
+
+
+class Ar1:
+    """NumPy statement of examples/plugin_target/ar1_target.hip (a USER plugin target), same
+    operation order: r_d = theta_d - a*theta_{d-1}; logp = (-0.5/s2) * sum r_d^2 summed in d
+    order; grad_d = -((r_d - a*r_{d+1}) * (1/s2))."""
+
+    def __init__(self, D, a, s2):
+        self.D, self.a, self.inv_s2 = D, a, 1.0 / s2
+
+    def dims(self):
+        return self.D
+
+    def _r(self, theta):
+        prev = np.concatenate([[0.0], theta[:-1]])
+        return theta - self.a * prev
+
+    def log_density(self, theta):
+        ss = 0.0
+        for v in self._r(theta):
+            ss = ss + v * v
+        return (-0.5 * self.inv_s2) * ss
+
+    def log_density_gradient(self, theta):
+        r = self._r(theta)
+        nxt = np.concatenate([r[1:], [0.0]])
+        g = np.empty(self.D)
+        g[:-1] = -((r[:-1] - self.a * nxt[:-1]) * self.inv_s2)
+        g[-1] = -(r[-1] * self.inv_s2)
+        return self.log_density(theta), g

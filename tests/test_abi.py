@@ -62,3 +62,19 @@ def test_product_rng_source_on_host_matches_numpy():
 
     for x in -np.random.default_rng(0).random(20000):
         assert lib.bk_host_log1p(float(x)) == math.log1p(float(x))
+
+
+def test_example_plugin_target_loads_and_exports_its_entry_point():
+    """The plugin ABI (bk_target_fn in include/bkhip.h): a user library exporting one function."""
+    import ctypes
+    import os
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    assert "typedef int (*bk_target_fn)(" in open(os.path.join(root, "include", "bkhip.h")).read()
+    lib = ctypes.CDLL(os.path.join(root, "examples", "plugin_target", "libar1_target.so"))
+    assert hasattr(lib, "ar1_target")
+    # argument validation happens before any launch: callable without a GPU
+    lib.ar1_target.restype = ctypes.c_int
+    lib.ar1_target.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                                       ctypes.c_int64, ctypes.c_void_p]
+    assert lib.ar1_target(None, None, None, 0, None, 1, 1, None) == -1

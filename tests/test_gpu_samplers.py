@@ -452,3 +452,42 @@ def test_metropolis_accept_functions_and_moments(ops):
     assert 0.2 < s.accept_rate() < 0.6, s.accept_rate()
     # 4096 independent chains x 50 (autocorrelated) draws x 3 dims: s.e. ~0.01 on both moments
     assert abs(float(draws.mean())) < 0.05 and abs(float(draws.var()) - 1.0) < 0.06, (draws.mean(), draws.var())
+
+
+def test_user_plugin_target_through_the_c_abi(ops):
+    """examples/plugin_target: a user-compiled target loaded with bk.CTarget (plugin ABI
+    bk_target_fn).  Its outputs and an HMC run on it are checked against the NumPy statement
+    of the same density (tests/host_models.Ar1) driven by the oracle sampler."""
+    import ctypes
+    import os
+
+    from oracle import samplers as osamp
+    from tests.host_models import Ar1
+
+    class Params(ctypes.Structure):
+        _fields_ = [("a", ctypes.c_double), ("s2", ctypes.c_double)]
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    C, D, a, s2 = 70, 16, 0.6, 0.8
+    tgt = bk.CTarget(os.path.join(root, "examples", "plugin_target", "libar1_target.so"), "ar1_target", D,
+                     Params(a, s2))
+    host = Ar1(D, a, s2)
+    Th = torch.randn((D, C), dtype=torch.float64, device=ops.device).t()  # (C, D) view, strides (1, C)
+    lp, g = tgt.log_density_gradient(Th)
+    for c in (0, 1, C - 1):
+        hlp, hg = host.log_density_gradient(Th[c].cpu().numpy())
+        assert np.array_equal(g[c].cpu().numpy(), hg) and float(lp[c]) == hlp
+    assert torch.equal(tgt.log_density(Th), lp)
+    s = bk.HMCDiag(tgt, 0.1, 6, chains=C, seed=909)
+    th0 = s._theta.cpu().numpy()
+    draws = [tuple(x.cpu().numpy() for x in s.sample()) for _ in range(12)]
+    assert 0.3 < s.accept_rate() <= 1.0
+    for c in (0, 33, C - 1):
+        o = osamp.HMCDiag(host, 0.1, 6, seed=np.random.Philox(key=[909, c]))
+        assert np.array_equal(o._theta, th0[c])
+        for n in range(12):
+            oth, olp = o.sample()
+            assert np.array_equal(oth, draws[n][0][c]), (c, n)
+            np.testing.assert_allclose(olp, draws[n][1][c], rtol=1e-12, atol=1e-12)
+    with pytest.raises(bk._lib.BkHipError):
+        bk.CTarget(os.path.join(root, "examples", "plugin_target", "libar1_target.so"), "no_such_symbol", D)
