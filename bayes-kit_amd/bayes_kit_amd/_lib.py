@@ -67,6 +67,7 @@ SIGNATURES = {
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
+    "bk_end_pos_pairs": [P, I, I, P, I, P],
     "bk_ess": [P, I, I, c_int, P, P, I, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
     "bk_rank_normalize": [P, F, P, I, P],
@@ -405,6 +406,10 @@ class Ops:
     def autocorr(self, x, out):
         N, C = x.shape
         self._call("bk_autocorr", ptr(x), _ld(x), N, ptr(out), _ld(out), C, self._s())
+
+    def end_pos_pairs(self, acor, out):
+        N, C = acor.shape
+        self._call("bk_end_pos_pairs", ptr(acor), max(C, acor.stride(0)) if N else C, N, ptr(out), C, self._s())
 
     def ess(self, x, estimator, ess_out, iat_out=None):
         N, C = x.shape

@@ -84,18 +84,36 @@ def _as_lp(x, C, dev):
     return t.contiguous()
 
 
-def metropolis_accept_test(lp_proposal, lp_current, rng: ChainRng) -> torch.Tensor:
-    """``log(rng.uniform()) < lp_proposal - lp_current`` per chain (metropolis.py:12-38):
-    (C,) tensors in, (C,) bool tensor out; consumes one uniform of every chain's stream."""
+def _accept_host_rng(lp_proposal, lp_current, fwd, rev, rng) -> bool:
+    """The reference's scalar form: ``rng`` is a host generator (anything with ``uniform()``, e.g. a
+    ``numpy.random.Generator``), the log densities are floats.  One uniform is taken from it, as
+    in the reference; the comparison itself is still the ``bk_mh_accept`` kernel (one chain)."""
+    ops = _lib.default_ops()
+    with np.errstate(divide="ignore"):
+        logu = float(np.log(rng.uniform()))
+    one = lambda v: None if v is None else torch.tensor([float(v)], dtype=torch.float64, device=ops.device)  # noqa: E731
+    mask = torch.empty(1, dtype=torch.uint8, device=ops.device)
+    ops.mh_accept(_lib.ACCEPT_MALA, one(lp_current), one(fwd), one(lp_proposal), one(rev), one(logu), mask, None,
+                  None)
+    return bool(mask[0].item())
+
+
+def metropolis_accept_test(lp_proposal, lp_current, rng):
+    """``log(rng.uniform()) < lp_proposal - lp_current`` (metropolis.py:12-38).  With a ``ChainRng``:
+    (C,) tensors in, (C,) bool tensor out, one uniform of every chain's stream consumed.  With a
+    host generator and floats: a bool, as in the reference."""
+    if not isinstance(rng, ChainRng):
+        return _accept_host_rng(lp_proposal, lp_current, None, None, rng)
     dev = rng._ops.device
     lp_p, lp_c = _as_lp(lp_proposal, rng._C, dev), _as_lp(lp_current, rng._C, dev)
     return _accept(rng._ops, rng._kind, rng._state, lp_p, lp_c, None, None)
 
 
-def metropolis_hastings_accept_test(lp_proposal, lp_current, lp_forward_transition, lp_reverse_transition,
-                                    rng: ChainRng) -> torch.Tensor:
-    """``log(rng.uniform()) < (lp_proposal - lp_current) + (lp_reverse - lp_forward)`` per chain
-    (metropolis.py:41-76)."""
+def metropolis_hastings_accept_test(lp_proposal, lp_current, lp_forward_transition, lp_reverse_transition, rng):
+    """``log(rng.uniform()) < (lp_proposal - lp_current) + (lp_reverse - lp_forward)``
+    (metropolis.py:41-76); many-chain or scalar form as above."""
+    if not isinstance(rng, ChainRng):
+        return _accept_host_rng(lp_proposal, lp_current, lp_forward_transition, lp_reverse_transition, rng)
     dev, C = rng._ops.device, rng._C
     return _accept(rng._ops, rng._kind, rng._state, _as_lp(lp_proposal, C, dev), _as_lp(lp_current, C, dev),
                    _as_lp(lp_forward_transition, C, dev), _as_lp(lp_reverse_transition, C, dev))

@@ -147,6 +147,9 @@ class TemperedLikelihoodSMC:
         self._group = group
         self._slot0 = int(slot_id0)
         self._model = model
+        # A reference-style model scores ONE particle per call on the host (smc.py:28-32); a
+        # batched device model (batched = True) scores all of them at once.
+        self._batched = getattr(model, "batched", False) is True
         self.kernel = kernel
         self._ops = ops if ops is not None else _lib.default_ops()
         dev = self._ops.device
@@ -174,14 +177,26 @@ class TemperedLikelihoodSMC:
     # -- reference API ------------------------------------------------------------------------
     @property
     def thetas(self):
-        """(M, D) view of the particles."""
-        return self._theta_dc.t()
+        """(M, D) particles: a device view for batched models, a NumPy array (as in the reference)
+        for reference-style host models."""
+        if self._batched:
+            return self._theta_dc.t()
+        return np.array(self._theta_dc.t().cpu().numpy())
+
+    def _per_particle(self, fn, Theta):
+        th = np.array(Theta.cpu().numpy())
+        vals = [float(fn(th[m])) for m in range(th.shape[0])]
+        return torch.tensor(vals, dtype=torch.float64, device=self._ops.device)
 
     def log_prior(self, Theta):
-        return self._model.log_prior(Theta)
+        if self._batched:
+            return self._model.log_prior(Theta)
+        return self._per_particle(self._model.log_prior, Theta)
 
     def log_likelihood(self, Theta):
-        return self._model.log_likelihood(Theta)
+        if self._batched:
+            return self._model.log_likelihood(Theta)
+        return self._per_particle(self._model.log_likelihood, Theta)
 
     def time(self, n: int) -> float:
         return n / self.N

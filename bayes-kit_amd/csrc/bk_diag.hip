@@ -157,6 +157,19 @@ __global__ __launch_bounds__(PC_BLOCK) void k_autocorr(const double* x, i64 ld, 
   }
 }
 
+// index one past the last even-aligned pair (0,1), (2,3), ... before the first pair with a negative
+// sum (iat.py:7-43), one lane per chain of an [N][ld] autocorrelation array
+__global__ __launch_bounds__(PC_BLOCK) void k_end_pos_pairs(const double* acor, i64 ld, i64 N, i64* out, i64 C) {
+  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
+  if (c >= C) return;
+  i64 n = 0;
+  while (n + 1 < N) {
+    if (acor[n * ld + c] + acor[(n + 1) * ld + c] < 0.0) break;
+    n += 2;
+  }
+  out[c] = n;
+}
+
 // Inverse standard-normal CDF: Cephes ndtri (what scipy.stats.norm.ppf evaluates; rhat.py:106),
 // same rational approximations and evaluation order, no FMA contraction.
 __device__ __forceinline__ double polevl(double x, const double* c, int n) {
@@ -263,6 +276,14 @@ int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo
   if (ld < C || ldo < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   k_autocorr<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, out, ldo, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_end_pos_pairs(const double* acor, int64_t ld, int64_t N, int64_t* out, int64_t C, void* stream) {
+  if (!out || N < 0 || C < 0 || (!acor && N > 0)) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_end_pos_pairs<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(acor, ld, N, out, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

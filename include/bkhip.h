@@ -377,6 +377,11 @@ int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void
 int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C,
                 void* stream);
 
+/* out[c] = index one past the last pair (0,1), (2,3), ... of acor[n*ld + c] before the first pair
+ * with a negative sum (iat.py:7-43, the truncation point of both IAT estimators). */
+int bk_end_pos_pairs(const double* acor, int64_t ld, int64_t N, int64_t* out, int64_t C,
+                     void* stream);
+
 /* ESS of each chain of a stored series (ess.py:52-69 -> iat.py:95-135 -> autocorr.py:6-33):
  * autocorrelations by direct summation (same quantity the reference gets by FFT), Geyer
  * initial-positive truncation at the first even lag pair with negative sum, initial

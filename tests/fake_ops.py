@@ -329,6 +329,14 @@ class FakeOps:
         for c in range(x.shape[1]):
             out.numpy()[:, c] = od.autocorr(x.numpy()[:, c])
 
+    def end_pos_pairs(self, acor, out):
+        a = acor.numpy()
+        for c in range(a.shape[1]):
+            n = 0
+            while n + 1 < a.shape[0] and not (a[n, c] + a[n + 1, c] < 0):
+                n += 2
+            out[c] = n
+
     def ess(self, x, estimator, ess_out, iat_out=None):
         from oracle import diagnostics as od
 

@@ -491,3 +491,14 @@ def test_user_plugin_target_through_the_c_abi(ops):
             np.testing.assert_allclose(olp, draws[n][1][c], rtol=1e-12, atol=1e-12)
     with pytest.raises(bk._lib.BkHipError):
         bk.CTarget(os.path.join(root, "examples", "plugin_target", "libar1_target.so"), "no_such_symbol", D)
+
+
+def test_reference_test_behaviours_on_device(ops):
+    """test/test_iat.py:72-80, test_metropolis.py:19-103, test_theta_initialization.py:17-54,
+    test_tempered_smc.py:8-30 in this repo's words, through the HIP library."""
+    from tests import dropin_behaviours as db
+
+    db.check_end_pos_pairs(ops)
+    db.check_accept_tests_with_host_rng(ops)
+    db.check_theta_initialization(ops)
+    db.check_smc_with_reference_style_model(ops)

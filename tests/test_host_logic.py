@@ -402,3 +402,14 @@ def test_accept_test_functions_many_chains():
     got = metropolis_hastings_accept_test(torch.from_numpy(lp_p), lp_cur, torch.from_numpy(fwd),
                                           torch.from_numpy(rev), rng)
     assert got.tolist() == [bool(l < (p - 0.0) + (r - f)) for l, p, f, r in zip(logu2, lp_p, fwd, rev)]
+
+
+# ---- drop-in behaviours pinned by the reference's own tests (shared bodies, fake ops here) ----------
+def test_reference_test_behaviours_with_fake_ops():
+    from tests import dropin_behaviours as db
+
+    ops = FakeOps()
+    db.check_end_pos_pairs(ops)
+    db.check_accept_tests_with_host_rng(ops)
+    db.check_theta_initialization(ops)
+    db.check_smc_with_reference_style_model(ops)
