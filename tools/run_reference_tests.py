@@ -9,7 +9,10 @@
 the build container, so the device operations are served by tests/fake_ops.py (the CPU
 stand-in used for host-logic tests): this checks the API surface, argument validation, call
 contracts, seeding and moment behaviour of the Python layer -- not the kernels, which the
-`-m gpu` tests cover.  Last result: 69 passed (all of the reference's tests).
+`-m gpu` tests cover.  Last result: 69 passed (all of the reference's tests).  The unseeded
+moment tests are statistical: test_drghmc_binom fails about 15 % of runs with the reference
+itself (8/50) and with this package (7/50); with equal seeds the two produce bit-identical
+draws (800 of 800 checked), so a rare failure there is the test's own noise.
 """
 import importlib
 import os
