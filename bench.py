@@ -96,6 +96,17 @@ def cpu_baseline(seconds_hint=12.0):
     }
 
 
+def _device_index(local_rank):
+    """LOCAL_RANK, unless BK_BENCH_SHARE_GPU=1: then ranks share the visible GPUs round-robin and
+    rendezvous over gloo.  That mode exists only to exercise the N > 1 code path on a one-GPU box
+    (RCCL refuses two ranks on one device); its numbers are not measurements."""
+    if os.environ.get("BK_BENCH_SHARE_GPU"):
+        import torch
+
+        return local_rank % max(1, torch.cuda.device_count())
+    return local_rank
+
+
 def run_other_config(args, rank, local_rank, world):
     """Secondary workloads (parity-test configs of BASELINE.json), not the headline line:
     --config 2: iso-Gaussian D=128, HMC L=32, 4096 chains (cache-resident, launch-bound);
@@ -105,10 +116,14 @@ def run_other_config(args, rank, local_rank, world):
 
     import bayes_kit_amd as bk
 
+    local_rank = _device_index(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        bk.dist.init_from_env()
+        if os.environ.get("BK_BENCH_SHARE_GPU"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            bk.dist.init_from_env()
 
     def barrier():
         if world > 1:
@@ -152,16 +167,20 @@ def run_other_config(args, rank, local_rank, world):
             rec.record(th, lp)
         barrier()
         el = time.perf_counter() - t0
-        rh = mom.rhat()
-        ess = rec.ess()
-        ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N)).min(dim=0).values
-        ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), device)
+        rh = mom.rhat() if N >= 2 else torch.full((D,), float("nan"))
+        if N >= 4:  # the reference's estimator needs 4 draws (ess.py:67-68)
+            ess = rec.ess()
+            ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N)).min(dim=0).values
+            ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), device)
+        else:
+            ess_total = None
         lane_total = bk.dist.sum_over_ranks(float(lane_steps), device)
         out = {"metric": "DRGHMC funnel D=101 K=3: gradient evaluations/sec (chain-steps actually run)",
                "value": lane_total / el, "unit": "gradient evaluations/sec", "n_gpus": world, "steps": N,
                "warmup": args.warmup, "ms_per_step": 1e3 * el / N, "draws_per_sec": C * world * N / el,
-               "mean_grad_evals_per_draw": lane_total / (C * world * N), "rhat_max": float(rh.max()),
-               "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "dtype": "f64", "data": "synthetic",
+               "mean_grad_evals_per_draw": lane_total / (C * world * N), "rhat_max": float(rh.max()) if N >= 2 else None,
+               "rhat_v": float(rh[0]) if N >= 2 else None,
+               "ess_per_sec": None if ess_total is None else ess_total / el, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "BASELINE.json configs[3]", "chains_per_gpu": C, "dims": D, "max_proposals": 3}}
     out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None})
     if rank == 0:
@@ -206,11 +225,15 @@ def main():
     import torch
     import torch.distributed as dist
 
+    local_rank = _device_index(local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if os.environ.get("BK_BENCH_SHARE_GPU"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     C = args.chains
     D, L = D_CFG3, L_CFG3
