@@ -189,8 +189,7 @@ class ManyChainSampler:
             self._metric_dev.copy_(new)  # in place: a captured hipGraph keeps pointing at this buffer
         else:
             self._metric_dev = new
-            if getattr(self, "_graph", None) is not None:
-                self._graph = None  # the captured launches had no metric argument: capture again
+            self._drop_graphs()  # the captured launches had no metric argument: capture again
 
     @property
     def _metric(self):
@@ -266,8 +265,7 @@ class ManyChainSampler:
         if hasattr(self, "_have_cache"):
             self._have_cache = meta["have_cache"]
         self._load_extra(meta.get("extra", {}))
-        if hasattr(self, "_graph"):
-            self._graph = None  # captured launches may refer to superseded state: capture again
+        self._drop_graphs()  # captured launches may refer to superseded state: capture again
         self._after_load()
 
     def _load_extra(self, extra):
@@ -282,35 +280,77 @@ class ManyChainSampler:
     # synchronisation (batched models; not the single-chain host-model mode, not DRGHMC).
     GRAPH_AUTO_MAX_ELEMS = 1 << 22  # D*C below which a draw is launch-bound (arrays <= 32 MiB)
 
-    def _init_graph(self, graph, prefer_streams: bool = False):
-        if graph is None and prefer_streams:
-            graph = False  # the caller explicitly asked for the side-stream RNG, which is not captured
+    def _init_graph(self, graph):
         if graph is None:
             # automatic only where capture is known to be safe (the library's own targets: no host
             # synchronisation, no allocation patterns of user code) and where it pays
             graph = (self._batched and hasattr(self._model, "bk_eval") and self._ops.device.type == "cuda"
                      and self._dim * self._C <= self.GRAPH_AUTO_MAX_ELEMS)
         self._use_graph = bool(graph)
-        self._graph = None
+        self._graphs = {}
         self._graph_warm = 0
         if self._use_graph and not self._batched:
             raise ValueError("graph=True needs a batched device model (the host-model mode synchronises)")
+
+    @property
+    def _graph(self):
+        """Any captured draw (None before the first capture)."""
+        return next(iter(self._graphs.values()), None)
+
+    def _drop_graphs(self):
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+        self._graph_warm = 0
+
+    # Samplers that generate the NEXT draw's randomness on a side stream capture it as a parallel
+    # branch of the draw's graph (fork at the start, join at the end): two graphs, one per
+    # double-buffer slot, replayed alternately.
+    def _graph_key(self):
+        return 0
+
+    def _graph_keys(self):
+        """Every key a draw can have; all are captured at the first opportunity (capturing does
+        not execute anything), so that no capture falls into a caller's timed region later."""
+        return [0]
+
+    def _set_graph_key(self, key):
+        pass
+
+    def _before_capture(self):
+        pass
+
+    def _capture_epilogue(self):
+        pass
+
+    def _before_replay(self):
+        pass
+
+    def _after_replay(self):
+        pass
 
     def _run_draw(self, draw_fn):
         if not self._use_graph:
             draw_fn()
             return
-        if self._graph is None:
+        if not self._graphs:
             if self._graph_warm < 1:
                 draw_fn()  # eager: first-use initialisation, lazy parameter uploads
                 self._graph_warm += 1
                 return
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                draw_fn()
-            self._graph = g
-        self._graph.replay()
+            self._before_capture()
+            now = self._graph_key()
+            for key in self._graph_keys():
+                self._set_graph_key(key)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    draw_fn()
+                    self._capture_epilogue()
+                self._graphs[key] = g
+            self._set_graph_key(now)
+        self._before_replay()
+        self._graphs[self._graph_key()].replay()
+        self._after_replay()
 
     def __next__(self):
         return self.sample()

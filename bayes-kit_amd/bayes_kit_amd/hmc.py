@@ -77,7 +77,7 @@ class HMCDiag(ManyChainSampler):
             self._M_inv = torch.linalg.inv(Mt)
             self._M_inv = (0.5 * (self._M_inv + self._M_inv.t())).to(dev_).contiguous()
             fuse_builtin = False
-        self._init_graph(graph, prefer_streams=prefetch_rng is True)
+        self._init_graph(graph)
         # built-in separable targets can run the whole trajectory in registers
         # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")
@@ -105,11 +105,15 @@ class HMCDiag(ManyChainSampler):
         # uniform: hmc.py:56,60).  With prefetch_rng it is generated on a second HIP stream
         # while draw n's trajectory streams through HBM on the main one: the RNG kernels are
         # integer bound and a small fraction of a draw, so they hide under the HBM-bound kernels.
+        # Under hipGraph replay the generation can be a parallel branch of the draw's graph
+        # (graph=True, prefetch_rng=True: correct, but measured SLOWER than one serial graph --
+        # 93 vs 79 us per draw at 4096 x 128, tools/graph_fork_bench.py -- so not the default).
         if prefetch_rng is None:
             prefetch_rng = self._batched and not self._use_graph and self._ops.device.type == "cuda"
-        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
-        self._pf_slot = 0
-        self._pf_event = None
+        self._prefetch = bool(prefetch_rng) and self._batched
+        self._pf_slot = 0           # double-buffer slot holding the NEXT draw's randomness
+        self._pf_ready = False      # ... once it has been generated
+        self._pf_event = None       # ... and the event that marks it complete (None: already joined)
         self._pf_kin_stale = False
         if self._prefetch:
             self._rho_bufs.append(torch.empty((D, C), **f64))
@@ -146,23 +150,55 @@ class HMCDiag(ManyChainSampler):
         self._pf_kin_stale = True  # a prefetched kinetic energy was computed with the old metric
 
     def rng_state(self):
-        if getattr(self, "_prefetch", False) and self._pf_event is not None:
-            self._pf_event.synchronize()
-            return self._rng_logical.cpu().numpy().view(np.uint64)
-        return super().rng_state()
+        return self._logical_rng().cpu().numpy().view(np.uint64)
 
     def _state_tensors(self):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
 
     def _logical_rng(self):
-        if self._prefetch and self._pf_event is not None:
-            self._pf_event.synchronize()
+        if getattr(self, "_prefetch", False) and self._pf_ready:
+            if self._pf_event is not None:
+                self._pf_event.synchronize()
             return self._rng_logical
         return self._rng_state
 
     def _after_load(self):
         # drop any randomness generated ahead: it is regenerated from the restored stream
-        self._pf_event, self._pf_slot, self._pf_kin_stale = None, 0, False
+        self._pf_event, self._pf_slot, self._pf_ready, self._pf_kin_stale = None, 0, False, False
+
+    # -- hipGraph replay with the generator as a parallel branch -------------------------------------
+    def _graph_key(self):
+        return self._pf_slot if self._prefetch else 0
+
+    def _graph_keys(self):
+        return [0, 1] if self._prefetch else [0]
+
+    def _set_graph_key(self, key):
+        if self._prefetch:
+            self._pf_slot = key
+
+    def _refresh_stale_kinetic(self):
+        if self._pf_kin_stale and self._pf_ready:
+            self._ops.leapfrog_finish(self._rho_bufs[self._pf_slot], None, None, self._metric_dev, 0.0, False,
+                                      self._kin0_bufs[self._pf_slot])
+        self._pf_kin_stale = False
+
+    def _before_capture(self):
+        self._pf_event = None  # the device was synchronised: nothing left to wait for
+        if self._prefetch:
+            self._refresh_stale_kinetic()
+
+    def _before_replay(self):
+        if self._prefetch:
+            self._refresh_stale_kinetic()
+
+    def _capture_epilogue(self):
+        if self._prefetch:
+            torch.cuda.current_stream().wait_stream(self._side)  # join the generator branch
+
+    def _after_replay(self):
+        if self._prefetch:
+            self._pf_slot, self._pf_ready, self._pf_event = 1 - self._pf_slot, True, None
 
     def _randomness(self, slot):
         """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
@@ -201,16 +237,24 @@ class HMCDiag(ManyChainSampler):
             self._randomness(0)
             return self._rho_bufs[0], self._kin0_bufs[0], self._logu_bufs[0]
         main = torch.cuda.current_stream()
-        if self._pf_event is None:
-            self._randomness(self._pf_slot)  # very first draw: nothing prefetched yet
-        else:
-            main.wait_event(self._pf_event)
-            if self._pf_kin_stale:
-                self._ops.leapfrog_finish(self._rho_bufs[self._pf_slot], None, None, self._metric_dev, 0.0,
-                                          False, self._kin0_bufs[self._pf_slot])
-        self._pf_kin_stale = False
         cur = self._pf_slot
         nxt = 1 - cur
+        if torch.cuda.is_current_stream_capturing():
+            # graph capture: slot `cur` is ready (eager warm-up draw or previous replay); fork the
+            # generator for slot `nxt` off the capture stream, joined in _capture_epilogue().  The
+            # slot bookkeeping advances after each replay (_after_replay), not here.
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                self._rng_logical.copy_(self._rng_state)
+                self._randomness(nxt)
+            return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
+        if not self._pf_ready:
+            self._randomness(cur)  # very first draw: nothing prefetched yet
+            self._pf_kin_stale = False
+        else:
+            if self._pf_event is not None:
+                main.wait_event(self._pf_event)
+            self._refresh_stale_kinetic()
         # the other slot was last read by the previous draw's kernels, already queued on `main`
         ready = torch.cuda.Event()
         ready.record(main)
@@ -220,7 +264,7 @@ class HMCDiag(ManyChainSampler):
             self._randomness(nxt)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._pf_event, self._pf_slot = ev, nxt
+        self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
         return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
 
     # -- one draw for every chain ------------------------------------------------------------------

@@ -21,7 +21,7 @@ class MALA(ManyChainSampler):
                  chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
-        self._init_graph(graph, prefer_streams=prefetch_rng is True)
+        self._init_graph(graph)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_p = torch.empty((D, C), **f64)
@@ -41,10 +41,12 @@ class MALA(ManyChainSampler):
         # are generated on a second HIP stream under draw n's HBM-bound kernels; the proposal
         # then is a pure elementwise kernel.  (At a quarter of a MALA draw the generator only
         # partly hides: DESIGN.md section 3, tools/overlap_probe.py.)
+        # Under hipGraph replay the generation can be a parallel branch of the draw's graph (explicit
+        # prefetch_rng=True; slower than one serial graph, see HMCDiag, so not the default).
         if prefetch_rng is None:
             prefetch_rng = self._batched and not self._use_graph and dev.type == "cuda"
-        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
-        self._pf_slot, self._pf_event = 0, None
+        self._prefetch = bool(prefetch_rng) and self._batched
+        self._pf_slot, self._pf_ready, self._pf_event = 0, False, None
         # Philox streams: the normals come from the wavefront-per-chain generator, chain-major
         # (zt[c, d]); the proposal kernel turns them through LDS.  Otherwise (PCG64 host-seeded
         # single chains, tiny D): one lane per chain, normals in the state layout.
@@ -67,8 +69,9 @@ class MALA(ManyChainSampler):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
 
     def _logical_rng(self):
-        if self._prefetch and self._pf_event is not None:
-            self._pf_event.synchronize()
+        if self._prefetch and self._pf_ready:
+            if self._pf_event is not None:
+                self._pf_event.synchronize()
             return self._rng_logical
         return self._rng_state
 
@@ -78,7 +81,29 @@ class MALA(ManyChainSampler):
         return self._logical_rng().cpu().numpy().view(np.uint64)
 
     def _after_load(self):
-        self._pf_event, self._pf_slot = None, 0
+        self._pf_event, self._pf_slot, self._pf_ready = None, 0, False
+
+    # -- hipGraph replay with the generator as a parallel branch (see HMCDiag) -------------------------
+    def _graph_key(self):
+        return self._pf_slot if self._prefetch else 0
+
+    def _graph_keys(self):
+        return [0, 1] if self._prefetch else [0]
+
+    def _set_graph_key(self, key):
+        if self._prefetch:
+            self._pf_slot = key
+
+    def _before_capture(self):
+        self._pf_event = None
+
+    def _capture_epilogue(self):
+        if self._prefetch:
+            torch.cuda.current_stream().wait_stream(self._side)
+
+    def _after_replay(self):
+        if self._prefetch:
+            self._pf_slot, self._pf_ready, self._pf_event = 1 - self._pf_slot, True, None
 
     def _gen(self, slot):
         if self._chain_major:
@@ -90,11 +115,17 @@ class MALA(ManyChainSampler):
 
     def _take_randomness(self):
         main = torch.cuda.current_stream()
-        if self._pf_event is None:
-            self._gen(self._pf_slot)
-        else:
-            main.wait_event(self._pf_event)
         cur, nxt = self._pf_slot, 1 - self._pf_slot
+        if torch.cuda.is_current_stream_capturing():
+            self._side.wait_stream(main)  # fork; joined in _capture_epilogue()
+            with torch.cuda.stream(self._side):
+                self._rng_logical.copy_(self._rng_state)
+                self._gen(nxt)
+            return self._z_bufs[cur], self._logu_bufs[cur]
+        if not self._pf_ready:
+            self._gen(cur)
+        elif self._pf_event is not None:
+            main.wait_event(self._pf_event)
         ready = torch.cuda.Event()
         ready.record(main)
         self._side.wait_event(ready)
@@ -103,7 +134,7 @@ class MALA(ManyChainSampler):
             self._gen(nxt)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._pf_event, self._pf_slot = ev, nxt
+        self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
         return self._z_bufs[cur], self._logu_bufs[cur]
 
     def accept_rate(self) -> float:

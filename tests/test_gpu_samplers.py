@@ -191,19 +191,29 @@ def test_full_size_cfg4_properties(ops):
     np.testing.assert_array_equal(big.rng_state()[:, 20000:20096], small.rng_state())
 
 
-def test_hipgraph_replay_equals_eager(ops):
-    """graph=True replays one captured draw; results identical to eager launches."""
-    for make in (lambda g: bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=20240, graph=g),
-                 lambda g: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 16)), 0.02, chains=512, seed=3, graph=g),
-                 lambda g: bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(dim=1), 8), 0.2, 6,
-                                      chains=256, seed=4, graph=g)):
-        a, b = make(False), make(True)
-        for _ in range(6):
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_hipgraph_replay_equals_eager(ops, prefetch):
+    """graph=True replays captured draws; results identical to eager launches.  With the RNG
+    prefetch the next draw's generator is a parallel branch inside the graph (two graphs, one per
+    double-buffer slot); without it the draw is one serial graph."""
+    for make in (lambda g, p: bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=20240, graph=g,
+                                         prefetch_rng=p),
+                 lambda g, p: bk.HMCDiag(bk.DiagGaussian(np.logspace(0, 1, 40)), 0.05, 7, chains=700, seed=2,
+                                         graph=g, prefetch_rng=p, fuse_builtin=False),
+                 lambda g, p: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 16)), 0.02, chains=512, seed=3, graph=g,
+                                      prefetch_rng=p),
+                 lambda g, p: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 48)), 0.02, chains=300, seed=5, graph=g,
+                                      prefetch_rng=p),
+                 lambda g, p: bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(dim=1), 8), 0.2, 6,
+                                         chains=256, seed=4, graph=g, prefetch_rng=p)):
+        a, b = make(False, False), make(True, prefetch)
+        for n in range(9):
             ta, la = a.sample()
             tb, lb = b.sample()
-            assert torch.equal(ta, tb) and torch.equal(la, lb)
-        assert b._graph is not None and a._graph is None
-        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+            assert torch.equal(ta, tb) and torch.equal(la, lb), n
+            if n in (0, 3, 8):  # the logical stream position is visible between draws
+                np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        assert len(b._graphs) == (2 if prefetch else 1) and a._graph is None
         assert a.accept_rate() == b.accept_rate()
 
 
@@ -399,9 +409,9 @@ def test_graph_replay_is_automatic_for_small_builtin_problems(ops):
     assert small._use_graph and not small._prefetch
     assert not big._use_graph and big._prefetch
     assert not torchm._use_graph
-    for _ in range(3):
+    for _ in range(2):
         small.sample()
-    assert small._graph is not None
+    assert small._graph is not None  # captured right after the single eager warm-up draw
 
 
 def test_metric_assignment_survives_graph_replay(ops):
