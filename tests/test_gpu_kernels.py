@@ -475,3 +475,110 @@ def test_chain_major_normals_and_transposing_proposal(ops, C, D):
     ops.mala_propose_from_normals(dev(th, ops), dev(gr, ops), z, pb, 0.03, math.sqrt(0.06))
     assert torch.equal(pa, pb)
     assert np.array_equal(pa.cpu().numpy(), (th + 0.03 * gr) + math.sqrt(0.06) * z.cpu().numpy())
+
+
+def test_differential_soak_against_the_cpu_stand_in(ops):
+    """Random shapes, padded leading dimensions (views of wider buffers, as the DRGHMC lane sets and
+    chain tiles use), column offsets that break 16-byte alignment, every gradient layout: each
+    elementwise kernel must agree bit for bit with tests/fake_ops.py (NumPy) on the same inputs."""
+    from tests.fake_ops import FakeOps
+
+    fake = FakeOps()
+    rng = np.random.default_rng(20260101)
+
+    def pair(D, C, pad=None, off=None):
+        """(device view, host view) of equal values and equal strides: [D, C] inside [D, off+C+pad]."""
+        pad = int(rng.choice([0, 0, 1, 3, 64])) if pad is None else pad
+        off = int(rng.choice([0, 0, 1, 2])) if off is None else off
+        base = rng.normal(size=(D, off + C + pad))
+        h = torch.from_numpy(base.copy())
+        d = h.to(ops.device)
+        return d[:, off:off + C], h[:, off:off + C], pad, off
+
+    def same_layout(D, C, pad, off):
+        return pair(D, C, pad, off)[:2]
+
+    def eq(a, b, what):
+        assert np.array_equal(a.cpu().numpy(), b.numpy()), what
+
+    for it in range(400):
+        C, D = int(rng.integers(1, 400)), int(rng.integers(1, 70))
+        th_d, th_h, pad, off = pair(D, C)
+        rho_d, rho_h = same_layout(D, C, pad, off)
+        tho_d, tho_h = same_layout(D, C, pad, off)
+        rhoo_d, rhoo_h = same_layout(D, C, pad, off)
+        metric = rng.random(D) + 0.5 if rng.random() < 0.6 else None
+        m_d = None if metric is None else torch.from_numpy(metric).to(ops.device)
+        m_h = None if metric is None else torch.from_numpy(metric)
+        # gradient in one of three layouts: the state layout, row-major (C, D) seen transposed, odd strides
+        lay = it % 3
+        if lay == 0:
+            g_d, g_h = same_layout(D, C, pad, off)
+        elif lay == 1:
+            gh = torch.from_numpy(rng.normal(size=(C, D)))
+            g_d, g_h = gh.to(ops.device).t(), gh.t()
+        else:
+            gh = torch.from_numpy(rng.normal(size=(D, 2 * C + 1)))
+            g_d, g_h = gh.to(ops.device)[:, ::2][:, :C], gh[:, ::2][:, :C]
+        eps, pre, kick = float(rng.normal()), float(rng.normal()), float(rng.normal())
+        up, uk = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        ops.kick_drift(th_d, tho_d, rho_d, rhoo_d, g_d, m_d, eps, up, pre, uk, kick)
+        fake.kick_drift(th_h, tho_h, rho_h, rhoo_h, g_h, m_h, eps, up, pre, uk, kick)
+        eq(tho_d, tho_h, ("kick_drift theta", it, C, D, pad, off, lay))
+        eq(rhoo_d, rhoo_h, ("kick_drift rho", it, C, D, pad, off, lay))
+
+        # finish: half step (+ negate) and kinetic energy
+        neg = bool(rng.integers(0, 2))
+        kin_d = torch.empty(C, dtype=torch.float64, device=ops.device)
+        kin_h = torch.empty(C, dtype=torch.float64)
+        ops.leapfrog_finish(rho_d, rhoo_d, g_d, m_d, eps, neg, kin_d)
+        fake.leapfrog_finish(rho_h, rhoo_h, g_h, m_h, eps, neg, kin_h)
+        eq(rhoo_d, rhoo_h, ("finish rho", it, C, D, pad, off, lay))
+        np.testing.assert_allclose(kin_d.cpu().numpy(), kin_h.numpy(), rtol=1e-13)
+
+        # gather-first-step over a random lane set into a dense buffer, then scatter some back
+        n = int(rng.integers(1, C + 1))
+        idx = np.sort(rng.choice(C, size=n, replace=False)).astype(np.int32)
+        idx_d, idx_h = torch.from_numpy(idx).to(ops.device), torch.from_numpy(idx)
+        gth_d, gth_h, p2, o2 = pair(D, n)
+        grh_d, grh_h = same_layout(D, n, p2, o2)
+        gs_d, gs_h = same_layout(D, C, pad, off)  # gradient at the source, state layout
+        ops.first_step_gather(th_d, rho_d, gs_d, idx_d, gth_d, grh_d, m_d, eps, pre)
+        fake.first_step_gather(th_h, rho_h, gs_h, idx_h, gth_h, grh_h, m_h, eps, pre)
+        eq(gth_d, gth_h, ("gather theta", it, C, D, n))
+        eq(grh_d, grh_h, ("gather rho", it, C, D, n))
+        acc = (rng.random(n) < 0.5).astype(np.uint8)
+        acc_d, acc_h = torch.from_numpy(acc).to(ops.device), torch.from_numpy(acc)
+        sd_d, sd_h = torch.zeros(C, dtype=torch.float64, device=ops.device), torch.zeros(C, dtype=torch.float64)
+        ss = torch.from_numpy(rng.normal(size=n))
+        ops.scatter_columns(acc_d, idx_d, n, [tho_d, rhoo_d], [gth_d, grh_d], sd_d, ss.to(ops.device))
+        fake.scatter_columns(acc_h, idx_h, n, [tho_h, rhoo_h], [gth_h, grh_h], sd_h, ss)
+        eq(tho_d, tho_h, ("scatter theta", it))
+        eq(rhoo_d, rhoo_h, ("scatter rho", it))
+        eq(sd_d, sd_h, ("scatter scalar", it))
+
+        # masked select with the fused output copy
+        mask = (rng.random(C) < rng.random()).astype(np.uint8)
+        mk_d, mk_h = torch.from_numpy(mask).to(ops.device), torch.from_numpy(mask)
+        out_d, out_h = same_layout(D, C, pad, off)
+        two = bool(rng.integers(0, 2))
+        ops.select_columns(mk_d, th_d, tho_d, rho_d if two else None, rhoo_d if two else None, out_d)
+        fake.select_columns(mk_h, th_h, tho_h, rho_h if two else None, rhoo_h if two else None, out_h)
+        eq(th_d, th_h, ("select dst0", it, C, D, pad, off))
+        eq(rho_d, rho_h, ("select dst1", it))
+        eq(out_d, out_h, ("select copy", it))
+
+        # MALA proposal from normals in either layout; relayout; column gather
+        zt = torch.from_numpy(rng.normal(size=(C, D + int(rng.integers(0, 5)))))
+        z_d, z_h = (zt.to(ops.device)[:, :D].t(), zt[:, :D].t()) if it % 2 else same_layout(D, C, pad, off)
+        ops.mala_propose_from_normals(th_d, gs_d, z_d, tho_d, 0.03, 0.2)
+        fake.mala_propose_from_normals(th_h, gs_h, z_h, tho_h, 0.03, 0.2)
+        eq(tho_d, tho_h, ("mala propose", it, C, D, pad, off))
+        ops.relayout(g_d, rhoo_d)
+        fake.relayout(g_h, rhoo_h)
+        eq(rhoo_d, rhoo_h, ("relayout", it, lay))
+        dst_d = torch.empty((D, n), dtype=torch.float64, device=ops.device)
+        dst_h = torch.empty((D, n), dtype=torch.float64)
+        ops.gather_columns(idx_d, th_d, dst_d)
+        fake.gather_columns(idx_h, th_h, dst_h)
+        eq(dst_d, dst_h, ("gather_columns", it))
