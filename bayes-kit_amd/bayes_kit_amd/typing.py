@@ -49,3 +49,32 @@ class LogPriorLikelihoodModel(LogDensityModel, Protocol):
     def log_prior(self, params_unc): ...
 
     def log_likelihood(self, params_unc): ...
+
+
+# ---- the batched device form (what the many-chain engine calls) ---------------------------------
+@runtime_checkable
+class BatchedLogDensityModel(Protocol):
+    """``batched = True`` marks a model that scores all chains in one call."""
+
+    batched: bool
+
+    def dims(self) -> int: ...
+
+    def log_density(self, Theta):
+        """(C, D) float64 device tensor (strides (1, ld)) -> (C,) log densities."""
+        ...
+
+
+@runtime_checkable
+class BatchedGradModel(BatchedLogDensityModel, Protocol):
+    def log_density_gradient(self, Theta):
+        """-> ((C,) log densities, (C, D) gradients in any strides)."""
+        ...
+
+
+@runtime_checkable
+class EngineTarget(Protocol):
+    """Fast path of the library's own targets and of ``CTarget`` plugins: results written in place
+    into the engine's [D, n] chain-contiguous buffers (either output may be None)."""
+
+    def bk_eval(self, theta_dc, grad_out, logp_out) -> None: ...
