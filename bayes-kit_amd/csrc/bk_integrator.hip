@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_mh_accept(int mode, double* lp_cur, con
 }
 
 // ---- masked column copy -----------------------------------------------------------------
-constexpr int SEL_ROWS = 8;
+constexpr int SEL_ROWS = 2;
 // copy0 (optional): the selected array as it stands after the select, for every chain -- the
 // stable array sample() hands back -- written in the same pass instead of by a second copy.
 __global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst0, const double* src0,
@@ -298,7 +298,11 @@ __global__ __launch_bounds__(256) void k_select(const uint8_t* mask, double* dst
     }
 }
 
-// two chains (16 B) per lane; a pair is copied only where needed (per-chain mask kept exact)
+// Two chains (16 B) per lane, written as a BLEND: every lane pair re-writes its 16 bytes, rejected
+// chains with their own old values.  Skipping the rejected chains instead (masked or 8-byte stores)
+// leaves holes inside HBM sectors, and each holed sector costs a read-modify-write in the memory
+// system: measured 881 -> 623 us for two array pairs + output copy at 65,536 x 1024, accept 0.8
+// (tools/select_bench.py); the blend runs at the streaming rate (6.0 TB/s) at any accept rate.
 template <bool COPY>
 __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* dst0, const double* src0,
                                                    double* dst1, const double* src1, double* copy0, i64 ld,
@@ -308,7 +312,6 @@ __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* 
   if (c2 >= C2) return;
   const bool m0 = mask[2 * c2] != 0, m1 = mask[2 * c2 + 1] != 0;
   const bool any = m0 || m1, both = m0 && m1;
-  if (!any && !COPY) return;
   dvec2 a[SEL_ROWS], b[SEL_ROWS];
 #pragma unroll
   for (int i = 0; i < SEL_ROWS; ++i)
@@ -318,36 +321,25 @@ __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* 
         a[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src0 + o));
         if (dst1) b[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(src1 + o));
       }
-      if (COPY && !both) {
+      if (!both) {
         dvec2 old = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(dst0 + o));
         if (!m0) a[i].x = old.x;
         if (!m1) a[i].y = old.y;
+        if (dst1) {
+          old = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(dst1 + o));
+          if (!m0) b[i].x = old.x;
+          if (!m1) b[i].y = old.y;
+        }
       }
     }
-  if (both) {
 #pragma unroll
-    for (int i = 0; i < SEL_ROWS; ++i)
-      if (d0 + i < D) {
-        const i64 o = (d0 + i) * ld + 2 * c2;
-        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(dst0 + o));
-        if (dst1) __builtin_nontemporal_store(b[i], reinterpret_cast<dvec2*>(dst1 + o));
-      }
-  } else if (any) {
-    const int k = m0 ? 0 : 1;
-#pragma unroll
-    for (int i = 0; i < SEL_ROWS; ++i)
-      if (d0 + i < D) {
-        const i64 o = (d0 + i) * ld + 2 * c2 + k;
-        dst0[o] = m0 ? a[i].x : a[i].y;
-        if (dst1) dst1[o] = m0 ? b[i].x : b[i].y;
-      }
-  }
-  if (COPY) {
-#pragma unroll
-    for (int i = 0; i < SEL_ROWS; ++i)
-      if (d0 + i < D)
-        __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(copy0 + (d0 + i) * ld + 2 * c2));
-  }
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) {
+      const i64 o = (d0 + i) * ld + 2 * c2;
+      __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(dst0 + o));
+      if (dst1) __builtin_nontemporal_store(b[i], reinterpret_cast<dvec2*>(dst1 + o));
+      if (COPY) __builtin_nontemporal_store(a[i], reinterpret_cast<dvec2*>(copy0 + o));
+    }
 }
 
 // ---- MALA proposal log densities --------------------------------------------------------

@@ -148,10 +148,12 @@ int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp
 
 /* dst[d*ld + c] = mask[c] ? src[d*ld + c] : dst[d*ld + c] for up to two array pairs
  * (pair 1 may be NULL): `self._theta = theta_prop` (hmc.py:61, mala.py:62-64,
- * drghmc.py:379) applied to the accepted chains only.  Rejected chains are neither read
- * nor written -- unless `copy0` (may be NULL) is given: then copy0 additionally receives
- * array 0 as it stands after the select, for every chain (the stable array that sample()
- * returns while the sampler keeps mutating its own; same leading dimension). */
+ * drghmc.py:379) applied to the accepted chains only.  Rejected chains keep their values; on
+ * the 16-byte path (even C and ld, aligned pointers) they are re-written with them, so that no
+ * partially written HBM sector results (a blend streams at full rate, holes do not).
+ * `copy0` (may be NULL) additionally receives array 0 as it stands after the select, for every
+ * chain (the stable array that sample() returns while the sampler keeps mutating its own; same
+ * leading dimension). */
 int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
                       double* dst1, const double* src1, double* copy0, int64_t ld,
                       int64_t C, int64_t D, void* stream);
