@@ -71,29 +71,41 @@ def cpu_baseline(seconds_hint=12.0):
     P = max(1, min(os.cpu_count() or 1, 32))
     chains_per_proc, draws = 8, 400  # 8*400*64 = 205k leapfrog steps per process (~1.5 s each)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
-    t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline", str(p * chains_per_proc),
-                               str(chains_per_proc), str(draws), str(D_CFG3), str(L_CFG3), str(EPS_CFG3),
-                               str(SEED_CFG3)], cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
-             for p in range(P)]
-    res = []
-    for pr in procs:
-        out, _ = pr.communicate(timeout=600)
-        if pr.returncode != 0:
-            raise RuntimeError("cpu baseline worker failed")
-        r = json.loads(out.strip().splitlines()[-1])
-        res.append((r["steps"], r["seconds"]))
-    wall = time.perf_counter() - t0
-    busy = max(r[1] for r in res)  # slowest worker's compute time (excludes process start-up)
-    steps = sum(r[0] for r in res)
-    return {
-        "value": steps / busy,
+
+    def fan_out(argv_of):
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_baseline"] + [str(a) for a in argv_of(p)],
+                                  cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True) for p in range(P)]
+        res = []
+        for pr in procs:
+            out, _ = pr.communicate(timeout=600)
+            if pr.returncode != 0:
+                raise RuntimeError("cpu baseline worker failed")
+            r = json.loads(out.strip().splitlines()[-1])
+            res.append((r["steps"], r["seconds"]))
+        wall = time.perf_counter() - t0
+        busy = max(r[1] for r in res)  # slowest worker's compute time (excludes process start-up)
+        return sum(r[0] for r in res) / busy, wall
+
+    rate, wall = fan_out(lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
+    out = {
+        "value": rate,
         "unit": "leapfrog steps/sec",
         "cores": P,
         "kind": "port",
         "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
                   f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s",
     }
+    try:
+        # context only: the same arithmetic hand-vectorised over [D, C] arrays (not how the reference runs)
+        bc, bd = 512, 6
+        brate, bwall = fan_out(lambda p: ["batched", bc, bd, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3 + 1 + p])
+        out["batched_numpy"] = {"value": brate, "unit": "leapfrog steps/sec", "cores": P,
+                                "sample": f"{P} procs x {bc} chains x {bd} draws, [D, C] arrays, in-place ufuncs; "
+                                          f"wall incl. spawn {bwall:.1f}s"}
+    except Exception as e:  # the context figure must not cost the baseline
+        out["batched_numpy"] = {"error": repr(e)}
+    return out
 
 
 def _device_index(local_rank):
