@@ -34,7 +34,8 @@ SEED_CFG3 = 20241
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
-def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False):
+def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False,
+                      prefetch_rng=None):
     """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
     import torch
 
@@ -43,7 +44,8 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     lam = torch.logspace(0, 4, D, dtype=torch.float64)
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
-                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused)
+                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused,
+                   prefetch_rng=prefetch_rng)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
     s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(device)[:, None])
@@ -212,6 +214,8 @@ def main():
     ap.add_argument("--chain-tile", type=int, default=None,
                     help="chains per Infinity-Cache tile (default: no tiling)")
     ap.add_argument("--no-graph", action="store_true", help="config 2: eager launches instead of hipGraph replay")
+    ap.add_argument("--no-rng-prefetch", action="store_true",
+                    help="generate each draw's randomness in line instead of on the side stream (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true")
@@ -249,7 +253,8 @@ def main():
 
     C = args.chains
     D, L = D_CFG3, L_CFG3
-    s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile)
+    s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile,
+                          prefetch_rng=False if args.no_rng_prefetch else None)
     Ct = s._chain_tile
     ops = s._ops
 
