@@ -78,3 +78,48 @@ def test_example_plugin_target_loads_and_exports_its_entry_point():
     lib.ar1_target.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                        ctypes.c_int64, ctypes.c_void_p]
     assert lib.ar1_target(None, None, None, 0, None, 1, 1, None) == -1
+
+
+def test_error_behaviour_of_the_c_abi_without_a_gpu():
+    """Status codes of include/bkhip.h: NULL / bad extents -> BK_E_ARG (-1), ld < C -> BK_E_ALIGN (-2),
+    empty problems (C == 0) -> BK_OK with nothing launched.  All three are decided before any HIP
+    call, so they can be checked on a machine without a GPU (dummy non-NULL pointers are never read)."""
+    import ctypes
+
+    from bayes_kit_amd import _lib
+
+    lib = _lib.load()
+    buf = (ctypes.c_double * 64)()
+    p = ctypes.addressof(buf)
+    OK, E_ARG, E_ALIGN = 0, -1, -2
+    # empty problems
+    assert lib.bk_momentum_refresh(0, p, 0, None, 0.0, 1.0, p, 0, None, None, None, 0, 8, None, 0, None) == OK
+    assert lib.bk_log_uniform(0, p, 0, p, None, 0, None) == OK
+    assert lib.bk_leapfrog_kick_drift(p, p, p, p, 0, p, 0, 1, None, 0.1, 0, 0.0, 1, 0.1, 0, 8, None) == OK
+    assert lib.bk_leapfrog_kick_drift(p, p, p, p, 4, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, 4, 0, None) == OK  # D = 0
+    assert lib.bk_leapfrog_finish(p, None, 0, p, 0, 1, None, 0.1, 0, p, 0, 8, None) == OK
+    assert lib.bk_mh_accept(0, p, p, p, p, p, p, p, None, 0, None) == OK
+    assert lib.bk_select_columns(p, p, p, None, None, None, 0, 0, 8, None) == OK
+    assert lib.bk_mala_logq(p, p, p, p, 0, 0.1, p, p, 0, 8, None) == OK
+    assert lib.bk_target_diag_gaussian_grad(p, p, None, 0, p, 0, 8, None) == OK
+    assert lib.bk_welford_update(p, p, p, 0, 1, 0, 8, None) == OK
+    assert lib.bk_ess(p, 0, 8, 0, p, None, 0, None) == OK
+    assert lib.bk_end_pos_pairs(p, 0, 0, p, 0, None) == OK
+    # argument errors
+    assert lib.bk_momentum_refresh(0, None, 4, None, 0.0, 1.0, p, 4, None, None, None, 4, 8, None, 0, None) == E_ARG
+    assert lib.bk_momentum_refresh(7, p, 4, None, 0.0, 1.0, p, 4, None, None, None, 4, 8, None, 0, None) == E_ARG  # rng kind
+    assert lib.bk_leapfrog_kick_drift(None, p, p, p, 4, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, 4, 8, None) == E_ARG
+    assert lib.bk_leapfrog_kick_drift(p, p, p, p, 4, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, -1, 8, None) == E_ARG
+    assert lib.bk_mh_accept(5, p, p, p, p, p, p, p, None, 4, None) == E_ARG      # unknown accept mode
+    assert lib.bk_select_columns(p, p, p, p, None, None, 4, 4, 8, None) == E_ARG  # dst1 without src1
+    assert lib.bk_target_diag_gaussian_grad(p, p, None, 4, None, 4, 8, None) == E_ARG  # lam required
+    assert lib.bk_ess(p, 4, 3, 0, p, None, 4, None) == E_ARG                     # N < 4 (ess.py:67-68)
+    assert lib.bk_autocorr(p, 4, 1, p, 4, 4, None) == E_ARG                      # N < 2 (autocorr.py:23-24)
+    assert lib.bk_normals_chain_major(1, p, 4, p, 8, 4, 8, None) == E_ARG        # Philox streams only
+    assert lib.bk_normals_chain_major(0, p, 4, p, 7, 4, 8, None) == E_ARG        # ldz < D
+    # layout errors
+    assert lib.bk_leapfrog_kick_drift(p, p, p, p, 3, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, 4, 8, None) == E_ALIGN
+    assert lib.bk_select_columns(p, p, p, None, None, None, 3, 4, 8, None) == E_ALIGN
+    assert lib.bk_mala_logq(p, p, p, p, 3, 0.1, p, p, 4, 8, None) == E_ALIGN
+    assert lib.bk_mala_propose_from_normals(p, p, p, 5, 3, p, 4, 0.1, 0.2, 4, 8, None) == E_ALIGN  # z strides
+    assert lib.bk_refresh_work_elems(5, 33) == 5 * 40
