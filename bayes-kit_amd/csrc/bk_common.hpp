@@ -24,3 +24,8 @@ static inline bool bk_aligned16(const void* p) { return (reinterpret_cast<uintpt
 // Whether a kernel touching `elems` doubles streams well past the 256 MiB Infinity Cache
 // (then non-temporal accesses pay) or can be served from it (then they hurt).
 static inline bool bk_streams_past_llc(i64 elems) { return elems * 8 > ((i64)192 << 20); }
+
+// Index of the calling wavefront inside its workgroup AS A SCALAR: threadIdx.x / 64 is the same for
+// all 64 lanes, but the compiler only knows that if told -- otherwise every loop bound, row guard and
+// address derived from it is per-lane vector work (selects, 64-bit VGPR address math).
+__device__ __forceinline__ int bk_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)); }

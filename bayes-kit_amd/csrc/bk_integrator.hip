@@ -206,7 +206,7 @@ __global__ __launch_bounds__(RED_BLOCK) void k_finish(const double* rho_in, doub
                                                       double* kin_out, i64 C, i64 D) {
   __shared__ double part[RED_WAVES][BK_WAVE];
   constexpr int PC_UNROLL = FIN_UNROLL;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
   const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
   const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(RED_BLOCK) void k_mala_logq(const double* th, const
                                                          i64 D) {
   __shared__ double part_f[RED_WAVES][BK_WAVE];
   __shared__ double part_r[RED_WAVES][BK_WAVE];
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
   const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
   const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp(const double* th, doub
                                                           const double* lam, i64 C, i64 D) {
   __shared__ double part[RED_WAVES][BK_WAVE];
   constexpr int PC_UNROLL = 8;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
   const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
   const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
@@ -160,7 +160,7 @@ __device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, 
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
                                                           i64 n, i64 D) {
   __shared__ FunnelLds lds;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
   double x[FN_ROWS];
@@ -198,22 +198,26 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
 // launch: gather chain idx[j] of the source point, first half-kick with the source's cached
 // gradient + drift, (steps-1) x {gradient, kick, drift}, final gradient + log density,
 // last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers.
+// ROWS = rows of x per wavefront kept in registers (>= ceil((D-1)/4)); HM = a metric is given.  Both
+// compile-time: with the generic 32 rows and a run-time metric flag the kernel needed 330 registers
+// (one wavefront per SIMD, AGPR spills); sized to the problem it fits three.
+template <int ROWS, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n, i64 D) {
   __shared__ FunnelLds lds;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
   const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
   const double half = 0.5 * h;
   const double hn = 0.5 * (double)(D - 1);
-  const bool hm = metric != nullptr;
-  double x[FN_ROWS], r[FN_ROWS];
+  constexpr bool hm = HM;
+  double x[ROWS], r[ROWS];
   // gather + first half-kick + drift (drghmc.py:276-278)
 #pragma unroll
-  for (int i = 0; i < FN_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     i64 d = 1 + w + (i64)FN_WAVES * i;
     bool ok = on && d < D;
     x[i] = ok ? th_in[d * ld_in + src] : 0.0;
@@ -223,6 +227,9 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     double t = hm ? mi * g0 : g0;
     r[i] = r[i] + half * t;
     x[i] = x[i] + h * r[i];
+    // the gather is issued in batches of 8 rows: all 3*ROWS loads in flight at once would set the
+    // kernel's register count (and so its occupancy for the whole trajectory)
+    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
   double v = on ? th_in[src] : 0.0, rv = on ? rho_in[src] : 0.0;
   const double mv = hm ? metric[0] : 1.0;
@@ -233,39 +240,66 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     v = v + h * rv;
   }
   int buf = 0;
-  double ev = 0.0, he = 0.0, s = 0.0;
-  for (int step = 0; step < steps; ++step) {
-    // gradient at the current theta (drghmc.py:281 / :285)
+  // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283); the sum x.x of a chain is formed by its
+  // 4 wavefronts: each adds its rows in order, the 4 partials are combined through LDS in wave order
+  for (int step = 0; step + 1 < steps; ++step) {
     double p = 0.0;
 #pragma unroll
-    for (int i = 0; i < FN_ROWS; ++i) {
+    for (int i = 0; i < ROWS; ++i) {
       i64 d = 1 + w + (i64)FN_WAVES * i;
       if (d < D) p = p + x[i] * x[i];
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
-    s = funnel_reduce(lds, buf, w, lane, p);
+    const double s = funnel_reduce(lds, buf, w, lane, p);
     buf ^= 1;
-    ev = exp(-v);
-    he = 0.5 * ev;
-    double gv = ((-v / 9.0) - hn) + he * s;
-    const bool last = step == steps - 1;
-    const double kick = last ? half : h;  // drghmc.py:286 vs :282
+    const double ev = exp(-v);
+    const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
     {
       double t = hm ? mv * gv : gv;
-      rv = rv + kick * t;
-      if (!last) v = v + h * rv;  // drghmc.py:283
+      rv = rv + h * t;
+      v = v + h * rv;
     }
 #pragma unroll
-    for (int i = 0; i < FN_ROWS; ++i) {
+    for (int i = 0; i < ROWS; ++i) {
       i64 d = 1 + w + (i64)FN_WAVES * i;
       if (d < D) {
         double gi = -(ev * x[i]);
         double t = hm ? metric[d] * gi : gi;
-        r[i] = r[i] + kick * t;
-        if (!last) x[i] = x[i] + h * r[i];
-        else if (on) g_out[d * ld_out + j] = gi;
+        r[i] = r[i] + h * t;
+        x[i] = x[i] + h * r[i];
+      }
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
+    }
+  }
+  // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
+  {
+    double p = 0.0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      i64 d = 1 + w + (i64)FN_WAVES * i;
+      if (d < D) p = p + x[i] * x[i];
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const double s = funnel_reduce(lds, buf, w, lane, p);
+    buf ^= 1;
+    const double ev = exp(-v);
+    const double he = 0.5 * ev;
+    const double gv = ((-v / 9.0) - hn) + he * s;
+    {
+      double t = hm ? mv * gv : gv;
+      rv = rv + half * t;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      i64 d = 1 + w + (i64)FN_WAVES * i;
+      if (d < D) {
+        double gi = -(ev * x[i]);
+        double t = hm ? metric[d] * gi : gi;
+        r[i] = r[i] + half * t;
+        if (on) g_out[d * ld_out + j] = gi;
       }
     }
-    if (last && on && w == 0) {
+    if (on && w == 0) {
       g_out[j] = gv;
       logp_out[j] = ((-(v * v) / 18.0) - hn * v) - he * s;
     }
@@ -273,7 +307,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250), outputs
   double kp = 0.0;
 #pragma unroll
-  for (int i = 0; i < FN_ROWS; ++i) {
+  for (int i = 0; i < ROWS; ++i) {
     i64 d = 1 + w + (i64)FN_WAVES * i;
     if (d < D) {
       double rr = -r[i];
@@ -487,9 +521,26 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
   if (D - 1 > FN_WAVES * FN_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (ld_out < n) return BK_E_ALIGN;
   if (n == 0) return BK_OK;
-  k_funnel_traj<<<dim3((unsigned)bk_cdiv(n, BK_WAVE)), dim3(FN_BLOCK), 0, bk_stream(stream)>>>(
-      theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out, ld_out, metric,
-      h, (int)steps, n, D);
+  const int need = (int)((D - 1 + FN_WAVES - 1) / FN_WAVES);
+  dim3 grid((unsigned)bk_cdiv(n, BK_WAVE));
+  hipStream_t s = bk_stream(stream);
+#define BK_FT(R, M)                                                                                             \
+  k_funnel_traj<R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,    \
+                                                      rho_out, grad_out, logp_out, kin_out, ld_out, metric, h,  \
+                                                      (int)steps, n, D)
+#define BK_FT_ROWS(R)    \
+  do {                   \
+    if (metric)          \
+      BK_FT(R, true);    \
+    else                 \
+      BK_FT(R, false);   \
+  } while (0)
+  if (need <= 8) BK_FT_ROWS(8);
+  else if (need <= 16) BK_FT_ROWS(16);
+  else if (need <= 25) BK_FT_ROWS(25);
+  else BK_FT_ROWS(32);
+#undef BK_FT_ROWS
+#undef BK_FT
   BK_RETURN_LAUNCH_STATUS();
 }
 
