@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
     if (cb_i >= chain_blocks) return;
   }
   const i64 r0 = (i64)rb_i * BM, c0 = (i64)cb_i * BN;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = bk_wave_id();
   const int wr = (w >> 1) * 64, wc = (w & 1) * 64;  // wavefront's 64 x 64 corner inside the tile
   const int l15 = lane & 15, l4 = lane >> 4;
 

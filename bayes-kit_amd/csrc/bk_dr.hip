@@ -15,7 +15,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n
                                                       uint32_t* count) {
   __shared__ uint32_t wave_cnt[CP_BLOCK / BK_WAVE];
   __shared__ uint32_t base;
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
   const bool aligned = (reinterpret_cast<uintptr_t>(mask) & 7u) == 0;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_kick_drift_tr(
     int use_kick, double kick, i64 C, i64 D) {
   __shared__ double tile[TR_TILE][TR_TILE + 1];
   i64 c0 = (i64)blockIdx.x * TR_TILE, d0 = (i64)blockIdx.y * TR_TILE;
-  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int tx = threadIdx.x & 63, ty = bk_wave_id();
 #pragma unroll 4
   for (int i = 0; i < TR_TILE / 4; ++i) {
     int cl = ty + 4 * i;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_relayout(const double* src, i64 s_d, i6
                                                   i64 t_d, i64 t_c, i64 C, i64 D) {
   __shared__ double tile[TR_TILE][TR_TILE + 1];
   i64 c0 = (i64)blockIdx.x * TR_TILE, d0 = (i64)blockIdx.y * TR_TILE;
-  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int tx = threadIdx.x & 63, ty = bk_wave_id();
   // read with the lane index along whichever source axis is contiguous
   bool src_d_fast = (s_d == 1);
 #pragma unroll 4

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
   __shared__ ZigLds tab;
   load_tables(tab);
   const int lane = threadIdx.x & (BK_WAVE - 1);
-  const i64 c = (i64)blockIdx.x * ZP_WAVES + (threadIdx.x / BK_WAVE);
+  const i64 c = (i64)blockIdx.x * ZP_WAVES + bk_wave_id();
   if (c >= C) return;  // whole wavefront
   bk::Philox ph;
   ph.key0 = st[0 * ldr + c];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_refresh_apply(const double* zt, i64 ldz
                                                        i64 D) {
   __shared__ double tile[64][65];
   i64 c0 = (i64)blockIdx.x * 64, d0 = (i64)blockIdx.y * 64;
-  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int tx = threadIdx.x & 63, ty = bk_wave_id();
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     int cl = ty + 4 * i;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_mala_propose_zt(const double* th, const
                                                          i64 C, i64 D) {
   __shared__ double tile[64][65];
   i64 c0 = (i64)blockIdx.x * 64, d0 = (i64)blockIdx.y * 64;
-  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int tx = threadIdx.x & 63, ty = bk_wave_id();
 #pragma unroll 4
   for (int i = 0; i < 16; ++i) {
     int cl = ty + 4 * i;

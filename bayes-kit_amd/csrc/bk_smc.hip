@@ -12,7 +12,7 @@ constexpr int SCAN_BLOCK = 1024;
 __global__ __launch_bounds__(SCAN_BLOCK) void k_cumsum(const double* w, double* cdf, i64 n) {
   __shared__ double wave_tot[SCAN_BLOCK / BK_WAVE];
   __shared__ double carry;
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = threadIdx.x / BK_WAVE;
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
   if (threadIdx.x == 0) carry = 0.0;
   __syncthreads();
   for (i64 start = 0; start < n; start += SCAN_BLOCK) {
