@@ -199,7 +199,10 @@ class DrGhmcDiag(ManyChainSampler):
         P = self._levels[lvl]
         ops.dr_level_begin(P.logp, P.kin, P.H, P.h, P.live, n)
         for i in range(k):
-            m, sub = self._compact(P.live, n, lvl + 1)
+            if i == 0:
+                m, sub = n, None  # dr_level_begin just set every lane live: no compaction, no host read
+            else:
+                m, sub = self._compact(P.live, n, lvl + 1)
             if m == 0:
                 break
             gtag = "G%d(%s)" % (i, tag)
