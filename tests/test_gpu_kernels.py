@@ -582,3 +582,26 @@ def test_differential_soak_against_the_cpu_stand_in(ops):
         ops.gather_columns(idx_d, th_d, dst_d)
         fake.gather_columns(idx_h, th_h, dst_h)
         eq(dst_d, dst_h, ("gather_columns", it))
+
+
+def test_accept_with_non_finite_log_densities(ops):
+    """IEEE semantics of `log(u) < ratio` (hmc.py:60, metropolis.py:70-76): NaN ratios reject,
+    +inf accepts, -inf rejects, inf - inf = NaN rejects -- as NumPy evaluates the same expressions."""
+    from bayes_kit_amd import _lib
+
+    inf, nan = np.inf, np.nan
+    lp0 = np.array([0.0, 0.0, 0.0, -inf, inf, nan, 0.0, -inf, 1.0])
+    lp1 = np.array([nan, inf, -inf, -inf, inf, 0.0, 0.5, 0.0, 1.0])
+    a0 = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, nan, 0.0, inf])
+    a1 = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, inf])
+    logu = np.full(9, -0.3)
+    for mode in (_lib.ACCEPT_HMC, _lib.ACCEPT_MALA):
+        with np.errstate(invalid="ignore"):
+            if mode == _lib.ACCEPT_HMC:
+                want = logu < (lp1 - a1) - (lp0 - a0)
+            else:
+                want = logu < (lp1 - lp0) + (a1 - a0)
+        mask = torch.empty(9, dtype=torch.uint8, device=ops.device)
+        cur = dev(lp0.copy(), ops)
+        ops.mh_accept(mode, cur, dev(a0, ops), dev(lp1, ops), dev(a1, ops), dev(logu, ops), mask, None, None)
+        assert mask.cpu().numpy().astype(bool).tolist() == want.tolist(), mode
