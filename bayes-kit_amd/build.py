@@ -80,6 +80,27 @@ def build_example_plugin(force=False, verbose=True):
     return lib
 
 
+C_HOST_SRC = os.path.join(HERE, "..", "examples", "c_host", "hmc_main.c")
+C_HOST_BIN = os.path.join(HERE, "..", "examples", "c_host", "hmc_main")
+
+
+def build_c_host_example(force=False, verbose=True):
+    """examples/c_host/hmc_main.c: a many-chain HMC loop in plain C (gcc) on the C ABI alone."""
+    src, exe = os.path.abspath(C_HOST_SRC), os.path.abspath(C_HOST_BIN)
+    if force or _stale(exe, [src, LIB, os.path.join(HERE, "..", "include", "bkhip.h")]):
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        cmd = ["gcc", "-std=gnu11", "-O2", "-D__HIP_PLATFORM_AMD__", src, "-I" + os.path.join(rocm, "include"),
+               "-I" + os.path.abspath(os.path.join(HERE, "..", "include")), "-L" + OUT_DIR, "-lbkhip",
+               "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+               "-Wl,-rpath,$ORIGIN/../../bayes-kit_amd/bayes_kit_amd/lib", "-Wl,-rpath," + os.path.join(rocm, "lib"),
+               "-o", exe]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_example_plugin(force="--force" in sys.argv))
+    print(build_c_host_example(force="--force" in sys.argv))

@@ -18,7 +18,8 @@ def pytest_sessionstart(session):
     # (hipcc cross-compiles without a GPU).  A failed build surfaces in the tests that load it.
     lib = os.path.join(ROOT, "bayes-kit_amd", "bayes_kit_amd", "lib", "libbkhip.so")
     plugin = os.path.join(ROOT, "examples", "plugin_target", "libar1_target.so")
-    if not (os.path.exists(lib) and os.path.exists(plugin)):
+    c_host = os.path.join(ROOT, "examples", "c_host", "hmc_main")
+    if not (os.path.exists(lib) and os.path.exists(plugin) and os.path.exists(c_host)):
         try:
             import __graft_entry__ as ge
 

@@ -567,3 +567,29 @@ def test_randomised_sampler_configurations_against_the_oracle(ops):
     for it in range(120):
         seen.add(str(mod.one(rng, it)))
     assert seen == {"hmc", "mala", "drghmc", "metropolis"}
+
+
+def test_plain_c_host_program_equals_the_python_driver(ops):
+    """examples/c_host/hmc_main.c drives a whole many-chain HMC run through the C ABI alone (gcc, no
+    Python, no torch).  Its final state must be bit-identical to bayes_kit_amd.HMCDiag issuing the same
+    calls through ctypes, and so (via the other tests) to the reference."""
+    import os
+    import subprocess
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    C, D, L, draws, seed = 130, 40, 5, 6, 77
+    out = subprocess.run([os.path.join(root, "examples", "c_host", "hmc_main"), str(C), str(D), str(L), str(draws),
+                          str(seed)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    accept = float(lines[0].split()[-1])
+    cols = {int(ln.split("]")[0].split("[")[1]): np.array([int(w, 16) for w in ln.split()[1:]], dtype=np.uint64)
+            for ln in lines[1:]}
+    s = bk.HMCDiag(bk.DiagGaussian(np.linspace(1.0, 2.0, D)), 0.05, L, chains=C, seed=seed, fuse_builtin=False,
+                   prefetch_rng=False, graph=False)
+    for _ in range(draws):
+        th, _ = s.sample()
+    th = th.cpu().numpy()
+    for c, words in cols.items():
+        assert np.array_equal(th[c].view(np.uint64), words), c
+    assert abs(accept - s.accept_rate()) < 1e-6
