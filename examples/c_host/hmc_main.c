@@ -28,10 +28,19 @@
     }                                                                           \
   } while (0)
 
+static size_t g_stagger = 0, g_nalloc = 0; /* BK_STAGGER: byte offset added per allocation (layout experiment) */
+static char* g_slab = NULL; /* BK_SLAB: carve every array out of ONE allocation (layout experiment) */
+static size_t g_slab_used = 0;
 static double* dalloc(size_t n) {
-  void* p = NULL;
-  CK(hipMalloc(&p, n * sizeof(double)));
-  return (double*)p;
+  char* p = NULL;
+  size_t bytes = n * sizeof(double) + 64 * g_stagger;
+  if (g_slab) {
+    p = g_slab + g_slab_used;
+    g_slab_used += (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  } else {
+    CK(hipMalloc((void**)&p, bytes));
+  }
+  return (double*)(p + (g_nalloc++) * g_stagger);
 }
 
 int main(int argc, char** argv) {
@@ -39,6 +48,9 @@ int main(int argc, char** argv) {
   const int64_t L = argc > 3 ? atoll(argv[3]) : 8, draws = argc > 4 ? atoll(argv[4]) : 10;
   const uint64_t seed = argc > 5 ? strtoull(argv[5], NULL, 10) : 2024;
   const double eps = 0.05, half = 0.5 * eps;
+  const int64_t ld = C + (getenv("BK_PAD") ? atoll(getenv("BK_PAD")) : 0); /* leading dimension (row pitch) */
+  g_stagger = getenv("BK_STAGGER") ? (size_t)atoll(getenv("BK_STAGGER")) : 0;
+  if (getenv("BK_SLAB")) CK(hipMalloc((void**)&g_slab, (size_t)(7 * D * ld + 16 * C + D) * sizeof(double) + ((size_t)64 << 20) + 20 * 65 * g_stagger));
   hipStream_t s;
   CK(hipStreamCreate(&s));
 
@@ -47,8 +59,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc((void**)&rng, BK_RNG_WORDS * C * sizeof(uint64_t)));
   CK(bk_rng_init_philox(rng, C, seed, 0, C, s));
 
-  double *theta = dalloc(D * C), *theta_p = dalloc(D * C), *rho = dalloc(D * C), *grad = dalloc(D * C),
-         *grad_p = dalloc(D * C), *lam = dalloc(D), *work = dalloc(bk_refresh_work_elems(C, D));
+  double *theta = dalloc(D * ld), *theta_p = dalloc(D * ld), *rho = dalloc(D * ld), *grad = dalloc(D * ld),
+         *grad_p = dalloc(D * ld), *lam = dalloc(D), *work = dalloc(bk_refresh_work_elems(C, D));
   double *lp = dalloc(C), *lp_p = dalloc(C), *kin0 = dalloc(C), *kin1 = dalloc(C), *logu = dalloc(C), *ret = dalloc(C);
   uint8_t* mask = NULL;
   uint32_t* accepted = NULL;
@@ -60,33 +72,44 @@ int main(int argc, char** argv) {
   CK(hipMemcpyAsync(lam, lam_h, D * sizeof(double), hipMemcpyHostToDevice, s));
 
   /* theta0 = rng.normal(size=D) from each chain's own stream (hmc.py:24-28) */
-  CK(bk_momentum_refresh(BK_RNG_PHILOX, rng, C, NULL, 0.0, 1.0, theta, C, NULL, NULL, NULL, C, D, work,
+  CK(bk_momentum_refresh(BK_RNG_PHILOX, rng, C, NULL, 0.0, 1.0, theta, ld, NULL, NULL, NULL, C, D, work,
                          bk_refresh_work_elems(C, D), s));
   /* (logp, grad) of the current point, kept across draws */
-  CK(bk_target_diag_gaussian_grad(theta, grad, lp, C, lam, C, D, s));
+  CK(bk_target_diag_gaussian_grad(theta, grad, lp, ld, lam, C, D, s));
 
+  hipEvent_t ev0, ev1;
+  CK(hipEventCreate(&ev0));
+  CK(hipEventCreate(&ev1));
   for (int64_t n = 0; n < draws; ++n) {
+    if (n == 1) CK(hipEventRecord(ev0, s)); /* timing from the second draw on */
     /* rho ~ N(0, I), kin0 = 1/2 rho.rho, then the accept uniform: the reference's stream order */
-    CK(bk_momentum_refresh(BK_RNG_PHILOX, rng, C, NULL, 0.0, 1.0, rho, C, NULL, kin0, NULL, C, D, work,
+    CK(bk_momentum_refresh(BK_RNG_PHILOX, rng, C, NULL, 0.0, 1.0, rho, ld, NULL, kin0, NULL, C, D, work,
                            bk_refresh_work_elems(C, D), s));
     CK(bk_log_uniform(BK_RNG_PHILOX, rng, C, logu, NULL, C, s));
     /* leapfrog (hmc.py:40-53): back half step folded into the first kick */
     const double* g = grad;
     for (int64_t k = 0; k < L; ++k) {
       if (k == 0)
-        CK(bk_leapfrog_kick_drift(theta, theta_p, rho, rho, C, g, C, 1, NULL, eps, 1, -half, 1, eps, C, D, s));
+        CK(bk_leapfrog_kick_drift(theta, theta_p, rho, rho, ld, g, ld, 1, NULL, eps, 1, -half, 1, eps, C, D, s));
       else
-        CK(bk_leapfrog_kick_drift(theta_p, theta_p, rho, rho, C, g, C, 1, NULL, eps, 0, 0.0, 1, eps, C, D, s));
-      CK(bk_target_diag_gaussian_grad(theta_p, grad_p, k == L - 1 ? lp_p : NULL, C, lam, C, D, s));
+        CK(bk_leapfrog_kick_drift(theta_p, theta_p, rho, rho, ld, g, ld, 1, NULL, eps, 0, 0.0, 1, eps, C, D, s));
+      CK(bk_target_diag_gaussian_grad(theta_p, grad_p, k == L - 1 ? lp_p : NULL, ld, lam, C, D, s));
       g = grad_p;
     }
     /* forward half step + kinetic energy of the proposal (hmc.py:52, :37) */
-    CK(bk_leapfrog_finish(rho, NULL, C, g, C, 1, NULL, half, 0, kin1, C, D, s));
+    CK(bk_leapfrog_finish(rho, NULL, ld, g, ld, 1, NULL, half, 0, kin1, C, D, s));
     /* accept iff log(u) < (lp' - kin') - (lp - kin) (hmc.py:57-63); accepted chains take the proposal */
     CK(bk_mh_accept(BK_ACCEPT_HMC, lp, kin0, lp_p, kin1, logu, mask, ret, accepted, C, s));
-    CK(bk_select_columns(mask, theta, theta_p, grad, grad_p, NULL, C, C, D, s));
+    CK(bk_select_columns(mask, theta, theta_p, grad, grad_p, NULL, ld, C, D, s));
   }
+  CK(hipEventRecord(ev1, s));
   CK(hipStreamSynchronize(s));
+  if (draws > 1) {
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, ev0, ev1));
+    fprintf(stderr, "%.3f ms per draw, %.4g leapfrog steps/s\n", ms / (double)(draws - 1),
+            (double)C * (double)L * (double)(draws - 1) / (ms * 1e-3));
+  }
 
   uint32_t acc = 0;
   CK(hipMemcpy(&acc, accepted, sizeof(acc), hipMemcpyDeviceToHost));
@@ -95,7 +118,7 @@ int main(int argc, char** argv) {
   double* col = (double*)malloc(D * sizeof(double));
   const int64_t show[2] = {0, C - 1};
   for (int i = 0; i < 2; ++i) {
-    CK(hipMemcpy2D(col, sizeof(double), theta + show[i], C * sizeof(double), sizeof(double), D, hipMemcpyDeviceToHost));
+    CK(hipMemcpy2D(col, sizeof(double), theta + show[i], ld * sizeof(double), sizeof(double), D, hipMemcpyDeviceToHost));
     printf("theta[%lld]", (long long)show[i]);
     for (int64_t d = 0; d < D; ++d) {
       uint64_t w;
