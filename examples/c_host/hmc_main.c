@@ -33,14 +33,14 @@ static char* g_slab = NULL; /* BK_SLAB: carve every array out of ONE allocation 
 static size_t g_slab_used = 0;
 static double* dalloc(size_t n) {
   char* p = NULL;
-  size_t bytes = n * sizeof(double) + 64 * g_stagger;
-  if (g_slab) {
+  const size_t bytes = n * sizeof(double);
+  if (g_slab) { /* consecutive arrays: 2 MiB-rounded size + BK_STAGGER bytes apart */
     p = g_slab + g_slab_used;
-    g_slab_used += (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-  } else {
-    CK(hipMalloc((void**)&p, bytes));
+    g_slab_used += ((bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1)) + g_stagger;
+    return (double*)p;
   }
-  return (double*)(p + (g_nalloc++) * g_stagger);
+  CK(hipMalloc((void**)&p, bytes + 32 * g_stagger)); /* separate allocations: the n-th is shifted by n * BK_STAGGER */
+  return (double*)(p + ((g_nalloc++) & 31) * g_stagger);
 }
 
 int main(int argc, char** argv) {
@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
   const double eps = 0.05, half = 0.5 * eps;
   const int64_t ld = C + (getenv("BK_PAD") ? atoll(getenv("BK_PAD")) : 0); /* leading dimension (row pitch) */
   g_stagger = getenv("BK_STAGGER") ? (size_t)atoll(getenv("BK_STAGGER")) : 0;
-  if (getenv("BK_SLAB")) CK(hipMalloc((void**)&g_slab, (size_t)(7 * D * ld + 16 * C + D) * sizeof(double) + ((size_t)64 << 20) + 20 * 65 * g_stagger));
+  if (getenv("BK_SLAB")) CK(hipMalloc((void**)&g_slab, (size_t)(7 * D * ld + 16 * C + D) * sizeof(double) + ((size_t)64 << 20) + 24 * g_stagger));
   hipStream_t s;
   CK(hipStreamCreate(&s));
 
