@@ -337,6 +337,20 @@ def main():
                 "achieved": 16.0 * D * Ct / (g_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
+        try:
+            # context for `frac`: what a plain device-to-device copy of the same arrays sustains on this
+            # box right now (the guide's measured copy ceiling is 6.29 TB/s = 79 % of the 8 TB/s spec)
+            src, dst = s._theta_p, s._grad_p
+            dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            out["roofline"]["device_copy_GBps"] = 10 * 2.0 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        except Exception as e:  # context only
+            out["roofline"]["device_copy_GBps"] = None
     if args.ess_draws > 0:
         try:
             # Second half of BASELINE.json's metric: ESS/sec.  Extra draws (outside the timed region
