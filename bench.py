@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
 def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False,
-                      prefetch_rng=None):
+                      prefetch_rng=None, tune_placement=None):
     """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
     import torch
 
@@ -45,7 +45,7 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
                    chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused,
-                   prefetch_rng=prefetch_rng)
+                   prefetch_rng=prefetch_rng, tune_placement=tune_placement)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
     s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(device)[:, None])
@@ -216,6 +216,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="config 2: eager launches instead of hipGraph replay")
     ap.add_argument("--no-rng-prefetch", action="store_true",
                     help="generate each draw's randomness in line instead of on the side stream (experiments)")
+    ap.add_argument("--no-placement-tuning", action="store_true",
+                    help="keep the scratch arrays in the roles they were allocated for (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true")
@@ -254,7 +256,8 @@ def main():
     C = args.chains
     D, L = D_CFG3, L_CFG3
     s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile,
-                          prefetch_rng=False if args.no_rng_prefetch else None)
+                          prefetch_rng=False if args.no_rng_prefetch else None,
+                          tune_placement=False if args.no_placement_tuning else None)
     Ct = s._chain_tile
     ops = s._ops
 
@@ -308,6 +311,7 @@ def main():
             "chain_tile": Ct,
         },
         "accept_rate": accept,
+        "placement": s.placement,  # which allocation plays which role was chosen by timing (HMCDiag._tune_placement)
         # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
         "path_hbm_frac": value / world * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
     }

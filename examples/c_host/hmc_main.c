@@ -82,6 +82,21 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&ev1));
   for (int64_t n = 0; n < draws; ++n) {
     if (n == 1) CK(hipEventRecord(ev0, s)); /* timing from the second draw on */
+    if (getenv("BK_TRACE") && n % 10 == 1) { /* per-10-draw timing (machine-state drift experiment) */
+      static hipEvent_t prev;
+      static int have = 0;
+      hipEvent_t cur;
+      CK(hipEventCreate(&cur));
+      CK(hipEventRecord(cur, s));
+      if (have) {
+        float ms = 0.f;
+        CK(hipEventSynchronize(cur));
+        CK(hipEventElapsedTime(&ms, prev, cur));
+        fprintf(stderr, "draws %lld-%lld: %.3f ms per draw\n", (long long)(n - 10), (long long)(n - 1), ms / 10.0);
+      }
+      prev = cur;
+      have = 1;
+    }
     /* rho ~ N(0, I), kin0 = 1/2 rho.rho, then the accept uniform: the reference's stream order */
     CK(bk_momentum_refresh(BK_RNG_PHILOX, rng, C, NULL, 0.0, 1.0, rho, ld, NULL, kin0, NULL, C, D, work,
                            bk_refresh_work_elems(C, D), s));
@@ -109,6 +124,9 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, ev0, ev1));
     fprintf(stderr, "%.3f ms per draw, %.4g leapfrog steps/s\n", ms / (double)(draws - 1),
             (double)C * (double)L * (double)(draws - 1) / (ms * 1e-3));
+    if (getenv("BK_SHOW_PTRS"))
+      fprintf(stderr, "theta %p theta_p %p rho %p grad %p grad_p %p\n", (void*)theta, (void*)theta_p, (void*)rho,
+              (void*)grad, (void*)grad_p);
   }
 
   uint32_t acc = 0;

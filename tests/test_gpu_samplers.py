@@ -593,3 +593,18 @@ def test_plain_c_host_program_equals_the_python_driver(ops):
     for c, words in cols.items():
         assert np.array_equal(th[c].view(np.uint64), words), c
     assert abs(accept - s.accept_rate()) < 1e-6
+
+
+def test_placement_tuning_is_only_a_choice_of_buffers(ops):
+    """tune_placement picks which scratch allocation plays which role by timing; draws are unchanged."""
+    lam = np.logspace(0, 1, 40)
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, fuse_builtin=False, graph=False,
+                   tune_placement=False)
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, fuse_builtin=False, graph=False,
+                   tune_placement=True)
+    assert a.placement is None and b.placement["assignments_tried"] == bk.HMCDiag.TUNE_PLACEMENT_TRIALS
+    for n in range(6):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb), n
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
