@@ -408,6 +408,63 @@ class ManyChainSampler:
         self._ops.relayout(g, grad_out)
         return grad_out
 
+    # -- which allocation plays which role -------------------------------------------------------
+    # The hot loops stream several arrays at equal offsets.  How fast that runs depends on where the
+    # driver placed them RELATIVE to each other: the same kick+drift launch takes 414-484 us on
+    # different triples of identically sized allocations (6.5 -> 5.6 TB/s; tools/placement_probe2.py,
+    # examples/c_host/placement_probe.c), while each array alone streams at the same rate.  A process
+    # cannot choose physical placement, but it can choose which of its allocations plays which role:
+    # a few assignments of the scratch arrays (plus spare ones, freed afterwards) are timed with the
+    # real kernels and the fastest is kept.  Scratch contents are irrelevant at that point (every array
+    # is written before it is read); results do not depend on the assignment.
+    TUNE_PLACEMENT_MIN_BYTES = 128 << 20
+    TUNE_PLACEMENT_TRIALS = 30
+    TUNE_PLACEMENT_SPARES = 3
+
+    def _wants_placement_tuning(self, tune_placement):
+        if tune_placement is not None:
+            return bool(tune_placement)
+        return (self._batched and self._ops.device.type == "cuda" and not self._use_graph
+                and self._dim * self._C * 8 >= self.TUNE_PLACEMENT_MIN_BYTES)
+
+    def _tune_roles(self, arrays, cost):
+        """arrays: interchangeable [D, C] scratch tensors, in role order.  cost(list in role order) ->
+        milliseconds.  Returns (the best assignment as a list in role order, report dict)."""
+        import random
+
+        pool = list(arrays) + [torch.empty_like(arrays[0]) for _ in range(self.TUNE_PLACEMENT_SPARES)]
+        for a in pool:
+            a.zero_()  # timing on defined values
+        rnd = random.Random(0)
+        ids = list(range(len(pool)))
+        candidates = [ids[:]]  # the allocation order itself
+        while len(candidates) < self.TUNE_PLACEMENT_TRIALS:
+            perm = ids[:]
+            rnd.shuffle(perm)
+            candidates.append(perm)
+        best, best_ms, first_ms = None, float("inf"), None
+        for perm in candidates:
+            ms = cost([pool[i] for i in perm[:len(arrays)]])
+            first_ms = ms if first_ms is None else first_ms
+            if ms < best_ms:
+                best, best_ms = perm, ms
+        chosen = [pool[i] for i in best[:len(arrays)]]
+        del pool
+        torch.cuda.empty_cache()  # hand the spare arrays back to the driver
+        return chosen, {"ms_as_allocated": first_ms, "ms_chosen": best_ms, "assignments_tried": len(candidates)}
+
+    @staticmethod
+    def _time_ms(fn, warm=2, reps=6):
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
     _out = None
 
     def _select(self, mask, th, thp, g=None, gp=None):

@@ -122,72 +122,26 @@ class HMCDiag(ManyChainSampler):
             self._logu_bufs.append(torch.empty(C, **f64))
             self._side = torch.cuda.Stream(device=dev)
             self._rng_logical = self._rng_state.clone()  # stream position after the last finished draw
-        if tune_placement is None:
-            tune_placement = (self._batched and dev.type == "cuda" and not self._fused and self._M is None
-                              and not self._use_graph and D * C * 8 >= self.TUNE_PLACEMENT_MIN_BYTES)
         self.placement = None
-        if tune_placement:
+        if self._wants_placement_tuning(tune_placement) and not self._fused and self._M is None:
             self._tune_placement()
 
-    # -- which allocation plays which role ------------------------------------------------------
-    # The leapfrog loop streams three arrays at equal offsets (theta', rho, grad').  How fast that
-    # runs depends on where the driver placed them RELATIVE to each other: the same kick+drift launch
-    # takes 414-484 us on different triples of identically sized allocations (6.5 -> 5.6 TB/s;
-    # tools/placement_probe2.py, examples/c_host/placement_probe.c), while each array alone streams at
-    # the same rate.  A process cannot choose physical placement, but it can choose which of its
-    # allocations plays which role: a few assignments of the scratch arrays (plus three spare ones,
-    # freed afterwards) to the roles (theta', rho of both slots, grad') are timed with the real kernel
-    # and the fastest is kept.  Scratch contents are irrelevant at this point (all are written before
-    # they are read); results do not depend on the assignment.
-    TUNE_PLACEMENT_MIN_BYTES = 128 << 20
-    TUNE_PLACEMENT_TRIALS = 30
-    TUNE_PLACEMENT_SPARES = 3
-
     def _tune_placement(self):
-        import random
-
-        ops, m = self._ops, self._metric_dev
-        D, C = self._dim, self._C
-        eps = float(self._stepsize)
+        """Roles (theta', grad', rho of each slot, grad): see ManyChainSampler._tune_roles."""
+        ops, m, eps = self._ops, self._metric_dev, float(self._stepsize)
         n_rho = len(self._rho_bufs)
-        pool = [self._theta_p, self._grad, self._grad_p] + list(self._rho_bufs)
-        pool += [torch.empty((D, C), dtype=torch.float64, device=ops.device) for _ in range(self.TUNE_PLACEMENT_SPARES)]
-        for a in pool:
-            a.zero_()  # timing on defined values
 
-        def cost(tp, r, g):
-            for _ in range(2):
-                ops.kick_drift(tp, tp, r, r, g, m, eps, False, 0.0, True, eps)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(6):
-                ops.kick_drift(tp, tp, r, r, g, m, eps, False, 0.0, True, eps)
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / 6.0
+        def cost(a):
+            tp, gp, rhos = a[0], a[1], a[2:2 + n_rho]
+            return sum(self._time_ms(lambda r=r: ops.kick_drift(tp, tp, r, r, gp, m, eps, False, 0.0, True, eps))
+                       for r in rhos) / n_rho
 
-        rnd = random.Random(0)
-        ids = list(range(len(pool)))
-        candidates = [ids[:]]  # the allocation order itself
-        while len(candidates) < self.TUNE_PLACEMENT_TRIALS:
-            perm = ids[:]
-            rnd.shuffle(perm)
-            candidates.append(perm)
-        best, best_ms, first_ms = None, float("inf"), None
-        for perm in candidates:
-            tp, g = pool[perm[0]], pool[perm[1]]
-            rhos = [pool[i] for i in perm[2:2 + n_rho]]
-            ms = sum(cost(tp, r, g) for r in rhos) / n_rho
-            first_ms = ms if first_ms is None else first_ms
-            if ms < best_ms:
-                best, best_ms = perm, ms
-        self._theta_p, self._grad_p = pool[best[0]], pool[best[1]]
-        self._rho_bufs = [pool[i] for i in best[2:2 + n_rho]]
-        self._grad = pool[best[2 + n_rho]]
-        self.placement = {"kick_drift_ms_as_allocated": first_ms, "kick_drift_ms_chosen": best_ms,
-                          "assignments_tried": len(candidates)}
-        del pool
-        torch.cuda.empty_cache()  # hand the spare arrays back to the driver
+        chosen, rep = self._tune_roles([self._theta_p, self._grad_p] + list(self._rho_bufs) + [self._grad], cost)
+        self._theta_p, self._grad_p = chosen[0], chosen[1]
+        self._rho_bufs = chosen[2:2 + n_rho]
+        self._grad = chosen[2 + n_rho]
+        self.placement = {"kick_drift_ms_as_allocated": rep["ms_as_allocated"],
+                          "kick_drift_ms_chosen": rep["ms_chosen"], "assignments_tried": rep["assignments_tried"]}
 
     # -- optional cache blocking ----------------------------------------------------------------
     # chain_tile=T runs the L steps tile by tile over blocks of T chains (chains are

@@ -18,7 +18,8 @@ from ._engine import ManyChainSampler
 
 class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
-                 chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None, ops=None):
+                 chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None,
+                 tune_placement: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph)
@@ -62,8 +63,34 @@ class MALA(ManyChainSampler):
             self._logu_bufs = [torch.empty(C, **f64) for _ in range(2)]
             self._side = torch.cuda.Stream(device=dev)
             self._rng_logical = self._rng_state.clone()
+        self.placement = None
+        if self._wants_placement_tuning(tune_placement):
+            self._tune_placement()
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+
+    def _tune_placement(self):
+        """Roles (theta', grad, grad') for the proposal, proposal-density and select kernels, which
+        stream four to five arrays at equal offsets: see ManyChainSampler._tune_roles."""
+        ops, th, eps = self._ops, self._theta_dc, float(self._epsilon)
+        z = self._z_bufs[0] if hasattr(self, "_z_bufs") else None
+        out = torch.empty_like(th)
+        self._mask.fill_(1)
+
+        def cost(a):
+            thp, g, gp = a
+            ms = self._time_ms(lambda: ops.mala_logq(th, g, thp, gp, eps, self._fwd, self._rev))
+            ms += self._time_ms(lambda: ops.select_columns(self._mask, th, thp, g, gp, out))
+            if z is not None:
+                ms += self._time_ms(lambda: ops.mala_propose_from_normals(th, g, z, thp, eps, math.sqrt(2 * eps)))
+            return ms
+
+        keep = th.clone()  # the select kernel writes theta: restore the initial state afterwards
+        (self._theta_p, self._grad, self._grad_p), rep = self._tune_roles([self._theta_p, self._grad, self._grad_p],
+                                                                          cost)
+        th.copy_(keep)
+        self.placement = {"draw_kernels_ms_as_allocated": rep["ms_as_allocated"],
+                          "draw_kernels_ms_chosen": rep["ms_chosen"], "assignments_tried": rep["assignments_tried"]}
 
     def _state_tensors(self):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}

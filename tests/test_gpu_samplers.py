@@ -608,3 +608,15 @@ def test_placement_tuning_is_only_a_choice_of_buffers(ops):
         tb, lb = b.sample()
         assert torch.equal(ta, tb) and torch.equal(la, lb), n
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+
+
+def test_mala_placement_tuning_is_only_a_choice_of_buffers(ops):
+    lam = np.logspace(0, 1, 48)
+    a = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=False)
+    b = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=True)
+    assert a.placement is None and b.placement["assignments_tried"] == bk.MALA.TUNE_PLACEMENT_TRIALS
+    for n in range(6):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb), n
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
