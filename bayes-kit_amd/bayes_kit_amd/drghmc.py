@@ -66,6 +66,7 @@ class DrGhmcDiag(ManyChainSampler):
         chains: Optional[int] = None,
         chain_id0: int = 0,
         fuse_builtin: bool = True,
+        tune_placement: Optional[bool] = None,
         ops=None,
     ):
         self._max_proposals = max_proposals
@@ -97,9 +98,31 @@ class DrGhmcDiag(ManyChainSampler):
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
         # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
+        self._use_graph = False
+        self.placement = None
+        if self._wants_placement_tuning(tune_placement) and not self._fused:
+            self._tune_placement()
         self.last_grad_evals = 0        # model calls in the last draw (each over a lane set)
         self.last_lane_steps = 0        # sum over trajectories of lanes x steps (useful work)
         self.last_stage_lanes = []      # (tag, lanes) of every trajectory run in the last draw
+
+    def _tune_placement(self):
+        """Every recursion level streams its own (theta, rho, grad) triple through kick+drift: the
+        3 K level arrays are assigned to those roles by timing (ManyChainSampler._tune_roles)."""
+        ops, m = self._ops, self._metric_dev
+        h = float(self._leapfrog_step_sizes[0])
+        flat = [a for lv in self._levels for a in (lv.theta, lv.rho, lv.grad)]
+
+        def cost(a):
+            return sum(self._time_ms(lambda t=a[3 * i], r=a[3 * i + 1], g=a[3 * i + 2]:
+                                     ops.kick_drift(t, t, r, r, g, m, h, False, 0.0, True, h))
+                       for i in range(len(self._levels)))
+
+        chosen, rep = self._tune_roles(flat, cost)
+        for i, lv in enumerate(self._levels):
+            lv.theta, lv.rho, lv.grad = chosen[3 * i], chosen[3 * i + 1], chosen[3 * i + 2]
+        self.placement = {"kick_drift_ms_as_allocated": rep["ms_as_allocated"],
+                          "kick_drift_ms_chosen": rep["ms_chosen"], "assignments_tried": rep["assignments_tried"]}
 
     # -- validation: same checks, error types and texts as drghmc.py:85-207 -----------------------
     def _validate_arguments(self) -> None:
