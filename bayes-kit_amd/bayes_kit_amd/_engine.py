@@ -432,7 +432,11 @@ class ManyChainSampler:
         milliseconds.  Returns (the best assignment as a list in role order, report dict)."""
         import random
 
-        pool = list(arrays) + [torch.empty_like(arrays[0]) for _ in range(self.TUNE_PLACEMENT_SPARES)]
+        pool = list(arrays)
+        try:
+            pool += [torch.empty_like(arrays[0]) for _ in range(self.TUNE_PLACEMENT_SPARES)]
+        except torch.cuda.OutOfMemoryError:
+            pool = list(arrays)  # no room for spare candidates: permute what there is
         for a in pool:
             a.zero_()  # timing on defined values
         rnd = random.Random(0)
