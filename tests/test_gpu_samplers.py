@@ -552,13 +552,13 @@ def test_long_run_stays_bit_identical_to_the_oracle(ops, alg):
 
 
 def test_randomised_sampler_configurations_against_the_oracle(ops):
-    """A fixed-seed slice of tools/soak_samplers.py: random algorithm, target, dims (both generator
+    """A fixed-seed slice of tests/soak_samplers.py: random algorithm, target, dims (both generator
     kernels), odd / even chain counts, metric, fused / step-by-step, hipGraph and RNG-prefetch
     switches; watched chains bit-identical to the oracle at every draw, stream states equal."""
     import importlib.util
     import os
 
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "soak_samplers.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "soak_samplers.py")
     spec = importlib.util.spec_from_file_location("soak_samplers", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
