@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run the REFERENCE'S OWN test-suite against bayes_kit_amd (build container only).
 
-    python tools/run_reference_tests.py [pytest args]
+    python tests/run_reference_tests.py [pytest args]
 
 `bayes_kit` and its sub-modules are aliased to `bayes_kit_amd` before pytest collects
 /root/reference/test (read in place: nothing is copied, nothing is written there), so every
