@@ -203,6 +203,9 @@ SAMPLER_CASES = [
     dict(name="mala_diag16", alg="mala",
          model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), epsilon=0.02,
          chains=8, draws=60, seed=203),
+    dict(name="mala_diag48", alg="mala",
+         model=dict(kind="diag_gaussian", D=48, log10_lo=0, log10_hi=1), epsilon=0.01,
+         chains=4, draws=40, seed=205),  # D >= 32: the wavefront-per-chain generator's path
     dict(name="mala_init", alg="mala", model=dict(kind="iso_gaussian", D=3), epsilon=0.15,
          init=[0.2, -1.0, 0.5], chains=3, draws=30, seed=204),
     # --- the reference's own Binomial test model (scipy densities, finite-difference gradient) ---
@@ -236,6 +239,10 @@ SAMPLER_CASES = [
          proposal=dict(kind="normal", a=0.8, scale=0.5, seed=9002), chains=6, draws=80, seed=502),
     dict(name="metropolis_pcg_seed", alg="metropolis", model=dict(kind="std_normal"),
          proposal=dict(kind="normal", scale=1.1, seed=9003), chains=2, draws=60, pcg_seed=77),
+    dict(name="drghmc_diag40", alg="drghmc",
+         model=dict(kind="diag_gaussian", D=40, log10_lo=0, log10_hi=1), max_proposals=2,
+         leapfrog_step_sizes=[0.3, 0.1], leapfrog_step_counts=[3, 9], damping=0.4,
+         chains=4, draws=60, seed=306),  # D >= 32: partial refresh through the wavefront-per-chain path
     dict(name="drghmc_diag16_metric", alg="drghmc",
          model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), max_proposals=3,
          leapfrog_step_sizes=[0.5, 0.25, 0.1], leapfrog_step_counts=[3, 6, 12], damping=0.3,

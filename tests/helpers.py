@@ -12,9 +12,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SAMPLER_CASES = [
     "hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric",
     "hmc_diag1024_cfg3", "hmc_pcg_seed",
-    "mala_readme_cfg1", "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_init",
+    "mala_readme_cfg1", "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_diag48", "mala_init",
     "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
-    "drghmc_funnel101_cfg4", "drghmc_diag16_metric",
+    "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40",
     "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
     "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed",
 ]
