@@ -131,17 +131,23 @@ class HMCDiag(ManyChainSampler):
         ops, m, eps = self._ops, self._metric_dev, float(self._stepsize)
         n_rho = len(self._rho_bufs)
 
+        builtin = hasattr(self._model, "bk_eval")  # the library's own gradient op: safe to time as well
+
         def cost(a):
             tp, gp, rhos = a[0], a[1], a[2:2 + n_rho]
-            return sum(self._time_ms(lambda r=r: ops.kick_drift(tp, tp, r, r, gp, m, eps, False, 0.0, True, eps))
-                       for r in rhos) / n_rho
+            ms = sum(self._time_ms(lambda r=r: ops.kick_drift(tp, tp, r, r, gp, m, eps, False, 0.0, True, eps))
+                     for r in rhos) / n_rho
+            if builtin:
+                ms += self._time_ms(lambda: self._model.bk_eval(tp, gp, None))
+            return ms
 
         chosen, rep = self._tune_roles([self._theta_p, self._grad_p] + list(self._rho_bufs) + [self._grad], cost)
         self._theta_p, self._grad_p = chosen[0], chosen[1]
         self._rho_bufs = chosen[2:2 + n_rho]
         self._grad = chosen[2 + n_rho]
-        self.placement = {"kick_drift_ms_as_allocated": rep["ms_as_allocated"],
-                          "kick_drift_ms_chosen": rep["ms_chosen"], "assignments_tried": rep["assignments_tried"]}
+        key = "step_ms" if builtin else "kick_drift_ms"
+        self.placement = {key + "_as_allocated": rep["ms_as_allocated"], key + "_chosen": rep["ms_chosen"],
+                          "assignments_tried": rep["assignments_tried"]}
 
     # -- optional cache blocking ----------------------------------------------------------------
     # chain_tile=T runs the L steps tile by tile over blocks of T chains (chains are

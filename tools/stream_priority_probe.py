@@ -21,7 +21,7 @@ def run(stream, prefetch):
         ms = 1e3 * (time.perf_counter() - t0) / 10
         timed, s._ops.timed = s._ops.timed, None
         per = {n.replace("bk_", ""): round(sum(a.elapsed_time(b) for a, b in v) / 10, 2) for n, v in timed.items()}
-        return ms, s.placement["kick_drift_ms_chosen"], per
+        return ms, s.placement.get("step_ms_chosen", s.placement.get("kick_drift_ms_chosen")), per
 hi = torch.cuda.Stream(priority=-1)
 for rep in range(int(os.environ.get("REPS", 2))):
     for name, st, pf in (("default stream, prefetch", None, True), ("high-priority stream, prefetch", hi, True),
