@@ -418,8 +418,8 @@ class ManyChainSampler:
     # real kernels and the fastest is kept.  Scratch contents are irrelevant at that point (every array
     # is written before it is read); results do not depend on the assignment.
     TUNE_PLACEMENT_MIN_BYTES = 128 << 20
-    TUNE_PLACEMENT_TRIALS = 30
-    TUNE_PLACEMENT_SPARES = 3
+    TUNE_PLACEMENT_TRIALS = 40
+    TUNE_PLACEMENT_SPARES = 5
 
     def _wants_placement_tuning(self, tune_placement):
         if tune_placement is not None:
