@@ -257,9 +257,21 @@ class ManyChainSampler:
         meta = sd["meta"]
         if (meta["class"], meta["chains"], meta["dims"]) != (type(self).__name__, self._C, self._dim):
             raise ValueError(f"checkpoint is for {meta['class']} with {meta['chains']} chains x {meta['dims']} dims")
+        # the wavefront-per-chain scratch and MALA's normals layout were chosen from the stream kind at
+        # construction, and the Philox key IS the global chain id: refuse a checkpoint of other streams
+        if meta["rng_kind"] != self._rng_kind:
+            raise ValueError(f"checkpoint holds rng kind {meta['rng_kind']}, this sampler was built for {self._rng_kind} "
+                             "(Philox = 0, PCG64 = 1): construct it with the same kind of seed")
+        if int(meta.get("chain_id0", self._chain_id0)) != self._chain_id0:
+            raise ValueError(f"checkpoint is for chains starting at global id {meta['chain_id0']}, "
+                             f"this sampler starts at {self._chain_id0}")
+        # A previous sample() may have queued the NEXT draw's generator on the side stream; it mutates
+        # the RNG table in place and nothing would wait for it once the prefetch bookkeeping is
+        # dropped below: let everything in flight finish before the table is overwritten.
+        if self._ops.device.type == "cuda":
+            torch.cuda.synchronize()
         for k, v in self._state_tensors().items():
             v.copy_(sd[k].to(v.device))
-        self._rng_kind = meta["rng_kind"]
         self._rng_state.copy_(sd["rng_state"].to(self._rng_state.device))
         self._draws = meta["draws"]
         if hasattr(self, "_have_cache"):

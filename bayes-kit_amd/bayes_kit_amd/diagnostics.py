@@ -175,6 +175,8 @@ def _rhat_of_columns(x, lens, ops, group=None):
     len_sum = torch.tensor([float(N * M) if lens is None else float(np.sum(lens))], dtype=torch.float64, device=dev)
     tot = _gather_sum(torch.cat([part, len_sum]), group)
     Mt = float(tot[3].item())
+    if Mt < 2:  # rhat.py:159-160, over all ranks' chains
+        raise ValueError(f"rhat requires len(chains) >= 2, but len(chains) = {int(Mt)}")
     centre = (tot[0:1] / Mt).contiguous()
     part2 = torch.zeros(4, dtype=torch.float64, device=dev)
     ops.rhat_partials(mean, var, 2, centre, part2)
@@ -290,13 +292,31 @@ def rank_normalize_chains(chains, *, ops=None):
     return out
 
 
+def _all_gather_counts(n: int, device, group=None):
+    """Every rank's value of the integer n, in rank order (dist.shard hands the remainder of an
+    uneven split to the first ranks, so shard widths may differ by one)."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return [int(p.item()) for p in parts]
+
+
 def _all_gather_columns(x: torch.Tensor, group=None):
     """[N, C_local] on every rank -> ([N, C_total] in rank order, first column of this rank).
-    Equal C_local on every rank (chains shard evenly)."""
+    C_local may differ between ranks: shards are padded to the widest for the collective and
+    the padding is dropped afterwards."""
     world = dist.get_world_size(group)
-    parts = [torch.empty_like(x) for _ in range(world)]
-    dist.all_gather(parts, x.contiguous(), group=group)
-    return torch.cat(parts, dim=1), dist.get_rank(group) * x.shape[1]
+    counts = _all_gather_counts(x.shape[1], x.device, group)
+    cmax = max(counts)
+    send = x.contiguous()
+    if x.shape[1] != cmax:
+        send = torch.zeros((x.shape[0], cmax), dtype=x.dtype, device=x.device)
+        send[:, : x.shape[1]] = x
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    full = torch.cat([p[:, :c] for p, c in zip(parts, counts)], dim=1)
+    return full, sum(counts[: dist.get_rank(group)])
 
 
 def rank_normalized_rhat(chains, *, ops=None, group=None):

@@ -69,6 +69,11 @@ class MALA(ManyChainSampler):
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
+    def refresh_cache(self):
+        """Recompute the cached (logp, grad) of the current point (mala.py:31-32) after ``_theta`` was
+        assigned or edited from outside, as the reference's constructor does for ``init``."""
+        self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+
     def _tune_placement(self):
         """Roles (theta', grad, grad') for the proposal, proposal-density and select kernels, which
         stream four to five arrays at equal offsets: see ManyChainSampler._tune_roles."""

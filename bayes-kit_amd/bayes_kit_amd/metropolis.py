@@ -86,16 +86,15 @@ def _as_lp(x, C, dev):
 
 def _accept_host_rng(lp_proposal, lp_current, fwd, rev, rng) -> bool:
     """The reference's scalar form: ``rng`` is a host generator (anything with ``uniform()``, e.g. a
-    ``numpy.random.Generator``), the log densities are floats.  One uniform is taken from it, as
-    in the reference; the comparison itself is still the ``bk_mh_accept`` kernel (one chain)."""
-    ops = _lib.default_ops()
+    ``numpy.random.Generator``), the log densities are host floats.  In the reference this is a pure
+    scalar helper (metropolis.py:12-76), so it stays one here: one uniform is taken from ``rng`` and
+    the comparison is evaluated on the host in the reference's operation order -- no device round
+    trip for a single comparison.  The many-chain form (``ChainRng``) is the ``bk_mh_accept`` kernel."""
     with np.errstate(divide="ignore"):
-        logu = float(np.log(rng.uniform()))
-    one = lambda v: None if v is None else torch.tensor([float(v)], dtype=torch.float64, device=ops.device)  # noqa: E731
-    mask = torch.empty(1, dtype=torch.uint8, device=ops.device)
-    ops.mh_accept(_lib.ACCEPT_MALA, one(lp_current), one(fwd), one(lp_proposal), one(rev), one(logu), mask, None,
-                  None)
-    return bool(mask[0].item())
+        log_u = np.log(rng.uniform())
+    if fwd is None and rev is None:
+        return bool(log_u < lp_proposal - lp_current)  # metropolis.py:37-38
+    return bool(log_u < (lp_proposal - lp_current) + (rev - fwd))  # metropolis.py:70-76
 
 
 def metropolis_accept_test(lp_proposal, lp_current, rng):

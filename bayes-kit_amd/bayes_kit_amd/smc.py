@@ -251,20 +251,30 @@ class TemperedLikelihoodSMC:
         import torch.distributed as dist
 
         ops, g = self._ops, self._group
+        from .diagnostics import _all_gather_counts
+
         world, M = dist.get_world_size(g), w.shape[0]
-        wparts = [torch.empty_like(w) for _ in range(world)]
-        dist.all_gather(wparts, w, group=g)
-        w_all = torch.cat(wparts)
+        # particle counts may differ by one between ranks (dist.shard gives the remainder to the
+        # first ranks): pad the weight shards to the widest for the collective, and find an
+        # ancestor's owner from the cumulative counts rather than by division
+        counts = _all_gather_counts(M, w.device, g)
+        mmax = max(counts)
+        send_w = w if M == mmax else torch.cat([w, torch.zeros(mmax - M, dtype=w.dtype, device=w.device)])
+        wparts = [torch.empty_like(send_w) for _ in range(world)]
+        dist.all_gather(wparts, send_w.contiguous(), group=g)
+        w_all = torch.cat([p[:c] for p, c in zip(wparts, counts)])
         self.last_ess = float((w_all.sum() ** 2 / (w_all * w_all).sum()).item())
         ops.resample_indices(w_all, self._u, torch.empty_like(w_all), self._idx)  # global ancestors
         idx = self._idx.to(torch.int64)
-        owner = torch.div(idx, M, rounding_mode="floor")
+        ends = torch.cumsum(torch.tensor(counts, dtype=torch.int64, device=idx.device), 0)
+        owner = torch.searchsorted(ends, idx, right=True)     # rank whose block holds global particle idx
+        first = ends - torch.tensor(counts, dtype=torch.int64, device=idx.device)
         order = torch.sort(owner, stable=True).indices       # my slots grouped by the rank that owns their ancestor
         want = torch.bincount(owner, minlength=world)         # how many columns I need from each rank
         give = torch.empty_like(want)
         dist.all_to_all_single(give, want, group=g)           # how many each rank needs from me
         want_l, give_l = want.tolist(), give.tolist()
-        req_out = (idx[order] - owner[order] * M).contiguous()
+        req_out = (idx[order] - first[owner[order]]).contiguous()
         req_in = torch.empty(sum(give_l), dtype=torch.int64, device=idx.device)
         dist.all_to_all_single(req_in, req_out, give_l, want_l, group=g)
         # the requested columns, particle-major so that each destination's block is contiguous

@@ -11,14 +11,27 @@ shard with no data-path collective; Philox key = (20241, global chain id)).  One
 by a separate device op (the C-ABI built-in target), i.e. the model-opaque path whose
 algorithmic HBM traffic is 56*D bytes per chain-step (40*D integrator + 16*D gradient).
 
-One JSON line is printed by rank 0.  `roofline` is for the dominant kernel (the fused
-kick+drift, 40*D algorithmic bytes per chain per launch), its duration measured live with
-HIP events on the launch stream over the timed region.  `cpu_baseline` times the oracle
-(NumPy restatement of the reference) on the host cores, rank 0 at N=1 only.
+Launching.  With WORLD_SIZE in the environment (torch.distributed.run, one process per GPU)
+this process is one rank.  Without it, `--gpus N` with N > 1 makes this process a LAUNCHER:
+it starts N rank processes itself (before anything touches the GPU), relays rank 0's JSON
+line and exits non-zero if any rank fails.  Ranks rendezvous over RCCL (`nccl` backend); on a
+box with fewer GPUs than ranks they share the visible GPUs and rendezvous over gloo instead
+(`"shared_gpu": true`: exercises the N > 1 code path, its numbers are not measurements).
+
+One JSON line is printed by rank 0.  `value` is the weak-scaling figure (65,536 chains per
+GPU); `value_strong` is the same metric with 65,536 chains per NODE (65,536 / N per GPU).
+`roofline` is for the dominant kernel (the fused kick+drift, 40*D algorithmic bytes per chain
+per launch), its duration measured live with HIP events on the launch stream over the timed
+region.  `cpu_baseline` times the oracle (NumPy restatement of the reference) on the host
+cores, rank 0 at N=1 only.  `secondary` (N=1) carries the other BASELINE.json configs, each
+with its own bound and bytes / flop model.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,9 +44,85 @@ D_CFG3 = 1024
 L_CFG3 = 64
 EPS_CFG3 = 0.006
 SEED_CFG3 = 20241
+C_CFG3 = 65536
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # spec, counts an FMA as 2 flop; kernels here may not contract: ceiling 39.3
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "cfg3_traffic.json")
+KD_SOURCE = os.path.join(ROOT, "bayes-kit_amd", "csrc", "bk_integrator.hip")
 
 
+# ---------------------------------------------------------------------------------------------
+# launcher: N rank processes on one node
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, child_argv, extra_env=None, timeout=3000.0, out=None):
+    """Start `child_argv` n times, one process per rank, with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set).  Rank 0's stdout is
+    relayed to `out` (default: this process's stdout); other ranks' stdout goes to stderr.
+    Returns 0 when every rank exited 0; otherwise the remaining ranks are terminated and the
+    first failing exit code is returned.  The launcher itself never touches the GPU."""
+    out = out if out is not None else sys.stdout
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(child_argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True))
+    deadline = time.monotonic() + timeout
+    rc = 0
+    pending = set(range(n))
+    outputs = {}
+    while pending:
+        for r in sorted(pending):
+            p = procs[r]
+            try:
+                o, _ = p.communicate(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            outputs[r] = o
+            if p.returncode != 0 and rc == 0:
+                rc = p.returncode or 1
+        if (rc != 0 or time.monotonic() > deadline) and pending:
+            rc = rc or 124
+            for r in pending:
+                procs[r].terminate()
+            for r in sorted(pending):
+                try:
+                    outputs[r], _ = procs[r].communicate(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    outputs[r], _ = procs[r].communicate()
+            pending.clear()
+    for r in range(1, n):
+        if outputs.get(r):
+            sys.stderr.write(outputs[r])
+    out.write(outputs.get(0) or "")
+    out.flush()
+    return rc
+
+
+def _visible_gpus():
+    """Number of GPUs visible to this process WITHOUT initialising any (device_count() only
+    enumerates on this image; the launcher must not touch the GPU before its children do)."""
+    try:
+        import torch
+
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+# ---------------------------------------------------------------------------------------------
+# workload builders
+# ---------------------------------------------------------------------------------------------
 def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False,
                       prefetch_rng=None, tune_placement=None):
     """Config-3 sampler for `chains` chains starting at global chain id `chain_id0`."""
@@ -52,13 +141,25 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     return s
 
 
+def source_hash(path=None):
+    """Hash of the kick+drift kernel's source text (the region of bk_integrator.hip between its
+    section marker and the next kernel), so that edits elsewhere in the file do not stale the stamp."""
+    with open(path or KD_SOURCE, "r") as f:
+        text = f.read()
+    a = text.find("// ---- fused kick + drift")
+    b = text.find("// any layout of the gradient")
+    region = text[a:b] if 0 <= a < b else text
+    return hashlib.sha256(region.encode()).hexdigest()[:16]
+
+
 def _pmc_traffic(C, D):
-    """HBM bytes per kick+drift launch from the committed PMC passes (rocprofv3 cannot run
-    inside this process); None if the profile is for another shape."""
+    """HBM bytes per kick+drift launch from the committed PMC passes (rocprofv3 cannot run inside
+    this process).  The file is stamped with the hash of the kernel's source file when the passes
+    were taken: None if the kernel source has changed since, or the profile is for another shape."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_cfg3_traffic.json")) as f:
+        with open(TRAFFIC_FILE) as f:
             t = json.load(f)
-        if t["chains"] == C and t["dims"] == D:
+        if t["chains"] == C and t["dims"] == D and t.get("source_sha256_16") == source_hash():
             return t["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -68,8 +169,6 @@ def _pmc_traffic(C, D):
 def cpu_baseline(seconds_hint=12.0):
     """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler
     object per chain, chains spread over P processes, config-3 shape, bounded sample."""
-    import subprocess
-
     P = max(1, min(os.cpu_count() or 1, 32))
     chains_per_proc, draws = 8, 400  # 8*400*64 = 205k leapfrog steps per process (~1.5 s each)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
@@ -121,139 +220,218 @@ def _device_index(local_rank):
     return local_rank
 
 
-def run_other_config(args, rank, local_rank, world):
-    """Secondary workloads (parity-test configs of BASELINE.json), not the headline line:
-    --config 2: iso-Gaussian D=128, HMC L=32, 4096 chains (cache-resident, launch-bound);
-    --config 4: Neal's funnel D=101, DRGHMC K=3, 32,768 chains per GPU + R-hat / ESS."""
-    import torch
-    import torch.distributed as dist
+class RankContext:
+    """Device, process group and barrier of one rank."""
 
-    import bayes_kit_amd as bk
+    def __init__(self, rank, local_rank, world):
+        import torch
+        import torch.distributed as dist
 
-    local_rank = _device_index(local_rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        if os.environ.get("BK_BENCH_SHARE_GPU"):
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            bk.dist.init_from_env()
-
-    def barrier():
+        self.rank, self.world = rank, world
+        self.shared_gpu = bool(os.environ.get("BK_BENCH_SHARE_GPU")) and world > 1
+        self.local = _device_index(local_rank)
+        torch.cuda.set_device(self.local)
+        self.device = torch.device("cuda", self.local)
+        self.backend = None
         if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.shared_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=self.device)
+            self.backend = dist.get_backend()
+
+    def barrier(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.config == 2:
-        C, D, L = args.chains or 4096, 128, 32
+    def max_over_ranks(self, seconds):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.shared_gpu else self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed_loop(self, fn, steps):
+        """EXACTLY `steps` calls of fn bracketed by barrier + synchronize; max over ranks."""
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        import torch.distributed as dist
+
+        if self.world > 1:
+            dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# secondary workloads (the other BASELINE.json configs), each a few draws
+# ---------------------------------------------------------------------------------------------
+def bench_cfg2(ctx, steps=60, warmup=6, chains=4096):
+    """configs[1]: iso-Gaussian D=128, HMC L=32, 4096 chains: arrays of 4 MiB, cache-resident and
+    launch/latency-bound.  Model-opaque (separate gradient op, hipGraph replay) and fused."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    C, D, L = chains, 128, 32
+    res = {"workload": "BASELINE.json configs[1]: iso-Gaussian D=128, HMC L=32 eps=0.05, 4096 chains", "bound": "launch/latency",
+           "note": "4 MiB arrays live in L2 / Infinity Cache: an HBM fraction is not meaningful; us per leapfrog step "
+                   "of all chains is the figure"}
+    for name, fused in (("model_opaque", False), ("fused_builtin", True)):
         s = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
-                       chains=C, chain_id0=rank * C, graph=False if args.no_graph else None)
-        for _ in range(args.warmup):
+                       chains=C, chain_id0=ctx.rank * C, fuse_builtin=fused)
+        for _ in range(warmup):
             s.sample()
-        barrier()
+        el = ctx.timed_loop(s.sample, steps)
+        res[name] = {"us_per_leapfrog_step": 1e6 * el / steps / L, "ms_per_draw": 1e3 * el / steps,
+                     "steps_per_sec": C * ctx.world * L * steps / el, "accept_rate": s.accept_rate(),
+                     "hipgraph": bool(s._use_graph)}
+        del s
+    return res
+
+
+def bench_cfg4(ctx, draws=40, warmup=3, chains=32768):
+    """configs[3]: Neal's funnel D=101, DRGHMC K=3, 32,768 chains per GPU + R-hat / ESS."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    C, D = chains, 101
+    s = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, chain_id0=ctx.rank * C,
+                      seed=20242)
+    mom = bk.RunningMoments(D, C)
+    rec = bk.DrawRecorder([0, 1, D - 1], draws, C)
+    for _ in range(warmup):
+        s.sample()
+    state = {"lane_steps": 0}
+
+    def one():
+        th, lp = s.sample()
+        state["lane_steps"] += s.last_lane_steps
+        mom.update(s._theta_dc)
+        rec.record(th, lp)
+
+    el = ctx.timed_loop(one, draws)
+    lane_steps = state["lane_steps"]
+    if hasattr(lane_steps, "item"):
+        lane_steps = float(lane_steps.item())
+    rh = mom.rhat()
+    ess = rec.ess()
+    ess = torch.where(ess > 0, ess, torch.full_like(ess, float(draws))).clamp(max=float(draws)).min(dim=0).values
+    ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), ctx.device)
+    lane_total = bk.dist.sum_over_ranks(float(lane_steps), ctx.device)
+    flop_per_eval = 13.0 * D  # see DESIGN.md section 3: funnel gradient + kick + drift, per chain-step
+    return {"workload": "BASELINE.json configs[3]: Neal's funnel D=101, DRGHMC K=3 eps=(0.2,0.05,0.0125) L=(10,40,160) "
+                        "damping 0.1, 32,768 chains per GPU, Welford R-hat over all dims + ESS of 3 dims and logp",
+            "bound": "fp64 VALU + exp latency (state register-resident inside a proposal; 26 MB arrays are cache-resident)",
+            "ms_per_draw": 1e3 * el / draws, "draws_per_sec": C * ctx.world * draws / el,
+            "grad_evals_per_sec": lane_total / el, "mean_grad_evals_per_draw": lane_total / (C * ctx.world * draws),
+            "fp64_tflops": lane_total * flop_per_eval / el / 1e12, "flop_model": "13*D flop per gradient evaluation",
+            "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "draws": draws,
+            "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False))}
+
+
+def bench_mala(ctx, draws=12, warmup=3, chains=C_CFG3):
+    """MALA at config-3 shape: 88*D algorithmic bytes per chain-draw."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    C, D = chains, D_CFG3
+    lam = torch.logspace(0, 4, D, dtype=torch.float64)
+    s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, chain_id0=ctx.rank * C, seed=7)
+    s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(ctx.device)[:, None])
+    s.refresh_cache() if hasattr(s, "refresh_cache") else None
+    for _ in range(warmup):
+        s.sample()
+    el = ctx.timed_loop(s.sample, draws)
+    per = el / draws
+    return {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), model-opaque gradient op",
+            "bound": "hbm", "ms_per_draw": 1e3 * per, "draws_per_sec": C * ctx.world / per,
+            "algorithmic_bytes_per_chain_draw": 88 * D, "achieved": 88.0 * D * C / per / 1e9, "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": 88.0 * D * C / per / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate(),
+            "path": getattr(s, "path", None), "placement": s.placement}
+
+
+def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
+    """Config-3 workload with the gradient supplied by user PyTorch code through autograd."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    C, D, L = chains, D_CFG3, L_CFG3
+    lam = torch.logspace(0, 4, D, dtype=torch.float64, device=ctx.device)
+    model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), D)
+    s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
+                   metric_diag=torch.ones(D, dtype=torch.float64), tune_placement=False)
+    s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
+    for _ in range(warmup):
+        s.sample()
+    el = ctx.timed_loop(s.sample, draws)
+    per = el / draws
+    return {"workload": "config-3 shape, gradient = torch autograd of a user log density (TorchModel)",
+            "bound": "hbm (the model's own temporaries and extra passes, not the integrator)",
+            "ms_per_draw": 1e3 * per, "steps_per_sec": C * ctx.world * L / per,
+            "path_hbm_frac_56D_model": C * L / per * 56.0 * D / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate()}
+
+
+def run_secondary(ctx, which):
+    import torch
+
+    table = {"cfg2": bench_cfg2, "cfg4": bench_cfg4, "mala": bench_mala, "torch_model": bench_torch_model}
+    out = {}
+    for name in which:
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            s.sample()
-        barrier()
-        el = time.perf_counter() - t0
-        out = {"metric": "leapfrog steps/sec, iso-Gaussian D=128 x 4096 chains per GPU, HMC L=32", "value": C * world * L * args.steps / el,
-               "unit": "leapfrog steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": 1e3 * el / args.steps, "us_per_leapfrog_step": 1e6 * el / args.steps / L,
-               "accept_rate": s.accept_rate(), "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[1]", "chains_per_gpu": C, "dims": D, "leapfrog_steps": L},
-               "note": "4 MiB arrays: cache-resident and launch-bound; HBM fraction not meaningful"}
-    else:
-        C, D = args.chains or 32768, 101
-        s = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, chain_id0=rank * C,
-                          seed=20242)
-        mom = bk.RunningMoments(D, C)
-        N = args.steps
-        rec = bk.DrawRecorder([0, 1, D - 1], N, C)
-        for _ in range(args.warmup):
-            s.sample()
-        lane_steps = 0
-        barrier()
-        t0 = time.perf_counter()
-        for n in range(N):
-            th, lp = s.sample()
-            lane_steps += s.last_lane_steps
-            mom.update(s._theta_dc)
-            rec.record(th, lp)
-        barrier()
-        el = time.perf_counter() - t0
-        rh = mom.rhat() if N >= 2 else torch.full((D,), float("nan"))
-        if N >= 4:  # the reference's estimator needs 4 draws (ess.py:67-68)
-            ess = rec.ess()
-            ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N)).min(dim=0).values
-            ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), device)
-        else:
-            ess_total = None
-        lane_total = bk.dist.sum_over_ranks(float(lane_steps), device)
-        out = {"metric": "DRGHMC funnel D=101 K=3: gradient evaluations/sec (chain-steps actually run)",
-               "value": lane_total / el, "unit": "gradient evaluations/sec", "n_gpus": world, "steps": N,
-               "warmup": args.warmup, "ms_per_step": 1e3 * el / N, "draws_per_sec": C * world * N / el,
-               "mean_grad_evals_per_draw": lane_total / (C * world * N), "rhat_max": float(rh.max()) if N >= 2 else None,
-               "rhat_v": float(rh[0]) if N >= 2 else None,
-               "ess_per_sec": None if ess_total is None else ess_total / el, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[3]", "chains_per_gpu": C, "dims": D, "max_proposals": 3}}
-    out.update({"higher_is_better": True, "scaling": "weak", "vs_baseline": None})
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+        try:
+            out[name] = table[name](ctx)
+        except Exception as e:  # a secondary figure must never cost the headline line
+            out[name] = {"error": repr(e)}
+        out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: the config's)")
-    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4],
-                    help="3 = headline (default); 2 and 4 = secondary workloads")
-    ap.add_argument("--chain-tile", type=int, default=None,
-                    help="chains per Infinity-Cache tile (default: no tiling)")
-    ap.add_argument("--no-graph", action="store_true", help="config 2: eager launches instead of hipGraph replay")
-    ap.add_argument("--no-rng-prefetch", action="store_true",
-                    help="generate each draw's randomness in line instead of on the side stream (experiments)")
-    ap.add_argument("--no-placement-tuning", action="store_true",
-                    help="keep the scratch arrays in the roles they were allocated for (experiments)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--no-fused-extra", action="store_true")
-    ap.add_argument("--ess-draws", type=int, default=50, help="extra draws for the ESS/sec figure (0 = skip)")
-    args = ap.parse_args()
-
+# ---------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-        args.gpus = world
-
-    if args.config != 3:
-        return run_other_config(args, rank, local_rank, world)
-    args.chains = args.chains or 65536
+    args.gpus = world
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.only is None:
         cpu = cpu_baseline()  # before the GPU is initialised (worker processes never touch it)
 
     import torch
-    import torch.distributed as dist
 
-    local_rank = _device_index(local_rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("BK_BENCH_SHARE_GPU"):
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    import bayes_kit_amd as bk
 
-    C = args.chains
+    ctx = RankContext(rank, local_rank, world)
+    device = ctx.device
+
+    if args.only is not None:  # one secondary workload on its own (profiling runs)
+        out = run_secondary(ctx, [args.only])[args.only]
+        out.update({"n_gpus": world, "secondary_only": args.only})
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        ctx.close()
+        return
+
+    C = args.chains or C_CFG3
     D, L = D_CFG3, L_CFG3
     s = make_cfg3_sampler(C, rank * C, device, chain_tile=args.chain_tile,
                           prefetch_rng=False if args.no_rng_prefetch else None,
@@ -261,27 +439,12 @@ def main():
     Ct = s._chain_tile
     ops = s._ops
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         s.sample()
     if not args.no_kernel_events:
         ops.timed = {"bk_leapfrog_kick_drift": [], "bk_target_diag_gaussian_grad": []}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s.sample()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = ctx.timed_loop(s.sample, args.steps)
     timed, ops.timed = ops.timed, None
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
     accept = s.accept_rate()
 
     total_steps = float(C) * world * L * args.steps
@@ -310,6 +473,10 @@ def main():
             "chains_per_gpu": C, "dims": D, "leapfrog_steps": L, "parallelism": f"chains sharded x{world}",
             "chain_tile": Ct,
         },
+        "comm_backend": ctx.backend,
+        "rccl_ranks": world if ctx.backend == "nccl" else 0,
+        "shared_gpu": ctx.shared_gpu,
+        "value_weak": value,
         "accept_rate": accept,
         "placement": s.placement,  # which allocation plays which role was chosen by timing (HMCDiag._tune_placement)
         # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
@@ -353,24 +520,24 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             out["roofline"]["device_copy_GBps"] = 10 * 2.0 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        except Exception as e:  # context only
+        except Exception:  # context only
             out["roofline"]["device_copy_GBps"] = None
     if args.ess_draws > 0:
         try:
             # Second half of BASELINE.json's metric: ESS/sec.  Extra draws (outside the timed region
             # above), three tracked coordinates + the returned log density, ESS by the reference's
             # estimator (ess.py:52-69 -> bk_ess), summed over chains of the per-chain minimum.
-            import bayes_kit_amd as bk
-
             N = args.ess_draws
             series = torch.empty((4, N, C), dtype=torch.float64, device=device)
-            barrier()
-            t0 = time.perf_counter()
-            for n in range(N):
+            it = {"n": 0}
+
+            def one():
                 th, lp = s.sample()
+                n = it["n"]
                 series[0, n], series[1, n], series[2, n], series[3, n] = th[:, 0], th[:, D // 2], th[:, D - 1], lp
-            barrier()
-            eel = time.perf_counter() - t0
+                it["n"] = n + 1
+
+            eel = ctx.timed_loop(one, N)
             ess = torch.stack([bk.ess(series[i]) for i in range(4)])
             # the reference's estimator returns N/IAT with IAT <= 0 possible for antithetic chains
             # (iat.py:151-152); for a throughput figure each series counts as at most N draws
@@ -385,24 +552,41 @@ def main():
             del series
         except Exception as e:
             out["ess"] = {"error": repr(e)}
+    del s
+    torch.cuda.empty_cache()
+
+    # Strong scaling: the same metric with 65,536 chains per NODE (65,536 / N per GPU).  At N = 1 it
+    # is the headline run itself.  At N = 8 each GPU holds 8,192 chains = 64 MiB arrays, which live
+    # in the Infinity Cache: a different regime from the HBM-bound weak figure, reported beside it.
+    if world == 1 or args.no_strong:
+        out["value_strong"] = value if world == 1 else None
+    else:
+        try:
+            first, n = bk.dist.shard(C_CFG3, rank, world)
+            n -= n % 2
+            ss = make_cfg3_sampler(n, first, device)
+            for _ in range(args.warmup):
+                ss.sample()
+            sel = ctx.timed_loop(ss.sample, args.steps)
+            out["value_strong"] = float(C_CFG3) * L * args.steps / sel
+            out["strong"] = {"chains_per_gpu": n, "chains_per_node": C_CFG3, "ms_per_step": 1e3 * sel / args.steps,
+                             "hipgraph": bool(ss._use_graph)}
+            del ss
+            torch.cuda.empty_cache()
+        except Exception as e:
+            out["value_strong"] = None
+            out["strong"] = {"error": repr(e)}
+
     if not args.no_fused_extra:
         try:
             # Separately reported (never priced on the 56*D model): the same workload through the
             # built-in target's register-resident trajectory kernel (bk_hmc_trajectory_gaussian).
             # Same results bit for bit; bound by the fp64 vector rate and by the per-draw RNG.
-            del s
-            torch.cuda.empty_cache()
             f = make_cfg3_sampler(C, rank * C, device, fused=True)
-            ops.timed = {"bk_hmc_trajectory_gaussian": []}
             for _ in range(2):
                 f.sample()
             ops.timed = {"bk_hmc_trajectory_gaussian": []}
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                f.sample()
-            barrier()
-            fel = time.perf_counter() - t0
+            fel = ctx.timed_loop(f.sample, args.steps)
             tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_trajectory_gaussian"]]
             ops.timed = None
             tj_ms = sum(tj) / len(tj)
@@ -410,20 +594,69 @@ def main():
             out["fused_builtin"] = {
                 "what": "built-in DiagGaussian, whole trajectory in registers; NOT the model-opaque path, reported "
                         "separately from `value`",
-                "value": float(C) * L * args.steps / fel, "unit": "leapfrog steps/sec (this rank)",
-                "ms_per_step": 1e3 * fel / args.steps,
+                "value": float(C) * world * L * args.steps / fel, "unit": "leapfrog steps/sec (whole job)",
+                "ms_per_step": 1e3 * fel / args.steps, "bound": "fp64 VALU (no FMA: bit parity)",
                 "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,
-                "fp64_vector_peak_tflops_spec": 78.6,
+                "trajectory_kernel_frac_of_no_fma_ceiling": flop / (tj_ms * 1e-3) / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2),
+                "draw_tflops_fp64": flop / (fel / args.steps) / 1e12,
+                "fp64_vector_peak_tflops_spec": FP64_VECTOR_PEAK_TFLOPS,
                 "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3",
             }
+            del f
+            torch.cuda.empty_cache()
         except Exception as e:  # the extra must never cost the headline line
+            ops.timed = None
             out["fused_builtin"] = {"error": repr(e)}
+    if world == 1 and not args.no_secondary:
+        out["secondary"] = run_secondary(ctx, ["cfg2", "cfg4", "mala", "torch_model"])
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    ctx.close()
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: 65,536)")
+    ap.add_argument("--only", choices=["cfg2", "cfg4", "mala", "torch_model"], default=None,
+                    help="run ONE secondary workload alone and print its record (profiling runs)")
+    ap.add_argument("--chain-tile", type=int, default=None,
+                    help="chains per Infinity-Cache tile (default: no tiling)")
+    ap.add_argument("--no-rng-prefetch", action="store_true",
+                    help="generate each draw's randomness in line instead of on the side stream (experiments)")
+    ap.add_argument("--no-placement-tuning", action="store_true",
+                    help="keep the scratch arrays in the roles they were allocated for (experiments)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-fused-extra", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' records (N=1 only)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N>1 only)")
+    ap.add_argument("--ess-draws", type=int, default=50, help="extra draws for the ESS/sec figure (0 = skip)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher: start the ranks before anything in this process touches the GPU
+        extra = {}
+        have = _visible_gpus()
+        if have < args.gpus and not os.environ.get("BK_BENCH_SHARE_GPU"):
+            if have == 0:
+                sys.exit("bench.py needs a GPU: none visible")
+            extra["BK_BENCH_SHARE_GPU"] = "1"
+            sys.stderr.write(f"bench.py: {have} GPU(s) visible for {args.gpus} ranks: ranks share them and rendezvous "
+                             "over gloo (code-path exercise, not a measurement)\n")
+        child = [sys.executable, os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+        sys.exit(launch_ranks(args.gpus, child, extra))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: using {world}\n")
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -78,6 +78,26 @@ def main():
                                     bk.metropolis_kernel(0.4), seed=21, group=solo_group, ops=ops)
     solo.run()
     assert np.array_equal(np.concatenate(parts, axis=0), solo.thetas.numpy())
+    # 6) uneven shards (dist.shard gives the remainder to the first ranks): 7 chains = 4 + 3,
+    #    11 particles = 6 + 5; the collectives must not assume equal widths
+    f6, n6 = bk.dist.shard(7)
+    assert (f6, n6) == ((0, 4) if rank == 0 else (4, 3))
+    x7 = torch.from_numpy(np.ascontiguousarray(rk[f6:f6 + n6].T))
+    want7 = od.rank_normalized_rhat([rk[c] for c in range(7)])
+    np.testing.assert_allclose(bk.rank_normalized_rhat(x7, ops=ops), want7, rtol=1e-12)
+    np.testing.assert_allclose(bk.rhat(x7, ops=ops), od.rhat([rk[c] for c in range(7)]), rtol=1e-12)
+    M_odd = 11
+    init_o = np.random.default_rng(5).normal(size=(M_odd, Dp))
+    f7, n7 = bk.dist.shard(M_odd)
+    smc_o = bk.TemperedLikelihoodSMC(bk.TorchPriorLikelihoodModel(lp_fn, ll_fn, Dp), n7, 4, init_o[f7:f7 + n7],
+                                     bk.metropolis_kernel(0.4), seed=22, slot_id0=f7, ops=ops)
+    smc_o.run()
+    parts_o = [None, None]
+    dist.all_gather_object(parts_o, smc_o.thetas.numpy().copy())
+    solo_o = bk.TemperedLikelihoodSMC(bk.TorchPriorLikelihoodModel(lp_fn, ll_fn, Dp), M_odd, 4, init_o,
+                                      bk.metropolis_kernel(0.4), seed=22, group=solo_group, ops=ops)
+    solo_o.run()
+    assert np.array_equal(np.concatenate(parts_o, axis=0), solo_o.thetas.numpy())
     total = bk.dist.sum_over_ranks(float(n))
     assert total == C
     dist.barrier()

@@ -11,7 +11,7 @@ def test_cli_help_and_defaults():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True,
                          timeout=120)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--config"):
+    for flag in ("--gpus", "--steps", "--warmup", "--only"):
         assert flag in out.stdout
 
 
@@ -24,12 +24,50 @@ def test_cpu_baseline_worker_is_the_oracle_and_reports_steps():
     assert r["steps"] == 2 * 3 * 4 and r["seconds"] > 0
 
 
-def test_committed_traffic_matches_the_algorithmic_bytes():
+def test_committed_traffic_matches_the_algorithmic_bytes(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
 
     t = bench._pmc_traffic(65536, 1024)
-    assert t is not None
+    assert t is not None  # the committed PMC passes are for the kernel source as it stands
     algorithmic = 40.0 * 1024 * 65536
     assert abs(t / algorithmic - 1.0) < 0.02  # PMC traffic == algorithmic bytes (no re-reads)
     assert bench._pmc_traffic(4096, 128) is None
+    # the figure is tied to the kernel's source text: any edit of the kernel nulls it
+    src = open(bench.KD_SOURCE).read()
+    edited = tmp_path / "bk_integrator.hip"
+    edited.write_text(src.replace("double t = has_m ? m * g : g;", "double t = has_m ? g * m : g;"))
+    assert bench.source_hash(str(edited)) != bench.source_hash()
+    monkeypatch.setattr(bench, "KD_SOURCE", str(edited))
+    assert bench._pmc_traffic(65536, 1024) is None
+
+
+def test_launcher_starts_one_process_per_rank_and_relays_rank0(capsys):
+    # bench.py --gpus N without WORLD_SIZE: the launcher path (no GPU involved: a rank stub over gloo)
+    sys.path.insert(0, ROOT)
+    import io
+
+    import bench
+
+    stub = [sys.executable, os.path.join(ROOT, "tests", "bench_rank_stub.py")]
+    buf = io.StringIO()
+    rc = bench.launch_ranks(2, stub + ["ok"], {"OMP_NUM_THREADS": "1"}, timeout=240, out=buf)
+    assert rc == 0
+    r = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert r == {"n_gpus": 2, "max_over_ranks": 2.0, "backend": "gloo"}
+    assert "rank 1 done" in capsys.readouterr().err  # other ranks' output goes to stderr
+    # a failing rank fails the launch and the other rank is not left hanging in the rendezvous
+    buf = io.StringIO()
+    rc = bench.launch_ranks(2, stub + ["fail1"], {"OMP_NUM_THREADS": "1"}, timeout=240, out=buf)
+    assert rc == 3
+
+
+def test_bench_refuses_multi_gpu_launch_without_any_gpu():
+    # on a box with no GPU the launcher must say so instead of spawning ranks that cannot run
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    import torch
+
+    if torch.cuda.device_count() == 0:
+        assert out.returncode != 0 and "needs a GPU" in out.stderr
