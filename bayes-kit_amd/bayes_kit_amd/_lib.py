@@ -51,6 +51,8 @@ SIGNATURES = {
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
     "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
+    "bk_mala_step_supported": [I, I, I],
+    "bk_mala_step": [P, P, P, P, P, I, P, P, P, P, I, F, F, P, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
@@ -306,6 +308,24 @@ class Ops:
         assert _ld(grad) == ld and _ld(theta_prop) == ld and _ld(grad_prop) == ld
         self._call("bk_mala_logq", ptr(theta), ptr(grad), ptr(theta_prop), ptr(grad_prop), ld, eps,
                    ptr(lp_forward), ptr(lp_reverse), C, D, self._s())
+
+    def mala_step_supported(self, C, D, ld):
+        return bool(self.lib.bk_mala_step_supported(C, D, ld))
+
+    def mala_step(self, theta, theta_out, grad, theta_prop, grad_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps,
+                  mask, ret, count):
+        """Proposal densities + accept + select (+ the next proposal from the chain-major normals
+        zt_next[c, :D], or None) in one pass; theta_out may be theta itself."""
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(theta_out) == ld and _ld(grad) == ld and _ld(theta_prop) == ld and _ld(grad_prop) == ld
+        ldz = 0
+        if zt_next is not None:
+            assert zt_next.shape[0] == C and zt_next.stride(1) == 1 and zt_next.shape[1] >= D
+            ldz = zt_next.stride(0)
+        self._call("bk_mala_step", ptr(theta), ptr(theta_out), ptr(grad), ptr(theta_prop), ptr(grad_prop), ld,
+                   ptr(lp), ptr(lp_prop), ptr(log_u), ptr(zt_next), ldz, eps, sqrt2eps, ptr(mask), ptr(ret),
+                   ptr(count), C, D, self._s())
 
     # -- built-in targets -----------------------------------------------------------------------
     def target_grad(self, kind, params, theta, grad, logp):

@@ -4,12 +4,27 @@ Per draw and chain: theta' = (theta + eps*grad) + sqrt(2 eps) z   [mala.py:41-45
 one gradient call at theta' [:46-48]; forward / reverse proposal densities [:50-53,68-79];
 Metropolis-Hastings accept with strict ``<`` [metropolis.py:70-76]; (logp, grad) of the
 current point are cached [mala.py:31-32,62-64]; the MODEL log density is returned [:66].
+
+Two ways through the device:
+
+* **two-pass** (many chains, Philox streams, 32 <= D <= 1024): a draw is the model's gradient op
+  plus ONE kernel (``bk_mala_step``) that keeps a block of 16 chains x all dimensions on chip
+  between the per-chain sums and the select, and also writes the NEXT draw's proposal from
+  normals generated ahead on a side stream -- 88*D bytes of HBM traffic per chain-draw.  The
+  state array is rebound every draw, as the reference rebinds ``_theta`` (mala.py:62): the
+  tensor ``sample()`` returns IS the new state and is never written again.
+* **step by step** (everything else: a single-chain host model, PCG64 streams, odd shapes):
+  proposal, gradient, proposal densities, accept and select as separate kernels.
+
+Both consume each chain's stream in the reference's order (D normals, then one uniform) and give
+the same draws bit for bit.
 """
 from __future__ import annotations
 
 import math
 from typing import Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -19,7 +34,7 @@ from ._engine import ManyChainSampler
 class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
                  chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None,
-                 tune_placement: Optional[bool] = None, ops=None):
+                 tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph)
@@ -39,9 +54,7 @@ class MALA(ManyChainSampler):
         self._draws = 0
         # As in HMCDiag: the D proposal normals and the accept uniform of draw n+1 do not depend
         # on draw n and are consumed in a fixed order (mala.py:44 then metropolis.py:74), so they
-        # are generated on a second HIP stream under draw n's HBM-bound kernels; the proposal
-        # then is a pure elementwise kernel.  (At a quarter of a MALA draw the generator only
-        # partly hides: DESIGN.md section 3, tools/overlap_probe.py.)
+        # are generated on a second HIP stream under draw n's HBM-bound kernels.
         # Under hipGraph replay the generation can be a parallel branch of the draw's graph (explicit
         # prefetch_rng=True; slower than one serial graph, see HMCDiag, so not the default).
         if prefetch_rng is None:
@@ -49,9 +62,17 @@ class MALA(ManyChainSampler):
         self._prefetch = bool(prefetch_rng) and self._batched
         self._pf_slot, self._pf_ready, self._pf_event = 0, False, None
         # Philox streams: the normals come from the wavefront-per-chain generator, chain-major
-        # (zt[c, d]); the proposal kernel turns them through LDS.  Otherwise (PCG64 host-seeded
+        # (zt[c, d]); the consuming kernel turns them through LDS.  Otherwise (PCG64 host-seeded
         # single chains, tiny D): one lane per chain, normals in the state layout.
         self._chain_major = self._rng_kind == _lib.RNG_PHILOX and D >= 32
+        ld = self._theta_dc.stride(0) if D > 1 else C
+        can_two_pass = (self._batched and self._chain_major and not (self._use_graph and self._prefetch)
+                        and self._ops.mala_step_supported(C, D, ld))
+        if two_pass and not can_two_pass:
+            raise ValueError("two_pass=True needs a batched model, Philox streams, 32 <= D <= 1024 and an even number "
+                             "of chains (and not hipGraph replay together with prefetch_rng)")
+        self._two_pass = can_two_pass if two_pass is None else bool(two_pass)
+        self.path = "two-pass (bk_mala_step)" if self._two_pass else "step-by-step"
         nbuf = 2 if self._prefetch else 1
         if self._chain_major:
             dp = (D + 7) // 8 * 8
@@ -59,20 +80,39 @@ class MALA(ManyChainSampler):
             self._z_bufs = [zt[:, :D].t() for zt in self._zt_bufs]
         elif self._prefetch:
             self._z_bufs = [torch.empty((D, C), **f64) for _ in range(2)]
+        if self._prefetch or self._two_pass:
+            self._logu_bufs = [torch.empty(C, **f64) for _ in range(nbuf)]
         if self._prefetch:
-            self._logu_bufs = [torch.empty(C, **f64) for _ in range(2)]
             self._side = torch.cuda.Stream(device=dev)
             self._rng_logical = self._rng_state.clone()
+        # two-pass pipeline: theta_p holds the proposal of the NEXT draw (made by the previous
+        # draw's kernel from normals generated one draw ahead).  A generation unit is
+        # (U_n, Z_{n+1}): the accept uniform of draw n, then the D normals of draw n+1 -- stream
+        # order.  The LOGICAL stream position after draw n lies inside unit n (after U_n): it is
+        # snapshotted there, per double-buffer slot.
+        self._pipe_valid = False   # theta_p is the proposal of the next draw
+        self._unit_ready = False   # slot _pf_slot holds the next draw's unit (prefetch)
+        self._cur_slot = 0         # slot whose unit the last draw consumed
+        if self._two_pass:
+            self._snap = [torch.empty_like(self._rng_state) for _ in range(nbuf)]
         self.placement = None
-        if self._wants_placement_tuning(tune_placement):
+        if self._wants_placement_tuning(tune_placement) and not self._two_pass:
             self._tune_placement()
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
     def refresh_cache(self):
         """Recompute the cached (logp, grad) of the current point (mala.py:31-32) after ``_theta`` was
-        assigned or edited from outside, as the reference's constructor does for ``init``."""
+        assigned or edited from outside, as the reference's constructor does for ``init``; a proposal
+        made ahead from the old point is discarded (its normals are drawn again, same values)."""
+        self._invalidate_pipe(restore_stream=True)
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+
+    def _invalidate_pipe(self, restore_stream):
+        if self._two_pass and self._pipe_valid and restore_stream:
+            self._rng_state.copy_(self._logical_rng())  # un-consume what was generated ahead
+        self._pipe_valid, self._unit_ready, self._pf_event = False, False, None
+        self._drop_graphs()
 
     def _tune_placement(self):
         """Roles (theta', grad, grad') for the proposal, proposal-density and select kernels, which
@@ -101,6 +141,12 @@ class MALA(ManyChainSampler):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
 
     def _logical_rng(self):
+        if self._two_pass:
+            if not self._pipe_valid:
+                return self._rng_state
+            if self._ops.device.type == "cuda":
+                torch.cuda.synchronize()
+            return self._snap[self._cur_slot]
         if self._prefetch and self._pf_ready:
             if self._pf_event is not None:
                 self._pf_event.synchronize()
@@ -108,12 +154,17 @@ class MALA(ManyChainSampler):
         return self._rng_state
 
     def rng_state(self):
-        import numpy as np
-
         return self._logical_rng().cpu().numpy().view(np.uint64)
+
+    def load_state_dict(self, sd):
+        if self._two_pass:
+            # draws handed out earlier alias past state arrays: restore into a fresh one
+            self._theta_dc = torch.empty_like(self._theta_dc)
+        super().load_state_dict(sd)
 
     def _after_load(self):
         self._pf_event, self._pf_slot, self._pf_ready = None, 0, False
+        self._invalidate_pipe(restore_stream=False)  # the stream was just restored to its logical position
 
     # -- hipGraph replay with the generator as a parallel branch (see HMCDiag) -------------------------
     def _graph_key(self):
@@ -169,6 +220,44 @@ class MALA(ManyChainSampler):
         self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
         return self._z_bufs[cur], self._logu_bufs[cur]
 
+    # -- two-pass: generation units (U_n, Z_{n+1}) ------------------------------------------------------
+    def _gen_unit(self, slot):
+        ops = self._ops
+        ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])     # U_n   [metropolis.py:74]
+        self._snap[slot].copy_(self._rng_state)                                     # position after draw n
+        ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)  # Z_{n+1} [mala.py:44]
+
+    def _take_unit(self):
+        """(log u of this draw, chain-major normals of the next); with prefetch also starts the
+        unit after that on the side stream."""
+        if not self._prefetch:
+            self._gen_unit(0)
+            self._cur_slot = 0
+            return self._logu_bufs[0], self._zt_bufs[0]
+        main = torch.cuda.current_stream()
+        cur, nxt = self._pf_slot, 1 - self._pf_slot
+        if not self._unit_ready:
+            self._gen_unit(cur)  # first draw after a (re)start: nothing generated ahead yet
+        elif self._pf_event is not None:
+            main.wait_event(self._pf_event)
+        # slot nxt was last read by the previous draw's kernel, already queued on `main`; the RNG
+        # table is shared, so the side stream also starts after anything generated in line above
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._gen_unit(nxt)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._pf_event, self._pf_slot, self._unit_ready, self._cur_slot = ev, nxt, True, cur
+        return self._logu_bufs[cur], self._zt_bufs[cur]
+
+    # bk_mala_step's workgroups each take a whole CU's register file: next to the generator's
+    # wavefronts they cannot be scheduled, and the two kernels only slow each other down (1.52 ms per
+    # draw at 65,536 x 1024 against 1.3 when the generator overlaps the model's gradient op alone).
+    # With serialize_step the step kernel starts after the generator of the next unit has finished.
+    serialize_step = True
+
     def accept_rate(self) -> float:
         n = self._draws * self._C
         return float(self._accepted.item()) / n if n else float("nan")
@@ -186,9 +275,31 @@ class MALA(ManyChainSampler):
         return self._grad.t() if self._batched else self._grad[:, 0].cpu().numpy()
 
     def sample(self):
-        self._run_draw(self._draw)
+        self._run_draw(self._draw2 if self._two_pass else self._draw)
         self._draws += 1
+        if self._two_pass and not self._use_graph:
+            return self._theta_dc.t(), self._ret.clone()  # the new state array itself (never written again)
         return self._draw_out(self._theta_dc, self._ret)
+
+    def _draw2(self):
+        ops = self._ops
+        eps = float(self._epsilon)
+        s2 = math.sqrt(2 * eps)
+        th, thp = self._theta_dc, self._theta_p
+        if not self._pipe_valid:
+            # this draw's proposal from the stream's next D normals (mala.py:41-45); later draws'
+            # proposals are written by the previous draw's kernel
+            ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[0], self._dim)
+            ops.mala_propose_from_normals(th, self._grad, self._z_bufs[0], thp, eps, s2)
+            self._pipe_valid, self._unit_ready = True, False
+        logu, zt_next = self._take_unit()
+        gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)   # mala.py:46-48
+        out = th if self._use_graph else torch.empty_like(th)
+        if self._prefetch and self.serialize_step and self._pf_event is not None:
+            torch.cuda.current_stream().wait_event(self._pf_event)
+        ops.mala_step(th, out, self._grad, thp, gp, self._lp, self._lp_p, logu, zt_next, eps, s2,
+                      self._mask, self._ret, self._accepted)                                   # mala.py:50-66
+        self._theta_dc = out
 
     def _draw(self):
         ops = self._ops

@@ -343,7 +343,7 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768):
             "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False))}
 
 
-def bench_mala(ctx, draws=12, warmup=3, chains=C_CFG3):
+def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
     """MALA at config-3 shape: 88*D algorithmic bytes per chain-draw."""
     import torch
 

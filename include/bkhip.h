@@ -245,6 +245,33 @@ int bk_mala_logq(const double* theta, const double* grad, const double* theta_pr
                  const double* grad_prop, int64_t ld, double eps, double* lp_forward,
                  double* lp_reverse, int64_t C, int64_t D, void* stream);
 
+/* The rest of a MALA draw in ONE pass over HBM (mala.py:50-66), plus the next draw's proposal
+ * (mala.py:41-45).  A workgroup owns 16 chains x all D dimensions and keeps them on chip (three
+ * arrays in registers, grad_prop in LDS) between the per-chain sums and the select:
+ *     fwd, rev as bk_mala_logq                                   mala.py:50-53, 68-79
+ *     accept[c] = log_u[c] < (lp_prop - lp) + (rev - fwd)        metropolis.py:70-76 (strict <)
+ *     theta_out = accept ? theta_prop : theta                    mala.py:62   (theta_out may be theta)
+ *     grad      = accept ? grad_prop  : grad      (in place)     mala.py:64
+ *     lp        = accept ? lp_prop    : lp        (in place);  ret[c] = the same   mala.py:63, :66
+ *     accept_mask[c], *accept_count += number accepted            (each may be NULL)
+ * and, if zt_next != NULL (chain-major normals zt_next[c*ldz + d] of the NEXT draw, from
+ * bk_normals_chain_major):
+ *     theta_prop = (theta_out + eps*grad) + sqrt2eps * z          mala.py:41-45   (in place)
+ * Every element of theta_out / grad is rewritten (rejected chains with their own values: whole
+ * sectors, no read-modify-write in the memory system).  HBM traffic: 32*D read + 16*D written per
+ * chain, + 8*D read and 8*D written with zt_next -- with the model's gradient op (16*D) and the
+ * generator's write of zt (8*D) a draw moves 88*D bytes per chain.
+ * The per-chain sums run per thread over rows r, r+64, ..., then over a fixed xor tree of the 8
+ * rows of a wavefront, then over the 8 wavefronts in order: an order that depends on D only.
+ * Supported shapes (bk_mala_step_supported): D <= 1024, C and ld even, 16-byte aligned arrays;
+ * otherwise BK_E_ALIGN -- callers then use bk_mala_logq + bk_mh_accept + bk_select_columns. */
+int bk_mala_step_supported(int64_t C, int64_t D, int64_t ld);
+int bk_mala_step(const double* theta, double* theta_out, double* grad, double* theta_prop,
+                 const double* grad_prop, int64_t ld, double* lp, const double* lp_prop,
+                 const double* log_u, const double* zt_next, int64_t ldz, double eps,
+                 double sqrt2eps, uint8_t* accept_mask, double* ret, uint32_t* accept_count,
+                 int64_t C, int64_t D, void* stream);
+
 /* ---- built-in targets: the "thin C-ABI callback" form of GradModel.log_density_gradient
  * (typing.py:25-27) batched over chains.  grad and/or logp may be NULL (HMC discards lp
  * inside the trajectory, hmc.py:45,50).  Operation order = oracle/models.py.

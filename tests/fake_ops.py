@@ -193,6 +193,39 @@ class FakeOps:
         lp_forward.numpy()[...] = k * sf
         lp_reverse.numpy()[...] = k * sr
 
+    def mala_step_supported(self, C, D, ld):
+        return C % 2 == 0 and ld % 2 == 0 and 0 < D <= 1024
+
+    def mala_step(self, theta, theta_out, grad, theta_prop, grad_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps,
+                  mask, ret, count):
+        self._count("mala_step")
+        th, g, thp, gp = theta.numpy(), grad.numpy(), theta_prop.numpy(), grad_prop.numpy()
+        xf = (thp - th) - eps * g
+        xr = (th - thp) - eps * gp
+        sf = np.zeros(th.shape[1])
+        sr = np.zeros(th.shape[1])
+        for d in range(th.shape[0]):
+            sf = sf + xf[d] * xf[d]
+            sr = sr + xr[d] * xr[d]
+        k = -0.25 / eps
+        l0, l1 = lp.numpy().copy(), lp_prop.numpy()
+        with np.errstate(invalid="ignore"):
+            acc = log_u.numpy() < (l1 - l0) + (k * sr - k * sf)
+        new_th = np.where(acc[None, :], thp, th)
+        new_g = np.where(acc[None, :], gp, g)
+        theta_out.numpy()[...] = new_th
+        grad.numpy()[...] = new_g
+        lp.numpy()[...] = np.where(acc, l1, l0)
+        if ret is not None:
+            ret.numpy()[...] = lp.numpy()
+        if mask is not None:
+            mask.numpy()[...] = acc
+        if count is not None:
+            count += int(acc.sum())
+        if zt_next is not None:
+            D = th.shape[0]
+            theta_prop.numpy()[...] = (new_th + eps * new_g) + sqrt2eps * zt_next.numpy()[:, :D].T
+
     # -- targets ----------------------------------------------------------------------------------
     def target_grad(self, kind, params, theta, grad, logp):
         self._count("target_grad")

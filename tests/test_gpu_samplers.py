@@ -4,7 +4,7 @@ import pytest
 import torch
 
 import bayes_kit_amd as bk
-from tests.sampler_parity import check_many_chain, check_single_chain_host_model
+from tests.sampler_parity import check_checkpoint_resume, check_many_chain, check_single_chain_host_model
 
 pytestmark = pytest.mark.gpu
 
@@ -612,11 +612,118 @@ def test_placement_tuning_is_only_a_choice_of_buffers(ops):
 
 def test_mala_placement_tuning_is_only_a_choice_of_buffers(ops):
     lam = np.logspace(0, 1, 48)
-    a = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=False)
-    b = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=True)
+    a = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=False, two_pass=False)
+    b = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=True, two_pass=False)
     assert a.placement is None and b.placement["assignments_tried"] == bk.MALA.TUNE_PLACEMENT_TRIALS
     for n in range(6):
         ta, la = a.sample()
         tb, lb = b.sample()
         assert torch.equal(ta, tb) and torch.equal(la, lb), n
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+
+
+@pytest.mark.parametrize("C,D", [(2, 32), (34, 33), (130, 129), (64, 200), (600, 513), (48, 1024), (18, 1000), (4096, 128)])
+def test_mala_two_pass_equals_step_by_step(ops, C, D):
+    """bk_mala_step (sums, decision, select and the next proposal in one kernel, state array rebound
+    every draw) against the separate kernels: same draws, same accept masks, same logical stream
+    position after every draw; both RNG schedules."""
+    lam = np.logspace(0, 1.5, D)
+    eps = 0.3 / D
+    for prefetch in (False, True):
+        a = bk.MALA(bk.DiagGaussian(lam), eps, chains=C, seed=77, two_pass=False, prefetch_rng=False, graph=False)
+        b = bk.MALA(bk.DiagGaussian(lam), eps, chains=C, seed=77, two_pass=True, prefetch_rng=prefetch, graph=False)
+        assert b.path.startswith("two-pass") and a.path == "step-by-step"
+        kept = []
+        for n in range(7):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (prefetch, n)
+            assert torch.equal(a.last_accept, b.last_accept)
+            kept.append((tb, tb.clone()))
+            if n in (0, 2, 6):
+                np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        assert 0.05 < a.accept_rate() == b.accept_rate()
+        for t, c in kept:  # returned draws are never written again (the state array is rebound)
+            assert torch.equal(t, c)
+        assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta) and torch.equal(a._log_p_theta, b._log_p_theta)
+
+
+def test_mala_step_kernel_against_its_cpu_statement(ops):
+    """The kernel alone on random inputs (ragged last block, odd D, in-place theta_out, no next
+    proposal) against tests/fake_ops.py's NumPy statement of bk_mala_step."""
+    from tests.fake_ops import FakeOps
+
+    fake = FakeOps()
+    rng = np.random.default_rng(5)
+    for C, D, inplace, with_z in [(34, 33, False, True), (16, 64, True, True), (50, 1000, False, False),
+                                  (300, 257, True, True), (2, 1024, False, True)]:
+        eps = 0.01
+        s2 = float(np.sqrt(2 * eps))
+        th = rng.normal(size=(D, C))
+        g = -th * rng.uniform(0.5, 2.0, size=(D, 1))
+        thp = th + eps * g + s2 * rng.normal(size=(D, C))
+        gp = -thp * rng.uniform(0.5, 2.0, size=(D, 1))
+        lp, lpp, logu = rng.normal(size=C), rng.normal(size=C), np.log(rng.uniform(size=C))
+        dp = (D + 7) // 8 * 8
+        zt = rng.normal(size=(C, dp))
+
+        def run(o, dev):
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+            a = dict(th=t(th), g=t(g), thp=t(thp), gp=t(gp), lp=t(lp), lpp=t(lpp), logu=t(logu), zt=t(zt))
+            out = a["th"] if inplace else torch.full_like(a["th"], float("nan"))
+            mask = torch.zeros(C, dtype=torch.uint8, device=dev)
+            ret = torch.zeros(C, dtype=torch.float64, device=dev)
+            cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+            o.mala_step(a["th"], out, a["g"], a["thp"], a["gp"], a["lp"], a["lpp"], a["logu"],
+                        a["zt"] if with_z else None, eps, s2, mask, ret, cnt)
+            return [x.cpu().numpy() for x in (out, a["g"], a["thp"], a["lp"], ret, mask, cnt)]
+
+        got, want = run(ops, ops.device), run(fake, "cpu")
+        for k, (x, y) in enumerate(zip(got, want)):
+            assert np.array_equal(x, y), (C, D, inplace, with_z, k)
+        assert 0 < int(got[6][0]) < C or C <= 2
+
+
+def test_mala_two_pass_checkpoint_cache_refresh_and_graph(ops):
+    lam = np.logspace(0, 1, 64)
+    make = lambda **kw: bk.MALA(bk.DiagGaussian(lam), 0.01, chains=700, seed=2, two_pass=True, graph=False, **kw)  # noqa: E731
+    check_checkpoint_resume(ops, make)
+    # load_state_dict right after sample(), no synchronisation in between: the generator queued on the
+    # side stream for the next draw must not overwrite the restored stream table
+    a = make()
+    for _ in range(3):
+        a.sample()
+    sd = a.state_dict()
+    want = [a.sample() for _ in range(4)]
+    for _ in range(5):
+        a.sample()
+        a.load_state_dict(sd)
+        for tw, lw in want:
+            tg, lg = a.sample()
+            assert torch.equal(tw, tg) and torch.equal(lw, lg)
+        a.sample()
+    # a state edited from outside + refresh_cache() == a sampler constructed at that state
+    b = make()
+    for _ in range(3):
+        b.sample()
+    th = b._theta.clone() * 0.5
+    b._theta_dc.copy_(th.t())
+    b.refresh_cache()
+    st = b.rng_state().copy()
+    c = make()
+    c._theta_dc.copy_(th.t())
+    c._rng_state.copy_(torch.from_numpy(st.view(np.int64)).to(ops.device))
+    c.refresh_cache()
+    for n in range(4):
+        tb, lb = b.sample()
+        tc, lc = c.sample()
+        assert torch.equal(tb, tc) and torch.equal(lb, lc), n
+    # one serial hipGraph per draw replays the two-pass draw (state updated in place)
+    e = bk.MALA(bk.DiagGaussian(lam), 0.01, chains=700, seed=2, two_pass=True, graph=False, prefetch_rng=False)
+    g = bk.MALA(bk.DiagGaussian(lam), 0.01, chains=700, seed=2, two_pass=True, graph=True)
+    for n in range(8):
+        te, le = e.sample()
+        tg, lg = g.sample()
+        assert torch.equal(te, tg) and torch.equal(le, lg), n
+    assert g._graph is not None
+    np.testing.assert_array_equal(e.rng_state(), g.rng_state())

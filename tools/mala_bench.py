@@ -7,8 +7,10 @@ import bayes_kit_amd as bk
 C, D = int(os.environ.get("C", 65536)), int(os.environ.get("D", 1024))
 lam = torch.logspace(0, 4, D, dtype=torch.float64)
 s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, graph=os.environ.get("GRAPH", "0") == "1",
-            prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None))
+            prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None),
+            two_pass={"0": False, "1": True}.get(os.environ.get("TWO_PASS", ""), None))
 s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(s._theta_dc.device)[:, None])
+s.refresh_cache()
 for _ in range(3):
     s.sample()
 torch.cuda.synchronize(); n = 20
@@ -18,4 +20,4 @@ for _ in range(n):
 torch.cuda.synchronize(); el = (time.perf_counter() - t0) / n
 print(json.dumps({"workload": f"MALA diag Gaussian D={D} x {C} chains", "ms_per_draw": 1e3 * el, "draws_per_sec": C / el,
                   "achieved_GBps_88D_model": 88.0 * D * C / el / 1e9, "frac_of_8TBps": 88.0 * D * C / el / 8e12,
-                  "accept_rate": s.accept_rate()}))
+                  "accept_rate": s.accept_rate(), "path": s.path, "prefetch": s._prefetch}))
