@@ -57,6 +57,7 @@ SIGNATURES = {
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
+    "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
@@ -349,6 +350,19 @@ class Ops:
         assert _ld(theta_out) == ld and _ld(rho_in) == ld and _ld(rho_out) == ld
         self._call("bk_hmc_trajectory_gaussian", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
                    ptr(lam), ptr(metric), eps, steps, C, D, self._s())
+
+    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out):
+        """Trajectory + both kinetic energies + end-point log density of one HMC draw; momentum from
+        rho_in ([D, C]) or from chain-major normals zt ([C, >=D]), exactly one of them."""
+        D, C = theta_in.shape
+        ld = _ld(theta_in)
+        assert _ld(theta_out) == ld and (rho_in is None or _ld(rho_in) == ld) and part.numel() >= 12 * C
+        ldz = 0
+        if zt is not None:
+            assert zt.shape[0] == C and zt.stride(1) == 1 and zt.shape[1] >= D
+            ldz = zt.stride(0)
+        self._call("bk_hmc_draw_gaussian", ptr(theta_in), ptr(theta_out), ld, ptr(rho_in), ptr(zt), ldz, ptr(lam),
+                   ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), C, D, self._s())
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps):

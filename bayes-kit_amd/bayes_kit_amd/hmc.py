@@ -82,9 +82,15 @@ class HMCDiag(ManyChainSampler):
         # built-in separable targets can run the whole trajectory in registers
         # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")
+        # ... and, where the target can also sum the energies along the way (bk_hmc_draw_gaussian),
+        # a draw is: generator, ONE pass over the state (trajectory + kin0 + kin1 + end-point log
+        # density), accept, select.  With Philox streams the momentum is consumed chain-major,
+        # straight from the wavefront-per-chain generator: no transpose, no kinetic-energy pass.
+        self._fused_draw = self._fused and hasattr(model, "bk_hmc_draw")
+        self._fused_zt = self._fused_draw and self._rng_kind == _lib.RNG_PHILOX and self._dim >= 32
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
-        self._rho_bufs = [torch.empty((D, C), **f64)]
+        self._rho_bufs = [None if self._fused_zt else torch.empty((D, C), **f64)]
         self._theta_p = torch.empty((D, C), **f64)
         self._grad = torch.empty((D, C), **f64)      # gradient at the current point
         self._grad_p = torch.empty((D, C), **f64)    # gradient along / at the end of the trajectory
@@ -96,6 +102,11 @@ class HMCDiag(ManyChainSampler):
         self._ret = torch.empty(C, **f64)
         self._mask = torch.empty(C, dtype=torch.uint8, device=dev)
         self._accepted = torch.zeros(1, dtype=torch.int32, device=dev)
+        if self._fused_draw:
+            self._part = torch.empty(12 * C, **f64)    # quarter partials of the three per-chain sums
+        if self._fused_zt:
+            dp = (D + 7) // 8 * 8
+            self._zt_bufs = [torch.empty((C, dp), **f64)]  # (the momentum never exists in the state layout)
         if self._M is not None:
             self._mv = torch.empty((D, C), **f64)      # M @ grad along the trajectory
             self._mv_rng = torch.empty((D, C), **f64)  # M @ rho of the (possibly prefetched) momentum
@@ -117,7 +128,11 @@ class HMCDiag(ManyChainSampler):
         self._pf_event = None       # ... and the event that marks it complete (None: already joined)
         self._pf_kin_stale = False
         if self._prefetch:
-            self._rho_bufs.append(torch.empty((D, C), **f64))
+            if self._fused_zt:
+                self._zt_bufs.append(torch.empty_like(self._zt_bufs[0]))
+                self._rho_bufs.append(None)
+            else:
+                self._rho_bufs.append(torch.empty((D, C), **f64))
             self._kin0_bufs.append(torch.empty(C, **f64))
             self._logu_bufs.append(torch.empty(C, **f64))
             self._side = torch.cuda.Stream(device=dev)
@@ -205,7 +220,7 @@ class HMCDiag(ManyChainSampler):
             self._pf_slot = key
 
     def _refresh_stale_kinetic(self):
-        if self._pf_kin_stale and self._pf_ready:
+        if self._pf_kin_stale and self._pf_ready and not self._fused_draw:
             self._ops.leapfrog_finish(self._rho_bufs[self._pf_slot], None, None, self._metric_dev, 0.0, False,
                                       self._kin0_bufs[self._pf_slot])
         self._pf_kin_stale = False
@@ -230,9 +245,13 @@ class HMCDiag(ManyChainSampler):
     def _randomness(self, slot):
         """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
         ops = self._ops
-        if self._M is None:
+        if self._fused_zt:
+            # D normals, chain-major; their kinetic energy is summed by the draw kernel itself
+            ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)
+        elif self._M is None:
             ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
-                                 self._metric_dev, self._kin0_bufs[slot], None, self._rng_work)
+                                 self._metric_dev, None if self._fused_draw else self._kin0_bufs[slot], None,
+                                 self._rng_work)
         else:
             ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._mv_rng, None, None,
                                  None, self._rng_work)
@@ -260,6 +279,7 @@ class HMCDiag(ManyChainSampler):
 
     def _take_randomness(self):
         """Buffers holding this draw's randomness; with prefetch also starts the next draw's."""
+        self._zt_slot = 0 if not self._prefetch else self._pf_slot
         if not self._prefetch:
             self._randomness(0)
             return self._rho_bufs[0], self._kin0_bufs[0], self._logu_bufs[0]
@@ -312,6 +332,16 @@ class HMCDiag(ManyChainSampler):
         # the next value of the stream whatever happens in between
         rho, kin0, logu = self._take_randomness()
 
+        if self._fused_draw:
+            if not self._have_cache:
+                self._eval_logp(th, self._lp)
+                self._have_cache = True
+            zt = self._zt_bufs[self._zt_slot] if self._fused_zt else None
+            self._model.bk_hmc_draw(th, thp, rho, zt, m, eps, L, self._part, kin0, self._kin1, self._lp_p)  # [hmc.py:56-59]
+            ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
+                          self._mask, self._ret, self._accepted)                                           # [hmc.py:60-63]
+            self._select(self._mask, th, thp)
+            return
         if self._fused:
             if not self._have_cache:
                 self._eval_logp(th, self._lp)

@@ -412,6 +412,95 @@ __global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_s(const double* th_in, 
   rho_out[d * ld + c] = r;
 }
 
+// The same trajectory as the trajectory + energies of a whole HMC draw (hmc.py:55-59): one thread
+// per (chain, QUARTER of the dimensions) walks its quarter in chunks of TQ_ROWS rows -- each chunk
+// is a register-resident trajectory as above -- and accumulates, sequentially in d, the three
+// per-chain sums a draw needs:
+//     kin0 = 1/2 sum rho0*(m*rho0)   [hmc.py:57 -> :37]    (momentum as drawn)
+//     kin1 = 1/2 sum rho1*(m*rho1)   [hmc.py:59 -> :37]    (momentum at the end)
+//     lp1  = -1/2 sum theta1*(lam*theta1)                   (the target's log density at the end)
+// as quarter partials part[k][q][c]; combined ((p0+p1)+p2)+p3 (k_quarter_sums) they are, bit for
+// bit, what bk_leapfrog_finish and bk_target_*_gaussian_grad compute with their four wavefronts
+// per 64 chains -- which is why the walk is per quarter and in d order.  The momentum is read
+// either in the state layout (rho_in) or straight from the wavefront-per-chain generator's
+// chain-major normals (zt[c*ldz + d], rho0 = 0.0 + 1.0*z as numpy's random_normal); the final
+// momentum is never stored (HMC discards it).  HBM traffic: 8 D (theta) + 8 D (momentum) read,
+// 8 D (theta') written per chain -- against 32 D for the trajectory kernel above plus 32 D for
+// the two reductions it replaces.
+constexpr int TQ_ROWS = 8;
+template <bool HL, bool HM, bool ZT>
+__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_q(const double* th_in, double* th_out, const double* rho_in,
+                                                           i64 ld, const double* zt, i64 ldz, const double* lam,
+                                                           const double* metric, double eps, int steps,
+                                                           double* part, i64 C, i64 D) {
+  const i64 c = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
+  const int q = blockIdx.y;
+  if (c >= C) return;
+  const i64 Dq = (D + 3) / 4;
+  const i64 dlo = q * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
+  const double half = 0.5 * eps;
+  double k0 = 0.0, k1 = 0.0, sl = 0.0;
+  for (i64 d0 = dlo; d0 < dhi; d0 += TQ_ROWS) {
+    double th[TQ_ROWS], r[TQ_ROWS], t[TQ_ROWS], l[TQ_ROWS], m[TQ_ROWS];
+#pragma unroll
+    for (int i = 0; i < TQ_ROWS; ++i) {
+      const i64 d = (d0 + i < dhi) ? d0 + i : dhi - 1;  // rows past the end recompute the last one, unused
+      th[i] = th_in[d * ld + c];
+      r[i] = ZT ? 0.0 + 1.0 * zt[c * ldz + d] : rho_in[d * ld + c];
+      l[i] = HL ? lam[d] : 1.0;
+      m[i] = HM ? metric[d] : 1.0;
+    }
+#pragma unroll
+    for (int i = 0; i < TQ_ROWS; ++i) {
+      if (d0 + i < dhi) {
+        const double mv = HM ? m[i] * r[i] : r[i];
+        k0 = k0 + r[i] * mv;
+      }
+      const double g = HL ? -(l[i] * th[i]) : -th[i];
+      t[i] = HM ? m[i] * g : g;
+      r[i] = r[i] + (-half) * t[i];  // hmc.py:46
+    }
+    for (int n = 0; n < steps; ++n) {
+#pragma unroll
+      for (int i = 0; i < TQ_ROWS; ++i) {
+        r[i] = r[i] + eps * t[i];    // hmc.py:48
+        th[i] = th[i] + eps * r[i];  // hmc.py:49
+        const double g = HL ? -(l[i] * th[i]) : -th[i];  // hmc.py:50
+        t[i] = HM ? m[i] * g : g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TQ_ROWS; ++i) {
+      r[i] = r[i] + half * t[i];  // hmc.py:52
+      if (d0 + i < dhi) {
+        th_out[(d0 + i) * ld + c] = th[i];
+        const double mv = HM ? m[i] * r[i] : r[i];
+        k1 = k1 + r[i] * mv;
+        const double lt = HL ? l[i] * th[i] : th[i];
+        sl = sl + th[i] * lt;
+      }
+    }
+  }
+  part[(0 * 4 + q) * C + c] = k0;
+  part[(1 * 4 + q) * C + c] = k1;
+  part[(2 * 4 + q) * C + c] = sl;
+}
+
+__global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double* kin0, double* kin1, double* lp,
+                                                      i64 C) {
+  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double v[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double* p = part + (i64)k * 4 * C + c;
+    v[k] = ((p[0] + p[C]) + p[2 * C]) + p[3 * C];
+  }
+  if (kin0) kin0[c] = 0.5 * v[0];
+  kin1[c] = 0.5 * v[1];
+  lp[c] = -0.5 * v[2];
+}
+
 int gauss(const double* theta, double* grad, double* logp, i64 ld, const double* lam, i64 C, i64 D,
           void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 0) return BK_E_ARG;
@@ -494,6 +583,35 @@ int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const 
     k_traj_gauss_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps,
                                                    (int)steps, C, D);
   }
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in,
+                         const double* zt, int64_t ldz, const double* lam, const double* metric, double eps,
+                         int64_t steps, double* part, double* kin0, double* kin1, double* lp_out, int64_t C,
+                         int64_t D, void* stream) {
+  if (!theta_in || !theta_out || (!rho_in && !zt) || (rho_in && zt) || !part || !kin1 || !lp_out || steps < 0 ||
+      steps > 0x7fffffff || C < 0 || D < 0)
+    return BK_E_ARG;
+  if (ld < C || (zt && ldz < D)) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), 4);
+#define BK_TQ(HL, HM)                                                                                               \
+  do {                                                                                                              \
+    if (zt)                                                                                                         \
+      k_traj_gauss_q<HL, HM, true><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,    \
+                                                                   metric, eps, (int)steps, part, C, D);            \
+    else                                                                                                            \
+      k_traj_gauss_q<HL, HM, false><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,   \
+                                                                    metric, eps, (int)steps, part, C, D);           \
+  } while (0)
+  if (lam && metric) BK_TQ(true, true);
+  else if (lam) BK_TQ(true, false);
+  else if (metric) BK_TQ(false, true);
+  else BK_TQ(false, false);
+#undef BK_TQ
+  k_quarter_sums<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, s>>>(part, kin0, kin1, lp_out, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -580,20 +580,21 @@ def run_rank(args):
     if not args.no_fused_extra:
         try:
             # Separately reported (never priced on the 56*D model): the same workload through the
-            # built-in target's register-resident trajectory kernel (bk_hmc_trajectory_gaussian).
-            # Same results bit for bit; bound by the fp64 vector rate and by the per-draw RNG.
+            # built-in target's register-resident whole-draw kernel (bk_hmc_draw_gaussian: trajectory
+            # + both kinetic energies + end-point log density in one pass over the state, momentum read
+            # chain-major from the generator).  Same results bit for bit; bound by the fp64 vector rate.
             f = make_cfg3_sampler(C, rank * C, device, fused=True)
             for _ in range(2):
                 f.sample()
-            ops.timed = {"bk_hmc_trajectory_gaussian": []}
+            ops.timed = {"bk_hmc_draw_gaussian": []}
             fel = ctx.timed_loop(f.sample, args.steps)
-            tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_trajectory_gaussian"]]
+            tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_draw_gaussian"]]
             ops.timed = None
             tj_ms = sum(tj) / len(tj)
             flop = 6.0 * D * C * L  # 4 mul + 2 add per element-step, individually rounded (no FMA)
             out["fused_builtin"] = {
-                "what": "built-in DiagGaussian, whole trajectory in registers; NOT the model-opaque path, reported "
-                        "separately from `value`",
+                "what": "built-in DiagGaussian, whole draw (trajectory + energies) in registers; NOT the model-opaque "
+                        "path, reported separately from `value`",
                 "value": float(C) * world * L * args.steps / fel, "unit": "leapfrog steps/sec (whole job)",
                 "ms_per_step": 1e3 * fel / args.steps, "bound": "fp64 VALU (no FMA: bit parity)",
                 "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,

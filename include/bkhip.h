@@ -312,6 +312,23 @@ int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const 
                                double* rho_out, int64_t ld, const double* lam, const double* metric,
                                double eps, int64_t steps, int64_t C, int64_t D, void* stream);
 
+/* Trajectory AND energies of one HMC draw (hmc.py:55-59) on the separable Gaussian targets, in
+ * one pass over the state: the trajectory above, plus
+ *     kin0[c]   = 0.5 * sum_d rho0*(metric*rho0)     hmc.py:57 -> :37   (optional, may be NULL)
+ *     kin1[c]   = 0.5 * sum_d rho1*(metric*rho1)     hmc.py:59 -> :37
+ *     lp_out[c] = -0.5 * sum_d theta1*(lam*theta1)   the target's log density at the end point
+ * with the per-chain sums taken exactly as bk_leapfrog_finish / bk_target_*_gaussian_grad take
+ * them (four contiguous quarters of the dimensions, each sequential in d, combined
+ * ((p0+p1)+p2)+p3), so the accept test sees bit-identical energies.  The momentum comes either
+ * in the state layout (rho_in [D][ld]) or chain-major straight from bk_normals_chain_major
+ * (zt[c*ldz + d], rho0 = 0.0 + 1.0*z: `rng.normal(size=D)`, hmc.py:56); exactly one of the two is
+ * given.  The end momentum is not stored (hmc.py:58-63 never uses it again).
+ * part: caller scratch of 12*C doubles.  HBM traffic 24*D bytes per chain. */
+int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in,
+                         const double* zt, int64_t ldz, const double* lam, const double* metric,
+                         double eps, int64_t steps, double* part, double* kin0, double* kin1,
+                         double* lp_out, int64_t C, int64_t D, void* stream);
+
 /* One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) on Neal's funnel in a
  * single launch, gradient callback inlined: chain j of the outputs starts from chain
  * src_index[j] (NULL = j) of the source point (theta_in, rho_in and the source's cached

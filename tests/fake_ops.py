@@ -271,6 +271,29 @@ class FakeOps:
         theta_out.numpy()[...] = th
         rho_out.numpy()[...] = r
 
+    @staticmethod
+    def _quarter_sum(x):
+        """sum over d of x[d, c], sequential in d like this file's other per-chain sums (the HIP
+        kernels sum four contiguous quarters and combine them: the same value to ~1e-16 relative)."""
+        s = np.zeros(x.shape[1])
+        for d in range(x.shape[0]):
+            s = s + x[d]
+        return s
+
+    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out):
+        self._count("hmc_draw_gaussian")
+        D = theta_in.shape[0]
+        r0 = torch.from_numpy(0.0 + 1.0 * zt.numpy()[:, :D].T.copy()) if zt is not None else rho_in
+        r1 = torch.empty_like(theta_in)
+        m = (lambda v: v) if metric is None else (lambda v: metric.numpy()[:, None] * v)
+        if kin0 is not None:
+            kin0.numpy()[...] = 0.5 * self._quarter_sum(r0.numpy() * m(r0.numpy()))
+        self.hmc_trajectory_gaussian(theta_in, theta_out, r0, r1, lam, metric, eps, steps)
+        kin1.numpy()[...] = 0.5 * self._quarter_sum(r1.numpy() * m(r1.numpy()))
+        th = theta_out.numpy()
+        lt = th if lam is None else lam.numpy()[:, None] * th
+        lp_out.numpy()[...] = -0.5 * self._quarter_sum(th * lt)
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps):
         self.first_step_gather(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, h, 0.5 * h)

@@ -727,3 +727,52 @@ def test_mala_two_pass_checkpoint_cache_refresh_and_graph(ops):
         assert torch.equal(te, tg) and torch.equal(le, lg), n
     assert g._graph is not None
     np.testing.assert_array_equal(e.rng_state(), g.rng_state())
+
+
+@pytest.mark.parametrize("C,D", [(2, 1), (65, 7), (64, 32), (130, 129), (257, 33), (96, 1000), (512, 1024), (4096, 128)])
+def test_hmc_whole_draw_kernel_equals_step_by_step(ops, C, D):
+    """bk_hmc_draw_gaussian (trajectory + kin0 + kin1 + end-point log density in one pass, momentum
+    consumed chain-major from the generator) against the separate kernels: theta AND the returned
+    joint log density bit-identical, same accept masks and stream positions; with and without a
+    metric, diag and iso targets, both RNG schedules."""
+    lam = np.logspace(0, 1.2, D)
+    for model_of, metric in ((lambda: bk.DiagGaussian(lam), np.linspace(0.9, 1.1, D)), (lambda: bk.DiagGaussian(lam), None),
+                             (lambda: bk.IsoGaussian(D), None)):
+        for prefetch in (False, True):
+            kw = dict(metric_diag=metric, chains=C, seed=31, graph=False)
+            a = bk.HMCDiag(model_of(), 0.11, 5, fuse_builtin=False, prefetch_rng=False, **kw)
+            b = bk.HMCDiag(model_of(), 0.11, 5, fuse_builtin=True, prefetch_rng=prefetch, **kw)
+            assert b._fused_draw and b._fused_zt == (D >= 32) and not a._fused
+            for n in range(6):
+                ta, la = a.sample()
+                tb, lb = b.sample()
+                assert torch.equal(ta, tb) and torch.equal(la, lb), (C, D, prefetch, n)
+                assert torch.equal(a.last_accept, b.last_accept)
+            np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+            assert a.accept_rate() == b.accept_rate()
+
+
+def test_hmc_whole_draw_kernel_energies_are_the_reduction_kernels_values(ops):
+    """kin0 / kin1 / lp of bk_hmc_draw_gaussian == bk_leapfrog_finish / bk_target_diag_gaussian_grad
+    on the same arrays, bit for bit (same quarter-wise summation order), for both momentum layouts."""
+    rng = np.random.default_rng(9)
+    for C, D in [(70, 37), (256, 256), (33, 1001)]:
+        dev = ops.device
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)  # noqa: E731
+        th, lam, met = t(rng.normal(size=(D, C))), t(np.logspace(0, 1, D)), t(rng.uniform(0.5, 2, size=D))
+        dp = (D + 7) // 8 * 8
+        zt = t(rng.normal(size=(C, dp)))
+        rho0 = zt[:, :D].t().contiguous()
+        eps, L = 0.07, 4
+        th_ref, rho_ref = torch.empty_like(th), torch.empty_like(th)
+        ops.hmc_trajectory_gaussian(th, th_ref, rho0, rho_ref, lam, met, eps, L)
+        k0_ref, k1_ref, lp_ref = (torch.empty(C, dtype=torch.float64, device=dev) for _ in range(3))
+        ops.leapfrog_finish(rho0, None, None, met, 0.0, False, k0_ref)
+        ops.leapfrog_finish(rho_ref, None, None, met, 0.0, False, k1_ref)
+        ops.target_grad("diag_gaussian", lam, th_ref, None, lp_ref)
+        for use_zt in (True, False):
+            out = torch.empty_like(th)
+            part = torch.empty(12 * C, dtype=torch.float64, device=dev)
+            k0, k1, lp = (torch.empty(C, dtype=torch.float64, device=dev) for _ in range(3))
+            ops.hmc_draw_gaussian(th, out, None if use_zt else rho0, zt if use_zt else None, lam, met, eps, L, part, k0, k1, lp)
+            assert torch.equal(out, th_ref) and torch.equal(k0, k0_ref) and torch.equal(k1, k1_ref) and torch.equal(lp, lp_ref)
