@@ -39,14 +39,14 @@ SIGNATURES = {
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
     "bk_select_columns": [P, P, P, P, P, P, I, I, I, P],
-    "bk_compact_indices": [P, I, P, P, P],
+    "bk_compact_indices": [P, I, P, P, P, P],
     "bk_dr_begin": [P, P, P, P, P, P, I, P],
     "bk_dr_retry_test": [c_int, P, I, P, F, P, I, P],
-    "bk_dr_level_begin": [P, P, P, P, P, I, P],
-    "bk_dr_ghost_update": [P, P, I, P, P, P, P],
-    "bk_dr_accept_prob": [P, P, P, P, P, F, P, P, I, P],
-    "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P],
-    "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P],
+    "bk_dr_level_begin": [P, P, P, P, P, I, P, P],
+    "bk_dr_ghost_update": [P, P, I, P, P, P, P, P],
+    "bk_dr_accept_prob": [P, P, P, P, P, F, P, P, I, P, P],
+    "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P, P],
+    "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
     "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P],
@@ -58,7 +58,7 @@ SIGNATURES = {
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, I, I, P],
-    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P],
+    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
@@ -245,8 +245,10 @@ class Ops:
                    C, D, self._s())
 
     # -- delayed rejection ---------------------------------------------------------------------
-    def compact_indices(self, mask, n, idx_out, count_out):
-        self._call("bk_compact_indices", ptr(mask), n, ptr(idx_out), ptr(count_out), self._s())
+    # n_dev (optional, everywhere below): int32 device tensor [1] holding the number of lanes really
+    # in the set; `n` / `m` is then only the bound the launch is sized for (include/bkhip.h).
+    def compact_indices(self, mask, n, idx_out, count_out, n_dev=None):
+        self._call("bk_compact_indices", ptr(mask), n, ptr(idx_out), ptr(count_out), ptr(n_dev), self._s())
 
     def dr_begin(self, logp, kin, cur_H, cur_h, rej, alive):
         self._call("bk_dr_begin", ptr(logp), ptr(kin), ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive),
@@ -256,28 +258,29 @@ class Ops:
         self._call("bk_dr_retry_test", kind, ptr(state), state.stride(0), ptr(rej), float(prob_retry),
                    ptr(alive), alive.shape[0], self._s())
 
-    def dr_level_begin(self, logp, kin, H, h, live, n):
-        self._call("bk_dr_level_begin", ptr(logp), ptr(kin), ptr(H), ptr(h), ptr(live), n, self._s())
+    def dr_level_begin(self, logp, kin, H, h, live, n, n_dev=None):
+        self._call("bk_dr_level_begin", ptr(logp), ptr(kin), ptr(H), ptr(h), ptr(live), n, ptr(n_dev), self._s())
 
-    def dr_ghost_update(self, ga, sub_index, m, h, live, a):
-        self._call("bk_dr_ghost_update", ptr(ga), ptr(sub_index), m, ptr(h), ptr(live), ptr(a), self._s())
+    def dr_ghost_update(self, ga, sub_index, m, h, live, a, n_dev=None):
+        self._call("bk_dr_ghost_update", ptr(ga), ptr(sub_index), m, ptr(h), ptr(live), ptr(a), ptr(n_dev),
+                   self._s())
 
-    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n):
+    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n, n_dev=None):
         self._call("bk_dr_accept_prob", ptr(H), ptr(cur_H), ptr(h), ptr(cur_h), ptr(cur_index),
-                   float(prob_retry), ptr(live), ptr(a), n, self._s())
+                   float(prob_retry), ptr(live), ptr(a), n, ptr(n_dev), self._s())
 
-    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted):
+    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev=None):
         self._call("bk_dr_accept_test", kind, ptr(state), state.stride(0), ptr(chain_index), ptr(a), ptr(H),
-                   n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), ptr(accepted), self._s())
+                   n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), ptr(accepted), ptr(n_dev), self._s())
 
-    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None):
+    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         """dsts/srcs: up to three [D, *] tensors each (same ld within each list)."""
         d = list(dsts) + [None] * (3 - len(dsts))
         s_ = list(srcs) + [None] * (3 - len(srcs))
         D = dsts[0].shape[0]
         self._call("bk_scatter_columns", ptr(mask), ptr(index), n, D, ptr(d[0]), ptr(s_[0]), ptr(d[1]),
                    ptr(s_[1]), ptr(d[2]), ptr(s_[2]), _ld(dsts[0]), _ld(srcs[0]), ptr(sdst), ptr(ssrc),
-                   self._s())
+                   ptr(n_dev), self._s())
 
     # -- MALA --------------------------------------------------------------------------------
     def mala_propose(self, kind, state, theta, grad, theta_prop, eps, sqrt2eps):
@@ -365,7 +368,7 @@ class Ops:
                    ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), C, D, self._s())
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None):
         D, n = theta_out.shape
         ld_in = _ld(theta_in)
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
@@ -373,7 +376,7 @@ class Ops:
         assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
         self._call("bk_dr_proposal_funnel", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                    ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
-                   h, steps, n, D, self._s())
+                   h, steps, n, D, ptr(n_dev), ptr(lanes_out), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape

@@ -67,6 +67,8 @@ class DrGhmcDiag(ManyChainSampler):
         chain_id0: int = 0,
         fuse_builtin: bool = True,
         tune_placement: Optional[bool] = None,
+        device_counts: Optional[bool] = None,
+        graph: Optional[bool] = None,
         ops=None,
     ):
         self._max_proposals = max_proposals
@@ -98,13 +100,79 @@ class DrGhmcDiag(ManyChainSampler):
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
         # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
-        self._use_graph = False
+        # Lane counts on the device (targets whose whole proposal is one library launch): the sizes of
+        # the lane sets -- which depend on the draw's own accept / retry decisions -- stay in device
+        # memory; every launch is sized for its parent set and surplus workgroups exit at once.  No
+        # host read inside sample(), so the draw is a FIXED launch sequence and replays as one
+        # hipGraph.  Other models keep compacted launches sized by three host reads per draw.
+        can_dev = self._fused and getattr(model, "bk_dr_proposal_supported", lambda: False)()
+        if device_counts and not can_dev:
+            raise ValueError("device_counts=True needs a built-in target with a one-launch proposal (bk.Funnel, D <= 129)")
+        self._dev_counts = can_dev if device_counts is None else bool(device_counts)
+        if graph is None:
+            graph = self._dev_counts and dev.type == "cuda"
+        if graph and not self._dev_counts:
+            raise ValueError("graph=True needs device_counts (the host-sized path reads lane counts back every draw)")
+        self._init_graph(graph)
+        self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
+            max(0, k - 1) for k in range(int(max_proposals)))
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._fused:
             self._tune_placement()
-        self.last_grad_evals = 0        # model calls in the last draw (each over a lane set)
-        self.last_lane_steps = 0        # sum over trajectories of lanes x steps (useful work)
-        self.last_stage_lanes = []      # (tag, lanes) of every trajectory run in the last draw
+        self._host_stats = (0, 0, [])   # (grad evals, lane steps, [(tag, lanes)]) of the last host-sized draw
+        self._first_eval = 0
+        if self._dev_counts:
+            # the fixed schedule of trajectories (slot order = launch order) and its lane counters
+            self._schedule = []
+            self._plan(int(max_proposals))
+            self._slot_lanes = torch.zeros(len(self._schedule), dtype=torch.int32, device=dev)
+            self._slot_steps = torch.tensor([st for _, st in self._schedule], dtype=torch.float64, device=dev)
+            self._lane_steps_total = torch.zeros((), dtype=torch.float64, device=dev)
+
+    def _plan(self, K):
+        """Tags and step counts of the trajectories of one draw in launch order, e.g. for K = 3:
+        P0 | P1 G0(P1) | P2 G0(P2) G1(P2) G0(G1(P2))   (SURVEY 3.3.1)."""
+        def ghosts(tag, k):
+            for i in range(k):
+                g = "G%d(%s)" % (i, tag)
+                self._schedule.append((g, int(self._leapfrog_step_counts[i])))
+                ghosts(g, i)
+        for k in range(K):
+            self._schedule.append(("P%d" % k, int(self._leapfrog_step_counts[k])))
+            ghosts("P%d" % k, k)
+
+    # -- statistics of the last draw ----------------------------------------------------------------------
+    # With device-side lane counts these READ BACK the counters (a host synchronisation); use
+    # lane_steps_device / lane_steps_total for figures that must not synchronise.
+    @property
+    def last_stage_lanes(self):
+        """(tag, lanes) of every trajectory that had at least one lane in the last draw."""
+        if not self._dev_counts:
+            return self._host_stats[2]
+        lanes = self._slot_lanes.cpu().tolist()
+        return [(tag, n) for (tag, _), n in zip(self._schedule, lanes) if n > 0]
+
+    @property
+    def last_grad_evals(self):
+        """Gradient evaluations (each over a lane set) in the last draw."""
+        if not self._dev_counts:
+            return self._host_stats[0]
+        lanes = self._slot_lanes.cpu().tolist()
+        return self._first_eval + sum(st for (_, st), n in zip(self._schedule, lanes) if n > 0)
+
+    @property
+    def last_lane_steps(self):
+        """Sum over the last draw's trajectories of lanes x steps (chain-steps actually run)."""
+        if not self._dev_counts:
+            return self._host_stats[1]
+        return int(round(float(self.lane_steps_device.item())))
+
+    @property
+    def lane_steps_device(self):
+        """The same as a 0-d device tensor (no host synchronisation)."""
+        if not self._dev_counts:
+            return torch.tensor(float(self._host_stats[1]), dtype=torch.float64, device=self._ops.device)
+        return (self._slot_lanes.to(torch.float64) * self._slot_steps).sum()
 
     def _tune_placement(self):
         """Every recursion level streams its own (theta, rho, grad) triple through kick+drift: the
@@ -202,9 +270,9 @@ class DrGhmcDiag(ManyChainSampler):
         h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
         dst = self._levels[lvl]
         th, rho, gbuf = dst.theta[:, :n], dst.rho[:, :n], dst.grad[:, :n]
-        self.last_grad_evals += steps
-        self.last_lane_steps += steps * n
-        self.last_stage_lanes.append((tag, n))
+        self._h_evals += steps
+        self._h_lane_steps += steps * n
+        self._h_stages.append((tag, n))
         if self._fused and self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, th, rho, gbuf,
                                                       dst.logp[:n], dst.kin[:n], m, h, steps):
             return
@@ -237,9 +305,20 @@ class DrGhmcDiag(ManyChainSampler):
 
     # -- one draw for every chain -----------------------------------------------------------------------------
     def sample(self):
+        if self._dev_counts:
+            if not self._have_cache:  # drghmc.py:243-245 (first draw only; outside any capture)
+                self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+                self._have_cache = True
+                self._first_eval = 1
+            else:
+                self._first_eval = 0
+            self._run_draw(self._draw_dev)
+            self._rho_sign = -1.0  # drghmc.py:388, applied lazily
+            self._draws += 1
+            return self._draw_out(self._theta_dc, self._cur_H)
         ops = self._ops
         C, m = self._C, self._metric_dev
-        self.last_grad_evals, self.last_lane_steps, self.last_stage_lanes = 0, 0, []
+        self._h_evals, self._h_lane_steps, self._h_stages = 0, 0, []
         damping = self._damping
         # partial momentum refresh (drghmc.py:360-364); the stored momentum may still carry the
         # previous draw's pending flip (drghmc.py:388), applied here through the sign of loc_mul
@@ -250,7 +329,7 @@ class DrGhmcDiag(ManyChainSampler):
         if not self._have_cache:  # drghmc.py:243-245 (first draw only)
             self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
             self._have_cache = True
-            self.last_grad_evals += 1
+            self._h_evals += 1
         ops.dr_begin(self._lp, self._kin, self._cur_H, self._cur_h, self._rej, self._alive)
         cur = _Cur(self)
         pr = 1.0 if self._prob_retry else 0.0
@@ -275,7 +354,70 @@ class DrGhmcDiag(ManyChainSampler):
                                 [P0.theta[:, :n], P0.rho[:, :n], P0.grad[:, :n]], self._lp, P0.logp)
         self._rho_sign = -1.0  # drghmc.py:388, applied lazily
         self._draws += 1
+        self._host_stats = (self._h_evals, self._h_lane_steps, self._h_stages)
         return self._draw_out(self._theta_dc, self._cur_H)
+
+    # -- the same draw with lane counts on the device: a fixed launch sequence ----------------------------
+    def _proposal_dev(self, src, idx, n_dev, k, lvl):
+        """Proposal k from lanes idx (count n_dev; None = all C chains) of `src` into level lvl."""
+        h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
+        dst = self._levels[lvl]
+        slot = self._slot
+        self._slot += 1
+        ok = self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, dst.theta, dst.rho, dst.grad, dst.logp,
+                                        dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
+                                        lanes_out=self._slot_lanes[slot:slot + 1])
+        assert ok
+
+    def _accept_dev(self, lvl, n_dev, k, cur_h, cur_H, cur_idx):
+        """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains)."""
+        ops, C = self._ops, self._C
+        P = self._levels[lvl]
+        ops.dr_level_begin(P.logp, P.kin, P.H, P.h, P.live, C, n_dev=n_dev)
+        for i in range(k):
+            if i == 0:
+                m_dev, sub = n_dev, None  # dr_level_begin just set every lane live
+            else:
+                nxt = self._levels[lvl + 1]
+                ops.compact_indices(P.live, C, nxt.idx, nxt.count, n_dev=n_dev)
+                m_dev, sub = nxt.count, nxt.idx
+            self._proposal_dev(P, sub, m_dev, i, lvl + 1)
+            ga = self._accept_dev(lvl + 1, m_dev, i, P.h, P.H, sub)
+            ops.dr_ghost_update(ga, sub, C, P.h, P.live, P.a, n_dev=m_dev)
+        ops.dr_accept_prob(P.H, cur_H, P.h, cur_h, cur_idx, 1.0 if self._prob_retry else 0.0, P.live, P.a, C,
+                           n_dev=n_dev)
+        return P.a
+
+    def _draw_dev(self):
+        ops = self._ops
+        C, m, damping = self._C, self._metric_dev, self._damping
+        ops.momentum_refresh(self._rng_kind, self._rng_state, self._rho_dc,
+                             self._rho_sign * math.sqrt(1 - damping), math.sqrt(damping), self._rho_dc, m,
+                             self._kin, None, self._rng_work)                                     # :360-364
+        ops.dr_begin(self._lp, self._kin, self._cur_H, self._cur_h, self._rej, self._alive)
+        cur = _Cur(self)
+        pr = 1.0 if self._prob_retry else 0.0
+        P0 = self._levels[0]
+        self._slot = 0
+        for k in range(int(self._max_proposals)):
+            ops.dr_retry_test(self._rng_kind, self._rng_state, self._rej, pr, self._alive)        # :369-371
+            if k == 0:
+                n_dev, idx = None, None  # every chain proposes at the first stage
+            else:
+                ops.compact_indices(self._alive, C, P0.idx, P0.count)
+                n_dev, idx = P0.count, P0.idx
+            self._proposal_dev(cur, idx, n_dev, k, 0)                                             # :373
+            a = self._accept_dev(0, n_dev, k, self._cur_h, self._cur_H, idx)                      # :374-376
+            ops.dr_accept_test(self._rng_kind, self._rng_state, idx, a, P0.H, C, self._cur_H, self._cur_h,
+                               self._rej, self._alive, P0.accepted, n_dev=n_dev)                  # :378-385
+            ops.scatter_columns(P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad],
+                                [P0.theta, P0.rho, P0.grad], self._lp, P0.logp, n_dev=n_dev)
+        self._lane_steps_total += (self._slot_lanes.to(torch.float64) * self._slot_steps).sum()
+
+    @property
+    def lane_steps_total(self):
+        """Chain-steps run since construction, accumulated on the device (0-d tensor)."""
+        return self._lane_steps_total
 
 
 class _View:

@@ -8,11 +8,22 @@ namespace {
 
 constexpr int SC_BLOCK = 256;
 
+// Lane count of a launch: `n` is what the host knows (an upper bound used to size the grid);
+// with n_dev the number of lanes actually in the set is read from device memory -- written by an
+// earlier kernel on the same stream (bk_compact_indices) -- so the host never has to read it back
+// and a whole delayed-rejection draw can be captured as one hipGraph.  Surplus threads exit.
+__device__ __forceinline__ i64 bk_lanes(i64 n, const uint32_t* n_dev) {
+  if (!n_dev) return n;
+  const i64 m = (i64)*n_dev;
+  return m < n ? m : n;
+}
+
 // ---- stable compaction: one workgroup, 16 wavefronts, 8 flags per thread per pass ---------
 constexpr int CP_BLOCK = 1024;
 constexpr int CP_ITEMS = 8;
-__global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n, int32_t* idx,
-                                                      uint32_t* count) {
+__global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n_host, int32_t* idx,
+                                                      uint32_t* count, const uint32_t* n_dev) {
+  const i64 n = bk_lanes(n_host, n_dev);
   __shared__ uint32_t wave_cnt[CP_BLOCK / BK_WAVE];
   __shared__ uint32_t base;
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
@@ -63,9 +74,10 @@ __device__ __forceinline__ double joint(double logp, double kin) {
 }
 
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_begin(const double* logp, const double* kin, double* H,
-                                                       double* h, double* rej, uint8_t* alive, i64 C) {
+                                                       double* h, double* rej, uint8_t* alive, i64 C,
+                                                       const uint32_t* n_dev) {
   i64 c = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
-  if (c >= C) return;
+  if (c >= bk_lanes(C, n_dev)) return;
   H[c] = joint(logp[c], kin[c]);
   h[c] = 0.0;
   if (rej) rej[c] = 0.0;
@@ -86,9 +98,10 @@ __global__ __launch_bounds__(64) void k_dr_retry(uint64_t* st, i64 ldr, const do
 }
 
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const int32_t* sub, i64 m,
-                                                       double* h, uint8_t* live, double* a) {
+                                                       double* h, uint8_t* live, double* a,
+                                                       const uint32_t* n_dev) {
   i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
-  if (j >= m) return;
+  if (j >= bk_lanes(m, n_dev)) return;
   i64 p = sub ? (i64)sub[j] : j;
   double g = ga[j];
   if (g == 0.0) {  // drghmc.py:430-432
@@ -102,9 +115,10 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const i
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, const double* cur_H,
                                                              const double* h, const double* cur_h,
                                                              const int32_t* cidx, double pr,
-                                                             const uint8_t* live, double* a, i64 n) {
+                                                             const uint8_t* live, double* a, i64 n,
+                                                             const uint32_t* n_dev) {
   i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
-  if (j >= n || !live[j]) return;
+  if (j >= bk_lanes(n, n_dev) || !live[j]) return;
   i64 p = cidx ? (i64)cidx[j] : j;
   double ph = h[j], ch = cur_h[p];
   double frac = ((H[j] - cur_H[p]) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
@@ -115,9 +129,9 @@ template <typename G>
 __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, const int32_t* cidx,
                                                        const double* a, const double* H, i64 n,
                                                        double* cur_H, double* cur_h, double* rej,
-                                                       uint8_t* alive, uint8_t* accepted) {
+                                                       uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev) {
   i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
-  if (j >= n) return;
+  if (j >= bk_lanes(n, n_dev)) return;
   i64 c = cidx ? (i64)cidx[j] : j;
   G g;
   g.load(st, ldr, c);
@@ -140,9 +154,9 @@ constexpr int SCT_UNROLL = 4;
 __global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32_t* idx, i64 n, i64 D,
                                                 double* d0, const double* s0, double* d1, const double* s1,
                                                 double* d2, const double* s2, i64 ldd, i64 lds, double* sd,
-                                                const double* ss) {
+                                                const double* ss, const uint32_t* n_dev) {
   i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
-  if (j >= n || !mask[j]) return;
+  if (j >= bk_lanes(n, n_dev) || !mask[j]) return;
   i64 g = idx ? (i64)idx[j] : j;
   if (sd) sd[g] = ss[j];
   for (i64 b = 0; b < D; b += SCT_UNROLL) {
@@ -168,9 +182,10 @@ __global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32
 
 extern "C" {
 
-int bk_compact_indices(const uint8_t* mask, int64_t n, int32_t* idx_out, uint32_t* count_out, void* stream) {
+int bk_compact_indices(const uint8_t* mask, int64_t n, int32_t* idx_out, uint32_t* count_out,
+                       const uint32_t* n_dev, void* stream) {
   if (!mask || !idx_out || !count_out || n < 0 || n > 0x7fffffff) return BK_E_ARG;
-  k_compact<<<dim3(1), dim3(CP_BLOCK), 0, bk_stream(stream)>>>(mask, n, idx_out, count_out);
+  k_compact<<<dim3(1), dim3(CP_BLOCK), 0, bk_stream(stream)>>>(mask, n, idx_out, count_out, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }
 
@@ -179,16 +194,16 @@ int bk_dr_begin(const double* logp, const double* kin, double* cur_H, double* cu
   if (!logp || !kin || !cur_H || !cur_h || !rej || !alive || C < 0) return BK_E_ARG;
   if (C == 0) return BK_OK;
   k_dr_begin<<<dim3((unsigned)bk_cdiv(C, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(logp, kin, cur_H, cur_h,
-                                                                                           rej, alive, C);
+                                                                                           rej, alive, C, nullptr);
   BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_dr_level_begin(const double* logp, const double* kin, double* H, double* h, uint8_t* live, int64_t n,
-                      void* stream) {
+                      const uint32_t* n_dev, void* stream) {
   if (!logp || !kin || !H || !h || !live || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   k_dr_begin<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(logp, kin, H, h, nullptr,
-                                                                                           live, n);
+                                                                                           live, n, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }
 
@@ -207,36 +222,36 @@ int bk_dr_retry_test(int rng_kind, uint64_t* state, int64_t ldr, const double* r
 }
 
 int bk_dr_ghost_update(const double* ga, const int32_t* sub_index, int64_t m, double* h, uint8_t* live,
-                       double* a, void* stream) {
+                       double* a, const uint32_t* n_dev, void* stream) {
   if (!ga || !h || !live || !a || m < 0) return BK_E_ARG;
   if (m == 0) return BK_OK;
   k_dr_ghost<<<dim3((unsigned)bk_cdiv(m, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(ga, sub_index, m, h, live,
-                                                                                           a);
+                                                                                           a, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, const double* cur_h,
                       const int32_t* cur_index, double prob_retry, const uint8_t* live, double* a, int64_t n,
-                      void* stream) {
+                      const uint32_t* n_dev, void* stream) {
   if (!H || !cur_H || !h || !cur_h || !live || !a || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   k_dr_accept_prob<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(
-      H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n);
+      H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* a,
                       const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
-                      uint8_t* accepted, void* stream) {
+                      uint8_t* accepted, const uint32_t* n_dev, void* stream) {
   if (!state || !a || !H || !cur_H || !cur_h || !rej || !alive || !accepted || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   dim3 grid((unsigned)bk_cdiv(n, 64)), block(64);
   if (rng_kind == BK_RNG_PHILOX)
     k_dr_accept_test<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                       cur_h, rej, alive, accepted);
+                                                                       cur_h, rej, alive, accepted, n_dev);
   else if (rng_kind == BK_RNG_PCG64)
     k_dr_accept_test<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                      cur_h, rej, alive, accepted);
+                                                                      cur_h, rej, alive, accepted, n_dev);
   else
     return BK_E_ARG;
   BK_RETURN_LAUNCH_STATUS();
@@ -244,12 +259,13 @@ int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t*
 
 int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int64_t D, double* dst0,
                        const double* src0, double* dst1, const double* src1, double* dst2, const double* src2,
-                       int64_t ld_dst, int64_t ld_src, double* sdst, const double* ssrc, void* stream) {
+                       int64_t ld_dst, int64_t ld_src, double* sdst, const double* ssrc, const uint32_t* n_dev,
+                       void* stream) {
   if (!mask || !dst0 || !src0 || (dst1 && !src1) || (dst2 && !src2) || (sdst && !ssrc) || n < 0 || D < 0)
     return BK_E_ARG;
   if (n == 0) return BK_OK;
   k_scatter<<<dim3((unsigned)bk_cdiv(n, 64)), dim3(64), 0, bk_stream(stream)>>>(
-      mask, index, n, D, dst0, src0, dst1, src1, dst2, src2, ld_dst, ld_src, sdst, ssrc);
+      mask, index, n, D, dst0, src0, dst1, src1, dst2, src2, ld_dst, ld_src, sdst, ssrc, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -205,9 +205,17 @@ template <int ROWS, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
-    const double* metric, double h, int steps, i64 n, i64 D) {
+    const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out) {
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  // lanes actually in the set: read from device memory when the host only knows an upper bound
+  i64 n = n_host;
+  if (n_dev) {
+    const i64 m = (i64)*n_dev;
+    n = m < n ? m : n;
+  }
+  if (lanes_out && blockIdx.x == 0 && threadIdx.x == 0) *lanes_out = (uint32_t)n;
+  if ((i64)blockIdx.x * BK_WAVE >= n) return;  // whole workgroup past the set (uniform: before any barrier)
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
   const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
@@ -632,20 +640,24 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
 int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
                           const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
                           double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
-                          int64_t steps, int64_t n, int64_t D, void* stream) {
+                          int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                          void* stream) {
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
   if (D - 1 > FN_WAVES * FN_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (ld_out < n) return BK_E_ALIGN;
-  if (n == 0) return BK_OK;
+  if (n == 0) {
+    if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
+    return BK_OK;
+  }
   const int need = (int)((D - 1 + FN_WAVES - 1) / FN_WAVES);
   dim3 grid((unsigned)bk_cdiv(n, BK_WAVE));
   hipStream_t s = bk_stream(stream);
 #define BK_FT(R, M)                                                                                             \
   k_funnel_traj<R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,    \
                                                       rho_out, grad_out, logp_out, kin_out, ld_out, metric, h,  \
-                                                      (int)steps, n, D)
+                                                      (int)steps, n, D, n_dev, lanes_out)
 #define BK_FT_ROWS(R)    \
   do {                   \
     if (metric)          \

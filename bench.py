@@ -316,17 +316,18 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768):
     for _ in range(warmup):
         s.sample()
     state = {"lane_steps": 0}
+    on_device = hasattr(s, "lane_steps_total") and s._dev_counts  # counted on the device: no host read per draw
+    base = float(s.lane_steps_total.item()) if on_device else 0.0
 
     def one():
         th, lp = s.sample()
-        state["lane_steps"] += s.last_lane_steps
+        if not on_device:
+            state["lane_steps"] += s.last_lane_steps
         mom.update(s._theta_dc)
         rec.record(th, lp)
 
     el = ctx.timed_loop(one, draws)
-    lane_steps = state["lane_steps"]
-    if hasattr(lane_steps, "item"):
-        lane_steps = float(lane_steps.item())
+    lane_steps = float(s.lane_steps_total.item()) - base if on_device else state["lane_steps"]
     rh = mom.rhat()
     ess = rec.ess()
     ess = torch.where(ess > 0, ess, torch.full_like(ess, float(draws))).clamp(max=float(draws)).min(dim=0).values

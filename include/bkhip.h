@@ -165,12 +165,20 @@ int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
  * bandwidth for the chains that actually take it.  Per-chain scalars of a level: H (joint
  * log density), h (log of the probability of rejecting all earlier proposals, the
  * "hastings" term), a (log acceptance probability), live (not yet early-exited).
+ *
+ * Lane counts on the device.  Every entry point that works on a lane set takes, besides the
+ * host-side extent `n` (or `m`), an optional `n_dev`: a device pointer to the number of lanes
+ * actually in the set, as written by bk_compact_indices earlier on the same stream.  With
+ * n_dev != NULL the launch is sized for `n` (an upper bound, e.g. the parent set) and works on
+ * min(n, *n_dev) lanes; surplus workgroups exit at once.  The host then never reads a count
+ * back, and a whole delayed-rejection draw -- whose lane sets depend on the draw's own accept
+ * decisions -- is a fixed launch sequence that can be captured as one hipGraph.
  */
 
 /* Stable compaction: idx_out[k] = position of the k-th nonzero entry of mask[0..n),
  * *count_out = number of nonzero entries (ballot/popcount prefix sums per wavefront). */
 int bk_compact_indices(const uint8_t* mask, int64_t n, int32_t* idx_out, uint32_t* count_out,
-                       void* stream);
+                       const uint32_t* n_dev, void* stream);
 
 /* Start of a draw (drghmc.py:365-366): cur_H = -((-logp) + kin) (joint_logp, :249-251),
  * cur_h = 0, rej = 0, alive = 1. */
@@ -186,20 +194,20 @@ int bk_dr_retry_test(int rng_kind, uint64_t* state, int64_t ldr, const double* r
 /* Level set-up for accept(): H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0,
  * live = 1 for the n lanes of a level. */
 int bk_dr_level_begin(const double* logp, const double* kin, double* H, double* h, uint8_t* live,
-                      int64_t n, void* stream);
+                      int64_t n, const uint32_t* n_dev, void* stream);
 
 /* After the recursive accept of ghost proposals (drghmc.py:426-436): ghost lane j belongs
  * to parent lane p = sub_index ? sub_index[j] : j.  If ga[j] == 0 the parent's result is
  * a = -inf and it stops (early-out, :430-432); otherwise h[p] += log1p(-exp(ga[j])). */
 int bk_dr_ghost_update(const double* ga, const int32_t* sub_index, int64_t m, double* h,
-                       uint8_t* live, double* a, void* stream);
+                       uint8_t* live, double* a, const uint32_t* n_dev, void* stream);
 
 /* Final acceptance probability of the still-live lanes (drghmc.py:438-446):
  * a = min(0, (H - cur_H) + (h - cur_h) + (pr*h - pr*cur_h)), with cur_* read at
  * cur_index ? cur_index[j] : j. */
 int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, const double* cur_h,
                       const int32_t* cur_index, double prob_retry, const uint8_t* live, double* a,
-                      int64_t n, void* stream);
+                      int64_t n, const uint32_t* n_dev, void* stream);
 
 /* Top-level accept test of a stage (drghmc.py:378-385) for the n compacted lanes; lane j is
  * chain g = chain_index ? chain_index[j] : j.  u from chain g's stream; if log(u) < a[j]:
@@ -207,7 +215,8 @@ int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, con
  * rej[g] = log1p(-exp(a[j])), cur_h[g] += rej[g]. */
 int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index,
                       const double* a, const double* H, int64_t n, double* cur_H, double* cur_h,
-                      double* rej, uint8_t* alive, uint8_t* accepted, void* stream);
+                      double* rej, uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev,
+                      void* stream);
 
 /* Accepted lanes replace their chain's current point (drghmc.py:379): for up to three
  * array pairs dst[d*ld_dst + g] = src[d*ld_src + j] and one per-chain vector
@@ -215,7 +224,7 @@ int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t*
 int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int64_t D,
                        double* dst0, const double* src0, double* dst1, const double* src1,
                        double* dst2, const double* src2, int64_t ld_dst, int64_t ld_src,
-                       double* sdst, const double* ssrc, void* stream);
+                       double* sdst, const double* ssrc, const uint32_t* n_dev, void* stream);
 
 /* ---- MALA ---------------------------------------------------------------------------
  * theta_prop = (theta + eps*grad) + sqrt2eps * z, z from chain c's stream in d order
@@ -337,12 +346,15 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
  * theta, -rho, gradient and log density at the proposal, kin = 0.5 sum rho*(metric*rho).
  * Requires D - 1 <= 128 (returns BK_E_ARG otherwise: use the step-by-step entry points).
  * The sum over coordinates uses the same fixed order as bk_target_funnel_grad, so the
- * proposal is bit-identical to the step-by-step path. */
+ * proposal is bit-identical to the step-by-step path.
+ * n_dev (may be NULL): device-side lane count, see "Lane counts on the device" above.
+ * lanes_out (may be NULL): receives the number of lanes the launch worked on (statistics:
+ * gradient evaluations = steps * lanes). */
 int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
-                          int64_t D, void* stream);
+                          int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, void* stream);
 
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix

@@ -294,8 +294,20 @@ class FakeOps:
         lt = th if lam is None else lam.numpy()[:, None] * th
         lp_out.numpy()[...] = -0.5 * self._quarter_sum(th * lt)
 
+    @staticmethod
+    def _lanes(n, n_dev):
+        return n if n_dev is None else min(int(n), int(n_dev[0]))
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None):
+        n = self._lanes(theta_out.shape[1], n_dev)
+        if lanes_out is not None:
+            lanes_out[0] = n
+        if n < theta_out.shape[1]:  # device-side lane count: only the first n lanes of the outputs exist
+            theta_out, rho_out, grad_out = theta_out[:, :n], rho_out[:, :n], grad_out[:, :n]
+            logp_out, kin_out = logp_out[:n], kin_out[:n]
+        if n == 0:
+            return
         self.first_step_gather(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, h, 0.5 * h)
         for _ in range(steps - 1):
             self.target_grad("funnel", None, theta_out, grad_out, None)
@@ -404,7 +416,8 @@ class FakeOps:
             ess_out[c] = X.shape[0] / it
 
     # -- delayed rejection --------------------------------------------------------------------------
-    def compact_indices(self, mask, n, idx_out, count_out):
+    def compact_indices(self, mask, n, idx_out, count_out, n_dev=None):
+        n = self._lanes(n, n_dev)
         nz = np.nonzero(mask.numpy()[:n])[0]
         idx_out.numpy()[: len(nz)] = nz
         count_out.numpy()[0] = len(nz)
@@ -431,12 +444,14 @@ class FakeOps:
                     alive[c] = 0
             self._put(kind, state, c, g)
 
-    def dr_level_begin(self, logp, kin, H, h, live, n):
+    def dr_level_begin(self, logp, kin, H, h, live, n, n_dev=None):
+        n = self._lanes(n, n_dev)
         H.numpy()[:n] = self._joint(logp.numpy()[:n], kin.numpy()[:n])
         h.numpy()[:n] = 0.0
         live.numpy()[:n] = 1
 
-    def dr_ghost_update(self, ga, sub_index, m, h, live, a):
+    def dr_ghost_update(self, ga, sub_index, m, h, live, a, n_dev=None):
+        m = self._lanes(m, n_dev)
         for j in range(m):
             p = j if sub_index is None else int(sub_index[j])
             g = ga.numpy()[j]
@@ -446,7 +461,8 @@ class FakeOps:
             else:
                 h.numpy()[p] = h.numpy()[p] + np.log1p(-np.exp(g))
 
-    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n):
+    def dr_accept_prob(self, H, cur_H, h, cur_h, cur_index, prob_retry, live, a, n, n_dev=None):
+        n = self._lanes(n, n_dev)
         for j in range(n):
             if not live[j]:
                 continue
@@ -456,7 +472,8 @@ class FakeOps:
                 frac = ((H.numpy()[j] - cur_H.numpy()[p]) + (ph - ch)) + (prob_retry * ph - prob_retry * ch)
             a[j] = frac if frac < 0 else 0.0
 
-    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted):
+    def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev=None):
+        n = self._lanes(n, n_dev)
         for j in range(n):
             c = j if chain_index is None else int(chain_index[j])
             g = self._gen(kind, state, c)
@@ -475,7 +492,8 @@ class FakeOps:
                 rej.numpy()[c] = r
                 cur_h.numpy()[c] = cur_h.numpy()[c] + r
 
-    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None):
+    def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
+        n = self._lanes(n, n_dev)
         for j in range(n):
             if not mask[j]:
                 continue

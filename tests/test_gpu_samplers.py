@@ -776,3 +776,34 @@ def test_hmc_whole_draw_kernel_energies_are_the_reduction_kernels_values(ops):
             k0, k1, lp = (torch.empty(C, dtype=torch.float64, device=dev) for _ in range(3))
             ops.hmc_draw_gaussian(th, out, None if use_zt else rho0, zt if use_zt else None, lam, met, eps, L, part, k0, k1, lp)
             assert torch.equal(out, th_ref) and torch.equal(k0, k0_ref) and torch.equal(k1, k1_ref) and torch.equal(lp, lp_ref)
+
+
+@pytest.mark.parametrize("D,K", [(11, 3), (101, 3), (21, 2), (129, 3), (40, 4)])
+def test_drghmc_device_side_lane_counts_equal_host_sized_launches(ops, D, K):
+    """Lane counts kept on the device (every launch sized for the parent set, no host read, the
+    draw replayed as one hipGraph) against launches sized by reading the counts back: same draws,
+    same joint log densities, same momenta, same stream positions, same trajectories run."""
+    sizes, counts = [0.3, 0.1, 0.03, 0.01][:K], [3, 6, 12, 24][:K]
+    for C in (700, 64):
+        mk = lambda **kw: bk.DrGhmcDiag(bk.Funnel(D), K, sizes, counts, 0.3, chains=C, seed=5, **kw)  # noqa: E731
+        a = mk(device_counts=False)
+        b = mk(device_counts=True, graph=False)
+        g = mk()  # default: device counts + hipGraph replay
+        assert g._dev_counts and g._use_graph and not a._dev_counts and g.host_syncs_per_draw == 0
+        seen = set()
+        for n in range(12):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            tg, lg = g.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (D, K, C, n)
+            assert torch.equal(ta, tg) and torch.equal(la, lg), (D, K, C, n, "graph")
+            assert a.last_stage_lanes == b.last_stage_lanes == g.last_stage_lanes
+            assert a.last_lane_steps == b.last_lane_steps == g.last_lane_steps
+            assert a.last_grad_evals == b.last_grad_evals == g.last_grad_evals
+            seen.update(t for t, _ in a.last_stage_lanes)
+        assert torch.equal(a._rho, b._rho) and torch.equal(a._rho, g._rho)
+        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        np.testing.assert_array_equal(a.rng_state(), g.rng_state())
+        assert g._graph is not None and len(seen) >= 3
+        total = float(g.lane_steps_total.item())
+        assert total > 0 and total == float(b.lane_steps_total.item())
