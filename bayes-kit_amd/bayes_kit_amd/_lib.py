@@ -58,7 +58,7 @@ SIGNATURES = {
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, I, I, P],
-    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P],
+    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
@@ -368,15 +368,18 @@ class Ops:
                    ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), C, D, self._s())
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):
+        """level: optional (H, h, live) tensors of the destination level -- its bk_dr_level_begin is then
+        done by the same launch."""
         D, n = theta_out.shape
+        H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
         ld_out = _ld(theta_out)
         assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
         self._call("bk_dr_proposal_funnel", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                    ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
-                   h, steps, n, D, ptr(n_dev), ptr(lanes_out), self._s())
+                   h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape

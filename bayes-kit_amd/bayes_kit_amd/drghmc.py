@@ -127,7 +127,7 @@ class DrGhmcDiag(ManyChainSampler):
             self._plan(int(max_proposals))
             self._slot_lanes = torch.zeros(len(self._schedule), dtype=torch.int32, device=dev)
             self._slot_steps = torch.tensor([st for _, st in self._schedule], dtype=torch.float64, device=dev)
-            self._lane_steps_total = torch.zeros((), dtype=torch.float64, device=dev)
+            self._slot_lanes_total = torch.zeros(len(self._schedule), dtype=torch.int64, device=dev)
 
     def _plan(self, K):
         """Tags and step counts of the trajectories of one draw in launch order, e.g. for K = 3:
@@ -364,19 +364,21 @@ class DrGhmcDiag(ManyChainSampler):
         dst = self._levels[lvl]
         slot = self._slot
         self._slot += 1
+        # the launch also counts its lanes (per draw and in total) and sets up its level for accept()
         ok = self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, dst.theta, dst.rho, dst.grad, dst.logp,
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
-                                        lanes_out=self._slot_lanes[slot:slot + 1])
+                                        lanes_out=self._slot_lanes[slot:slot + 1],
+                                        lanes_total=self._slot_lanes_total[slot:slot + 1],
+                                        level=(dst.H, dst.h, dst.live))
         assert ok
 
     def _accept_dev(self, lvl, n_dev, k, cur_h, cur_H, cur_idx):
         """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains)."""
         ops, C = self._ops, self._C
-        P = self._levels[lvl]
-        ops.dr_level_begin(P.logp, P.kin, P.H, P.h, P.live, C, n_dev=n_dev)
+        P = self._levels[lvl]  # (H, h, live of the level were set by the proposal's own launch)
         for i in range(k):
             if i == 0:
-                m_dev, sub = n_dev, None  # dr_level_begin just set every lane live
+                m_dev, sub = n_dev, None  # every lane of the level is still live
             else:
                 nxt = self._levels[lvl + 1]
                 ops.compact_indices(P.live, C, nxt.idx, nxt.count, n_dev=n_dev)
@@ -412,12 +414,12 @@ class DrGhmcDiag(ManyChainSampler):
                                self._rej, self._alive, P0.accepted, n_dev=n_dev)                  # :378-385
             ops.scatter_columns(P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad],
                                 [P0.theta, P0.rho, P0.grad], self._lp, P0.logp, n_dev=n_dev)
-        self._lane_steps_total += (self._slot_lanes.to(torch.float64) * self._slot_steps).sum()
 
     @property
     def lane_steps_total(self):
-        """Chain-steps run since construction, accumulated on the device (0-d tensor)."""
-        return self._lane_steps_total
+        """Chain-steps run since construction (0-d device tensor; the per-trajectory lane counts are
+        accumulated by the proposal launches themselves)."""
+        return (self._slot_lanes_total.to(torch.float64) * self._slot_steps).sum()
 
 
 class _View:

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, co
   }
 }
 
-constexpr int SCT_UNROLL = 4;
+// lane = chain of the compacted set, blockIdx.y = a block of SCT_ROWS dimensions: the copy of an
+// accepted column is spread over D / SCT_ROWS workgroups (one lane walking all D rows with dependent
+// load -> store pairs took 22 us per launch at D = 101, whatever the number of accepted lanes)
+constexpr int SCT_ROWS = 8;
 __global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32_t* idx, i64 n, i64 D,
                                                 double* d0, const double* s0, double* d1, const double* s1,
                                                 double* d2, const double* s2, i64 ldd, i64 lds, double* sd,
@@ -158,24 +161,23 @@ __global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32
   i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
   if (j >= bk_lanes(n, n_dev) || !mask[j]) return;
   i64 g = idx ? (i64)idx[j] : j;
-  if (sd) sd[g] = ss[j];
-  for (i64 b = 0; b < D; b += SCT_UNROLL) {
-    double x0[SCT_UNROLL], x1[SCT_UNROLL], x2[SCT_UNROLL];
+  if (sd && blockIdx.y == 0) sd[g] = ss[j];
+  const i64 b = (i64)blockIdx.y * SCT_ROWS;
+  double x0[SCT_ROWS], x1[SCT_ROWS], x2[SCT_ROWS];
 #pragma unroll
-    for (int u = 0; u < SCT_UNROLL; ++u)
-      if (b + u < D) {
-        x0[u] = s0[(b + u) * lds + j];
-        if (d1) x1[u] = s1[(b + u) * lds + j];
-        if (d2) x2[u] = s2[(b + u) * lds + j];
-      }
+  for (int u = 0; u < SCT_ROWS; ++u)
+    if (b + u < D) {
+      x0[u] = s0[(b + u) * lds + j];
+      if (d1) x1[u] = s1[(b + u) * lds + j];
+      if (d2) x2[u] = s2[(b + u) * lds + j];
+    }
 #pragma unroll
-    for (int u = 0; u < SCT_UNROLL; ++u)
-      if (b + u < D) {
-        d0[(b + u) * ldd + g] = x0[u];
-        if (d1) d1[(b + u) * ldd + g] = x1[u];
-        if (d2) d2[(b + u) * ldd + g] = x2[u];
-      }
-  }
+  for (int u = 0; u < SCT_ROWS; ++u)
+    if (b + u < D) {
+      d0[(b + u) * ldd + g] = x0[u];
+      if (d1) d1[(b + u) * ldd + g] = x1[u];
+      if (d2) d2[(b + u) * ldd + g] = x2[u];
+    }
 }
 
 }  // namespace
@@ -264,7 +266,7 @@ int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int
   if (!mask || !dst0 || !src0 || (dst1 && !src1) || (dst2 && !src2) || (sdst && !ssrc) || n < 0 || D < 0)
     return BK_E_ARG;
   if (n == 0) return BK_OK;
-  k_scatter<<<dim3((unsigned)bk_cdiv(n, 64)), dim3(64), 0, bk_stream(stream)>>>(
+  k_scatter<<<dim3((unsigned)bk_cdiv(n, 64), (unsigned)bk_cdiv(D > 0 ? D : 1, SCT_ROWS)), dim3(64), 0, bk_stream(stream)>>>(
       mask, index, n, D, dst0, src0, dst1, src1, dst2, src2, ld_dst, ld_src, sdst, ssrc, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }

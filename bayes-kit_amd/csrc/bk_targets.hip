@@ -205,7 +205,8 @@ template <int ROWS, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
-    const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out) {
+    const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
+    unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out) {
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   // lanes actually in the set: read from device memory when the host only knows an upper bound
@@ -214,7 +215,10 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const i64 m = (i64)*n_dev;
     n = m < n ? m : n;
   }
-  if (lanes_out && blockIdx.x == 0 && threadIdx.x == 0) *lanes_out = (uint32_t)n;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lanes_out) *lanes_out = (uint32_t)n;
+    if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
+  }
   if ((i64)blockIdx.x * BK_WAVE >= n) return;  // whole workgroup past the set (uniform: before any barrier)
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
@@ -333,7 +337,16 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     double mr = hm ? mv * rr : rr;
     rho_out[j] = rr;
     th_out[j] = v;
-    kin_out[j] = 0.5 * (rr * mr + ksum);
+    const double kin = 0.5 * (rr * mr + ksum);
+    kin_out[j] = kin;
+    if (H_out) {
+      // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
+      // H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0, live = 1
+      const double potential = -logp_out[j];
+      H_out[j] = -(potential + kin);
+      hh_out[j] = 0.0;
+      live_out[j] = 1;
+    }
   }
 }
 
@@ -641,11 +654,12 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
                           const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
                           double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
                           int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
-                          void* stream) {
+                          uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
   if (D - 1 > FN_WAVES * FN_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
+  if (H_out && (!h_out || !live_out)) return BK_E_ARG;
   if (ld_out < n) return BK_E_ALIGN;
   if (n == 0) {
     if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
@@ -657,7 +671,9 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
 #define BK_FT(R, M)                                                                                             \
   k_funnel_traj<R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,    \
                                                       rho_out, grad_out, logp_out, kin_out, ld_out, metric, h,  \
-                                                      (int)steps, n, D, n_dev, lanes_out)
+                                                      (int)steps, n, D, n_dev, lanes_out,                        \
+                                                      reinterpret_cast<unsigned long long*>(lanes_total), H_out, \
+                                                      h_out, live_out)
 #define BK_FT_ROWS(R)    \
   do {                   \
     if (metric)          \

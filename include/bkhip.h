@@ -349,12 +349,15 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
  * proposal is bit-identical to the step-by-step path.
  * n_dev (may be NULL): device-side lane count, see "Lane counts on the device" above.
  * lanes_out (may be NULL): receives the number of lanes the launch worked on (statistics:
- * gradient evaluations = steps * lanes). */
+ * gradient evaluations = steps * lanes); lanes_total (may be NULL): the same count is ADDED to it.
+ * H_out, h_out, live_out (all or none): additionally perform bk_dr_level_begin for the produced
+ * lanes in the same launch (H = -((-logp) + kin), h = 0, live = 1). */
 int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
-                          int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, void* stream);
+                          int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
+                          double* H_out, double* h_out, uint8_t* live_out, void* stream);
 
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix

@@ -299,10 +299,13 @@ class FakeOps:
         return n if n_dev is None else min(int(n), int(n_dev[0]))
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):
         n = self._lanes(theta_out.shape[1], n_dev)
         if lanes_out is not None:
             lanes_out[0] = n
+        if lanes_total is not None:
+            lanes_total[0] += n
+        lvl_logp, lvl_kin = logp_out, kin_out
         if n < theta_out.shape[1]:  # device-side lane count: only the first n lanes of the outputs exist
             theta_out, rho_out, grad_out = theta_out[:, :n], rho_out[:, :n], grad_out[:, :n]
             logp_out, kin_out = logp_out[:n], kin_out[:n]
@@ -314,6 +317,8 @@ class FakeOps:
             self.kick_drift(theta_out, theta_out, rho_out, rho_out, grad_out, metric, h, False, 0.0, True, h)
         self.target_grad("funnel", None, theta_out, grad_out, logp_out)
         self.leapfrog_finish(rho_out, rho_out, grad_out, metric, 0.5 * h, True, kin_out)
+        if level is not None:
+            self.dr_level_begin(lvl_logp, lvl_kin, level[0], level[1], level[2], n)
 
     def dense_metric_apply(self, M, X, Y):
         Y.numpy()[...] = M.numpy() @ X.numpy()
