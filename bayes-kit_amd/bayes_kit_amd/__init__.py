@@ -8,7 +8,7 @@ signatures, while the arithmetic runs in hand-written HIP kernels for gfx950
 """
 from . import _lib  # noqa: F401
 from . import dist  # noqa: F401
-from .diagnostics import DrawRecorder, RunningMoments, rhat_from_moments
+from .diagnostics import DrawRecorder, DrawStore, RunningMoments, rhat_from_moments
 # like the reference (bayes_kit/__init__.py:2-13) the function names shadow the sub-modules of
 # the same name; importing them through the sub-modules keeps `bayes_kit_amd.rhat` a function
 # even after `from bayes_kit_amd.rhat import ...`
@@ -44,6 +44,7 @@ __all__ = [
     "autocorr",
     "RunningMoments",
     "DrawRecorder",
+    "DrawStore",
     "rhat_from_moments",
     "IsoGaussian",
     "DiagGaussian",

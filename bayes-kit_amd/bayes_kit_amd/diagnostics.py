@@ -97,6 +97,18 @@ class RunningMoments:
     def rhat(self, group=None) -> np.ndarray:
         return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
 
+    # checkpoint / resume: the Welford state is (n, mean, M2); restored, the stream of
+    # updates continues bit for bit
+    def state_dict(self):
+        return {"n": self.n, "mean": self.mean.detach().cpu().clone(), "m2": self.m2.detach().cpu().clone()}
+
+    def load_state_dict(self, sd):
+        if tuple(sd["mean"].shape) != tuple(self.mean.shape):
+            raise ValueError(f"checkpoint holds moments of shape {tuple(sd['mean'].shape)}, expected {tuple(self.mean.shape)}")
+        self.mean.copy_(sd["mean"].to(self.mean.device))
+        self.m2.copy_(sd["m2"].to(self.m2.device))
+        self.n = int(sd["n"])
+
 
 class DrawRecorder:
     """Draw storage for post-processing: the full series of a few tracked
@@ -139,7 +151,149 @@ class DrawRecorder:
         return np.array([rhat(self.view(k), ops=self._ops, group=group) for k in range(self.series.shape[0])])
 
     def state_dict(self):
-        return {"series": self.series[:, : self.n].cpu().clone(), "dims": self.dims, "with_logp": self.with_logp}
+        return {"series": self.series[:, : self.n].cpu().clone(), "dims": self.dims, "with_logp": self.with_logp,
+                "n": self.n}
+
+    def load_state_dict(self, sd):
+        if list(sd["dims"]) != self.dims or bool(sd["with_logp"]) != self.with_logp:
+            raise ValueError(f"checkpoint tracks dims {sd['dims']} (logp: {sd['with_logp']}), this recorder {self.dims} "
+                             f"(logp: {self.with_logp})")
+        ser = sd["series"]
+        if ser.shape[0] != self.series.shape[0] or ser.shape[2] != self.series.shape[2] or ser.shape[1] > self.series.shape[1]:
+            raise ValueError(f"checkpoint series {tuple(ser.shape)} does not fit the recorder {tuple(self.series.shape)}")
+        self.n = int(ser.shape[1])
+        self.series[:, : self.n].copy_(ser.to(self.series.device))
+
+
+class DrawStore:
+    """Chunked draw storage: every coordinate of every draw of this rank's chains, as
+    fixed-size chunks ``[draws, D, C]`` -- draw-major, chain-contiguous: the series of coordinate d
+    of a chunk is the strided view ``chunk[:, d, :]`` (``[n, C]``, chains contiguous), which ``ess`` /
+    ``rhat`` / ``autocorr`` consume as it is, no reshaping.  Draws are staged in a device buffer and
+    written one ``chunk_#####.npy`` file per full chunk (plus ``meta.json``); one directory per rank.
+
+        store = DrawStore.create(path, D, C, chunk=64)        # writer
+        store.append(theta)  ...  store.close()
+        store = DrawStore.open(path)                           # reader
+        x = store.series(d)        # [N, C] device tensor      r = rhat(x); e = ess(x)
+
+    A store can be re-opened for appending (``DrawStore.create(..., resume=True)``): with the
+    sampler's ``state_dict`` this makes a run restartable at any chunk boundary or in between (the
+    partial chunk is kept in ``state_dict()`` of the store).
+    """
+
+    def __init__(self, path, D, C, chunk, ops, chunks):
+        import os
+
+        self.path, self.D, self.C, self.chunk = str(path), int(D), int(C), int(chunk)
+        self._ops = _ops(ops)
+        self._os = os
+        self._chunks = list(chunks)  # draws per completed chunk file
+        self._buf = torch.empty((self.chunk, self.D, self.C), dtype=torch.float64, device=self._ops.device)
+        self._fill = 0
+
+    # -- writer -----------------------------------------------------------------------------------
+    @classmethod
+    def create(cls, path, D, C, chunk=64, ops=None, resume=False):
+        import json
+        import os
+
+        os.makedirs(path, exist_ok=True)
+        meta = os.path.join(path, "meta.json")
+        chunks = []
+        if os.path.exists(meta):
+            if not resume:
+                raise FileExistsError(f"{path} already holds a draw store (pass resume=True to append)")
+            with open(meta) as f:
+                m = json.load(f)
+            if (m["D"], m["C"], m["chunk"]) != (int(D), int(C), int(chunk)):
+                raise ValueError(f"{path} holds a store of D={m['D']}, C={m['C']}, chunk={m['chunk']}")
+            chunks = m["chunks"]
+        st = cls(path, D, C, chunk, ops, chunks)
+        st._write_meta()
+        return st
+
+    def _write_meta(self):
+        import json
+
+        with open(self._os.path.join(self.path, "meta.json"), "w") as f:
+            json.dump({"D": self.D, "C": self.C, "chunk": self.chunk, "chunks": self._chunks, "dtype": "float64",
+                       "layout": "[draw, D, C], C contiguous"}, f)
+
+    def append(self, theta) -> None:
+        """theta: the sampler's draw -- the (C, D) view returned by ``sample()`` or a [D, C] buffer."""
+        t = theta if tuple(theta.shape) == (self.D, self.C) else theta.t()
+        self._buf[self._fill].copy_(t)
+        self._fill += 1
+        if self._fill == self.chunk:
+            self._flush()
+
+    def _flush(self):
+        if self._fill == 0:
+            return
+        arr = self._buf[: self._fill].cpu().numpy()
+        np.save(self._os.path.join(self.path, "chunk_%05d.npy" % len(self._chunks)), arr)
+        self._chunks.append(int(self._fill))
+        self._fill = 0
+        self._write_meta()
+
+    def close(self):
+        self._flush()
+
+    def state_dict(self):
+        """The not yet written part of the current chunk (what a checkpoint must carry besides the files)."""
+        return {"chunks": list(self._chunks), "partial": self._buf[: self._fill].cpu().clone()}
+
+    def load_state_dict(self, sd):
+        if len(sd["chunks"]) > len(self._chunks) or sd["chunks"] != self._chunks[: len(sd["chunks"])]:
+            raise ValueError("the checkpoint refers to chunk files this store does not hold")
+        # chunks written after the checkpoint are superseded by the resumed run
+        for k in range(len(sd["chunks"]), len(self._chunks)):
+            self._os.remove(self._os.path.join(self.path, "chunk_%05d.npy" % k))
+        self._chunks = list(sd["chunks"])
+        part = sd["partial"]
+        self._fill = int(part.shape[0])
+        self._buf[: self._fill].copy_(part.to(self._buf.device))
+        self._write_meta()
+
+    # -- reader -----------------------------------------------------------------------------------
+    @classmethod
+    def open(cls, path, ops=None):
+        import json
+        import os
+
+        with open(os.path.join(path, "meta.json")) as f:
+            m = json.load(f)
+        return cls(path, m["D"], m["C"], m["chunk"], ops, m["chunks"])
+
+    @property
+    def draws(self) -> int:
+        return sum(self._chunks) + self._fill
+
+    def chunk_array(self, k) -> np.ndarray:
+        """Chunk k as a memory-mapped [n, D, C] array."""
+        return np.load(self._os.path.join(self.path, "chunk_%05d.npy" % k), mmap_mode="r")
+
+    def series(self, d: int) -> torch.Tensor:
+        """All draws of coordinate d: [N, C] device tensor (each chunk contributes its [n, C] slice; only
+        that slice is read from disk)."""
+        N = self.draws
+        out = torch.empty((N, self.C), dtype=torch.float64, device=self._ops.device)
+        pos = 0
+        for k, n in enumerate(self._chunks):
+            out[pos:pos + n].copy_(torch.from_numpy(np.ascontiguousarray(self.chunk_array(k)[:, d, :])))
+            pos += n
+        if self._fill:
+            out[pos:pos + self._fill].copy_(self._buf[: self._fill, d, :])
+        return out
+
+    def rhat(self, dims=None, group=None) -> np.ndarray:
+        dims = range(self.D) if dims is None else dims
+        return np.array([rhat(self.series(d), ops=self._ops, group=group) for d in dims])
+
+    def ess(self, dims=None) -> torch.Tensor:
+        dims = range(self.D) if dims is None else dims
+        return torch.stack([ess(self.series(d), ops=self._ops) for d in dims])
 
 
 # ---------------------------------------------------------------------------------------------

@@ -86,3 +86,63 @@ def check_diagnostics(ops, ess_rtol):
             f([1.0, 2.0, 3.0], ops=ops)
     with pytest.raises(ValueError):
         bk.autocorr([1.0], ops=ops)
+
+
+def check_checkpoint_of_sampler_and_diagnostics(ops, tmpdir, chains=40, D=12, draws=40, at=20):
+    """{sampler, Welford moments, tracked series, chunked draw store} checkpointed after
+    `at` draws and restored into FRESH objects give, after the remaining draws, bit for bit what an
+    uninterrupted run gives (moments, R-hat, ESS, every stored draw)."""
+    import io
+    import os
+
+    import bayes_kit_amd as bk
+
+    lam = np.logspace(0, 1, D)
+
+    def fresh(path, resume=False):
+        s = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.15, 4, chains=chains, seed=77, ops=ops)
+        return (s, bk.RunningMoments(D, chains, ops=ops), bk.DrawRecorder([0, D - 1], draws, chains, ops=ops),
+                bk.DrawStore.create(path, D, chains, chunk=8, ops=ops, resume=resume))
+
+    def step(objs, n):
+        s, mom, rec, store = objs
+        for _ in range(n):
+            th, lp = s.sample()
+            mom.update(th)
+            rec.record(th, lp)
+            store.append(th)
+
+    def summary(objs):
+        s, mom, rec, store = objs
+        store.close()
+        rd = bk.DrawStore.open(store.path, ops=ops)
+        assert rd.draws == draws
+        return dict(mean=mom.mean.cpu().numpy().copy(), m2=mom.m2.cpu().numpy().copy(), rhat=mom.rhat(),
+                    series=rec.series[:, : rec.n].cpu().numpy().copy(), ess=rec.ess().cpu().numpy(),
+                    store0=rd.series(0).cpu().numpy(), store5=rd.series(D // 2).cpu().numpy(), store_rhat=rd.rhat([1, D - 2]),
+                    store_ess=rd.ess([D - 1]).cpu().numpy(), theta=np.asarray(s._theta.cpu()).copy(), rng=s.rng_state())
+
+    a = fresh(os.path.join(tmpdir, "a"))
+    step(a, draws)
+    want = summary(a)
+
+    b = fresh(os.path.join(tmpdir, "b"))
+    step(b, at)
+    buf = io.BytesIO()
+    torch.save({"sampler": b[0].state_dict(), "moments": b[1].state_dict(), "recorder": b[2].state_dict(),
+                "store": b[3].state_dict()}, buf)
+    step(b, 13)  # the interrupted run went on for a while (one more chunk file reached the disk) and died
+    del b
+    c = fresh(os.path.join(tmpdir, "b"), resume=True)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    c[0].load_state_dict(ck["sampler"])
+    c[1].load_state_dict(ck["moments"])
+    c[2].load_state_dict(ck["recorder"])
+    c[3].load_state_dict(ck["store"])
+    step(c, draws - at)
+    got = summary(c)
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+    # the stored series of a coordinate is what ess / rhat of the recorder saw
+    assert np.array_equal(want["store0"], want["series"][0])

@@ -7,16 +7,28 @@ from tests.helpers import case_metric, case_seed, host_proposal, load_case, orac
 
 # Tolerances (DESIGN.md "Parity"): theta bit-exact for elementwise-gradient targets; logp and
 # energies are reductions summed in a different order than BLAS ddot -> rel 1e-12.
-# Funnel (exp + a reduction inside the gradient): the Hamiltonian flow on the funnel is
-# chaotic, so last-bit differences (sum order, exp) grow ~10x every 10-15 draws; the funnel
-# fixtures are kept to <= 60 draws and compared at rel 1e-7 / abs 1e-9.  A single flipped
-# accept/retry decision would be an O(1) jump, and the bit generator's final state, which
-# pins every decision's RNG consumption, must match exactly.
+# Funnel (exp + a reduction inside the gradient): SURVEY 8c's bar is rel 1e-9 -- held for the
+# first 20 draws (measured on MI355X, tools/funnel_parity_report.py -> profiles/r2_funnel_parity.md:
+# max abs error 5e-13, max rel 2e-11 in the first 20 draws of both funnel fixtures).  The
+# Hamiltonian flow on the funnel is chaotic: last-bit differences (summation order, exp) grow by
+# ~1.23x per draw (1e-15 -> 2.4e-10 absolute over 60 draws), so from draw 20 on the bar widens by
+# 1.15x per draw (2.3e-7 relative at draw 59).  The absolute floor (5e-11 = the relative bar at
+# |x| = 0.05) covers coordinates that pass through zero.  A single flipped accept / retry decision would be an O(1) jump, and the bit
+# generator's final state, which pins every decision's RNG consumption, must match exactly.
 LOGP_RTOL = 1e-12
+FUNNEL_RTOL0, FUNNEL_ATOL0, FUNNEL_EXACT_DRAWS, FUNNEL_GROWTH = 1e-9, 5e-11, 20, 1.15
 
 
 def funnel_tol(n):
-    return dict(rtol=1e-7, atol=1e-9)
+    g = FUNNEL_GROWTH ** max(0, n - FUNNEL_EXACT_DRAWS + 1)
+    return dict(rtol=FUNNEL_RTOL0 * g, atol=FUNNEL_ATOL0 * g)
+
+
+def report_funnel_error(name, n, got, want):
+    """One line per draw in the test log (pytest -s / on failure): the measured parity error."""
+    err = np.abs(got - want)
+    print(f"funnel parity {name} draw {n:3d}: max abs err {err.max():.2e}, max err/(atol+rtol|x|) "
+          f"{(err / (funnel_tol(n)['atol'] + funnel_tol(n)['rtol'] * np.abs(want))).max():.3f}")
 
 
 def product_model(spec, ops):
@@ -105,6 +117,7 @@ def check_many_chain(name, ops, **extra):
         if exact:
             assert np.array_equal(th, z["draws"][n]), (name, n, np.abs(th - z["draws"][n]).max())
         else:
+            report_funnel_error(name, n, th, z["draws"][n])
             np.testing.assert_allclose(th, z["draws"][n], err_msg=f"{name} draw {n}", **funnel_tol(n))
         tol = dict(rtol=LOGP_RTOL, atol=1e-12) if exact else funnel_tol(n)
         np.testing.assert_allclose(lp, z["logp"][n], err_msg=f"{name} draw {n}", **tol)

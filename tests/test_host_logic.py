@@ -413,3 +413,9 @@ def test_reference_test_behaviours_with_fake_ops():
     db.check_accept_tests_with_host_rng(ops)
     db.check_theta_initialization(ops)
     db.check_smc_with_reference_style_model(ops)
+
+
+def test_checkpoint_of_sampler_moments_recorder_and_draw_store(tmp_path):
+    from tests.diag_parity import check_checkpoint_of_sampler_and_diagnostics
+
+    check_checkpoint_of_sampler_and_diagnostics(FakeOps(), str(tmp_path), chains=6, D=5, draws=24, at=11)
