@@ -72,6 +72,7 @@ SIGNATURES = {
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
     "bk_end_pos_pairs": [P, I, I, P, I, P],
     "bk_ess": [P, I, I, c_int, P, P, I, P],
+    "bk_iat_from_acor": [P, I, I, c_int, P, P, I, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
     "bk_rank_normalize": [P, F, P, I, P],
     "bk_host_normals": [c_int, P, P, I],
@@ -450,6 +451,10 @@ class Ops:
     def end_pos_pairs(self, acor, out):
         N, C = acor.shape
         self._call("bk_end_pos_pairs", ptr(acor), max(C, acor.stride(0)) if N else C, N, ptr(out), C, self._s())
+
+    def iat_from_acor(self, acor, estimator, ess_out, iat_out=None):
+        N, C = acor.shape
+        self._call("bk_iat_from_acor", ptr(acor), _ld(acor), N, estimator, ptr(ess_out), ptr(iat_out), C, self._s())
 
     def ess(self, x, estimator, ess_out, iat_out=None):
         N, C = x.shape

@@ -2,6 +2,7 @@
 // (bayes_kit/rhat.py:111-171) and per-chain effective sample size (ess.py:52-69,
 // iat.py:7-43,95-135, autocorr.py:6-33).
 #include "bk_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -9,6 +10,12 @@ constexpr int EL_ROWS = 4;
 constexpr int PC_BLOCK = 64;
 
 // Welford: after the n-th draw, mean = np.mean(draws[:n]) and m2/(n-1) = np.var(ddof=1)
+__device__ __forceinline__ void welford_elem(double x, double& mu, double& q, double n) {
+  double delta = x - mu;
+  mu = mu + delta / n;
+  q = q + delta * (x - mu);
+}
+
 __global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const double* th, i64 ld,
                                                  double n, i64 C, i64 D) {
   i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -18,11 +25,50 @@ __global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const
   for (int i = 0; i < EL_ROWS; ++i)
     if (d0 + i < D) {
       i64 o = (d0 + i) * ld + c;
-      double x = th[o], mu = mean[o];
-      double delta = x - mu;
-      mu = mu + delta / n;
+      double mu = mean[o], q = m2[o];
+      welford_elem(th[o], mu, q, n);
       mean[o] = mu;
-      m2[o] = m2[o] + delta * (x - mu);
+      m2[o] = q;
+    }
+}
+
+// two chains (16 B) per lane, 40 algorithmic bytes per element (R theta, mean, M2; W mean, M2);
+// non-temporal when the three arrays stream past the Infinity Cache
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ __launch_bounds__(256) void k_welford_v2(double* mean, double* m2, const double* th, i64 ld,
+                                                    double n, i64 C2, i64 D) {
+  i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * EL_ROWS;
+  if (c2 >= C2) return;
+  dvec2 x[EL_ROWS], mu[EL_ROWS], q[EL_ROWS];
+#pragma unroll
+  for (int i = 0; i < EL_ROWS; ++i)
+    if (d0 + i < D) {
+      i64 o = (d0 + i) * ld + 2 * c2;
+      const dvec2 *px = reinterpret_cast<const dvec2*>(th + o), *pm = reinterpret_cast<const dvec2*>(mean + o),
+                  *pq = reinterpret_cast<const dvec2*>(m2 + o);
+      x[i] = NT ? __builtin_nontemporal_load(px) : *px;
+      mu[i] = NT ? __builtin_nontemporal_load(pm) : *pm;
+      q[i] = NT ? __builtin_nontemporal_load(pq) : *pq;
+    }
+#pragma unroll
+  for (int i = 0; i < EL_ROWS; ++i)
+    if (d0 + i < D) {
+      double m0 = mu[i].x, m1 = mu[i].y, q0 = q[i].x, q1 = q[i].y;
+      welford_elem(x[i].x, m0, q0, n);
+      welford_elem(x[i].y, m1, q1, n);
+      mu[i] = dvec2{m0, m1};
+      q[i] = dvec2{q0, q1};
+      i64 o = (d0 + i) * ld + 2 * c2;
+      dvec2 *pm = reinterpret_cast<dvec2*>(mean + o), *pq = reinterpret_cast<dvec2*>(m2 + o);
+      if (NT) {
+        __builtin_nontemporal_store(mu[i], pm);
+        __builtin_nontemporal_store(q[i], pq);
+      } else {
+        *pm = mu[i];
+        *pq = q[i];
+      }
     }
 }
 
@@ -157,6 +203,145 @@ __global__ __launch_bounds__(PC_BLOCK) void k_autocorr(const double* x, i64 ld, 
   }
 }
 
+// ---- ESS / autocorrelation with the series staged in LDS ----------------------------------------
+// A workgroup owns G consecutive chains: their N draws are read once, in rows of G*8 contiguous
+// bytes, into LDS (chain-major, pitch odd: the transposing writes are conflict-free), centred there,
+// and every chain is then worked on by one WAVEFRONT: lane l owns lag n0 + l of a block of 64 lags
+// and accumulates  a[n] = sum_t xc[t] * xc[t+n]  sequentially in t -- xc[t] is an LDS broadcast,
+// xc[t+n0+l] a conflict-free consecutive read -- so 64 lags cost N steps, against 2 N strided
+// global loads PER LAG in the one-lane-per-chain kernel above.  The Geyer scan (iat.py:38-43,
+// :127-135) runs after each block and stops the chain at the first negative pair; typical chains
+// need one block.  Per-lag summation order = the one-lane kernel's (sequential in t).
+// Work per chain: O(N * ceil(lags/64)); all lags (bk_autocorr): O(N^2 / 64) per wavefront.
+constexpr int ET_BLOCK = 256, ET_WAVES = ET_BLOCK / BK_WAVE;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 1; m < BK_WAVE; m <<= 1) v = v + __shfl_xor(v, m);
+  return v;
+}
+
+template <int G>
+__global__ __launch_bounds__(ET_BLOCK) void k_ess_tile(const double* x, i64 ld, i64 N, int pitch, int estimator,
+                                                       double* ess_out, double* iat_out, double* acor_out, i64 ldo,
+                                                       i64 C) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];  // [G][pitch]
+  const int t = threadIdx.x, lane = t & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 c0 = (i64)blockIdx.x * G;
+  {
+    const int cl = t % G, r0 = t / G;
+    constexpr int RS = ET_BLOCK / G;
+    const bool ok = c0 + cl < C;
+    for (i64 r = r0; r < N; r += RS) xs[cl * pitch + r] = ok ? x[r * ld + c0 + cl] : 0.0;
+  }
+  __syncthreads();
+  for (int cl = w; cl < G; cl += ET_WAVES) {
+    const i64 c = c0 + cl;
+    if (c >= C) break;  // wave-uniform
+    double* xc = xs + cl * pitch;
+    double s = 0.0;
+    for (i64 r = lane; r < N; r += BK_WAVE) s = s + xc[r];
+    const double mu = wave_sum(s) / (double)N;
+    double q = 0.0;
+    for (i64 r = lane; r < N; r += BK_WAVE) {
+      const double dv = xc[r] - mu;
+      xc[r] = dv;
+      q = q + dv * dv;
+    }
+    const double var0 = wave_sum(q) / (double)N;
+    // (each lane re-reads values other lanes centred: same wavefront, LDS ops are issued in order)
+    double total = 0.0, prev_min = 0.0;
+    bool first = true, done = false;
+    for (i64 n0 = 0; n0 < N && !done; n0 += BK_WAVE) {
+      const i64 n = n0 + lane;
+      double a = 0.0;
+      const i64 tmax = N - n0;  // lane 0's term count; lane l stops l terms earlier
+      // main part: every lane's index is in range, 8 steps per pass with all 16 LDS reads issued before
+      // the (ordered) accumulation -- one read-use dependency per step would cost an LDS latency each
+      const i64 tsafe = tmax - (BK_WAVE - 1);  // tt + n0 + 63 < N  for tt < tsafe
+      i64 tt = 0;
+      for (; tt + 8 <= tsafe; tt += 8) {
+        double u[8], v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          u[k] = xc[tt + k];
+          v[k] = xc[tt + k + n];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a = a + u[k] * v[k];
+      }
+      for (; tt < tmax; ++tt) {
+        const double u = xc[tt];
+        const i64 j = tt + n;
+        const double v = j < N ? xc[j] : 0.0;
+        if (j < N) a = a + u * v;
+      }
+      const double r = n < N ? a / var0 / (double)N : 0.0;
+      if (acor_out) {
+        if (n < N) acor_out[n * ldo + c] = r;
+        continue;  // all lags wanted: no truncation
+      }
+      const double pair = r + __shfl_down(r, 1);  // valid in even lanes
+      for (int k = 0; k < BK_WAVE / 2; ++k) {
+        if (n0 + 2 * k + 1 >= N) { done = true; break; }  // iat.py:38 `while n + 1 < N`
+        const double pk = __shfl(pair, 2 * k);
+        if (first) {
+          // iat.py:127-128: the first pair always enters the IMSE sum, even when negative
+          prev_min = pk;
+          if (estimator == 0) total = pk;
+          first = false;
+          if (pk < 0.0) { done = true; break; }
+          if (estimator == 1) total = pk;
+        } else {
+          if (pk < 0.0) { done = true; break; }
+          if (estimator == 0) {
+            prev_min = prev_min < pk ? prev_min : pk;  // iat.py:132
+            total = total + prev_min;
+          } else {
+            total = total + pk;
+          }
+        }
+      }
+    }
+    if (!acor_out && lane == 0) {
+      const double iat = 2.0 * total - 1.0;
+      if (iat_out) iat_out[c] = iat;
+      ess_out[c] = (double)N / iat;
+    }
+  }
+}
+
+// IAT / ESS from an autocorrelation array acor[n*ld + c] (e.g. produced by an FFT for very long
+// chains): the Geyer scan alone, one lane per chain, reads coalesced across chains.
+__global__ __launch_bounds__(256) void k_iat_from_acor(const double* acor, i64 ld, i64 N, int estimator,
+                                                       double* ess_out, double* iat_out, i64 C) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double total = 0.0, prev_min = 0.0;
+  bool first = true;
+  for (i64 n = 0; n + 1 < N; n += 2) {
+    const double pk = acor[n * ld + c] + acor[(n + 1) * ld + c];
+    if (first) {
+      prev_min = pk;
+      if (estimator == 0) total = pk;
+      first = false;
+      if (pk < 0.0) break;
+      if (estimator == 1) total = pk;
+    } else {
+      if (pk < 0.0) break;
+      if (estimator == 0) {
+        prev_min = prev_min < pk ? prev_min : pk;
+        total = total + prev_min;
+      } else {
+        total = total + pk;
+      }
+    }
+  }
+  const double iat = 2.0 * total - 1.0;
+  if (iat_out) iat_out[c] = iat;
+  ess_out[c] = (double)N / iat;
+}
+
 // index one past the last even-aligned pair (0,1), (2,3), ... before the first pair with a negative
 // sum (iat.py:7-43), one lane per chain of an [N][ld] autocorrelation array
 __global__ __launch_bounds__(PC_BLOCK) void k_end_pos_pairs(const double* acor, i64 ld, i64 N, i64* out, i64 C) {
@@ -239,8 +424,16 @@ int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld,
   if (!mean || !m2 || !theta || n < 1 || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, EL_ROWS));
-  k_welford<<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C, D);
+  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(mean) && bk_aligned16(m2) && bk_aligned16(theta)) {
+    dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, EL_ROWS));
+    if (bk_streams_past_llc(3 * C * D))
+      k_welford_v2<true><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C / 2, D);
+    else
+      k_welford_v2<false><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C / 2, D);
+  } else {
+    dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, EL_ROWS));
+    k_welford<<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C, D);
+  }
   BK_RETURN_LAUNCH_STATUS();
 }
 
@@ -271,11 +464,58 @@ int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void
   BK_RETURN_LAUNCH_STATUS();
 }
 
+// LDS-staged launch for N draws: the widest chain group whose tile fits (G*pitch doubles <= 160 KiB
+// less a margin); 0 if even one chain does not fit (the one-lane-per-chain kernels then serve).
+static int ess_tile_launch(const double* x, i64 ld, i64 N, int estimator, double* ess_out, double* iat_out,
+                           double* acor_out, i64 ldo, i64 C, hipStream_t s) {
+  static const bool lane_only = []() { const char* e = getenv("BK_ESS_LANE_PER_CHAIN"); return e && e[0] == '1'; }();
+  if (lane_only) return 0;  // experiments: the one-lane-per-chain kernels
+  const int pitch = (int)(N | 1);
+  const i64 cap = (i64)(160 * 1024 - 512) / 8;
+  int G = 0;
+  for (int g : {16, 8, 4, 2, 1})
+    if ((i64)g * pitch <= cap) { G = g; break; }
+  if (!G || N > 0x3fffffff) return 0;
+  const size_t bytes = (size_t)G * pitch * 8;
+  dim3 grid((unsigned)bk_cdiv(C, G)), block(ET_BLOCK);
+#define BK_ET(GG)                                                                                                   \
+  do {                                                                                                              \
+    if (bytes > 64 * 1024) {                                                                                        \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ess_tile<GG>),                            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                   \
+      if (e != hipSuccess) return -(int)e - 1000;                                                                   \
+    }                                                                                                               \
+    k_ess_tile<GG><<<grid, block, bytes, s>>>(x, ld, N, pitch, estimator, ess_out, iat_out, acor_out, ldo, C);      \
+  } while (0)
+  switch (G) {
+    case 16: BK_ET(16); break;
+    case 8: BK_ET(8); break;
+    case 4: BK_ET(4); break;
+    case 2: BK_ET(2); break;
+    default: BK_ET(1); break;
+  }
+#undef BK_ET
+  return 1;
+}
+
 int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C, void* stream) {
   if (!x || !out || N < 2 || C < 0) return BK_E_ARG;
   if (ld < C || ldo < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_autocorr<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, out, ldo, C);
+  int r = ess_tile_launch(x, ld, N, 0, nullptr, nullptr, out, ldo, C, bk_stream(stream));
+  if (r < 0) return -(r + 1000);
+  if (r == 0)
+    k_autocorr<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, out, ldo, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_iat_from_acor(const double* acor, int64_t ld, int64_t N, int estimator, double* ess_out, double* iat_out,
+                     int64_t C, void* stream) {
+  if (!acor || !ess_out || N < 4 || C < 0 || (estimator != 0 && estimator != 1)) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  k_iat_from_acor<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, bk_stream(stream)>>>(acor, ld, N, estimator,
+                                                                                       ess_out, iat_out, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 
@@ -292,8 +532,11 @@ int bk_ess(const double* x, int64_t ld, int64_t N, int estimator, double* ess_ou
   if (!x || !ess_out || N < 4 || C < 0 || (estimator != 0 && estimator != 1)) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_ess<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, estimator,
-                                                                                     ess_out, iat_out, C);
+  int r = ess_tile_launch(x, ld, N, estimator, ess_out, iat_out, nullptr, 0, C, bk_stream(stream));
+  if (r < 0) return -(r + 1000);
+  if (r == 0)
+    k_ess<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, estimator,
+                                                                                       ess_out, iat_out, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -434,9 +434,15 @@ int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N
 int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void* stream);
 
 /* Autocorrelation at all lags 0..N-1 of each chain of a stored series, out[n*ldo + c]
- * (autocorr.py:6-33; same normalisation: / np.var(x) / N).  Direct summation. */
+ * (autocorr.py:6-33; same normalisation: / np.var(x) / N).  Direct summation, the series staged in
+ * LDS (16 chains per workgroup, one wavefront per chain, one lane per lag: N steps per 64 lags). */
 int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C,
                 void* stream);
+
+/* IAT / ESS of each chain from an autocorrelation array acor[n*ld + c], n < N (iat.py:46-135: the
+ * Geyer scan alone) -- for autocorrelations obtained elsewhere, e.g. by an FFT for very long chains. */
+int bk_iat_from_acor(const double* acor, int64_t ld, int64_t N, int estimator, double* ess_out,
+                     double* iat_out, int64_t C, void* stream);
 
 /* out[c] = index one past the last pair (0,1), (2,3), ... of acor[n*ld + c] before the first pair
  * with a negative sum (iat.py:7-43, the truncation point of both IAT estimators). */
@@ -444,7 +450,8 @@ int bk_end_pos_pairs(const double* acor, int64_t ld, int64_t N, int64_t* out, in
                      void* stream);
 
 /* ESS of each chain of a stored series (ess.py:52-69 -> iat.py:95-135 -> autocorr.py:6-33):
- * autocorrelations by direct summation (same quantity the reference gets by FFT), Geyer
+ * autocorrelations by direct summation (same quantity the reference gets by FFT) from an LDS-staged
+ * tile -- 64 lags per N steps per wavefront, only as many 64-lag blocks as the truncation needs --, Geyer
  * initial-positive truncation at the first even lag pair with negative sum, initial
  * monotone running-min sum, IAT = 2*sum - 1, ESS = N/IAT.  estimator 0 = IMSE (ess /
  * ess_imse), 1 = IPSE (ess_ipse).  iat_out may be NULL. */

@@ -410,6 +410,35 @@ class FakeOps:
                 n += 2
             out[c] = n
 
+    def iat_from_acor(self, acor, estimator, ess_out, iat_out=None):
+        a = acor.numpy()
+        N = a.shape[0]
+        for c in range(a.shape[1]):
+            total, prev_min, first, n = 0.0, 0.0, True, 0
+            while n + 1 < N:
+                pk = a[n, c] + a[n + 1, c]
+                if first:
+                    prev_min, first = pk, False
+                    if estimator == 0:
+                        total = pk
+                    if pk < 0:
+                        break
+                    if estimator == 1:
+                        total = pk
+                else:
+                    if pk < 0:
+                        break
+                    if estimator == 0:
+                        prev_min = min(prev_min, pk)
+                        total += prev_min
+                    else:
+                        total += pk
+                n += 2
+            it = 2.0 * total - 1.0
+            if iat_out is not None:
+                iat_out[c] = it
+            ess_out[c] = N / it
+
     def ess(self, x, estimator, ess_out, iat_out=None):
         from oracle import diagnostics as od
 

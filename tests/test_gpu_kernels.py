@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+import bayes_kit_amd as bk
+
 pytestmark = pytest.mark.gpu
 
 
@@ -605,3 +607,57 @@ def test_accept_with_non_finite_log_densities(ops):
         cur = dev(lp0.copy(), ops)
         ops.mh_accept(mode, cur, dev(a0, ops), dev(lp1, ops), dev(a1, ops), dev(logu, ops), mask, None, None)
         assert mask.cpu().numpy().astype(bool).tolist() == want.tolist(), mode
+
+
+@pytest.mark.parametrize("N,C", [(4, 3), (5, 70), (63, 17), (64, 33), (65, 16), (130, 100), (1000, 37), (1271, 20),
+                                 (1300, 9), (3000, 5), (6001, 3), (12000, 2)])
+def test_lds_staged_ess_and_autocorr_vs_oracle(ops, N, C):
+    """bk_ess / bk_autocorr with the series staged in LDS (16 / 8 / 4 / 2 / 1 chains per workgroup by N,
+    one wavefront per chain, one lane per lag) against oracle/diagnostics.py (the reference's FFT
+    formulation): AR(1) chains of several persistences, antithetic chains (negative first pair), both
+    estimators, ragged last workgroup."""
+    from oracle import diagnostics as od
+
+    rng = np.random.default_rng(N * 1000 + C)
+    x = np.empty((N, C))
+    for c in range(C):
+        phi = [-0.6, 0.0, 0.5, 0.9, 0.98][c % 5]
+        e = rng.normal(size=N)
+        x[0, c] = e[0]
+        for t in range(1, N):
+            x[t, c] = phi * x[t - 1, c] + e[t]
+    xd = torch.from_numpy(x).to(ops.device)
+    ac = bk.autocorr(xd).cpu().numpy()
+    for c in range(C):
+        np.testing.assert_allclose(ac[:, c], od.autocorr(x[:, c]), rtol=0, atol=1e-12)
+    for fn, ofn in ((bk.ess, od.ess), (bk.ess_ipse, od.ess_ipse), (bk.iat, od.iat), (bk.iat_ipse, od.iat_ipse)):
+        got = fn(xd).cpu().numpy()
+        want = np.array([ofn(x[:, c]) for c in range(C)])
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+
+
+def test_long_chains_take_the_fft_formulation(ops):
+    """N >= FFT_MIN_DRAWS: autocorrelation by the reference's own FFT formula (rocFFT) + the library's
+    Geyer scan kernel; against the oracle, and against the direct-sum kernel at the switch-over."""
+    from oracle import diagnostics as od
+    from bayes_kit_amd import diagnostics as dg
+
+    rng = np.random.default_rng(3)
+    N, C = 20000, 6
+    x = np.empty((N, C))
+    for c in range(C):
+        phi = [0.3, 0.9, 0.99][c % 3]
+        e = rng.normal(size=N)
+        x[0, c] = e[0]
+        for t in range(1, N):
+            x[t, c] = phi * x[t - 1, c] + e[t]
+    xd = torch.from_numpy(x).to(ops.device)
+    assert N >= dg.FFT_MIN_DRAWS
+    np.testing.assert_allclose(bk.ess(xd).cpu().numpy(), [od.ess(x[:, c]) for c in range(C)], rtol=1e-9)
+    np.testing.assert_allclose(bk.autocorr(xd)[:, 1].cpu().numpy(), od.autocorr(x[:, 1]), rtol=0, atol=1e-12)
+    # the two formulations agree where they meet
+    short = xd[:12000].contiguous()
+    direct = bk.ess(short).cpu().numpy()
+    e2 = torch.empty(C, dtype=torch.float64, device=ops.device)
+    ops.iat_from_acor(dg._autocorr_fft(short), 0, e2, None)
+    np.testing.assert_allclose(direct, e2.cpu().numpy(), rtol=1e-9)
