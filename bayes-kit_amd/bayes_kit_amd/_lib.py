@@ -75,11 +75,15 @@ SIGNATURES = {
     "bk_iat_from_acor": [P, I, I, c_int, P, P, I, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
     "bk_rank_normalize": [P, F, P, I, P],
+    "bk_sort_by_key_work_bytes": [I],
+    "bk_sort_by_key": [P, P, P, P, I, P, I, P],
+    "bk_count_below": [P, I, P, I, P, P],
+    "bk_scatter_ranks": [P, I, F, P, P],
     "bk_host_normals": [c_int, P, P, I],
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
 }
-_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64}
+_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64}
 
 
 class BkHipError(RuntimeError):
@@ -443,6 +447,28 @@ class Ops:
 
     def rank_normalize(self, rank, S, out):
         self._call("bk_rank_normalize", ptr(rank), float(S), ptr(out), rank.numel(), self._s())
+
+    def sort_by_key(self, keys, vals):
+        """Stable ascending sort of (float64 key, int64 payload) pairs -> (sorted keys, payloads)."""
+        n = keys.numel()
+        ko, vo = torch.empty_like(keys), torch.empty_like(vals)
+        if n == 0:
+            return ko, vo
+        nb = self.lib.bk_sort_by_key_work_bytes(n)
+        if nb < 0:
+            raise BkHipError("bk_sort_by_key_work_bytes failed")
+        work = torch.empty(max(1, nb), dtype=torch.uint8, device=keys.device)
+        self._call("bk_sort_by_key", ptr(keys), ptr(ko), ptr(vals), ptr(vo), n, ptr(work), work.numel(), self._s())
+        return ko, vo
+
+    def count_below(self, sorted_keys, queries):
+        out = torch.empty(queries.numel(), dtype=torch.int64, device=queries.device)
+        self._call("bk_count_below", ptr(sorted_keys), sorted_keys.numel(), ptr(queries), queries.numel(), ptr(out),
+                   self._s())
+        return out
+
+    def scatter_ranks(self, payload, base, out):
+        self._call("bk_scatter_ranks", ptr(payload), payload.numel(), float(base), ptr(out), self._s())
 
     def autocorr(self, x, out):
         N, C = x.shape

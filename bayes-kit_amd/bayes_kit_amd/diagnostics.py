@@ -391,14 +391,88 @@ def split_rhat(chains, *, ops=None, group=None):
     return rhat(split_chains(chains), ops=ops, group=group)
 
 
-def _ranks_pooled(flat: torch.Tensor) -> torch.Tensor:
+def _ranks_pooled(flat: torch.Tensor, ops) -> torch.Tensor:
     """Ascending 1-based ranks of the pooled draws (rhat.py:51-52: argsort().argsort() + 1).
     Ties get distinct consecutive ranks; numpy leaves their order to its sort, here it is the
-    order of appearance (stable sort)."""
-    order = torch.argsort(flat, stable=True)
+    order of appearance (stable sort).  bk_sort_by_key + bk_scatter_ranks."""
+    n = flat.numel()
+    idx = torch.arange(n, dtype=torch.int64, device=flat.device)
+    _, payload = ops.sort_by_key(flat.contiguous(), idx)
     ranks = torch.empty_like(flat)
-    ranks[order] = torch.arange(1, flat.numel() + 1, dtype=flat.dtype, device=flat.device)
+    ops.scatter_ranks(payload, 0.0, ranks)
     return ranks
+
+
+SAMPLES_PER_RANK = 64  # regular samples each rank contributes per destination bucket
+
+
+def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor:
+    """Global pooled ranks of this rank's [N, C_local] shard WITHOUT replicating the draws: a sample
+    sort.  Pooled order = chain-major over all ranks' chains in rank order (what rank_chains sees
+    when handed every chain); equal values rank in that order.
+
+      1. local stable sort of (value, global flat index)                       bk_sort_by_key
+      2. 64*world regular samples per rank -> all_gather -> world-1 splitters
+      3. bucket boundaries by binary search (bk_count_below); bucket k belongs to rank k
+      4. all_to_all of the buckets (values + indices): S_local*16 bytes sent per rank, over RCCL/xGMI,
+         instead of S_total*8 bytes RECEIVED by every rank
+      5. owner: stable sort of what arrived (sorted runs in source-rank order: ties stay in global
+         order); rank of position j = (sizes of the lower buckets) + j + 1      bk_scatter_ranks
+      6. ranks travel back to the elements' home ranks (all_to_all)
+    Returns the ranks as doubles, shaped like x."""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    N, C = x.shape
+    dev = x.device
+    flat = x.t().contiguous().reshape(-1)
+    S_local = flat.numel()
+    sizes = _all_gather_counts(S_local, dev, group)
+    ends = torch.cumsum(torch.tensor(sizes, dtype=torch.int64, device=dev), 0)
+    first = int(ends[me].item()) - S_local
+    gidx = torch.arange(S_local, dtype=torch.int64, device=dev) + first
+    keys, pay = ops.sort_by_key(flat, gidx)
+    # 2. splitters
+    s = SAMPLES_PER_RANK * world
+    samp = torch.full((s,), float("inf"), dtype=torch.float64, device=dev)
+    if S_local > 0:
+        k = min(s, S_local)
+        pos = ((torch.arange(k, dtype=torch.float64, device=dev) + 0.5) * (S_local / k)).to(torch.int64).clamp_(max=S_local - 1)
+        samp[:k] = keys[pos]
+    parts = [torch.empty_like(samp) for _ in range(world)]
+    dist.all_gather(parts, samp, group=group)
+    allsamp = torch.sort(torch.cat(parts)).values          # world*s values: tiny
+    nreal = int(torch.isfinite(allsamp).sum().item())
+    cut_pos = [(nreal * (r + 1)) // world for r in range(world - 1)]
+    splitters = allsamp[torch.tensor(cut_pos, dtype=torch.int64, device=dev).clamp_(max=max(nreal - 1, 0))]
+    # 3. buckets (values equal to a splitter go to the bucket above it, on every rank alike)
+    cuts = ops.count_below(keys, splitters.contiguous()) if world > 1 else torch.empty(0, dtype=torch.int64, device=dev)
+    bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), cuts, torch.tensor([S_local], dtype=torch.int64, device=dev)])
+    bounds = torch.cummax(bounds, 0).values                # (monotone even if splitters repeat)
+    send_counts = (bounds[1:] - bounds[:-1])
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    # 4. the buckets travel
+    R = sum(rc)
+    rk = torch.empty(R, dtype=torch.float64, device=dev)
+    rp = torch.empty(R, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rk, keys, rc, sc, group=group)
+    dist.all_to_all_single(rp, pay, rc, sc, group=group)
+    # 5. ranks inside my bucket
+    _, ps = ops.sort_by_key(rk, rp)
+    bsz = _all_gather_counts(R, dev, group)
+    my_base = float(sum(bsz[:me]))
+    # 6. back home: group the sorted positions by the rank that owns the element
+    owner = torch.searchsorted(ends, ps, right=True)
+    _, order = ops.sort_by_key(owner.to(torch.float64), torch.arange(R, dtype=torch.int64, device=dev))
+    back_idx = ps[order].contiguous()
+    back_rank = (my_base + (order + 1).to(torch.float64)).contiguous()
+    hi = torch.empty(S_local, dtype=torch.int64, device=dev)
+    hr = torch.empty(S_local, dtype=torch.float64, device=dev)
+    dist.all_to_all_single(hi, back_idx, sc, rc, group=group)
+    dist.all_to_all_single(hr, back_rank, sc, rc, group=group)
+    ranks = torch.empty(S_local, dtype=torch.float64, device=dev)
+    ranks[hi - first] = hr
+    return ranks.reshape(C, N).t()
 
 
 def _pooled(chains, ops):
@@ -417,7 +491,7 @@ def rank_chains(chains, *, ops=None):
         return chains
     ops = _ops(ops)
     flat, lens = _pooled(chains, ops)
-    ranks = _ranks_pooled(flat)
+    ranks = _ranks_pooled(flat, ops)
     if _is_matrix(chains):
         return ranks.reshape(len(lens), lens[0]).t()
     out, pos = [], 0
@@ -435,7 +509,7 @@ def rank_normalize_chains(chains, *, ops=None):
     flat, lens = _pooled(chains, ops)
     S = flat.numel()
     z = torch.empty_like(flat)
-    ops.rank_normalize(_ranks_pooled(flat), float(S), z)
+    ops.rank_normalize(_ranks_pooled(flat, ops), float(S), z)
     if _is_matrix(chains):
         return z.reshape(len(lens), lens[0]).t().contiguous()
     out, pos = [], 0
@@ -476,21 +550,21 @@ def _all_gather_columns(x: torch.Tensor, group=None):
 def rank_normalized_rhat(chains, *, ops=None, group=None):
     """bayes_kit/rhat.py:205-236: split R-hat of the rank-normalised chains.
 
-    Across ranks (an [N, C_local] shard per rank): ranks are global, so every rank receives all
-    draws (one all_gather of N x C_total doubles over RCCL/xGMI; fine up to a few GB per
-    parameter), ranks the pooled values redundantly, keeps its own chains' normal scores and
-    joins the usual cross-rank split R-hat.  (A distributed sample sort would avoid the
-    replication; not needed at the sizes of BASELINE.json.)"""
+    Across ranks (an [N, C_local] shard per rank) the ranks are global: they come from a sample
+    sort over the process group (_ranks_pooled_across_ranks: each rank sends and receives its own
+    share of the draws once, nothing is replicated); every rank then turns its own chains' ranks
+    into normal scores and joins the usual cross-rank split R-hat."""
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not multi:
         return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops)
     if not _is_matrix(chains):
         raise ValueError("across ranks rank_normalized_rhat takes this rank's [N, C_local] device tensor")
     ops = _ops(ops)
-    full, first = _all_gather_columns(chains, group)
-    z = rank_normalize_chains(full, ops=ops)
-    mine = z[:, first:first + chains.shape[1]].contiguous()
-    return split_rhat(mine, ops=ops, group=group)
+    ranks = _ranks_pooled_across_ranks(chains, ops, group).contiguous()
+    S = float(sum(_all_gather_counts(chains.numel(), chains.device, group)))
+    z = torch.empty_like(ranks)
+    ops.rank_normalize(ranks, S, z)
+    return split_rhat(z, ops=ops, group=group)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -433,6 +433,22 @@ int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N
  * scipy.stats.norm.ppf, evaluated in the same order. */
 int bk_rank_normalize(const double* rank, double S, double* out, int64_t n, void* stream);
 
+/* Building blocks of pooled ranks (rhat.py:27-59: every draw replaced by its rank among ALL draws
+ * of ALL chains) without replicating the draws on every rank -- a sample sort:
+ *   bk_sort_by_key    stable ascending sort of (key, payload) pairs (keys double, -0.0 < +0.0, NaNs
+ *                     last; equal keys keep their input order).  `work`: caller scratch of
+ *                     bk_sort_by_key_work_bytes(n) bytes.  In and out arrays must not overlap.
+ *   bk_count_below    out[i] = number of sorted_keys[0..n) strictly below queries[i]  (bucket
+ *                     boundaries for the splitters)
+ *   bk_scatter_ranks  out[payload[j]] = base + (j + 1), j < n: the (1-based, as doubles) ranks of a
+ *                     sorted run whose first element has `base` elements before it. */
+int64_t bk_sort_by_key_work_bytes(int64_t n);
+int bk_sort_by_key(const double* keys_in, double* keys_out, const int64_t* vals_in, int64_t* vals_out,
+                   int64_t n, void* work, int64_t work_bytes, void* stream);
+int bk_count_below(const double* sorted_keys, int64_t n, const double* queries, int64_t m, int64_t* out,
+                   void* stream);
+int bk_scatter_ranks(const int64_t* payload, int64_t n, double base, double* out, void* stream);
+
 /* Autocorrelation at all lags 0..N-1 of each chain of a stored series, out[n*ldo + c]
  * (autocorr.py:6-33; same normalisation: / np.var(x) / N).  Direct summation, the series staged in
  * LDS (16 chains per workgroup, one wavefront per chain, one lane per lag: N steps per 64 lags). */

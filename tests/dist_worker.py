@@ -98,6 +98,24 @@ def main():
                                       bk.metropolis_kernel(0.4), seed=22, group=solo_group, ops=ops)
     solo_o.run()
     assert np.array_equal(np.concatenate(parts_o, axis=0), solo_o.thetas.numpy())
+    # 7) the sample sort behind the cross-rank rank normalisation: global ranks of a sharded series ==
+    #    ranks of the pooled series in one process, including ties (resolved by pooled order) and a
+    #    heavily skewed split of the value range between the ranks
+    from bayes_kit_amd import diagnostics as dg
+
+    rs = np.random.default_rng(11)
+    for C_tot, N_t, make in ((7, 50, lambda: rs.integers(0, 9, size=(50, 7)).astype(np.float64)),
+                             (6, 40, lambda: np.sort(rs.normal(size=(40 * 6))).reshape(6, 40).T.copy()),
+                             (9, 31, lambda: rs.normal(size=(31, 9)))):
+        full_np = make()
+        shared = [full_np if rank == 0 else None]
+        dist.broadcast_object_list(shared, src=0)
+        full_np = shared[0]
+        f8, n8 = bk.dist.shard(C_tot)
+        mine = torch.from_numpy(np.ascontiguousarray(full_np[:, f8:f8 + n8]))
+        got = dg._ranks_pooled_across_ranks(mine, ops)
+        want = dg.rank_chains(torch.from_numpy(full_np), ops=ops)[:, f8:f8 + n8]
+        assert torch.equal(got, want), (C_tot, N_t)
     total = bk.dist.sum_over_ranks(float(n))
     assert total == C
     dist.barrier()

@@ -396,6 +396,16 @@ class FakeOps:
 
         out.numpy().reshape(-1)[...] = scipy.stats.norm.ppf((rank.numpy().reshape(-1) - 0.325) / (S - 0.25))
 
+    def sort_by_key(self, keys, vals):
+        ko, order = torch.sort(keys, stable=True)
+        return ko, vals[order]
+
+    def count_below(self, sorted_keys, queries):
+        return torch.searchsorted(sorted_keys.contiguous(), queries.contiguous(), right=False)
+
+    def scatter_ranks(self, payload, base, out):
+        out[payload] = base + torch.arange(1, payload.numel() + 1, dtype=out.dtype)
+
     def autocorr(self, x, out):
         from oracle import diagnostics as od
 

@@ -661,3 +661,74 @@ def test_long_chains_take_the_fft_formulation(ops):
     e2 = torch.empty(C, dtype=torch.float64, device=ops.device)
     ops.iat_from_acor(dg._autocorr_fft(short), 0, e2, None)
     np.testing.assert_allclose(direct, e2.cpu().numpy(), rtol=1e-9)
+
+
+def test_sort_entry_points_and_pooled_ranks(ops):
+    """bk_sort_by_key (stable, -0.0 < +0.0, duplicates, infinities), bk_count_below, bk_scatter_ranks and
+    the pooled ranks built on them, against torch's stable sort / NumPy."""
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 63, 1000, 3_000_001):
+        v = rng.normal(size=n)
+        if n >= 63:
+            v[::7] = np.round(v[::7])          # many exact ties
+            v[3], v[5], v[11], v[12] = 0.0, -0.0, np.inf, -np.inf
+        keys = torch.from_numpy(v).to(ops.device)
+        pay = torch.arange(n, dtype=torch.int64, device=ops.device)
+        ks, ps = ops.sort_by_key(keys, pay)
+        ref = torch.sort(keys, stable=True)
+        assert torch.equal(ks, ref.values) or n < 63
+        assert torch.equal(ks.abs(), ref.values.abs()) and bool((ks[1:] >= ks[:-1]).all())
+        if n < 63:
+            assert torch.equal(ps, ref.indices)
+        else:  # stable within equal keys (radix order puts -0.0 before +0.0, torch treats them as equal)
+            same = ks[1:] == ks[:-1]
+            signed_same = same & (torch.signbit(ks[1:]) == torch.signbit(ks[:-1]))
+            assert bool((ps[1:][signed_same] > ps[:-1][signed_same]).all())
+        q = torch.from_numpy(np.array([-np.inf, -1.0, 0.0, 0.5, np.inf])).to(ops.device)
+        np.testing.assert_array_equal(ops.count_below(ks, q).cpu().numpy(), np.searchsorted(np.sort(v), q.cpu().numpy(), side="left"))
+        ranks = torch.empty(n, dtype=torch.float64, device=ops.device)
+        ops.scatter_ranks(ps, 10.0, ranks)
+        assert torch.equal(ranks[ps], torch.arange(11, n + 11, dtype=torch.float64, device=ops.device))
+    x = torch.from_numpy(rng.normal(size=(200, 37))).to(ops.device)
+    from bayes_kit_amd import diagnostics as dg
+
+    r = dg.rank_chains(x).cpu().numpy()
+    flat = x.t().contiguous().reshape(-1).cpu().numpy()
+    want = (flat.argsort(kind="stable").argsort() + 1).reshape(37, 200).T
+    np.testing.assert_array_equal(r, want)
+
+
+def test_sample_sort_and_rhat_collectives_run_on_rccl(ops):
+    """The cross-rank code paths on the real collective library: a one-rank `nccl` (= RCCL) process group
+    on the GPU -- all_gather, all_to_all_single and the gathered partial sums run through RCCL with
+    device tensors; results equal the no-group paths."""
+    import socket
+
+    import torch.distributed as dist
+    from bayes_kit_amd import diagnostics as dg
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=ops.device)
+    try:
+        assert dist.get_backend() == "nccl"
+        rng = np.random.default_rng(2)
+        x = torch.from_numpy(rng.normal(size=(300, 64))).to(ops.device)
+        x[::5] = torch.round(x[::5])
+        got = dg._ranks_pooled_across_ranks(x, ops)
+        assert torch.equal(got, dg.rank_chains(x))
+        t = torch.ones(5, dtype=torch.float64, device=ops.device)
+        dist.all_reduce(t)
+        assert float(t.sum().item()) == 5.0
+        np.testing.assert_allclose(bk.rhat(x), dg._rhat_of_columns(x, None, ops, None), rtol=0)
+        mom = bk.RunningMoments(3, 64)
+        for i in range(4):
+            mom.update(x[i * 3:(i + 1) * 3].contiguous())
+        assert np.isfinite(mom.rhat()).all()
+        assert bk.dist.sum_over_ranks(2.5, ops.device) == 2.5
+    finally:
+        dist.destroy_process_group()
