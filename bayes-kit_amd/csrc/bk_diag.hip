@@ -355,7 +355,9 @@ __global__ __launch_bounds__(PC_BLOCK) void k_end_pos_pairs(const double* acor, 
   out[c] = n;
 }
 
-// Inverse standard-normal CDF: Cephes ndtri (what scipy.stats.norm.ppf evaluates; rhat.py:106),
+// Inverse standard-normal CDF: port of Cephes ndtri.c (Cephes Math Library, Copyright 1984-2000 by
+// Stephen L. Moshier; redistributed by SciPy under BSD-3-Clause; see THIRD_PARTY.md) -- the routine
+// scipy.stats.norm.ppf evaluates (rhat.py:106),
 // same rational approximations and evaluation order, no FMA contraction.
 __device__ __forceinline__ double polevl(double x, const double* c, int n) {
   double a = c[0];

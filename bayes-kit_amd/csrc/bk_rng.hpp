@@ -230,7 +230,11 @@ struct Pcg64 {
 
 // ---- glibc 2.35 log1p (sysdeps/ieee754/dbl-64/s_log1p.c) for finite x > -1 -----------
 // fdlibm argument reduction with glibc's split polynomial; every operation individually
-// rounded (the library is built with -ffp-contract=off).
+// rounded (the library is built with -ffp-contract=off).  Ported algorithm and constants:
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this software is freely granted,
+//   provided that this notice is preserved.                       (see THIRD_PARTY.md)
 BK_HD double bk_log1p(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double Lp1 = 6.666666666666735130e-01, Lp2 = 3.999999999940941908e-01,
