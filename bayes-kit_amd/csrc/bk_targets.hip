@@ -132,51 +132,99 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
   }
 }
 
-// Neal's funnel.  The only coupling between the coordinates of a chain is s = sum_{i>=1}
-// theta_i^2, so a workgroup of 16 wavefronts serves 64 chains: lane = chain, wavefront w owns
-// the rows d = 1 + w + 16 i (kept in registers), and s is reduced through LDS in a FIXED
-// order (each wavefront's rows in increasing d, then wavefronts 0..15), so the result does
-// not depend on how many chains are in flight.  Every wavefront integrates v = theta_0
-// redundantly (it needs exp(-v) for its own rows); wavefront 0 writes it.
+// Neal's funnel.  The only coupling between the coordinates of a chain is s = sum_{d>=1}
+// theta_d^2, so a workgroup splits the ROWS of its chains over wavefronts (and lane groups) and
+// reduces s through LDS.
+//
+// Canonical summation order (every funnel kernel below; results do not depend on how many chains
+// are in flight, on the grid, or on which geometry runs).  Row d belongs to class c = (d-1) mod 16,
+// slot i = (d-1) div 16:
+//     cs[c] = sum over i, in order, of x[1 + c + 16 i]^2              (16 class sums)
+//     q[g]  = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12],  g = 0..3     (4 group sums)
+//     s     = ((q[0] + q[1]) + q[2]) + q[3]
+// Two geometries of a 4-wavefront workgroup produce exactly these values:
+//   * WIDE (throughput: a large lane set).  64 chains, lane = chain; wavefront w owns the four
+//     classes of group w (up to 32 rows in registers) and contributes q[w].
+//   * NARROW (latency: small lane sets, long trajectories).  16 chains; lane = (chain, h), h = lane/16;
+//     wavefront w, lane group h own class w + 4h (up to 8 rows); q[w] is formed across the four
+//     lane groups by shuffles, in order.  A leapfrog step then has a quarter of the dependent work per
+//     lane and a set of n chains spreads over 4x as many CUs -- the sparse 40- and 160-step stages
+//     of config 4 (a few per cent of the chains) are latency bound: 170 -> ~60 us per launch.
+// Every lane integrates v = theta_0 redundantly (it needs exp(-v) for its own rows); one lane per
+// chain writes it.
 constexpr int FN_WAVES = 4;
-constexpr int FN_ROWS = 32;  // rows per wavefront held in registers: D - 1 <= 128
+constexpr int FN_CLASSES = 16;
+constexpr int FN_MAX_SLOTS = 8;  // slots per class held in registers: D - 1 <= 128
+constexpr int FN_MAX_ROWS = FN_CLASSES * FN_MAX_SLOTS;
 constexpr int FN_BLOCK = FN_WAVES * BK_WAVE;
 
 struct FunnelLds {
   double part[2][FN_WAVES][BK_WAVE];
 };
 
-// sum over the 16 wavefronts' partials for this lane's chain, fixed order; buf alternates per call
-__device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, int lane, double partial) {
-  lds.part[buf][w][lane] = partial;
+// Geometry: which rows live in a lane's registers and which chain a lane serves.
+//   NARROW = false: register slot u = k*SL + i holds class w + 4k, slot i; chain = lane.
+//   NARROW = true : u = i holds class w + 4*(lane/16), slot i;          chain = lane % 16.
+template <bool NARROW, int SL>
+struct FunnelGeo {
+  static constexpr int KC = NARROW ? 1 : 4;   // classes per lane
+  static constexpr int NU = KC * SL;          // register slots per lane
+  static constexpr int CHAINS = NARROW ? 16 : BK_WAVE;
+  __device__ static __forceinline__ i64 row(int w, int lane, int u) {
+    const int k = NARROW ? (lane >> 4) : (u / SL), i = NARROW ? u : (u % SL);
+    return 1 + (w + 4 * k) + (i64)FN_CLASSES * i;
+  }
+  __device__ static __forceinline__ int chain(int lane) { return NARROW ? (lane & 15) : lane; }
+};
+
+// s (canonical order) for this lane's chain from the lane's class sums cs[KC]; buf alternates per call
+template <bool NARROW>
+__device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, int lane, const double* cs) {
+  double q;
+  if (NARROW) {
+    // the four lane groups of this wavefront hold classes w, w+4, w+8, w+12 of the same 16 chains
+    const int cl = lane & 15;
+    const double c0 = __shfl(cs[0], cl), c1 = __shfl(cs[0], cl + 16), c2 = __shfl(cs[0], cl + 32),
+                 c3 = __shfl(cs[0], cl + 48);
+    q = ((c0 + c1) + c2) + c3;
+  } else {
+    q = ((cs[0] + cs[1]) + cs[2]) + cs[3];
+  }
+  lds.part[buf][w][lane] = q;
   __syncthreads();
-  double s = 0.0;
-#pragma unroll
-  for (int k = 0; k < FN_WAVES; ++k) s = s + lds.part[buf][k][lane];
-  return s;
+  return ((lds.part[buf][0][lane] + lds.part[buf][1][lane]) + lds.part[buf][2][lane]) + lds.part[buf][3][lane];
 }
 
+// class sums of `expr` over this lane's rows < D, each class sequential in its slots
+#define BK_FN_CLASS_SUMS(cs, expr)                                   \
+  _Pragma("unroll") for (int k = 0; k < G::KC; ++k) {                \
+    double acc_ = 0.0;                                               \
+    _Pragma("unroll") for (int i = 0; i < SL; ++i) {                 \
+      const int u = k * SL + i;                                      \
+      if (G::row(w, lane, u) < D) acc_ = acc_ + (expr);              \
+    }                                                                \
+    cs[k] = acc_;                                                    \
+  }
+
 // gradient / log density for n chains (chain j in column j)
+template <int SL>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
                                                           i64 n, i64 D) {
+  using G = FunnelGeo<false, SL>;
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
-  double x[FN_ROWS];
-  double p = 0.0;
+  double x[G::NU];
 #pragma unroll
-  for (int i = 0; i < FN_ROWS; ++i) {
-    i64 d = 1 + w + (i64)FN_WAVES * i;
-    x[i] = (on && d < D) ? th[d * ld + j] : 0.0;
+  for (int u = 0; u < G::NU; ++u) {
+    const i64 d = G::row(w, lane, u);
+    x[u] = (on && d < D) ? th[d * ld + j] : 0.0;
   }
-#pragma unroll
-  for (int i = 0; i < FN_ROWS; ++i) {
-    i64 d = 1 + w + (i64)FN_WAVES * i;
-    if (d < D) p = p + x[i] * x[i];
-  }
+  double cs[G::KC];
+  BK_FN_CLASS_SUMS(cs, x[u] * x[u])
   double v = on ? th[j] : 0.0;
-  double s = funnel_reduce(lds, 0, w, lane, p);
+  double s = funnel_reduce<false>(lds, 0, w, lane, cs);
   if (!on) return;
   double ev = exp(-v);
   double hn = 0.5 * (double)(D - 1);
@@ -187,9 +235,9 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
   }
   if (g) {
 #pragma unroll
-    for (int i = 0; i < FN_ROWS; ++i) {
-      i64 d = 1 + w + (i64)FN_WAVES * i;
-      if (d < D) g[d * ld + j] = -(ev * x[i]);
+    for (int u = 0; u < G::NU; ++u) {
+      const i64 d = G::row(w, lane, u);
+      if (d < D) g[d * ld + j] = -(ev * x[u]);
     }
   }
 }
@@ -198,15 +246,17 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
 // launch: gather chain idx[j] of the source point, first half-kick with the source's cached
 // gradient + drift, (steps-1) x {gradient, kick, drift}, final gradient + log density,
 // last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers.
-// ROWS = rows of x per wavefront kept in registers (>= ceil((D-1)/4)); HM = a metric is given.  Both
-// compile-time: with the generic 32 rows and a run-time metric flag the kernel needed 330 registers
-// (one wavefront per SIMD, AGPR spills); sized to the problem it fits three.
-template <int ROWS, bool HM>
+// NARROW: geometry (above); SL = slots per class kept in registers (>= ceil((D-1)/16)); HM = a
+// metric is given.  All compile-time: with generic sizes and a run-time metric flag the kernel
+// needed 330 registers (one wavefront per SIMD, AGPR spills).
+template <bool NARROW, int SL, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
     unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out) {
+  using G = FunnelGeo<NARROW, SL>;
+  constexpr int NU = G::NU;
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   // lanes actually in the set: read from device memory when the host only knows an upper bound
@@ -219,29 +269,30 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     if (lanes_out) *lanes_out = (uint32_t)n;
     if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
   }
-  if ((i64)blockIdx.x * BK_WAVE >= n) return;  // whole workgroup past the set (uniform: before any barrier)
-  const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
+  if ((i64)blockIdx.x * G::CHAINS >= n) return;  // whole workgroup past the set (uniform: before any barrier)
+  const i64 j = (i64)blockIdx.x * G::CHAINS + G::chain(lane);
   const bool on = j < n;
+  const bool writer = on && w == 0 && (!NARROW || lane < 16);  // the lane that owns theta_0 / the scalars
   const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
   const double half = 0.5 * h;
   const double hn = 0.5 * (double)(D - 1);
   constexpr bool hm = HM;
-  double x[ROWS], r[ROWS];
+  double x[NU], r[NU];
   // gather + first half-kick + drift (drghmc.py:276-278)
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    i64 d = 1 + w + (i64)FN_WAVES * i;
+  for (int u = 0; u < NU; ++u) {
+    const i64 d = G::row(w, lane, u);
     bool ok = on && d < D;
-    x[i] = ok ? th_in[d * ld_in + src] : 0.0;
-    r[i] = ok ? rho_in[d * ld_in + src] : 0.0;
+    x[u] = ok ? th_in[d * ld_in + src] : 0.0;
+    r[u] = ok ? rho_in[d * ld_in + src] : 0.0;
     double g0 = ok ? g_in[d * ld_in + src] : 0.0;
-    const double mi = (hm && d < D) ? metric[d] : 1.0;  // wave-uniform index: scalar load
+    const double mi = (hm && d < D) ? metric[d] : 1.0;
     double t = hm ? mi * g0 : g0;
-    r[i] = r[i] + half * t;
-    x[i] = x[i] + h * r[i];
-    // the gather is issued in batches of 8 rows: all 3*ROWS loads in flight at once would set the
+    r[u] = r[u] + half * t;
+    x[u] = x[u] + h * r[u];
+    // the gather is issued in batches of 8 rows: all 3*NU loads in flight at once would set the
     // kernel's register count (and so its occupancy for the whole trajectory)
-    if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
   double v = on ? th_in[src] : 0.0, rv = on ? rho_in[src] : 0.0;
   const double mv = hm ? metric[0] : 1.0;
@@ -252,17 +303,11 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     v = v + h * rv;
   }
   int buf = 0;
-  // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283); the sum x.x of a chain is formed by its
-  // 4 wavefronts: each adds its rows in order, the 4 partials are combined through LDS in wave order
+  double cs[G::KC];
+  // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283)
   for (int step = 0; step + 1 < steps; ++step) {
-    double p = 0.0;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      i64 d = 1 + w + (i64)FN_WAVES * i;
-      if (d < D) p = p + x[i] * x[i];
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    const double s = funnel_reduce(lds, buf, w, lane, p);
+    BK_FN_CLASS_SUMS(cs, x[u] * x[u])
+    const double s = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
     buf ^= 1;
     const double ev = exp(-v);
     const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
@@ -272,27 +317,22 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
       v = v + h * rv;
     }
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      i64 d = 1 + w + (i64)FN_WAVES * i;
+    for (int u = 0; u < NU; ++u) {
+      const i64 d = G::row(w, lane, u);
       if (d < D) {
-        double gi = -(ev * x[i]);
+        double gi = -(ev * x[u]);
         double t = hm ? metric[d] * gi : gi;
-        r[i] = r[i] + h * t;
-        x[i] = x[i] + h * r[i];
+        r[u] = r[u] + h * t;
+        x[u] = x[u] + h * r[u];
       }
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
+      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
     }
   }
   // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
+  double logp_j = 0.0;
   {
-    double p = 0.0;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      i64 d = 1 + w + (i64)FN_WAVES * i;
-      if (d < D) p = p + x[i] * x[i];
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
-    const double s = funnel_reduce(lds, buf, w, lane, p);
+    BK_FN_CLASS_SUMS(cs, x[u] * x[u])
+    const double s = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
     buf ^= 1;
     const double ev = exp(-v);
     const double he = 0.5 * ev;
@@ -302,37 +342,36 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
       rv = rv + half * t;
     }
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      i64 d = 1 + w + (i64)FN_WAVES * i;
+    for (int u = 0; u < NU; ++u) {
+      const i64 d = G::row(w, lane, u);
       if (d < D) {
-        double gi = -(ev * x[i]);
+        double gi = -(ev * x[u]);
         double t = hm ? metric[d] * gi : gi;
-        r[i] = r[i] + half * t;
+        r[u] = r[u] + half * t;
         if (on) g_out[d * ld_out + j] = gi;
       }
     }
-    if (on && w == 0) {
+    logp_j = ((-(v * v) / 18.0) - hn * v) - he * s;
+    if (writer) {
       g_out[j] = gv;
-      logp_out[j] = ((-(v * v) / 18.0) - hn * v) - he * s;
+      logp_out[j] = logp_j;
     }
   }
-  // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250), outputs
-  double kp = 0.0;
+  // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250; same canonical order), outputs
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    i64 d = 1 + w + (i64)FN_WAVES * i;
+  for (int u = 0; u < NU; ++u) {
+    const i64 d = G::row(w, lane, u);
     if (d < D) {
-      double rr = -r[i];
-      double mr = hm ? metric[d] * rr : rr;
-      kp = kp + rr * mr;
+      r[u] = -r[u];
       if (on) {
-        rho_out[d * ld_out + j] = rr;
-        th_out[d * ld_out + j] = x[i];
+        rho_out[d * ld_out + j] = r[u];
+        th_out[d * ld_out + j] = x[u];
       }
     }
   }
-  double ksum = funnel_reduce(lds, buf, w, lane, kp);
-  if (on && w == 0) {
+  BK_FN_CLASS_SUMS(cs, r[u] * (hm ? metric[G::row(w, lane, u)] * r[u] : r[u]))
+  double ksum = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
+  if (writer) {
     double rr = -rv;
     double mr = hm ? mv * rr : rr;
     rho_out[j] = rr;
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     if (H_out) {
       // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
       // H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0, live = 1
-      const double potential = -logp_out[j];
+      const double potential = -logp_j;
       H_out[j] = -(potential + kin);
       hh_out[j] = 0.0;
       live_out[j] = 1;
@@ -641,9 +680,15 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
   if (!theta || (!grad && !logp) || C < 0 || D < 1) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  if (D - 1 <= FN_WAVES * FN_ROWS)
-    k_funnel_coop<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(FN_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
-                                                                                               ld, C, D);
+  if (D - 1 <= FN_MAX_ROWS) {
+    const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
+    dim3 grid((unsigned)bk_cdiv(C, BK_WAVE)), block(FN_BLOCK);
+    hipStream_t s = bk_stream(stream);
+    if (need <= 2) k_funnel_coop<2><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
+    else if (need <= 4) k_funnel_coop<4><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
+    else if (need <= 7) k_funnel_coop<7><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
+    else k_funnel_coop<8><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
+  }
   else
     k_funnel<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
                                                                                            ld, C, D);
@@ -658,33 +703,44 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
-  if (D - 1 > FN_WAVES * FN_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
+  if (D - 1 > FN_MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (H_out && (!h_out || !live_out)) return BK_E_ARG;
   if (ld_out < n) return BK_E_ALIGN;
   if (n == 0) {
     if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
     return BK_OK;
   }
-  const int need = (int)((D - 1 + FN_WAVES - 1) / FN_WAVES);
-  dim3 grid((unsigned)bk_cdiv(n, BK_WAVE));
+  const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
   hipStream_t s = bk_stream(stream);
-#define BK_FT(R, M)                                                                                             \
-  k_funnel_traj<R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,    \
-                                                      rho_out, grad_out, logp_out, kin_out, ld_out, metric, h,  \
-                                                      (int)steps, n, D, n_dev, lanes_out,                        \
-                                                      reinterpret_cast<unsigned long long*>(lanes_total), H_out, \
-                                                      h_out, live_out)
-#define BK_FT_ROWS(R)    \
-  do {                   \
-    if (metric)          \
-      BK_FT(R, true);    \
-    else                 \
-      BK_FT(R, false);   \
+  // Geometry.  A set that is small, or whose size only the device knows (every set after the first
+  // stage: a few per cent of the chains) -> NARROW, 16 chains per workgroup; a set known to be large ->
+  // WIDE, 64 chains per workgroup.  Same values either way.  BK_FUNNEL_GEOMETRY=wide|narrow overrides.
+  static const int forced = []() {
+    const char* e = getenv("BK_FUNNEL_GEOMETRY");
+    return !e ? 0 : (e[0] == 'n' ? 2 : 1);
+  }();
+  const bool narrow = forced ? forced == 2 : (n_dev != nullptr || n < 8192);
+  dim3 grid((unsigned)bk_cdiv(n, narrow ? 16 : BK_WAVE));
+#define BK_FT(NW, R, M)                                                                                           \
+  k_funnel_traj<NW, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,  \
+                                                          rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
+                                                          (int)steps, n, D, n_dev, lanes_out,                      \
+                                                          reinterpret_cast<unsigned long long*>(lanes_total),     \
+                                                          H_out, h_out, live_out)
+#define BK_FT_ROWS(R)                     \
+  do {                                    \
+    if (narrow) {                         \
+      if (metric) BK_FT(true, R, true);   \
+      else BK_FT(true, R, false);         \
+    } else {                              \
+      if (metric) BK_FT(false, R, true);  \
+      else BK_FT(false, R, false);        \
+    }                                     \
   } while (0)
-  if (need <= 8) BK_FT_ROWS(8);
-  else if (need <= 16) BK_FT_ROWS(16);
-  else if (need <= 25) BK_FT_ROWS(25);
-  else BK_FT_ROWS(32);
+  if (need <= 2) BK_FT_ROWS(2);
+  else if (need <= 4) BK_FT_ROWS(4);
+  else if (need <= 7) BK_FT_ROWS(7);
+  else BK_FT_ROWS(8);
 #undef BK_FT_ROWS
 #undef BK_FT
   BK_RETURN_LAUNCH_STATUS();
