@@ -149,7 +149,7 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
 //     wavefront w, lane group h own class w + 4h (up to 8 rows); q[w] is formed across the four
 //     lane groups by shuffles, in order.  A leapfrog step then has a quarter of the dependent work per
 //     lane and a set of n chains spreads over 4x as many CUs -- the sparse 40- and 160-step stages
-//     of config 4 (a few per cent of the chains) are latency bound: 170 -> ~60 us per launch.
+//     of config 4 (a few per cent of the chains) are latency bound: 170 -> 94 us for the 160-step launch.
 // Every lane integrates v = theta_0 redundantly (it needs exp(-v) for its own rows); one lane per
 // chain writes it.
 constexpr int FN_WAVES = 4;
