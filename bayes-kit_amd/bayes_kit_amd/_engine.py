@@ -292,80 +292,83 @@ class ManyChainSampler:
     # synchronisation (batched models; not the single-chain host-model mode, not DRGHMC).
     GRAPH_AUTO_MAX_ELEMS = 1 << 22  # D*C below which a draw is launch-bound (arrays <= 32 MiB)
 
-    def _init_graph(self, graph):
+    def _init_graph(self, graph, prefetch_rng=None):
+        if graph is None and prefetch_rng:
+            graph = False  # an explicit request for the side-stream generator: eager launches
         if graph is None:
             # automatic only where capture is known to be safe (the library's own targets: no host
             # synchronisation, no allocation patterns of user code) and where it pays
             graph = (self._batched and hasattr(self._model, "bk_eval") and self._ops.device.type == "cuda"
                      and self._dim * self._C <= self.GRAPH_AUTO_MAX_ELEMS)
         self._use_graph = bool(graph)
-        self._graphs = {}
+        self._graph = None  # the captured draw
         self._graph_warm = 0
         if self._use_graph and not self._batched:
             raise ValueError("graph=True needs a batched device model (the host-model mode synchronises)")
 
-    @property
-    def _graph(self):
-        """Any captured draw (None before the first capture)."""
-        return next(iter(self._graphs.values()), None)
-
     def _drop_graphs(self):
-        if getattr(self, "_graphs", None):
-            self._graphs = {}
+        self._graph = None
         self._graph_warm = 0
 
-    # Samplers that generate the NEXT draw's randomness on a side stream capture it as a parallel
-    # branch of the draw's graph (fork at the start, join at the end): two graphs, one per
-    # double-buffer slot, replayed alternately.
-    def _graph_key(self):
-        return 0
-
-    def _graph_keys(self):
-        """Every key a draw can have; all are captured at the first opportunity (capturing does
-        not execute anything), so that no capture falls into a caller's timed region later."""
-        return [0]
-
-    def _set_graph_key(self, key):
-        pass
-
-    def _before_capture(self):
-        pass
-
-    def _capture_epilogue(self):
-        pass
-
-    def _before_replay(self):
-        pass
-
-    def _after_replay(self):
-        pass
-
+    # A captured draw is a LINEAR graph: samplers that otherwise generate the next draw's randomness on
+    # a side stream (prefetch_rng) generate it in line when they replay a graph.  Capturing the side
+    # stream as a parallel branch (fork at the start of the draw, join at the end) is both slower
+    # (93 vs 79 us per draw at 4096 x 128: the replay pays for the fork/join markers and the branch
+    # runs on an internal stream) and unsafe on this ROCm: once such a hipGraphExec is destroyed the
+    # runtime's signal thread decrements a counter inside the freed queue object of that internal
+    # stream.  tools/heapguard.c pins it down -- a 920-byte block freed in one completion callback of
+    # libamdhip64 and written at offset 152 by the next -- and it is what flipped the last bit of
+    # unrelated host doubles and tripped glibc's heap checks under tests/soak_samplers.py (several
+    # hundred short-lived samplers a second).  Linear graphs, eager two-stream prefetch and plain
+    # PyTorch graphs all run clean under the same tool (profiles/r2_heapguard.md).
     def _run_draw(self, draw_fn):
         if not self._use_graph:
             draw_fn()
             return
-        if not self._graphs:
+        if self._graph is None:
             if self._graph_warm < 1:
                 draw_fn()  # eager: first-use initialisation, lazy parameter uploads
                 self._graph_warm += 1
                 return
             torch.cuda.synchronize()
-            self._before_capture()
-            now = self._graph_key()
-            for key in self._graph_keys():
-                self._set_graph_key(key)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    draw_fn()
-                    self._capture_epilogue()
-                self._graphs[key] = g
-            self._set_graph_key(now)
-        self._before_replay()
-        self._graphs[self._graph_key()].replay()
-        self._after_replay()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                draw_fn()
+            self._graph = g
+        self._graph.replay()
 
     def __next__(self):
         return self.sample()
+
+    # -- the RNG side stream ----------------------------------------------------------------------------
+    # Events are created ONCE per sampler and re-recorded every draw.  Creating two torch.cuda.Event
+    # objects per draw and dropping them while GPU-side waits on them were still pending corrupted the
+    # host heap under the randomised soak (glibc "malloc(): invalid size", a chain off by one ulp) --
+    # about once per 100,000 short-lived samplers, more often the more events a draw used
+    # (tensor.record_stream() made it frequent).  With persistent events, a GPU-side join at the end of
+    # every draw and a drained side stream before the sampler's buffers are released, it is gone.
+    def _init_side_stream(self):
+        dev = self._ops.device
+        self._side = torch.cuda.Stream(device=dev)
+        self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]  # main -> side: slot free, RNG table consistent
+        self._ev_done = [torch.cuda.Event(), torch.cuda.Event()]   # side -> main: slot filled
+
+    def _join_side_stream(self):
+        """Order everything queued later on the main stream after the side stream's pending generator
+        (its buffers were allocated on the main stream: without this a sampler dropped right after a draw
+        could see them handed to the next allocation while still being written).  A GPU-side wait: free
+        when the generator has finished, and the next draw's first kernel waits for the same event anyway."""
+        ev = getattr(self, "_pf_event", None)
+        if ev is not None and getattr(self, "_prefetch", False):
+            torch.cuda.current_stream().wait_event(ev)
+
+    def __del__(self):
+        try:
+            side = getattr(self, "_side", None)
+            if side is not None:
+                side.synchronize()  # nothing of this sampler is in flight when its events and buffers go
+        except Exception:  # interpreter shutdown
+            pass
 
     # -- model bridge ----------------------------------------------------------------------------
     def _eval_grad(self, theta_dc, grad_out, logp_out):

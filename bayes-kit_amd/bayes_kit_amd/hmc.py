@@ -29,6 +29,9 @@ from ._engine import ManyChainSampler
 
 
 class HMCDiag(ManyChainSampler):
+    ENABLE_FUSED_DRAW = True  # experiments / bisection: the one-pass draw kernel for built-in targets
+    ENABLE_FUSED_ZT = True    # ... and its chain-major momentum input
+
     def __init__(
         self,
         model,
@@ -78,7 +81,7 @@ class HMCDiag(ManyChainSampler):
             self._M_inv = torch.linalg.inv(Mt)
             self._M_inv = (0.5 * (self._M_inv + self._M_inv.t())).to(dev_).contiguous()
             fuse_builtin = False
-        self._init_graph(graph)
+        self._init_graph(graph, prefetch_rng)
         # built-in separable targets can run the whole trajectory in registers
         # (bk_hmc_trajectory_gaussian); results are bit-identical to the step-by-step path
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_hmc_trajectory")
@@ -86,8 +89,9 @@ class HMCDiag(ManyChainSampler):
         # a draw is: generator, ONE pass over the state (trajectory + kin0 + kin1 + end-point log
         # density), accept, select.  With Philox streams the momentum is consumed chain-major,
         # straight from the wavefront-per-chain generator: no transpose, no kinetic-energy pass.
-        self._fused_draw = self._fused and hasattr(model, "bk_hmc_draw")
-        self._fused_zt = self._fused_draw and self._rng_kind == _lib.RNG_PHILOX and self._dim >= 32
+        self._fused_draw = self._fused and hasattr(model, "bk_hmc_draw") and self.ENABLE_FUSED_DRAW
+        self._fused_zt = (self._fused_draw and self._rng_kind == _lib.RNG_PHILOX and self._dim >= 32
+                          and self.ENABLE_FUSED_ZT)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._rho_bufs = [None if self._fused_zt else torch.empty((D, C), **f64)]
@@ -117,12 +121,12 @@ class HMCDiag(ManyChainSampler):
         # uniform: hmc.py:56,60).  With prefetch_rng it is generated on a second HIP stream
         # while draw n's trajectory streams through HBM on the main one: the RNG kernels are
         # integer bound and a small fraction of a draw, so they hide under the HBM-bound kernels.
-        # Under hipGraph replay the generation can be a parallel branch of the draw's graph
-        # (graph=True, prefetch_rng=True: correct, but measured SLOWER than one serial graph --
-        # 93 vs 79 us per draw at 4096 x 128, tools/graph_fork_bench.py -- so not the default).
+        # A hipGraph replay is launch-free already and its graph stays linear (ManyChainSampler: a forked
+        # capture is slower and unsafe on this ROCm): with graph=True the randomness is generated in line,
+        # whatever prefetch_rng says -- the draws are bit-identical either way.
         if prefetch_rng is None:
-            prefetch_rng = self._batched and not self._use_graph and self._ops.device.type == "cuda"
-        self._prefetch = bool(prefetch_rng) and self._batched
+            prefetch_rng = self._batched and self._ops.device.type == "cuda"
+        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
         self._pf_slot = 0           # double-buffer slot holding the NEXT draw's randomness
         self._pf_ready = False      # ... once it has been generated
         self._pf_event = None       # ... and the event that marks it complete (None: already joined)
@@ -135,7 +139,7 @@ class HMCDiag(ManyChainSampler):
                 self._rho_bufs.append(torch.empty((D, C), **f64))
             self._kin0_bufs.append(torch.empty(C, **f64))
             self._logu_bufs.append(torch.empty(C, **f64))
-            self._side = torch.cuda.Stream(device=dev)
+            self._init_side_stream()
             self._rng_logical = self._rng_state.clone()  # stream position after the last finished draw
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._fused and self._M is None:
@@ -191,6 +195,7 @@ class HMCDiag(ManyChainSampler):
         super()._set_metric(m)
         self._pf_kin_stale = True  # a prefetched kinetic energy was computed with the old metric
 
+
     def rng_state(self):
         return self._logical_rng().cpu().numpy().view(np.uint64)
 
@@ -208,39 +213,11 @@ class HMCDiag(ManyChainSampler):
         # drop any randomness generated ahead: it is regenerated from the restored stream
         self._pf_event, self._pf_slot, self._pf_ready, self._pf_kin_stale = None, 0, False, False
 
-    # -- hipGraph replay with the generator as a parallel branch -------------------------------------
-    def _graph_key(self):
-        return self._pf_slot if self._prefetch else 0
-
-    def _graph_keys(self):
-        return [0, 1] if self._prefetch else [0]
-
-    def _set_graph_key(self, key):
-        if self._prefetch:
-            self._pf_slot = key
-
     def _refresh_stale_kinetic(self):
         if self._pf_kin_stale and self._pf_ready and not self._fused_draw:
             self._ops.leapfrog_finish(self._rho_bufs[self._pf_slot], None, None, self._metric_dev, 0.0, False,
                                       self._kin0_bufs[self._pf_slot])
         self._pf_kin_stale = False
-
-    def _before_capture(self):
-        self._pf_event = None  # the device was synchronised: nothing left to wait for
-        if self._prefetch:
-            self._refresh_stale_kinetic()
-
-    def _before_replay(self):
-        if self._prefetch:
-            self._refresh_stale_kinetic()
-
-    def _capture_epilogue(self):
-        if self._prefetch:
-            torch.cuda.current_stream().wait_stream(self._side)  # join the generator branch
-
-    def _after_replay(self):
-        if self._prefetch:
-            self._pf_slot, self._pf_ready, self._pf_event = 1 - self._pf_slot, True, None
 
     def _randomness(self, slot):
         """Momentum, kinetic energy and accept uniform of one draw [hmc.py:56, :37, :60]."""
@@ -286,15 +263,6 @@ class HMCDiag(ManyChainSampler):
         main = torch.cuda.current_stream()
         cur = self._pf_slot
         nxt = 1 - cur
-        if torch.cuda.is_current_stream_capturing():
-            # graph capture: slot `cur` is ready (eager warm-up draw or previous replay); fork the
-            # generator for slot `nxt` off the capture stream, joined in _capture_epilogue().  The
-            # slot bookkeeping advances after each replay (_after_replay), not here.
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                self._rng_logical.copy_(self._rng_state)
-                self._randomness(nxt)
-            return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
         if not self._pf_ready:
             self._randomness(cur)  # very first draw: nothing prefetched yet
             self._pf_kin_stale = False
@@ -303,13 +271,12 @@ class HMCDiag(ManyChainSampler):
                 main.wait_event(self._pf_event)
             self._refresh_stale_kinetic()
         # the other slot was last read by the previous draw's kernels, already queued on `main`
-        ready = torch.cuda.Event()
+        ready, ev = self._ev_ready[nxt], self._ev_done[nxt]
         ready.record(main)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             self._rng_logical.copy_(self._rng_state)
             self._randomness(nxt)
-            ev = torch.cuda.Event()
             ev.record(self._side)
         self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
         return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
@@ -317,6 +284,7 @@ class HMCDiag(ManyChainSampler):
     # -- one draw for every chain ------------------------------------------------------------------
     def sample(self):
         self._run_draw(self._draw)
+        self._join_side_stream()
         self._draws += 1
         return self._draw_out(self._theta_dc, self._ret)
 

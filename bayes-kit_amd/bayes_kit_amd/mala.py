@@ -37,7 +37,7 @@ class MALA(ManyChainSampler):
                  tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
-        self._init_graph(graph)
+        self._init_graph(graph, prefetch_rng)
         D, C, dev = self._dim, self._C, self._ops.device
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_p = torch.empty((D, C), **f64)
@@ -55,22 +55,21 @@ class MALA(ManyChainSampler):
         # As in HMCDiag: the D proposal normals and the accept uniform of draw n+1 do not depend
         # on draw n and are consumed in a fixed order (mala.py:44 then metropolis.py:74), so they
         # are generated on a second HIP stream under draw n's HBM-bound kernels.
-        # Under hipGraph replay the generation can be a parallel branch of the draw's graph (explicit
-        # prefetch_rng=True; slower than one serial graph, see HMCDiag, so not the default).
+        # With graph=True the randomness is generated in line (a captured draw stays a linear graph,
+        # see ManyChainSampler), whatever prefetch_rng says; the draws are bit-identical either way.
         if prefetch_rng is None:
-            prefetch_rng = self._batched and not self._use_graph and dev.type == "cuda"
-        self._prefetch = bool(prefetch_rng) and self._batched
+            prefetch_rng = self._batched and dev.type == "cuda"
+        self._prefetch = bool(prefetch_rng) and self._batched and not self._use_graph
         self._pf_slot, self._pf_ready, self._pf_event = 0, False, None
         # Philox streams: the normals come from the wavefront-per-chain generator, chain-major
         # (zt[c, d]); the consuming kernel turns them through LDS.  Otherwise (PCG64 host-seeded
         # single chains, tiny D): one lane per chain, normals in the state layout.
         self._chain_major = self._rng_kind == _lib.RNG_PHILOX and D >= 32
         ld = self._theta_dc.stride(0) if D > 1 else C
-        can_two_pass = (self._batched and self._chain_major and not (self._use_graph and self._prefetch)
-                        and self._ops.mala_step_supported(C, D, ld))
+        can_two_pass = self._batched and self._chain_major and self._ops.mala_step_supported(C, D, ld)
         if two_pass and not can_two_pass:
             raise ValueError("two_pass=True needs a batched model, Philox streams, 32 <= D <= 1024 and an even number "
-                             "of chains (and not hipGraph replay together with prefetch_rng)")
+                             "of chains")
         self._two_pass = can_two_pass if two_pass is None else bool(two_pass)
         self.path = "two-pass (bk_mala_step)" if self._two_pass else "step-by-step"
         nbuf = 2 if self._prefetch else 1
@@ -83,7 +82,7 @@ class MALA(ManyChainSampler):
         if self._prefetch or self._two_pass:
             self._logu_bufs = [torch.empty(C, **f64) for _ in range(nbuf)]
         if self._prefetch:
-            self._side = torch.cuda.Stream(device=dev)
+            self._init_side_stream()
             self._rng_logical = self._rng_state.clone()
         # two-pass pipeline: theta_p holds the proposal of the NEXT draw (made by the previous
         # draw's kernel from normals generated one draw ahead).  A generation unit is
@@ -166,28 +165,6 @@ class MALA(ManyChainSampler):
         self._pf_event, self._pf_slot, self._pf_ready = None, 0, False
         self._invalidate_pipe(restore_stream=False)  # the stream was just restored to its logical position
 
-    # -- hipGraph replay with the generator as a parallel branch (see HMCDiag) -------------------------
-    def _graph_key(self):
-        return self._pf_slot if self._prefetch else 0
-
-    def _graph_keys(self):
-        return [0, 1] if self._prefetch else [0]
-
-    def _set_graph_key(self, key):
-        if self._prefetch:
-            self._pf_slot = key
-
-    def _before_capture(self):
-        self._pf_event = None
-
-    def _capture_epilogue(self):
-        if self._prefetch:
-            torch.cuda.current_stream().wait_stream(self._side)
-
-    def _after_replay(self):
-        if self._prefetch:
-            self._pf_slot, self._pf_ready, self._pf_event = 1 - self._pf_slot, True, None
-
     def _gen(self, slot):
         if self._chain_major:
             self._ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)
@@ -199,23 +176,16 @@ class MALA(ManyChainSampler):
     def _take_randomness(self):
         main = torch.cuda.current_stream()
         cur, nxt = self._pf_slot, 1 - self._pf_slot
-        if torch.cuda.is_current_stream_capturing():
-            self._side.wait_stream(main)  # fork; joined in _capture_epilogue()
-            with torch.cuda.stream(self._side):
-                self._rng_logical.copy_(self._rng_state)
-                self._gen(nxt)
-            return self._z_bufs[cur], self._logu_bufs[cur]
         if not self._pf_ready:
             self._gen(cur)
         elif self._pf_event is not None:
             main.wait_event(self._pf_event)
-        ready = torch.cuda.Event()
+        ready, ev = self._ev_ready[nxt], self._ev_done[nxt]
         ready.record(main)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             self._rng_logical.copy_(self._rng_state)
             self._gen(nxt)
-            ev = torch.cuda.Event()
             ev.record(self._side)
         self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
         return self._z_bufs[cur], self._logu_bufs[cur]
@@ -242,12 +212,11 @@ class MALA(ManyChainSampler):
             main.wait_event(self._pf_event)
         # slot nxt was last read by the previous draw's kernel, already queued on `main`; the RNG
         # table is shared, so the side stream also starts after anything generated in line above
-        ready = torch.cuda.Event()
+        ready, ev = self._ev_ready[nxt], self._ev_done[nxt]
         ready.record(main)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             self._gen_unit(nxt)
-            ev = torch.cuda.Event()
             ev.record(self._side)
         self._pf_event, self._pf_slot, self._unit_ready, self._cur_slot = ev, nxt, True, cur
         return self._logu_bufs[cur], self._zt_bufs[cur]
@@ -276,6 +245,7 @@ class MALA(ManyChainSampler):
 
     def sample(self):
         self._run_draw(self._draw2 if self._two_pass else self._draw)
+        self._join_side_stream()
         self._draws += 1
         if self._two_pass and not self._use_graph:
             return self._theta_dc.t(), self._ret.clone()  # the new state array itself (never written again)

@@ -16,8 +16,56 @@ from oracle import models as om
 from oracle import samplers as osamp
 
 
+if os.environ.get("SOAK_NO_FUSED_DRAW"):
+    bk.HMCDiag.ENABLE_FUSED_DRAW = False
+if os.environ.get("SOAK_NO_FUSED_ZT"):
+    bk.HMCDiag.ENABLE_FUSED_ZT = False
+MALA_KW = dict(two_pass=False) if os.environ.get("SOAK_NO_TWO_PASS") else {}
+
+
+NO_GRAPH = bool(os.environ.get("SOAK_NO_GRAPH"))
+NO_PREFETCH = bool(os.environ.get("SOAK_NO_PREFETCH"))
+
+
+def _forced(name, drawn):
+    v = os.environ.get(name)
+    return drawn if v is None else v == "1"
+
+
+class Sentinels:
+    """Zero-filled host blocks scattered through the malloc arena: any word that stops being zero was
+    written by somebody else (SOAK_SENTINELS=1)."""
+
+    def __init__(self, n=4000, words=64):
+        blocks = [np.zeros(words, dtype=np.int64) for _ in range(2 * n)]
+        self.keep = blocks[::2]  # every other block is freed again: holes for the samplers' own allocations
+        del blocks
+
+    def check(self):
+        for i, b in enumerate(self.keep):
+            if b.any():
+                j = np.nonzero(b)[0]
+                raise AssertionError(("sentinel", i, hex(b.ctypes.data), j.tolist(), [hex(int(v) & (2**64 - 1)) for v in b[j]]))
+
+
+HISTORY = []  # the last few configurations: a corrupted sampler is usually the victim of an earlier one
+
+
 def one(rng, it):
-    alg = rng.choice(["hmc", "mala", "drghmc", "metropolis"])
+    alg = rng.choice(os.environ["ALGS"].split(",")) if os.environ.get("ALGS") else rng.choice(["hmc", "mala", "drghmc", "metropolis"])
+    if alg == "torchgraph":
+        # control: a hipGraph of two plain PyTorch kernels, captured and replayed the way a sampler's draw is
+        x = torch.zeros(int(rng.choice([3, 64, 500])), dtype=torch.float64, device="cuda")
+        x.add_(1.0)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            x.add_(1.0)
+            x.mul_(1.0)
+        for _ in range(int(rng.integers(2, 10))):
+            g.replay()
+        assert float(x[0].item()) >= 3.0
+        return "torchgraph"
     D = int(rng.choice([1, 2, 7, 31, 32, 33, 40, 64, 70]))
     C = int(rng.choice([1, 2, 3, 63, 64, 65, 130, 257, 500]))
     N = int(rng.integers(3, 12))
@@ -28,18 +76,21 @@ def one(rng, it):
     otgt = (lambda: om.IsoGaussian(D)) if iso else (lambda: om.DiagGaussian(lam))
     metric = np.linspace(0.8, 1.2, D) if (rng.random() < 0.4 and alg in ("hmc", "drghmc")) else None
     eps = float(rng.uniform(0.02, 0.3))
-    desc = dict(alg=alg, D=D, C=C, N=N, seed=seed, iso=iso, metric=metric is not None, eps=eps)
+    desc = dict(alg=str(alg), D=D, C=C, N=N, seed=seed, iso=bool(iso), metric=metric is not None, eps=eps)
+    HISTORY.append(desc)
+    del HISTORY[:-8]
     if alg == "hmc":
         L = int(rng.integers(0, 7))
-        kw = dict(fuse_builtin=bool(rng.integers(0, 2)), graph=bool(rng.integers(0, 2)),
-                  prefetch_rng=bool(rng.integers(0, 2)))
+        kw = dict(fuse_builtin=bool(rng.integers(0, 2)), graph=bool(rng.integers(0, 2)) and not NO_GRAPH,
+                  prefetch_rng=bool(rng.integers(0, 2)) and not NO_PREFETCH)
         desc.update(L=L, **kw)
         s = bk.HMCDiag(tgt, eps, L, metric_diag=metric, chains=C, seed=seed, **kw)
         mk = lambda sd: osamp.HMCDiag(otgt(), eps, L, metric_diag=metric, seed=sd)
     elif alg == "mala":
-        kw = dict(graph=bool(rng.integers(0, 2)), prefetch_rng=bool(rng.integers(0, 2)))
+        kw = dict(graph=_forced("SOAK_MALA_GRAPH", bool(rng.integers(0, 2)) and not NO_GRAPH),
+                  prefetch_rng=_forced("SOAK_MALA_PREFETCH", bool(rng.integers(0, 2)) and not NO_PREFETCH))
         desc.update(**kw)
-        s = bk.MALA(tgt, eps * 0.3, chains=C, seed=seed, **kw)
+        s = bk.MALA(tgt, eps * 0.3, chains=C, seed=seed, **kw, **MALA_KW)
         mk = lambda sd: osamp.MALA(otgt(), eps * 0.3, seed=sd)
     elif alg == "drghmc":
         K = int(rng.integers(1, 4))
@@ -67,11 +118,18 @@ def one(rng, it):
         th, _ = s.sample()
         got.append(th[watch].cpu().numpy())
     state = s.rng_state()
+    if os.environ.get("SOAK_SYNC_BEFORE_DROP"):
+        torch.cuda.synchronize()
     for j, c in enumerate(watch):
         o = mk(np.random.Philox(key=[seed, c]))
         for n in range(N):
             oth, _ = o.sample()
-            assert np.array_equal(oth, got[n][j]), ("theta", desc, c, n)
+            if not np.array_equal(oth, got[n][j]):
+                bad = np.nonzero(oth != got[n][j])[0]
+                raise AssertionError(("theta", desc, dict(chain=c, draw=n, dims_differing=bad[:8].tolist(),
+                                                          n_differing=int(bad.size),
+                                                          max_abs=float(np.abs(oth - got[n][j]).max()),
+                                                          lam=None if lam is None else [float(lam[0]), float(lam[-1])])))
         st = o._rng.bit_generator.state
         assert [int(v) for v in st["state"]["counter"]] == [int(v) for v in state[2:6, c]], ("counter", desc, c)
         assert int(st["buffer_pos"]) == int(state[10, c]), ("pos", desc, c)
@@ -82,7 +140,19 @@ if __name__ == "__main__":
     rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
     budget = float(os.environ.get("SECONDS", 60))
     t0, counts = time.time(), {}
+    sent = Sentinels() if os.environ.get("SOAK_SENTINELS") else None
+    guard = os.environ.get("SOAK_HEAPGUARD")  # tools/heapguard.c, which must also be in LD_PRELOAD
     while time.time() - t0 < budget:
-        a = one(rng, sum(counts.values()))
+        try:
+            if guard and sum(counts.values()) == 40:
+                import ctypes, faulthandler
+                faulthandler.enable()
+                ctypes.CDLL(guard).heapguard_enable()
+            a = one(rng, sum(counts.values()))
+            if sent is not None:
+                sent.check()
+        except BaseException:
+            print("history (oldest first):", *HISTORY, sep="\n  ", flush=True)
+            raise
         counts[a] = counts.get(a, 0) + 1
     print("soak ok:", sum(counts.values()), "random sampler configurations", counts, f"in {time.time()-t0:.0f} s")

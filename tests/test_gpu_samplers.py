@@ -193,9 +193,9 @@ def test_full_size_cfg4_properties(ops):
 
 @pytest.mark.parametrize("prefetch", [False, True])
 def test_hipgraph_replay_equals_eager(ops, prefetch):
-    """graph=True replays captured draws; results identical to eager launches.  With the RNG
-    prefetch the next draw's generator is a parallel branch inside the graph (two graphs, one per
-    double-buffer slot); without it the draw is one serial graph."""
+    """graph=True replays captured draws; results identical to eager launches.  A captured draw is one
+    linear graph: prefetch_rng is accepted with graph=True but the randomness is generated in line
+    (a forked capture is slower and makes this ROCm's runtime touch freed memory)."""
     for make in (lambda g, p: bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=20240, graph=g,
                                          prefetch_rng=p),
                  lambda g, p: bk.HMCDiag(bk.DiagGaussian(np.logspace(0, 1, 40)), 0.05, 7, chains=700, seed=2,
@@ -213,7 +213,7 @@ def test_hipgraph_replay_equals_eager(ops, prefetch):
             assert torch.equal(ta, tb) and torch.equal(la, lb), n
             if n in (0, 3, 8):  # the logical stream position is visible between draws
                 np.testing.assert_array_equal(a.rng_state(), b.rng_state())
-        assert len(b._graphs) == (2 if prefetch else 1) and a._graph is None
+        assert b._graph is not None and not b._prefetch and a._graph is None
         assert a.accept_rate() == b.accept_rate()
 
 
