@@ -160,6 +160,7 @@ class ManyChainSampler:
         wave_rng = self._rng_kind == _lib.RNG_PHILOX and D >= 32
         self._rng_work = self._ops.refresh_work(C, D) if wave_rng else None
         self._metric_dev: Optional[torch.Tensor] = None
+        self._metric_identity = True
         if metric_diag is not None:
             self._set_metric(metric_diag)
         f64 = dict(dtype=torch.float64, device=dev)
@@ -185,6 +186,12 @@ class ManyChainSampler:
         if mt.shape[0] != self._dim:
             raise ValueError(f"metric_diag has {mt.shape[0]} entries, model has {self._dim} dims")
         new = mt.to(self._ops.device).contiguous()
+        # a metric of ones (what the reference uses when none is given, hmc.py:22) multiplies by 1.0:
+        # an exact identity in IEEE arithmetic, so ALU-bound kernels may be launched without it
+        ident = bool((mt == 1.0).all())
+        if ident != getattr(self, "_metric_identity", ident):
+            self._drop_graphs()  # captured launches chose their kernel variant by this
+        self._metric_identity = ident
         if getattr(self, "_metric_dev", None) is not None:
             self._metric_dev.copy_(new)  # in place: a captured hipGraph keeps pointing at this buffer
         else:

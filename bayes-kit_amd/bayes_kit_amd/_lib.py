@@ -39,6 +39,7 @@ SIGNATURES = {
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
     "bk_select_columns": [P, P, P, P, P, P, I, I, I, P],
+    "bk_blend_columns": [P, P, P, P, I, I, I, P],
     "bk_compact_indices": [P, I, P, P, P, P],
     "bk_dr_begin": [P, P, P, P, P, P, I, P],
     "bk_dr_retry_test": [c_int, P, I, P, F, P, I, P],
@@ -49,7 +50,7 @@ SIGNATURES = {
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
-    "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P],
+    "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_mala_step_supported": [I, I, I],
     "bk_mala_step": [P, P, P, P, P, I, P, P, P, P, I, F, F, P, P, P, I, I, P],
@@ -252,6 +253,14 @@ class Ops:
     # -- delayed rejection ---------------------------------------------------------------------
     # n_dev (optional, everywhere below): int32 device tensor [1] holding the number of lanes really
     # in the set; `n` / `m` is then only the bound the launch is sized for (include/bkhip.h).
+
+    def blend_columns(self, mask, a, b, out):
+        """out = mask ? b : a (a, b read-only): the select of a sampler that rebinds its state array."""
+        D, C = a.shape
+        ld = _ld(a)
+        assert _ld(b) == ld and _ld(out) == ld
+        self._call("bk_blend_columns", ptr(mask), ptr(a), ptr(b), ptr(out), ld, C, D, self._s())
+
     def compact_indices(self, mask, n, idx_out, count_out, n_dev=None):
         self._call("bk_compact_indices", ptr(mask), n, ptr(idx_out), ptr(count_out), ptr(n_dev), self._s())
 
@@ -304,12 +313,14 @@ class Ops:
         self._call("bk_mala_propose_from_normals", ptr(theta), ptr(grad), ptr(z), z.stride(0), z.stride(1),
                    ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
 
-    def normals_chain_major(self, kind, state, zt, D):
-        """zt[c, :D] = the next D standard normals of chain c (one wavefront per chain)."""
+    def normals_chain_major(self, kind, state, zt, D, snapshot=None):
+        """zt[c, :D] = the next D standard normals of chain c; `snapshot` (optional, a table like
+        `state`) receives the stream table as it was before the call."""
         C = zt.shape[0]
         assert zt.stride(1) == 1 and zt.shape[1] >= D
+        assert snapshot is None or (snapshot.shape == state.shape and snapshot.stride(0) == state.stride(0))
         self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
-                   self._s())
+                   ptr(snapshot), self._s())
 
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         D, C = theta.shape

@@ -131,6 +131,7 @@ class HMCDiag(ManyChainSampler):
         self._pf_ready = False      # ... once it has been generated
         self._pf_event = None       # ... and the event that marks it complete (None: already joined)
         self._pf_kin_stale = False
+        self._snap = None           # per slot: the stream table before that slot's normals were generated
         if self._prefetch:
             if self._fused_zt:
                 self._zt_bufs.append(torch.empty_like(self._zt_bufs[0]))
@@ -140,7 +141,10 @@ class HMCDiag(ManyChainSampler):
             self._kin0_bufs.append(torch.empty(C, **f64))
             self._logu_bufs.append(torch.empty(C, **f64))
             self._init_side_stream()
-            self._rng_logical = self._rng_state.clone()  # stream position after the last finished draw
+            if self._fused_zt:
+                self._snap = [torch.empty_like(self._rng_state) for _ in range(2)]
+            else:
+                self._rng_logical = self._rng_state.clone()  # stream position after the last finished draw
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._fused and self._M is None:
             self._tune_placement()
@@ -206,8 +210,14 @@ class HMCDiag(ManyChainSampler):
         if getattr(self, "_prefetch", False) and self._pf_ready:
             if self._pf_event is not None:
                 self._pf_event.synchronize()
-            return self._rng_logical
+            return self._rng_logical if self._snap is None else self._snap[self._pf_slot]
         return self._rng_state
+
+    def load_state_dict(self, sd):
+        if self._fused_draw and not self._use_graph:
+            # the state array is the last draw handed out (see _draw): restore into a fresh one
+            self._theta_dc = torch.empty_like(self._theta_dc)
+        super().load_state_dict(sd)
 
     def _after_load(self):
         # drop any randomness generated ahead: it is regenerated from the restored stream
@@ -224,7 +234,10 @@ class HMCDiag(ManyChainSampler):
         ops = self._ops
         if self._fused_zt:
             # D normals, chain-major; their kinetic energy is summed by the draw kernel itself
-            ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)
+            # (with prefetch the generator also leaves the table as it found it -- the logical stream
+            # position while this slot is the one generated ahead -- in snap[slot])
+            ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim,
+                                    None if self._snap is None else self._snap[slot])
         elif self._M is None:
             ops.momentum_refresh(self._rng_kind, self._rng_state, None, 0.0, 1.0, self._rho_bufs[slot],
                                  self._metric_dev, None if self._fused_draw else self._kin0_bufs[slot], None,
@@ -254,32 +267,49 @@ class HMCDiag(ManyChainSampler):
         self._ops.relayout(g, self._grad_p)
         return self._grad_p
 
-    def _take_randomness(self):
-        """Buffers holding this draw's randomness; with prefetch also starts the next draw's."""
+    # The side-stream generator (prefetch_rng) runs ONE draw ahead: at the start of draw n the generator
+    # of draw n+1 is queued.  `_pf_slot` is the slot the next draw consumes, and the stream position the
+    # reference's generator would have between two sample() calls is the table as it was when that
+    # slot's generation began: snap[slot], written by the chain-major generator itself, or else
+    # _rng_logical (a copy queued in front of the generator).
+    # For the one-pass draw (bk_hmc_draw), which is fp64-VALU bound like the generator, two other
+    # schedules were measured at 65,536 x 1024 on one box (tools/fused_hmc_profile_run.py): queueing the
+    # generator of draw n+2 right after draw n's accept test, so that it starts under the HBM-bound
+    # blend -- 1.37 ms per draw, the generator then takes the ALUs from the next draw's trajectories
+    # (1.0-1.1 ms instead of 0.78) -- and no side stream at all, 1.38 ms; one ahead gives 1.29 ms: the
+    # trajectories keep the ALUs, the generator takes what they leave and finishes under the blend.
+    def _current_randomness(self):
+        """Buffers holding this draw's randomness (generated ahead with prefetch_rng)."""
         self._zt_slot = 0 if not self._prefetch else self._pf_slot
         if not self._prefetch:
             self._randomness(0)
             return self._rho_bufs[0], self._kin0_bufs[0], self._logu_bufs[0]
-        main = torch.cuda.current_stream()
         cur = self._pf_slot
-        nxt = 1 - cur
         if not self._pf_ready:
-            self._randomness(cur)  # very first draw: nothing prefetched yet
+            self._randomness(cur)  # very first draw: nothing generated ahead yet
             self._pf_kin_stale = False
         else:
             if self._pf_event is not None:
-                main.wait_event(self._pf_event)
+                torch.cuda.current_stream().wait_event(self._pf_event)
             self._refresh_stale_kinetic()
-        # the other slot was last read by the previous draw's kernels, already queued on `main`
+        return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
+
+    def _start_next_randomness(self):
+        """Queue the next draw's generator on the side stream, into the other double-buffer slot (last
+        read by the previous draw's kernels, which are already queued on the main stream)."""
+        if not self._prefetch:
+            return
+        main = torch.cuda.current_stream()
+        nxt = 1 - self._pf_slot
         ready, ev = self._ev_ready[nxt], self._ev_done[nxt]
         ready.record(main)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
-            self._rng_logical.copy_(self._rng_state)
+            if self._snap is None:
+                self._rng_logical.copy_(self._rng_state)
             self._randomness(nxt)
             ev.record(self._side)
         self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
-        return self._rho_bufs[cur], self._kin0_bufs[cur], self._logu_bufs[cur]
 
     # -- one draw for every chain ------------------------------------------------------------------
     def sample(self):
@@ -298,17 +328,29 @@ class HMCDiag(ManyChainSampler):
         # momentum + kinetic energy + accept uniform [hmc.py:56, :37, :60]; the uniform is drawn
         # right after the D normals -- the same stream order as the reference, whose uniform is
         # the next value of the stream whatever happens in between
-        rho, kin0, logu = self._take_randomness()
+        rho, kin0, logu = self._current_randomness()
+        self._start_next_randomness()  # hides under this draw's launches
 
         if self._fused_draw:
             if not self._have_cache:
                 self._eval_logp(th, self._lp)
                 self._have_cache = True
             zt = self._zt_bufs[self._zt_slot] if self._fused_zt else None
-            self._model.bk_hmc_draw(th, thp, rho, zt, m, eps, L, self._part, kin0, self._kin1, self._lp_p)  # [hmc.py:56-59]
+            # (fp64-VALU bound: a metric of ones is not multiplied in -- x * 1.0 is x, bit for bit)
+            m_draw = None if (m is None or self._metric_identity) else m
+            self._model.bk_hmc_draw(th, thp, rho, zt, m_draw, eps, L, self._part, kin0, self._kin1,
+                                    self._lp_p)                                                 # [hmc.py:56-59]
             ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                           self._mask, self._ret, self._accepted)                                           # [hmc.py:60-63]
-            self._select(self._mask, th, thp)
+            if self._use_graph:
+                self._select(self._mask, th, thp)
+            else:
+                # `self._theta = theta_prop` [hmc.py:61] as a REBIND: the blend of state and proposal is
+                # written to a fresh array that becomes the state and is what sample() returns (never
+                # written again) -- one array written instead of two (bk_blend_columns)
+                self._out = torch.empty_like(th)
+                ops.blend_columns(self._mask, th, thp, self._out)
+                self._theta_dc = self._out
             return
         if self._fused:
             if not self._have_cache:

@@ -194,8 +194,9 @@ class MALA(ManyChainSampler):
     def _gen_unit(self, slot):
         ops = self._ops
         ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])     # U_n   [metropolis.py:74]
-        self._snap[slot].copy_(self._rng_state)                                     # position after draw n
-        ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim)  # Z_{n+1} [mala.py:44]
+        # Z_{n+1} [mala.py:44]; the generator leaves the table as it found it -- the position after draw n
+        # -- in snap[slot]
+        ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim, self._snap[slot])
 
     def _take_unit(self):
         """(log u of this draw, chain-major normals of the next); with prefetch also starts the

@@ -342,6 +342,45 @@ __global__ __launch_bounds__(256) void k_select_v2(const uint8_t* mask, double* 
     }
 }
 
+// out = mask ? b : a, nothing else written: the select for samplers that REBIND their state array every
+// draw (the reference's `self._theta = theta_prop`, hmc.py:61) -- `out` becomes the state and is what
+// sample() returns, so the old state is only read: ~9 B read + 8 B written per element instead of
+// 9 + 16 for the in-place select with its returned copy.
+__global__ __launch_bounds__(256) void k_blend(const uint8_t* mask, const double* a, const double* b, double* out,
+                                               i64 ld, i64 C, i64 D) {
+  i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * SEL_ROWS;
+  if (c >= C) return;
+  const double* src = mask[c] ? b : a;
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) out[(d0 + i) * ld + c] = src[(d0 + i) * ld + c];
+}
+
+__global__ __launch_bounds__(256) void k_blend_v2(const uint8_t* mask, const double* a, const double* b,
+                                                  double* out, i64 ld, i64 C2, i64 D) {
+  i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
+  i64 d0 = (i64)blockIdx.y * SEL_ROWS;
+  if (c2 >= C2) return;
+  const bool m0 = mask[2 * c2] != 0, m1 = mask[2 * c2 + 1] != 0;
+  dvec2 v[SEL_ROWS];
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D) {
+      const i64 o = (d0 + i) * ld + 2 * c2;
+      if (m0 || m1) v[i] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(b + o));
+      if (!(m0 && m1)) {
+        dvec2 old = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(a + o));
+        if (!m0) v[i].x = old.x;
+        if (!m1) v[i].y = old.y;
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < SEL_ROWS; ++i)
+    if (d0 + i < D)
+      __builtin_nontemporal_store(v[i], reinterpret_cast<dvec2*>(out + (d0 + i) * ld + 2 * c2));
+}
+
 // ---- MALA proposal log densities --------------------------------------------------------
 __global__ __launch_bounds__(RED_BLOCK) void k_mala_logq(const double* th, const double* g,
                                                          const double* thp, const double* gp, i64 ld,
@@ -515,6 +554,22 @@ int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0, dou
   } else {
     dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
     k_select<<<grid, dim3(256), 0, s>>>(mask, dst0, src0, dst1, src1, copy0, ld, C, D);
+  }
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_blend_columns(const uint8_t* mask, const double* a, const double* b, double* out, int64_t ld, int64_t C,
+                     int64_t D, void* stream) {
+  if (!mask || !a || !b || !out || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(a) && bk_aligned16(b) && bk_aligned16(out)) {
+    dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
+    k_blend_v2<<<grid, dim3(256), 0, s>>>(mask, a, b, out, ld, C / 2, D);
+  } else {
+    dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, SEL_ROWS));
+    k_blend<<<grid, dim3(256), 0, s>>>(mask, a, b, out, ld, C, D);
   }
   BK_RETURN_LAUNCH_STATUS();
 }

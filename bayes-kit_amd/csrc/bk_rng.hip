@@ -204,34 +204,51 @@ __device__ SlowRes zig_slow_at(WordWindow& win, int k, int idx, uint64_t rabs, d
   return r;
 }
 
-constexpr int ZP_WAVES = 4;  // chains per workgroup (one wavefront each)
+// LPC lanes per chain: a wavefront serves 64/LPC chains at once, each through a window of 4*LPC
+// words per pass.  Every pass costs the same whatever part of it is used, so the window should divide
+// the chain's ~1.008*D words with little left over: D = 1024 takes 5 passes of 256 words (the fifth
+// for ~10 words) but 17 of 64 -- 4.25 wavefront passes per chain instead of 5 -- and D = 101 takes one
+// 256-word pass per chain or two 64-word passes shared by four chains (half a wavefront pass per
+// chain).  Fewer lanes per chain also mean fewer wavefronts, so small launches keep LPC = 64
+// (zp_lanes_per_chain).  The stream is the same whatever LPC is: every quantity below that was
+// wavefront-wide with LPC = 64 (ballots, ranks, the covered range) is per SEGMENT of LPC lanes.
+constexpr int ZP_WAVES = 4;  // wavefronts per workgroup
+template <int LPC>
 __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st, i64 ldr, double* zt, i64 ldz,
-                                                                    i64 C, i64 D) {
+                                                                    i64 C, i64 D, uint64_t* snap) {
+  constexpr int G = BK_WAVE / LPC;  // chains per wavefront
   __shared__ ZigLds tab;
   load_tables(tab);
   const int lane = threadIdx.x & (BK_WAVE - 1);
-  const i64 c = (i64)blockIdx.x * ZP_WAVES + bk_wave_id();
-  if (c >= C) return;  // whole wavefront
+  const int seg = lane / LPC, l = lane % LPC;
+  const i64 c = ((i64)blockIdx.x * ZP_WAVES + bk_wave_id()) * G + seg;
+  if ((c - seg) >= C) return;  // whole wavefront
+  const bool live = c < C;     // (a wavefront's last segments may have no chain)
+  const i64 cs = live ? c : C - 1;
+  const unsigned long long segmask = (LPC == 64 ? ~0ULL : ((1ULL << (LPC & 63)) - 1)) << (seg * LPC);
+  const unsigned long long below = (lane == 0 ? 0ULL : (~0ULL >> (64 - lane))) & segmask;
+  if (snap && live && l < BK_RNG_WORDS) snap[l * ldr + c] = st[l * ldr + c];  // the table before this call
   bk::Philox ph;
-  ph.key0 = st[0 * ldr + c];
-  ph.key1 = st[1 * ldr + c];
-  const uint64_t k0 = st[2 * ldr + c], k1 = st[3 * ldr + c], k2 = st[4 * ldr + c], k3 = st[5 * ldr + c];
-  const i64 v0 = (i64)st[10 * ldr + c];  // words of block `counter` already consumed (4 = all)
-  i64 cover_until = v0;                  // words below this position are consumed / not attempt starts
-  i64 d_base = 0, p_end = v0;
-  for (i64 t = 0; d_base < D; ++t) {
-    // 1. one Philox block per lane: block (counter + 64 t + lane), words v = 256 t + 4 lane + k
+  ph.key0 = st[0 * ldr + cs];
+  ph.key1 = st[1 * ldr + cs];
+  const uint64_t k0 = st[2 * ldr + cs], k1 = st[3 * ldr + cs], k2 = st[4 * ldr + cs], k3 = st[5 * ldr + cs];
+  const i64 v0 = (i64)st[10 * ldr + cs];  // words of block `counter` already consumed (4 = all)
+  i64 cover_until = v0;                   // words below this position are consumed / not attempt starts
+  i64 d_base = live ? 0 : D, p_end = v0;
+  for (i64 t = 0; __any(d_base < D); ++t) {
+    // 1. one Philox block per lane: block (counter + LPC t + l), words v = 4 LPC t + 4 l + k
     WordWindow win;
     win.ph = &ph;
-    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)(64 * t + lane), win.c0, win.c1, win.c2, win.c3);
+    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)(LPC * t + l), win.c0, win.c1, win.c2, win.c3);
     ph.block_at(win.c0, win.c1, win.c2, win.c3, win.w0, win.w1, win.w2, win.w3);
     win.w4 = __shfl_down((unsigned long long)win.w0, 1);
     win.w5 = __shfl_down((unsigned long long)win.w1, 1);
     win.w6 = __shfl_down((unsigned long long)win.w2, 1);
     win.w7 = __shfl_down((unsigned long long)win.w3, 1);
-    win.has_next = lane < BK_WAVE - 1;
+    win.has_next = l < LPC - 1;
     win.eblk = -1;
-    const i64 vbase = 256 * t + 4 * lane;
+    const i64 wbase = 4 * LPC * t;  // stream position of the window's first word
+    const i64 vbase = wbase + 4 * l;
     // 2. fast test on the four words; 3. full slow path where it fails
     double val[4];
     int len[4];
@@ -253,7 +270,8 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
         emitf[k] = r.emit;
       }
     }
-    // 4. which words start an attempt: scan the exceptions in stream order
+    // 4. which words start an attempt: scan the exceptions in stream order (lanes ascend within
+    //    every segment; segments are independent streams)
     unsigned long long ex[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) ex[k] = __ballot(!okf[k]);
@@ -265,12 +283,13 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
     while (any) {
       int L = __ffsll((long long)any) - 1;
       any &= any - 1;
+      const bool mine = (L / LPC) == seg;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if ((ex[k] >> L) & 1ULL) {
-          i64 pos = 256 * t + 4 * L + k;
+          i64 pos = wbase + 4 * (L % LPC) + k;
           int ln = __shfl(len[k], L);
-          if (pos >= cover_until) {  // an actual attempt: it consumes words pos .. pos+ln-1
+          if (mine && pos >= cover_until) {  // an actual attempt: it consumes words pos .. pos+ln-1
             cover_until = pos + ln;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -287,7 +306,6 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
       em[k] = !((cov >> k) & 1u) && emitf[k];
       mk[k] = __ballot(em[k]);
     }
-    const unsigned long long below = lane == 0 ? 0ULL : (~0ULL >> (64 - lane));
     i64 rank = __popcll(mk[0] & below) + __popcll(mk[1] & below) + __popcll(mk[2] & below) + __popcll(mk[3] & below);
     bool last_here = false;
     i64 my_end = 0;
@@ -303,13 +321,15 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
         ++rank;
       }
     }
-    unsigned long long lb = __ballot(last_here);
-    if (lb) p_end = __shfl(my_end, __ffsll((long long)lb) - 1);
-    d_base += __popcll(mk[0]) + __popcll(mk[1]) + __popcll(mk[2]) + __popcll(mk[3]);
-    // an attempt that started in this chunk may reach into the next one: cover_until carries over
+    const unsigned long long lb = __ballot(last_here) & segmask;
+    const i64 end_of_seg = __shfl(my_end, lb ? __ffsll((long long)lb) - 1 : lane);
+    if (lb) p_end = end_of_seg;
+    d_base += __popcll(mk[0] & segmask) + __popcll(mk[1] & segmask) + __popcll(mk[2] & segmask) +
+              __popcll(mk[3] & segmask);
+    // an attempt that started in this window may reach into the next one: cover_until carries over
   }
   // new stream position: p_end words into the block stream that starts at `counter`
-  if (lane == 0 && p_end > v0) {
+  if (l == 0 && live && p_end > v0) {
     i64 bf = (p_end - 1) / 4;
     uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
     bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)bf, a0, a1, a2, a3);
@@ -318,6 +338,37 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
     st[6 * ldr + c] = b0; st[7 * ldr + c] = b1; st[8 * ldr + c] = b2; st[9 * ldr + c] = b3;
     st[10 * ldr + c] = (uint64_t)(p_end - 4 * bf);
   }
+}
+
+// Lanes per chain for a launch.  Measured (tools/zig_bench.py), a launch that fills the GPU costs
+// passes x LPC per chain and nothing else -- 456 / 416 / 390 us at 65,536 x 1024 for LPC 64 / 32 / 16
+// (5, 9, 17 passes), 72 / 44 / 38 us at 32,768 x 101 -- so among the choices that still give every SIMD
+// several wavefronts the smallest product wins.  Small launches are latency bound: fewest passes
+// first, then the fewest lanes (8.1 vs 9.6 us at 1000 x 70 with 32 instead of 64 lanes per chain).
+static int zp_lanes_per_chain(i64 C, i64 D) {
+  static const int forced = []() { const char* e = getenv("BK_ZP_LANES"); return e ? atoi(e) : 0; }();
+  if (forced == 16 || forced == 32 || forced == 64) return forced;
+  const double words = 1.0085 * (double)D + 6.0;  // a chain's D normals take ~0.85 % extra words
+  const bool fills = C >= 8192;                    // LPC = 64 then gives >= 8 wavefronts per SIMD
+  int best = 64;
+  double best_cost = 0.0;
+  for (int lpc = 64; lpc >= 16; lpc /= 2) {
+    if (fills && C * lpc / 64 < 8192) break;
+    const double passes = ceil(words / (4.0 * lpc));
+    const double cost = fills ? passes * lpc : passes;
+    if (lpc == 64 || cost <= best_cost) best = lpc, best_cost = cost;
+  }
+  return best;
+}
+
+static void zig_parallel_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, uint64_t* snap,
+                                hipStream_t s) {
+  const int lpc = zp_lanes_per_chain(C, D);
+  const i64 chains_per_wg = (i64)ZP_WAVES * (BK_WAVE / lpc);
+  dim3 grid((unsigned)bk_cdiv(C, chains_per_wg)), block(ZP_WAVES * BK_WAVE);
+  if (lpc == 16) k_zig_parallel<16><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
+  else if (lpc == 32) k_zig_parallel<32><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
+  else k_zig_parallel<64><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
 }
 
 // out[d][c] = loc + scale * zt[c][d]  (64 x 64 LDS tiles; zt is chain-major, out chain-contiguous)
@@ -429,7 +480,7 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr, const double
     // that one-lane-per-chain would leave SIMDs idle or latency bound: one wavefront per chain.
     if (work && !active && D >= 32 && work_elems >= bk_refresh_work_elems(C, D)) {
       i64 dp = (D + 7) / 8 * 8;
-      k_zig_parallel<<<dim3((unsigned)bk_cdiv(C, ZP_WAVES)), dim3(ZP_WAVES * BK_WAVE), 0, s>>>(state, ldr, work, dp, C, D);
+      zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
       dim3 g2((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
       k_refresh_apply<<<g2, dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out, ld, C, D);
       hipError_t e = hipGetLastError();
@@ -516,12 +567,17 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
 }
 
 int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
-                           int64_t D, void* stream) {
+                           int64_t D, uint64_t* snapshot, void* stream) {
   if (!state || !zt || C < 0 || D < 0 || ldr < C || ldz < D) return BK_E_ARG;
   if (rng_kind != BK_RNG_PHILOX) return BK_E_ARG;
-  if (C == 0 || D == 0) return BK_OK;
-  k_zig_parallel<<<dim3((unsigned)bk_cdiv(C, ZP_WAVES)), dim3(ZP_WAVES * BK_WAVE), 0, bk_stream(stream)>>>(
-      state, ldr, zt, ldz, C, D);
+  if (C == 0) return BK_OK;
+  if (D == 0) {
+    if (snapshot)
+      return (int)hipMemcpy2DAsync(snapshot, ldr * sizeof(uint64_t), state, ldr * sizeof(uint64_t), C * sizeof(uint64_t),
+                                   BK_RNG_WORDS, hipMemcpyDeviceToDevice, bk_stream(stream));
+    return BK_OK;
+  }
+  zig_parallel_launch(state, ldr, zt, ldz, C, D, snapshot, bk_stream(stream));
   BK_RETURN_LAUNCH_STATUS();
 }
 

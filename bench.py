@@ -585,14 +585,21 @@ def run_rank(args):
             # + both kinetic energies + end-point log density in one pass over the state, momentum read
             # chain-major from the generator).  Same results bit for bit; bound by the fp64 vector rate.
             f = make_cfg3_sampler(C, rank * C, device, fused=True)
-            for _ in range(2):
+            for _ in range(3):
                 f.sample()
-            ops.timed = {"bk_hmc_draw_gaussian": []}
             fel = ctx.timed_loop(f.sample, args.steps)
+            # the draw kernel's own time, in a second pass: the event pairs around it are extra markers on
+            # the main stream and cost the draw a few per cent, so they stay out of the loop timed above
+            ops.timed = {"bk_hmc_draw_gaussian": []}
+            for _ in range(args.steps):
+                f.sample()
+            torch.cuda.synchronize()
             tj = [a.elapsed_time(b) for a, b in ops.timed["bk_hmc_draw_gaussian"]]
             ops.timed = None
             tj_ms = sum(tj) / len(tj)
-            flop = 6.0 * D * C * L  # 4 mul + 2 add per element-step, individually rounded (no FMA)
+            # per element-step, individually rounded (no FMA): 3 mul + 2 add, + 1 mul by the metric unless it
+            # is all ones (BASELINE's config: x * 1.0 is x bit for bit, so the kernel is launched without it)
+            flop = (5.0 if f._metric_identity else 6.0) * D * C * L
             out["fused_builtin"] = {
                 "what": "built-in DiagGaussian, whole draw (trajectory + energies) in registers; NOT the model-opaque "
                         "path, reported separately from `value`",
@@ -602,7 +609,9 @@ def run_rank(args):
                 "trajectory_kernel_frac_of_no_fma_ceiling": flop / (tj_ms * 1e-3) / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2),
                 "draw_tflops_fp64": flop / (fel / args.steps) / 1e12,
                 "fp64_vector_peak_tflops_spec": FP64_VECTOR_PEAK_TFLOPS,
-                "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3",
+                "flop_per_element_step": 5 if f._metric_identity else 6,
+                "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3; "
+                        "trajectory_kernel_ms is measured while the next draw's generator shares the ALUs",
             }
             del f
             torch.cuda.empty_cache()

@@ -158,6 +158,13 @@ int bk_select_columns(const uint8_t* mask, double* dst0, const double* src0,
                       double* dst1, const double* src1, double* copy0, int64_t ld,
                       int64_t C, int64_t D, void* stream);
 
+/* out[d*ld + c] = mask[c] ? b[d*ld + c] : a[d*ld + c]; a and b are only read.  The select for a sampler
+ * that rebinds its state array every draw, as the reference does (`self._theta = theta_prop`,
+ * hmc.py:61): `out` is the new state AND the array sample() returns, never written again.  About
+ * 17 bytes of HBM traffic per element against 25 for bk_select_columns with copy0. */
+int bk_blend_columns(const uint8_t* mask, const double* a, const double* b, double* out,
+                     int64_t ld, int64_t C, int64_t D, void* stream);
+
 /* ---- delayed rejection (DRGHMC) stage helpers -------------------------------------------
  * The reference's recursive accept() with its gradient-cache stack (drghmc.py:82,391-446)
  * is run as a lockstep state machine over lane sets: the chains still inside the stage
@@ -243,10 +250,14 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
                                  void* stream);
 
 /* zt[c*ldz + d] = d-th next standard normal of chain c's stream, d = 0..D-1 (what
- * `rng.normal(size=D)` returns, mala.py:44 / hmc.py:56), one wavefront per chain, Philox streams
- * only; state advanced exactly as by sequential consumption.  ldz >= D. */
+ * `rng.normal(size=D)` returns, mala.py:44 / hmc.py:56), 16 to 64 lanes of a wavefront per chain,
+ * Philox streams only; state advanced exactly as by sequential consumption.  ldz >= D.
+ * `snapshot` (may be NULL; a second table with the same ldr) receives the stream table as it was BEFORE
+ * the call: a sampler that generates a draw's normals one draw ahead keeps its logical stream
+ * position (where the reference's generator stands between two sample() calls) that way, without a
+ * separate copy of the table. */
 int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz,
-                           int64_t C, int64_t D, void* stream);
+                           int64_t C, int64_t D, uint64_t* snapshot, void* stream);
 
 /* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
  * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */

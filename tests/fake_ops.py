@@ -159,6 +159,11 @@ class FakeOps:
         if copy0 is not None:
             copy0.numpy()[...] = dst0.numpy()
 
+    def blend_columns(self, mask, a, b, out):
+        self._count("blend_columns")
+        m = mask.numpy().astype(bool)
+        out.numpy()[...] = np.where(m[None, :], b.numpy(), a.numpy())
+
     # -- MALA ------------------------------------------------------------------------------------
     def mala_propose(self, kind, state, theta, grad, theta_prop, eps, sqrt2eps):
         self._count("mala_propose")
@@ -169,8 +174,10 @@ class FakeOps:
             theta_prop.numpy()[:, c] = (theta.numpy()[:, c] + eps * grad.numpy()[:, c]) + sqrt2eps * z
             self._put(kind, state, c, g)
 
-    def normals_chain_major(self, kind, state, zt, D):
+    def normals_chain_major(self, kind, state, zt, D, snapshot=None):
         self._count("normals_chain_major")
+        if snapshot is not None:
+            snapshot.numpy()[...] = state.numpy()
         for c in range(zt.shape[0]):
             g = self._gen(kind, state, c)
             zt.numpy()[c, :D] = g.standard_normal(D)

@@ -115,8 +115,8 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_target_diag_gaussian_grad(p, p, None, 4, None, 4, 8, None) == E_ARG  # lam required
     assert lib.bk_ess(p, 4, 3, 0, p, None, 4, None) == E_ARG                     # N < 4 (ess.py:67-68)
     assert lib.bk_autocorr(p, 4, 1, p, 4, 4, None) == E_ARG                      # N < 2 (autocorr.py:23-24)
-    assert lib.bk_normals_chain_major(1, p, 4, p, 8, 4, 8, None) == E_ARG        # Philox streams only
-    assert lib.bk_normals_chain_major(0, p, 4, p, 7, 4, 8, None) == E_ARG        # ldz < D
+    assert lib.bk_normals_chain_major(1, p, 4, p, 8, 4, 8, None, None) == E_ARG        # Philox streams only
+    assert lib.bk_normals_chain_major(0, p, 4, p, 7, 4, 8, None, None) == E_ARG        # ldz < D
     # layout errors
     assert lib.bk_leapfrog_kick_drift(p, p, p, p, 3, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, 4, 8, None) == E_ALIGN
     assert lib.bk_select_columns(p, p, p, None, None, None, 3, 4, 8, None) == E_ALIGN

@@ -453,19 +453,38 @@ def test_select_with_fused_output_copy(ops, C, D):
             assert np.array_equal(d1.cpu().numpy(), np.where(acc[None, :], gp, g) if two else g)
 
 
-@pytest.mark.parametrize("C,D", [(5, 32), (70, 100), (64, 257)])
+@pytest.mark.parametrize("C,D", [(1, 1), (64, 9), (129, 17), (130, 8), (1024, 33)])
+def test_blend_columns_writes_only_the_output(ops, C, D):
+    """bk_blend_columns: out = mask ? b : a with both inputs left alone (16-byte and scalar paths, masks
+    mixed inside a lane pair, all / none accepted)."""
+    rng = np.random.default_rng(C * 7 + D)
+    a, b = rng.normal(size=(D, C)), rng.normal(size=(D, C))
+    for acc in (rng.random(C) < 0.5, np.zeros(C, bool), np.ones(C, bool)):
+        mask = torch.as_tensor(acc.astype(np.uint8)).to(ops.device)
+        da, db = dev(a, ops), dev(b, ops)
+        out = torch.full((D, C), np.nan, dtype=torch.float64, device=ops.device)
+        ops.blend_columns(mask, da, db, out)
+        assert np.array_equal(out.cpu().numpy(), np.where(acc[None, :], b, a))
+        assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b)
+
+
+@pytest.mark.parametrize("C,D", [(5, 32), (70, 100), (64, 257), (9000, 40), (20000, 101)])
 def test_chain_major_normals_and_transposing_proposal(ops, C, D):
-    """bk_normals_chain_major leaves the normals chain-major; the MALA proposal kernel reading them
-    through LDS tiles must equal the one reading the state layout, and numpy."""
+    """bk_normals_chain_major leaves the normals chain-major (64, 32 or 16 lanes per chain depending on
+    the launch: the last two shapes take the narrow ones); the MALA proposal kernel reading them
+    through LDS tiles must equal the one reading the state layout, and numpy.  The optional snapshot
+    is the table as it was before the call."""
     kind, st_a = make_state(4242, C, ops)
     _, st_b = make_state(4242, C, ops)
     dp = (D + 7) // 8 * 8
     zt = torch.full((C, dp), np.nan, dtype=torch.float64, device=ops.device)
     z = torch.empty((D, C), dtype=torch.float64, device=ops.device)
+    snap = torch.zeros_like(st_a)
     for _ in range(2):
-        ops.normals_chain_major(kind, st_a, zt, D)
+        before = st_a.clone()
+        ops.normals_chain_major(kind, st_a, zt, D, snap)
         ops.momentum_refresh(kind, st_b, None, 0.0, 1.0, z, None, None)
-        assert torch.equal(zt[:, :D].t(), z) and torch.equal(st_a, st_b)
+        assert torch.equal(zt[:, :D].t(), z) and torch.equal(st_a, st_b) and torch.equal(snap, before)
     g = np.random.Generator(np.random.Philox(key=[4242, C - 1]))
     g.normal(size=D)
     assert np.array_equal(zt[C - 1, :D].cpu().numpy(), g.normal(size=D))

@@ -649,6 +649,54 @@ def test_mala_two_pass_equals_step_by_step(ops, C, D):
         assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta) and torch.equal(a._log_p_theta, b._log_p_theta)
 
 
+def test_whole_draw_hmc_rebinds_its_state_and_keeps_returned_draws(ops):
+    """The one-pass HMC draw writes the blend of state and proposal to a fresh array that becomes the
+    state (bk_blend_columns): draws handed out earlier are never written again, not by later draws and
+    not by load_state_dict(); the chain equals the in-place path's bit for bit."""
+    lam = np.logspace(0, 1, 48)
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, fuse_builtin=False)
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, fuse_builtin=True)
+    assert b._fused_draw and not a._fused
+    kept, sd = [], None
+    for n in range(8):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb), n
+        kept.append((tb, tb.clone()))
+        if n == 3:
+            sd = b.state_dict()
+    tail = [t.clone() for t, _ in kept[4:]]
+    b.load_state_dict(sd)  # back to the state after draw 3: draws 4.. are produced again
+    for n in range(4, 8):
+        tb, _ = b.sample()
+        assert torch.equal(tb, tail[n - 4]), n
+    for t, c in kept:
+        assert torch.equal(t, c)
+    assert 0.1 < a.accept_rate() < 1.0
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_identity_metric_is_not_multiplied_in_but_changes_nothing(ops, graph):
+    """A metric of ones (the reference's default, hmc.py:22) is an exact identity: the one-pass draw runs
+    without it; a metric assigned later (also under hipGraph replay, which must be captured again) is
+    multiplied in.  Every variant equals the step-by-step path, which always multiplies."""
+    D, C = 40, 130
+    lam = np.logspace(0, 1, D)
+    mk = lambda fused, metric: bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 4, metric_diag=metric, chains=C, seed=21,
+                                          graph=graph and fused, fuse_builtin=fused)
+    a, b, c = mk(False, np.ones(D)), mk(True, np.ones(D)), mk(True, None)
+    assert b._fused_draw and b._metric_identity and a._metric_dev is not None
+    for n in range(10):
+        if n == 5:
+            for s in (a, b, c):
+                s._metric = np.linspace(0.8, 1.3, D)
+            assert not b._metric_identity
+        ta, la = a.sample()
+        for s in (b, c):
+            t, l = s.sample()
+            assert torch.equal(ta, t) and torch.equal(la, l), n
+
+
 def test_mala_step_kernel_against_its_cpu_statement(ops):
     """The kernel alone on random inputs (ragged last block, odd D, in-place theta_out, no next
     proposal) against tests/fake_ops.py's NumPy statement of bk_mala_step."""
