@@ -587,7 +587,8 @@ def run_rank(args):
             f = make_cfg3_sampler(C, rank * C, device, fused=True)
             for _ in range(3):
                 f.sample()
-            fel = ctx.timed_loop(f.sample, args.steps)
+            n_f = max(args.steps, 20)  # (a draw is ~1.3 ms: enough of them that the pipeline's fill and drain vanish)
+            fel = ctx.timed_loop(f.sample, n_f) * args.steps / n_f
             # the draw kernel's own time, in a second pass: the event pairs around it are extra markers on
             # the main stream and cost the draw a few per cent, so they stay out of the loop timed above
             ops.timed = {"bk_hmc_draw_gaussian": []}
@@ -613,6 +614,15 @@ def run_rank(args):
                 "note": "peak counts an FMA as 2 flop; this kernel may not contract (bit-parity), ceiling 39.3; "
                         "trajectory_kernel_ms is measured while the next draw's generator shares the ALUs",
             }
+            # the same draws with the metric multiplied in (6 flop per element-step): one entry an ulp off 1.0
+            # keeps the chain what it was and makes the metric a non-identity
+            m = torch.ones(D, dtype=torch.float64)
+            m[0] = 1.0 + 2.0 ** -52
+            f._metric = m
+            for _ in range(2):
+                f.sample()
+            fel6 = ctx.timed_loop(f.sample, n_f)
+            out["fused_builtin"]["ms_per_step_metric_multiplied_in"] = 1e3 * fel6 / n_f
             del f
             torch.cuda.empty_cache()
         except Exception as e:  # the extra must never cost the headline line
