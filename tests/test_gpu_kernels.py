@@ -468,10 +468,10 @@ def test_blend_columns_writes_only_the_output(ops, C, D):
         assert np.array_equal(da.cpu().numpy(), a) and np.array_equal(db.cpu().numpy(), b)
 
 
-@pytest.mark.parametrize("C,D", [(5, 32), (70, 100), (64, 257), (9000, 40), (20000, 101)])
+@pytest.mark.parametrize("C,D", [(5, 32), (70, 100), (64, 257), (9000, 40), (20000, 101), (33000, 33), (40000, 200)])
 def test_chain_major_normals_and_transposing_proposal(ops, C, D):
     """bk_normals_chain_major leaves the normals chain-major (64, 32 or 16 lanes per chain depending on
-    the launch: the last two shapes take the narrow ones); the MALA proposal kernel reading them
+    the launch: 32 lanes for the 9000- and 20,000-chain shapes, 16 for the last two); the MALA proposal kernel reading them
     through LDS tiles must equal the one reading the state layout, and numpy.  The optional snapshot
     is the table as it was before the call."""
     kind, st_a = make_state(4242, C, ops)
