@@ -58,7 +58,7 @@ SIGNATURES = {
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
-    "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, I, I, P],
+    "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
@@ -370,9 +370,12 @@ class Ops:
         self._call("bk_hmc_trajectory_gaussian", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
                    ptr(lam), ptr(metric), eps, steps, C, D, self._s())
 
-    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out):
+    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out,
+                          accept=None):
         """Trajectory + both kinetic energies + end-point log density of one HMC draw; momentum from
-        rho_in ([D, C]) or from chain-major normals zt ([C, >=D]), exactly one of them."""
+        rho_in ([D, C]) or from chain-major normals zt ([C, >=D]), exactly one of them.
+        accept: optional (lp_cur, log_u, mask, ret, count) -- the draw's accept test in the same launches
+        (what mh_accept(ACCEPT_HMC, lp_cur, kin0, lp_out, kin1, log_u, mask, ret, count) does)."""
         D, C = theta_in.shape
         ld = _ld(theta_in)
         assert _ld(theta_out) == ld and (rho_in is None or _ld(rho_in) == ld) and part.numel() >= 12 * C
@@ -380,8 +383,10 @@ class Ops:
         if zt is not None:
             assert zt.shape[0] == C and zt.stride(1) == 1 and zt.shape[1] >= D
             ldz = zt.stride(0)
+        lp_cur, log_u, mask, ret, count = accept if accept is not None else (None,) * 5
         self._call("bk_hmc_draw_gaussian", ptr(theta_in), ptr(theta_out), ld, ptr(rho_in), ptr(zt), ldz, ptr(lam),
-                   ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), C, D, self._s())
+                   ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), ptr(lp_cur), ptr(log_u),
+                   ptr(mask), ptr(ret), ptr(count), C, D, self._s())
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):

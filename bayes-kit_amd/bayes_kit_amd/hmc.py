@@ -338,10 +338,8 @@ class HMCDiag(ManyChainSampler):
             zt = self._zt_bufs[self._zt_slot] if self._fused_zt else None
             # (fp64-VALU bound: a metric of ones is not multiplied in -- x * 1.0 is x, bit for bit)
             m_draw = None if (m is None or self._metric_identity) else m
-            self._model.bk_hmc_draw(th, thp, rho, zt, m_draw, eps, L, self._part, kin0, self._kin1,
-                                    self._lp_p)                                                 # [hmc.py:56-59]
-            ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
-                          self._mask, self._ret, self._accepted)                                           # [hmc.py:60-63]
+            self._model.bk_hmc_draw(th, thp, rho, zt, m_draw, eps, L, self._part, kin0, self._kin1, self._lp_p,
+                                    accept=(self._lp, logu, self._mask, self._ret, self._accepted))  # [hmc.py:56-63]
             if self._use_graph:
                 self._select(self._mask, th, thp)
             else:

@@ -69,10 +69,10 @@ class IsoGaussian(_BuiltinTarget):
         """Whole leapfrog trajectory with the gradient inlined (register-resident)."""
         self._get_ops().hmc_trajectory_gaussian(theta_in, theta_out, rho_in, rho_out, None, metric, eps, steps)
 
-    def bk_hmc_draw(self, theta_in, theta_out, rho_in, zt, metric, eps, steps, part, kin0, kin1, lp_out):
-        """Trajectory + energies of one HMC draw in one pass (bk_hmc_draw_gaussian)."""
+    def bk_hmc_draw(self, theta_in, theta_out, rho_in, zt, metric, eps, steps, part, kin0, kin1, lp_out, accept=None):
+        """Trajectory + energies (+ accept test) of one HMC draw in one pass (bk_hmc_draw_gaussian)."""
         self._get_ops().hmc_draw_gaussian(theta_in, theta_out, rho_in, zt, None, metric, eps, steps, part, kin0, kin1,
-                                          lp_out)
+                                          lp_out, accept)
 
 
 class DiagGaussian(_BuiltinTarget):
@@ -99,10 +99,10 @@ class DiagGaussian(_BuiltinTarget):
         self._get_ops().hmc_trajectory_gaussian(theta_in, theta_out, rho_in, rho_out, self._lam(theta_in.device),
                                                 metric, eps, steps)
 
-    def bk_hmc_draw(self, theta_in, theta_out, rho_in, zt, metric, eps, steps, part, kin0, kin1, lp_out):
-        """Trajectory + energies of one HMC draw in one pass (bk_hmc_draw_gaussian)."""
+    def bk_hmc_draw(self, theta_in, theta_out, rho_in, zt, metric, eps, steps, part, kin0, kin1, lp_out, accept=None):
+        """Trajectory + energies (+ accept test) of one HMC draw in one pass (bk_hmc_draw_gaussian)."""
         self._get_ops().hmc_draw_gaussian(theta_in, theta_out, rho_in, zt, self._lam(theta_in.device), metric, eps,
-                                          steps, part, kin0, kin1, lp_out)
+                                          steps, part, kin0, kin1, lp_out, accept)
 
 
 class Funnel(_BuiltinTarget):

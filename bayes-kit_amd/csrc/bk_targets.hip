@@ -546,19 +546,37 @@ __global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_q(const double* th_in, 
   part[(2 * 4 + q) * C + c] = sl;
 }
 
+// ... and, when the caller hands over the rest of the accept test's inputs, the test itself
+// (hmc.py:60-63, the arithmetic of bk_mh_accept in HMC mode): one launch less per draw.
 __global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double* kin0, double* kin1, double* lp,
-                                                      i64 C) {
+                                                      double* lp_cur, const double* log_u, uint8_t* mask, double* ret,
+                                                      uint32_t* count, i64 C) {
   const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double v[3];
+  bool acc = false;
+  if (c < C) {
+    double v[3];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const double* p = part + (i64)k * 4 * C + c;
-    v[k] = ((p[0] + p[C]) + p[2 * C]) + p[3 * C];
+    for (int k = 0; k < 3; ++k) {
+      const double* p = part + (i64)k * 4 * C + c;
+      v[k] = ((p[0] + p[C]) + p[2 * C]) + p[3 * C];
+    }
+    const double a0 = 0.5 * v[0], a1 = 0.5 * v[1], l1 = -0.5 * v[2];
+    if (kin0) kin0[c] = a0;
+    kin1[c] = a1;
+    lp[c] = l1;
+    if (lp_cur) {
+      const double l0 = lp_cur[c];
+      const double h0 = l0 - a0, h1 = l1 - a1;  // hmc.py:36-38
+      acc = log_u[c] < h1 - h0;                 // hmc.py:60
+      if (mask) mask[c] = acc ? 1 : 0;
+      if (ret) ret[c] = acc ? h1 : h0;
+      if (acc) lp_cur[c] = l1;
+    }
   }
-  if (kin0) kin0[c] = 0.5 * v[0];
-  kin1[c] = 0.5 * v[1];
-  lp[c] = -0.5 * v[2];
+  if (lp_cur && count) {
+    unsigned long long b = __ballot(acc);
+    if ((threadIdx.x & (BK_WAVE - 1)) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+  }
 }
 
 int gauss(const double* theta, double* grad, double* logp, i64 ld, const double* lam, i64 C, i64 D,
@@ -648,10 +666,11 @@ int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const 
 
 int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in,
                          const double* zt, int64_t ldz, const double* lam, const double* metric, double eps,
-                         int64_t steps, double* part, double* kin0, double* kin1, double* lp_out, int64_t C,
+                         int64_t steps, double* part, double* kin0, double* kin1, double* lp_out, double* lp_cur,
+                         const double* log_u, uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C,
                          int64_t D, void* stream) {
   if (!theta_in || !theta_out || (!rho_in && !zt) || (rho_in && zt) || !part || !kin1 || !lp_out || steps < 0 ||
-      steps > 0x7fffffff || C < 0 || D < 0)
+      steps > 0x7fffffff || C < 0 || D < 0 || (lp_cur && !log_u))
     return BK_E_ARG;
   if (ld < C || (zt && ldz < D)) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
@@ -671,7 +690,8 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
   else if (metric) BK_TQ(false, true);
   else BK_TQ(false, false);
 #undef BK_TQ
-  k_quarter_sums<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, s>>>(part, kin0, kin1, lp_out, C);
+  k_quarter_sums<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, s>>>(part, kin0, kin1, lp_out, lp_cur, log_u,
+                                                                       accept_mask, ret, accept_count, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

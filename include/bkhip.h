@@ -343,11 +343,16 @@ int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const 
  * in the state layout (rho_in [D][ld]) or chain-major straight from bk_normals_chain_major
  * (zt[c*ldz + d], rho0 = 0.0 + 1.0*z: `rng.normal(size=D)`, hmc.py:56); exactly one of the two is
  * given.  The end momentum is not stored (hmc.py:58-63 never uses it again).
- * part: caller scratch of 12*C doubles.  HBM traffic 24*D bytes per chain. */
+ * part: caller scratch of 12*C doubles.  HBM traffic 24*D bytes per chain.
+ * With lp_cur != NULL (the target's log density at theta_in, per chain) and log_u, the accept test
+ * of the draw (hmc.py:60-63) is evaluated by the same launch sequence, exactly as
+ * bk_mh_accept(BK_ACCEPT_HMC, lp_cur, kin0, lp_out, kin1, log_u, accept_mask, ret, accept_count)
+ * would: accept_mask / ret / accept_count optional, lp_cur updated in place on accepted chains. */
 int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in,
                          const double* zt, int64_t ldz, const double* lam, const double* metric,
                          double eps, int64_t steps, double* part, double* kin0, double* kin1,
-                         double* lp_out, int64_t C, int64_t D, void* stream);
+                         double* lp_out, double* lp_cur, const double* log_u, uint8_t* accept_mask,
+                         double* ret, uint32_t* accept_count, int64_t C, int64_t D, void* stream);
 
 /* One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) on Neal's funnel in a
  * single launch, gradient callback inlined: chain j of the outputs starts from chain

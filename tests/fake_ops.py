@@ -287,7 +287,8 @@ class FakeOps:
             s = s + x[d]
         return s
 
-    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out):
+    def hmc_draw_gaussian(self, theta_in, theta_out, rho_in, zt, lam, metric, eps, steps, part, kin0, kin1, lp_out,
+                          accept=None):
         self._count("hmc_draw_gaussian")
         D = theta_in.shape[0]
         r0 = torch.from_numpy(0.0 + 1.0 * zt.numpy()[:, :D].T.copy()) if zt is not None else rho_in
@@ -300,6 +301,11 @@ class FakeOps:
         th = theta_out.numpy()
         lt = th if lam is None else lam.numpy()[:, None] * th
         lp_out.numpy()[...] = -0.5 * self._quarter_sum(th * lt)
+        if accept is not None:
+            lp_cur, log_u, mask, ret, count = accept
+            if kin0 is None:
+                kin0 = torch.from_numpy(0.5 * self._quarter_sum(r0.numpy() * m(r0.numpy())))
+            self.mh_accept(0, lp_cur, kin0, lp_out, kin1, log_u, mask, ret, count)
 
     @staticmethod
     def _lanes(n, n_dev):

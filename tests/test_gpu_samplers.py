@@ -825,6 +825,19 @@ def test_hmc_whole_draw_kernel_energies_are_the_reduction_kernels_values(ops):
             k0, k1, lp = (torch.empty(C, dtype=torch.float64, device=dev) for _ in range(3))
             ops.hmc_draw_gaussian(th, out, None if use_zt else rho0, zt if use_zt else None, lam, met, eps, L, part, k0, k1, lp)
             assert torch.equal(out, th_ref) and torch.equal(k0, k0_ref) and torch.equal(k1, k1_ref) and torch.equal(lp, lp_ref)
+            # the accept test folded into the same launches == bk_mh_accept on those energies
+            lp_cur = (lp_ref - k1_ref + k0_ref) + t(rng.normal(size=C))  # energy errors of order one
+            logu = t(np.log(rng.uniform(size=C)))
+            f64 = dict(dtype=torch.float64, device=dev)
+            la, lb = lp_cur.clone(), lp_cur.clone()
+            ma, mb = (torch.zeros(C, dtype=torch.uint8, device=dev) for _ in range(2))
+            ra, rb = torch.empty(C, **f64), torch.empty(C, **f64)
+            na, nb = (torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2))
+            ops.mh_accept(0, la, k0_ref, lp_ref, k1_ref, logu, ma, ra, na)
+            ops.hmc_draw_gaussian(th, out, None if use_zt else rho0, zt if use_zt else None, lam, met, eps, L, part, k0, k1, lp,
+                                  accept=(lb, logu, mb, rb, nb))
+            assert torch.equal(ma, mb) and torch.equal(ra, rb) and torch.equal(la, lb) and int(na) == int(nb)
+            assert 0 < int(nb) < C
 
 
 @pytest.mark.parametrize("D,K", [(11, 3), (101, 3), (21, 2), (129, 3), (40, 4)])
