@@ -493,7 +493,7 @@ __global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_q(const double* th_in, 
                                                            i64 ld, const double* zt, i64 ldz, const double* lam,
                                                            const double* metric, double eps, int steps,
                                                            double* part, i64 C, i64 D) {
-  const i64 c = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
+  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;  // (64-thread workgroups for small launches)
   const int q = blockIdx.y;
   if (c >= C) return;
   const i64 Dq = (D + 3) / 4;
@@ -675,14 +675,16 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
   if (ld < C || (zt && ldz < D)) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
-  dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), 4);
+  // one wavefront per workgroup while that still leaves CUs idle (4096 chains: 256 workgroups instead of 64)
+  const int tq_block = C * 4 <= 256 * TG_BLOCK ? BK_WAVE : TG_BLOCK;
+  dim3 grid((unsigned)bk_cdiv(C, tq_block), 4);
 #define BK_TQ(HL, HM)                                                                                               \
   do {                                                                                                              \
     if (zt)                                                                                                         \
-      k_traj_gauss_q<HL, HM, true><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,    \
+      k_traj_gauss_q<HL, HM, true><<<grid, dim3(tq_block), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,    \
                                                                    metric, eps, (int)steps, part, C, D);            \
     else                                                                                                            \
-      k_traj_gauss_q<HL, HM, false><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,   \
+      k_traj_gauss_q<HL, HM, false><<<grid, dim3(tq_block), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,   \
                                                                     metric, eps, (int)steps, part, C, D);           \
   } while (0)
   if (lam && metric) BK_TQ(true, true);
