@@ -66,6 +66,36 @@ def one(rng, it):
             g.replay()
         assert float(x[0].item()) >= 3.0
         return "torchgraph"
+    if alg == "torchfork":
+        # control: the same with a parallel branch (fork onto a side stream, join), PyTorch kernels only,
+        # shaped like the samplers' former forked capture: a device-to-device copy and a few kernels on
+        # the branch, two graphs sharing the side stream, replayed alternately
+        n = int(rng.choice([3, 64, 500]))
+        f64 = dict(dtype=torch.float64, device="cuda")
+        x, y, z = torch.zeros(n, **f64), torch.zeros((11, n), **f64), torch.zeros((11, n), **f64)
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        graphs = []
+        for _ in range(2):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                main = torch.cuda.current_stream()
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    z.copy_(y)
+                    y.add_(1.0)
+                    y.mul_(1.0)
+                x.add_(1.0)
+                x.mul_(1.0)
+                x.add_(0.0)
+                main.wait_stream(side)
+            graphs.append(g)
+        reps = int(rng.integers(2, 10))
+        for i in range(reps):
+            graphs[i % 2].replay()
+        got = x.cpu().numpy()
+        assert got[0] == reps and float(y[0, 0].item()) == reps and float(z[0, 0].item()) == reps - 1
+        return "torchfork"
     D = int(rng.choice([1, 2, 7, 31, 32, 33, 40, 64, 70]))
     C = int(rng.choice([1, 2, 3, 63, 64, 65, 130, 257, 500]))
     N = int(rng.integers(3, 12))
