@@ -47,6 +47,8 @@ SIGNATURES = {
     "bk_dr_ghost_update": [P, P, I, P, P, P, P, P],
     "bk_dr_accept_prob": [P, P, P, P, P, F, P, P, I, P, P],
     "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P, P],
+    "bk_dr_accept_prob_test": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P],
+    "bk_dr_accept_prob_ghost": [P, P, P, P, P, F, P, P, I, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
@@ -286,6 +288,19 @@ class Ops:
     def dr_accept_test(self, kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev=None):
         self._call("bk_dr_accept_test", kind, ptr(state), state.stride(0), ptr(chain_index), ptr(a), ptr(H),
                    n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), ptr(accepted), ptr(n_dev), self._s())
+
+    def dr_accept_prob_test(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
+                            accepted, n_dev=None):
+        """dr_accept_prob against the chains' current point + dr_accept_test, one launch."""
+        self._call("bk_dr_accept_prob_test", kind, ptr(state), state.stride(0), ptr(chain_index), ptr(H), ptr(h),
+                   ptr(live), ptr(a), float(prob_retry), n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive),
+                   ptr(accepted), ptr(n_dev), self._s())
+
+    def dr_accept_prob_ghost(self, H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, parent_live, parent_a,
+                             n_dev=None):
+        """dr_accept_prob of a ghost level + dr_ghost_update of its parent level, one launch."""
+        self._call("bk_dr_accept_prob_ghost", ptr(H), ptr(parent_H), ptr(h), ptr(parent_h), ptr(sub_index),
+                   float(prob_retry), ptr(live), ptr(a), n, ptr(n_dev), ptr(parent_live), ptr(parent_a), self._s())
 
     def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         """dsts/srcs: up to three [D, *] tensors each (same ld within each list)."""

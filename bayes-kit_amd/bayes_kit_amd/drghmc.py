@@ -372,23 +372,26 @@ class DrGhmcDiag(ManyChainSampler):
                                         level=(dst.H, dst.h, dst.live))
         assert ok
 
-    def _accept_dev(self, lvl, n_dev, k, cur_h, cur_H, cur_idx):
-        """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains)."""
+    def _accept_dev(self, lvl, n_dev, k, parent=None, sub=None):
+        """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains): the ghost
+        proposals of level `lvl` and their recursive accepts.  For a ghost level (`parent` given: the level
+        its lanes belong to, paired by `sub`) the level's own accept probability and the update of the
+        parent are one launch (bk_dr_accept_prob_ghost); for the stage's proposal itself (level 0) the
+        probability is evaluated by the accept test's launch (bk_dr_accept_prob_test, in _draw_dev)."""
         ops, C = self._ops, self._C
         P = self._levels[lvl]  # (H, h, live of the level were set by the proposal's own launch)
         for i in range(k):
             if i == 0:
-                m_dev, sub = n_dev, None  # every lane of the level is still live
+                m_dev, gsub = n_dev, None  # every lane of the level is still live
             else:
                 nxt = self._levels[lvl + 1]
                 ops.compact_indices(P.live, C, nxt.idx, nxt.count, n_dev=n_dev)
-                m_dev, sub = nxt.count, nxt.idx
-            self._proposal_dev(P, sub, m_dev, i, lvl + 1)
-            ga = self._accept_dev(lvl + 1, m_dev, i, P.h, P.H, sub)
-            ops.dr_ghost_update(ga, sub, C, P.h, P.live, P.a, n_dev=m_dev)
-        ops.dr_accept_prob(P.H, cur_H, P.h, cur_h, cur_idx, 1.0 if self._prob_retry else 0.0, P.live, P.a, C,
-                           n_dev=n_dev)
-        return P.a
+                m_dev, gsub = nxt.count, nxt.idx
+            self._proposal_dev(P, gsub, m_dev, i, lvl + 1)
+            self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub)
+        if parent is not None:
+            ops.dr_accept_prob_ghost(P.H, parent.H, P.h, parent.h, sub, 1.0 if self._prob_retry else 0.0, P.live, P.a,
+                                     C, parent.live, parent.a, n_dev=n_dev)                   # :426-446
 
     def _draw_dev(self):
         ops = self._ops
@@ -409,9 +412,10 @@ class DrGhmcDiag(ManyChainSampler):
                 ops.compact_indices(self._alive, C, P0.idx, P0.count)
                 n_dev, idx = P0.count, P0.idx
             self._proposal_dev(cur, idx, n_dev, k, 0)                                             # :373
-            a = self._accept_dev(0, n_dev, k, self._cur_h, self._cur_H, idx)                      # :374-376
-            ops.dr_accept_test(self._rng_kind, self._rng_state, idx, a, P0.H, C, self._cur_H, self._cur_h,
-                               self._rej, self._alive, P0.accepted, n_dev=n_dev)                  # :378-385
+            self._accept_dev(0, n_dev, k)                                                         # :374-376
+            ops.dr_accept_prob_test(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
+                                    self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted,
+                                    n_dev=n_dev)                                                  # :441-446, :378-385
             ops.scatter_columns(P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad],
                                 [P0.theta, P0.rho, P0.grad], self._lp, P0.logp, n_dev=n_dev)
 

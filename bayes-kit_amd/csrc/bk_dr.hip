@@ -112,6 +112,38 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const i
   }
 }
 
+// the acceptance log-probability of lane j against its current point p (drghmc.py:441-446)
+__device__ __forceinline__ double dr_accept_logprob(double Hj, double cH, double ph, double ch, double pr) {
+  const double frac = ((Hj - cH) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
+  return frac < 0.0 ? frac : 0.0;                                      // min(0, frac), :446
+}
+
+// accept probability of a GHOST level followed by the update of its parent level (k_dr_accept_prob +
+// k_dr_ghost in one launch: ghost lane j has exactly one parent lane p, so nobody else touches p)
+__global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob_ghost(const double* H, const double* par_H,
+                                                                   const double* h, double* par_h,
+                                                                   const int32_t* sub, double pr,
+                                                                   const uint8_t* live, double* a, i64 n,
+                                                                   const uint32_t* n_dev, uint8_t* par_live,
+                                                                   double* par_a) {
+  i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
+  if (j >= bk_lanes(n, n_dev)) return;
+  i64 p = sub ? (i64)sub[j] : j;
+  double g;
+  if (live[j]) {
+    g = dr_accept_logprob(H[j], par_H[p], h[j], par_h[p], pr);
+    a[j] = g;
+  } else {
+    g = a[j];  // (-inf: set when one of this lane's own ghosts was accepted with probability one)
+  }
+  if (g == 0.0) {  // drghmc.py:430-432
+    par_a[p] = -INFINITY;
+    par_live[p] = 0;
+  } else {
+    par_h[p] = par_h[p] + log1p(-exp(g));  // drghmc.py:434-435
+  }
+}
+
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, const double* cur_H,
                                                              const double* h, const double* cur_h,
                                                              const int32_t* cidx, double pr,
@@ -120,16 +152,17 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, co
   i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
   if (j >= bk_lanes(n, n_dev) || !live[j]) return;
   i64 p = cidx ? (i64)cidx[j] : j;
-  double ph = h[j], ch = cur_h[p];
-  double frac = ((H[j] - cur_H[p]) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
-  a[j] = frac < 0.0 ? frac : 0.0;                                          // min(0, frac), :446
+  a[j] = dr_accept_logprob(H[j], cur_H[p], h[j], cur_h[p], pr);
 }
 
+// h / live given: the stage's accept probability (k_dr_accept_prob against the chain's current point) is
+// evaluated here first, one launch less per stage; `a` is then an output as well
 template <typename G>
 __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, const int32_t* cidx,
-                                                       const double* a, const double* H, i64 n,
+                                                       double* a, const double* H, i64 n,
                                                        double* cur_H, double* cur_h, double* rej,
-                                                       uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev) {
+                                                       uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev,
+                                                       const double* h, const uint8_t* live, double pr) {
   i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
   if (j >= bk_lanes(n, n_dev)) return;
   i64 c = cidx ? (i64)cidx[j] : j;
@@ -137,6 +170,7 @@ __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, co
   g.load(st, ldr, c);
   double lu = log(bk::next_double(g));
   g.store(st, ldr, c);
+  if (h && live[j]) a[j] = dr_accept_logprob(H[j], cur_H[c], h[j], cur_h[c], pr);
   double aj = a[j];
   if (lu < aj) {  // drghmc.py:378-381
     accepted[j] = 1;
@@ -242,20 +276,47 @@ int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, con
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* a,
-                      const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
-                      uint8_t* accepted, const uint32_t* n_dev, void* stream) {
+static int dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, double* a,
+                          const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
+                          uint8_t* accepted, const uint32_t* n_dev, const double* h, const uint8_t* live, double pr,
+                          void* stream) {
   if (!state || !a || !H || !cur_H || !cur_h || !rej || !alive || !accepted || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   dim3 grid((unsigned)bk_cdiv(n, 64)), block(64);
   if (rng_kind == BK_RNG_PHILOX)
     k_dr_accept_test<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                       cur_h, rej, alive, accepted, n_dev);
+                                                                       cur_h, rej, alive, accepted, n_dev, h, live, pr);
   else if (rng_kind == BK_RNG_PCG64)
     k_dr_accept_test<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                      cur_h, rej, alive, accepted, n_dev);
+                                                                      cur_h, rej, alive, accepted, n_dev, h, live, pr);
   else
     return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* a,
+                      const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
+                      uint8_t* accepted, const uint32_t* n_dev, void* stream) {
+  return dr_accept_test(rng_kind, state, ldr, chain_index, const_cast<double*>(a), H, n, cur_H, cur_h, rej, alive,
+                        accepted, n_dev, nullptr, nullptr, 0.0, stream);
+}
+
+int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* H,
+                           const double* h, const uint8_t* live, double* a, double prob_retry, int64_t n,
+                           double* cur_H, double* cur_h, double* rej, uint8_t* alive, uint8_t* accepted,
+                           const uint32_t* n_dev, void* stream) {
+  if (!h || !live) return BK_E_ARG;
+  return dr_accept_test(rng_kind, state, ldr, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev, h,
+                        live, prob_retry, stream);
+}
+
+int bk_dr_accept_prob_ghost(const double* H, const double* parent_H, const double* h, double* parent_h,
+                            const int32_t* sub_index, double prob_retry, const uint8_t* live, double* a, int64_t n,
+                            const uint32_t* n_dev, uint8_t* parent_live, double* parent_a, void* stream) {
+  if (!H || !parent_H || !h || !parent_h || !live || !a || !parent_live || !parent_a || n < 0) return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_dr_accept_prob_ghost<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(
+      H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev, parent_live, parent_a);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -225,6 +225,22 @@ int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t*
                       double* rej, uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev,
                       void* stream);
 
+/* bk_dr_accept_prob for the chains' CURRENT point followed by bk_dr_accept_test, in one launch: lane j's
+ * accept probability a[j] (written, if live[j]) is evaluated against cur_H / cur_h of its chain right before
+ * the test draws its uniform.  Same arithmetic, one launch less per stage. */
+int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index,
+                           const double* H, const double* h, const uint8_t* live, double* a,
+                           double prob_retry, int64_t n, double* cur_H, double* cur_h, double* rej,
+                           uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev, void* stream);
+
+/* bk_dr_accept_prob of a GHOST level (against its parent level's H / h, lanes paired by sub_index) followed
+ * by bk_dr_ghost_update of the parent (parent_h, parent_live, parent_a), in one launch: every ghost lane has
+ * exactly one parent lane.  drghmc.py:426-446. */
+int bk_dr_accept_prob_ghost(const double* H, const double* parent_H, const double* h, double* parent_h,
+                            const int32_t* sub_index, double prob_retry, const uint8_t* live, double* a,
+                            int64_t n, const uint32_t* n_dev, uint8_t* parent_live, double* parent_a,
+                            void* stream);
+
 /* Accepted lanes replace their chain's current point (drghmc.py:379): for up to three
  * array pairs dst[d*ld_dst + g] = src[d*ld_src + j] and one per-chain vector
  * sdst[g] = ssrc[j], where g = index ? index[j] : j and mask[j] != 0. */

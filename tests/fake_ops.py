@@ -549,6 +549,18 @@ class FakeOps:
                 rej.numpy()[c] = r
                 cur_h.numpy()[c] = cur_h.numpy()[c] + r
 
+    def dr_accept_prob_test(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
+                            accepted, n_dev=None):
+        # (every chain is in the lane set once: evaluating all probabilities first changes nothing)
+        self.dr_accept_prob(H, cur_H, h, cur_h, chain_index, prob_retry, live, a, n, n_dev)
+        self.dr_accept_test(kind, state, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev)
+
+    def dr_accept_prob_ghost(self, H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, parent_live, parent_a,
+                             n_dev=None):
+        # (every parent lane has one ghost lane)
+        self.dr_accept_prob(H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev)
+        self.dr_ghost_update(a, sub_index, n, parent_h, parent_live, parent_a, n_dev)
+
     def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         n = self._lanes(n, n_dev)
         for j in range(n):
