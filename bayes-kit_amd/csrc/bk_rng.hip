@@ -280,6 +280,37 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st
     for (int k = 0; k < 4; ++k)
       if (vbase + k < cover_until) cov |= 1u << k;
     unsigned long long any = ex[0] | ex[1] | ex[2] | ex[3];
+    // The common window: every exception is a two-word attempt (wedge), none of them sits on a word that is
+    // already covered, no two are neighbours in the stream.  Then every exception starts an attempt, covers
+    // exactly the word behind it, and nothing has to be walked in order: a word is covered iff its
+    // predecessor in the segment is an exception (or the carry-in covers it).
+    if (any) {
+      bool odd = false;  // this lane holds an exception the shortcut cannot take
+#pragma unroll
+      for (int k = 0; k < 4; ++k) odd |= !okf[k] && (len[k] != 2 || vbase + k < cover_until);
+      // neighbours: words k, k+1 of one lane; word 3 of lane L and word 0 of lane L+1 of the same segment
+      constexpr unsigned long long seg_last =  // lanes that are the last of their segment
+          LPC == 64 ? 0x8000000000000000ULL : LPC == 32 ? 0x8000000080000000ULL : 0x8000800080008000ULL;
+      const unsigned long long adj = (ex[0] & ex[1]) | (ex[1] & ex[2]) | (ex[2] & ex[3]) | (ex[3] & (ex[0] >> 1) & ~seg_last);
+      if (!__any(odd) && !adj) {
+        const unsigned long long mine_mask = any & segmask;
+        if (mine_mask) {
+          // covered: the word behind an exception
+          if (!okf[0]) cov |= 1u << 1;
+          if (!okf[1]) cov |= 1u << 2;
+          if (!okf[2]) cov |= 1u << 3;
+          if (l > 0 && ((ex[3] >> (lane - 1)) & 1ULL)) cov |= 1u << 0;
+          // the last exception of the segment ends the covered range (its second word may be the next window's first)
+          const int Ll = 63 - __clzll((long long)mine_mask);  // last lane of the segment holding an exception
+          int kl = 0;
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if ((ex[k] >> Ll) & 1ULL) kl = k;
+          cover_until = wbase + 4 * (Ll % LPC) + kl + 2;
+        }
+        any = 0;
+      }
+    }
     while (any) {
       int L = __ffsll((long long)any) - 1;
       any &= any - 1;
