@@ -1,7 +1,8 @@
 """Randomised differential soak: many-chain HIP samplers vs the NumPy oracle (one object per chain).
 
-Random algorithm (HMC / MALA / DRGHMC / Metropolis), target (iso / diag Gaussian), dims (1..70: both
-generator kernels), chains (odd and even: scalar and 16-byte kernels), step sizes, trajectory lengths,
+Random algorithm (HMC / MALA / DRGHMC / Metropolis), target (iso / diag Gaussian / AR(1)), model provider
+(library target, PyTorch autograd, user code returning a row-major or strided gradient, compiled plugin),
+dims (1..70: both generator kernels), chains (odd and even: scalar and 16-byte kernels), step sizes, trajectory lengths,
 metric on/off, fused / step-by-step, hipGraph on/off, RNG prefetch on/off.  For a few watched chains
 theta must be bit-identical to the oracle at every draw and the stream state equal at the end.
 SECONDS env var = duration (default 60); SEED = rng seed."""
@@ -14,6 +15,8 @@ import bayes_kit_amd as bk
 from bayes_kit_amd.metropolis import ChainRng
 from oracle import models as om
 from oracle import samplers as osamp
+from tests import provider_parity as pp
+from tests.host_models import Ar1
 
 
 if os.environ.get("SOAK_NO_FUSED_DRAW"):
@@ -48,6 +51,7 @@ class Sentinels:
                 raise AssertionError(("sentinel", i, hex(b.ctypes.data), j.tolist(), [hex(int(v) & (2**64 - 1)) for v in b[j]]))
 
 
+PROVIDERS_SEEN = {}
 HISTORY = []  # the last few configurations: a corrupted sampler is usually the victim of an earlier one
 
 
@@ -102,11 +106,28 @@ def one(rng, it):
     seed = int(rng.integers(1, 2**40))
     iso = rng.random() < 0.4
     lam = None if iso else np.logspace(0, rng.uniform(0.2, 1.0), D)
-    tgt = bk.IsoGaussian(D) if iso else bk.DiagGaussian(lam)
-    otgt = (lambda: om.IsoGaussian(D)) if iso else (lambda: om.DiagGaussian(lam))
+    # who supplies the gradient: the library's own target, autograd of user torch code,
+    # user code with a gradient layout of its own, or a compiled plugin behind bk_target_fn
+    prov = str(rng.choice(os.environ["PROVIDERS"].split(","))) if os.environ.get("PROVIDERS") else \
+        str(rng.choice(["builtin", "builtin", "builtin", "torch", "row", "strided", "plugin"]))
+    lam_eff = np.ones(D) if iso else lam
+    if prov == "builtin":
+        tgt = bk.IsoGaussian(D) if iso else bk.DiagGaussian(lam)
+    elif prov == "torch":
+        tgt = pp.torch_diag_gaussian(lam_eff, "cuda")
+    elif prov in ("row", "strided"):
+        tgt = pp.RowMajorDiag(lam_eff, "cuda", prov)
+    else:
+        a_ar, s2_ar = float(rng.uniform(-0.8, 0.8)), float(rng.uniform(0.5, 1.5))
+        tgt = pp.ar1_plugin(D, a_ar, s2_ar)
+    if prov == "plugin":
+        otgt = lambda: Ar1(D, a_ar, s2_ar)
+    else:
+        otgt = (lambda: om.IsoGaussian(D)) if iso else (lambda: om.DiagGaussian(lam))
     metric = np.linspace(0.8, 1.2, D) if (rng.random() < 0.4 and alg in ("hmc", "drghmc")) else None
     eps = float(rng.uniform(0.02, 0.3))
-    desc = dict(alg=str(alg), D=D, C=C, N=N, seed=seed, iso=bool(iso), metric=metric is not None, eps=eps)
+    desc = dict(alg=str(alg), D=D, C=C, N=N, seed=seed, iso=bool(iso), metric=metric is not None, eps=eps, provider=prov)
+    PROVIDERS_SEEN[prov] = PROVIDERS_SEEN.get(prov, 0) + 1
     HISTORY.append(desc)
     del HISTORY[:-8]
     if alg == "hmc":
@@ -185,4 +206,5 @@ if __name__ == "__main__":
             print("history (oldest first):", *HISTORY, sep="\n  ", flush=True)
             raise
         counts[a] = counts.get(a, 0) + 1
-    print("soak ok:", sum(counts.values()), "random sampler configurations", counts, f"in {time.time()-t0:.0f} s")
+    print("soak ok:", sum(counts.values()), "random sampler configurations", counts, "providers", PROVIDERS_SEEN,
+          f"in {time.time()-t0:.0f} s")

@@ -553,8 +553,8 @@ def test_long_run_stays_bit_identical_to_the_oracle(ops, alg):
 
 
 def test_randomised_sampler_configurations_against_the_oracle(ops):
-    """A fixed-seed slice of tests/soak_samplers.py: random algorithm, target, dims (both generator
-    kernels), odd / even chain counts, metric, fused / step-by-step, hipGraph and RNG-prefetch
+    """A fixed-seed slice of tests/soak_samplers.py: random algorithm, target, model provider (library target,
+    autograd, user gradient layouts, compiled plugin), dims (both generator kernels), odd / even chain counts, metric, fused / step-by-step, hipGraph and RNG-prefetch
     switches; watched chains bit-identical to the oracle at every draw, stream states equal."""
     import importlib.util
     import os
@@ -568,6 +568,7 @@ def test_randomised_sampler_configurations_against_the_oracle(ops):
     for it in range(120):
         seen.add(str(mod.one(rng, it)))
     assert seen == {"hmc", "mala", "drghmc", "metropolis"}
+    assert set(mod.PROVIDERS_SEEN) == {"builtin", "torch", "row", "strided", "plugin"}, mod.PROVIDERS_SEEN
 
 
 def test_plain_c_host_program_equals_the_python_driver(ops):
