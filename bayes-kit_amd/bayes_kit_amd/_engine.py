@@ -317,6 +317,12 @@ class ManyChainSampler:
         self._graph = None
         self._graph_warm = 0
 
+    def _graph_key(self):
+        """The host scalars a captured draw bakes into its launches (step sizes, step counts, damping ...:
+        plain attributes in the reference, which e.g. a step-size adaptation assigns between draws).  They are
+        compared before every replay; a change -- assignment or in-place edit of a list -- captures again."""
+        return None
+
     # A captured draw is a LINEAR graph: samplers that otherwise generate the next draw's randomness on
     # a side stream (prefetch_rng) generate it in line when they replay a graph.  Capturing the side
     # stream as a parallel branch (fork at the start of the draw, join at the end) is both slower
@@ -339,9 +345,14 @@ class ManyChainSampler:
                 return
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
+            self._graph_scalars = self._graph_key()
             with torch.cuda.graph(g):
                 draw_fn()
             self._graph = g
+        elif self._graph_key() != self._graph_scalars:
+            self._drop_graphs()
+            self._graph_warm = 1  # (already warm: capture right away with the new scalars)
+            return self._run_draw(draw_fn)
         self._graph.replay()
 
     def __next__(self):

@@ -21,6 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
+from . import dist as _bkdist
 
 
 def _ops(ops):
@@ -33,17 +34,9 @@ def _ops(ops):
 def _gather_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """Sum of `t` over the ranks of `group`, accumulated in rank order (deterministic).
     No-op without an initialised process group."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return t
-    world = dist.get_world_size(group)
-    if world == 1:
-        return t
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t.contiguous(), group=group)
-    out = parts[0].clone()
-    for p in parts[1:]:
-        out += p
-    return out
+    from .dist import gather_sum
+
+    return gather_sum(t, group)
 
 
 def rhat_from_moments(mean_dc, m2_dc, n: int, ops=None, group=None) -> np.ndarray:
@@ -75,6 +68,38 @@ def rhat_from_moments(mean_dc, m2_dc, n: int, ops=None, group=None) -> np.ndarra
     return torch.sqrt((nf - 1.0) / nf + var_means / mean_var).cpu().numpy()
 
 
+def _as_dc(theta, D: int, C: int, layout=None):
+    """A sampler's draw as a logical [D, C] tensor.  ``sample()`` returns the (C, D) transpose view of the
+    engine's [D, C] buffer.  For C != D the shape tells the two apart; for a square draw the strides do
+    (the (C, D) view of a chain-contiguous buffer has stride(0) == 1, the buffer itself stride(1) == 1),
+    and ``layout`` ("dc" or "cd") overrides both."""
+    if theta.dim() != 2:
+        raise ValueError(f"expected a 2-D draw, got shape {tuple(theta.shape)}")
+    if layout not in (None, "dc", "cd"):
+        raise ValueError("layout must be 'dc' ([D, C]) or 'cd' ((C, D))")
+    shape = tuple(theta.shape)
+    if layout is None:
+        if C != D:
+            if shape not in ((D, C), (C, D)):
+                raise ValueError(f"draw of shape {shape} is neither [{D}, {C}] nor ({C}, {D})")
+            layout = "dc" if shape == (D, C) else "cd"
+        elif shape != (D, C):
+            raise ValueError(f"draw of shape {shape}, expected ({C}, {D})")
+        elif theta.stride(1) == 1 and theta.stride(0) != 1:
+            layout = "dc"
+        elif theta.stride(0) == 1 and theta.stride(1) != 1:
+            layout = "cd"
+        elif D == 1:
+            layout = "dc"
+        else:
+            raise ValueError(f"a square {shape} draw with strides {tuple(theta.stride())}: pass layout='cd' for sample()'s "
+                             "(C, D) or layout='dc' for a [D, C] buffer")
+    want = (D, C) if layout == "dc" else (C, D)
+    if shape != want:
+        raise ValueError(f"draw of shape {shape} with layout={layout!r}, expected {want}")
+    return theta if layout == "dc" else theta.t()
+
+
 class RunningMoments:
     """Streaming per-chain mean / M2 of every dimension (Welford), fed one draw at a time."""
 
@@ -85,10 +110,10 @@ class RunningMoments:
         self.m2 = torch.zeros((D, C), dtype=torch.float64, device=dev)
         self.n = 0
 
-    def update(self, theta) -> None:
+    def update(self, theta, layout=None) -> None:
         """theta: the sampler's draw, either the engine's [D, C] buffer or the (C, D) view
-        returned by ``sample()``."""
-        t = theta if theta.shape == self.mean.shape else theta.t()
+        returned by ``sample()`` (told apart by shape, for C == D by strides: see _as_dc)."""
+        t = _as_dc(theta, self.mean.shape[0], self.mean.shape[1], layout)
         if t.stride(1) != 1:
             t = t.contiguous()
         self.n += 1
@@ -189,8 +214,16 @@ class DrawStore:
         self._ops = _ops(ops)
         self._os = os
         self._chunks = list(chunks)  # draws per completed chunk file
-        self._buf = torch.empty((self.chunk, self.D, self.C), dtype=torch.float64, device=self._ops.device)
+        self._buf_t = None           # [chunk, D, C] device staging buffer: allocated by the first append()
         self._fill = 0
+
+    @property
+    def _buf(self):
+        # a reader (DrawStore.open) never appends and never pays for the staging buffer: at config-3
+        # size and chunk = 64 it would be 34 GB of HBM
+        if self._buf_t is None:
+            self._buf_t = torch.empty((self.chunk, self.D, self.C), dtype=torch.float64, device=self._ops.device)
+        return self._buf_t
 
     # -- writer -----------------------------------------------------------------------------------
     @classmethod
@@ -220,9 +253,10 @@ class DrawStore:
             json.dump({"D": self.D, "C": self.C, "chunk": self.chunk, "chunks": self._chunks, "dtype": "float64",
                        "layout": "[draw, D, C], C contiguous"}, f)
 
-    def append(self, theta) -> None:
-        """theta: the sampler's draw -- the (C, D) view returned by ``sample()`` or a [D, C] buffer."""
-        t = theta if tuple(theta.shape) == (self.D, self.C) else theta.t()
+    def append(self, theta, layout=None) -> None:
+        """theta: the sampler's draw -- the (C, D) view returned by ``sample()`` or a [D, C] buffer (told
+        apart by shape; for C == D by strides, or say ``layout="cd"`` / ``"dc"``)."""
+        t = _as_dc(theta, self.D, self.C, layout)
         self._buf[self._fill].copy_(t)
         self._fill += 1
         if self._fill == self.chunk:
@@ -242,18 +276,30 @@ class DrawStore:
 
     def state_dict(self):
         """The not yet written part of the current chunk (what a checkpoint must carry besides the files)."""
-        return {"chunks": list(self._chunks), "partial": self._buf[: self._fill].cpu().clone()}
+        part = self._buf[: self._fill].cpu().clone() if self._fill else torch.empty((0, self.D, self.C), dtype=torch.float64)
+        return {"chunks": list(self._chunks), "partial": part}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, truncate=False):
+        """Rewind the store to a checkpoint.  Chunk files written AFTER the checkpoint belong to draws the
+        resumed run will produce again: with ``truncate=True`` they are deleted, otherwise they are kept on
+        disk under ``superseded_<k>_chunk_#####.npy`` (never read again by this store) -- nothing is removed
+        unless asked for."""
         if len(sd["chunks"]) > len(self._chunks) or sd["chunks"] != self._chunks[: len(sd["chunks"])]:
             raise ValueError("the checkpoint refers to chunk files this store does not hold")
-        # chunks written after the checkpoint are superseded by the resumed run
         for k in range(len(sd["chunks"]), len(self._chunks)):
-            self._os.remove(self._os.path.join(self.path, "chunk_%05d.npy" % k))
+            f = self._os.path.join(self.path, "chunk_%05d.npy" % k)
+            if truncate:
+                self._os.remove(f)
+            else:
+                gen = 0
+                while self._os.path.exists(self._os.path.join(self.path, "superseded_%d_chunk_%05d.npy" % (gen, k))):
+                    gen += 1
+                self._os.replace(f, self._os.path.join(self.path, "superseded_%d_chunk_%05d.npy" % (gen, k)))
         self._chunks = list(sd["chunks"])
         part = sd["partial"]
         self._fill = int(part.shape[0])
-        self._buf[: self._fill].copy_(part.to(self._buf.device))
+        if self._fill:
+            self._buf[: self._fill].copy_(part.to(self._ops.device))
         self._write_meta()
 
     # -- reader -----------------------------------------------------------------------------------
@@ -391,13 +437,22 @@ def split_rhat(chains, *, ops=None, group=None):
     return rhat(split_chains(chains), ops=ops, group=group)
 
 
+def _canonical_keys(flat: torch.Tensor) -> torch.Tensor:
+    """Sort keys whose RADIX order (the order of the raw bit patterns, which is what bk_sort_by_key and the
+    splitter search see) is numpy's comparison order (rhat.py:51-52): -0.0 becomes +0.0, so that the two
+    zeros tie and rank in pooled order, and every NaN becomes the positive quiet NaN, which sorts last
+    as in ``np.argsort`` (a sign-bit NaN would sort first)."""
+    flat = flat + 0.0  # (-0.0) + (+0.0) = +0.0 in round-to-nearest; every other value unchanged
+    return torch.where(torch.isnan(flat), torch.full_like(flat, float("nan")), flat)
+
+
 def _ranks_pooled(flat: torch.Tensor, ops) -> torch.Tensor:
     """Ascending 1-based ranks of the pooled draws (rhat.py:51-52: argsort().argsort() + 1).
     Ties get distinct consecutive ranks; numpy leaves their order to its sort, here it is the
     order of appearance (stable sort).  bk_sort_by_key + bk_scatter_ranks."""
     n = flat.numel()
     idx = torch.arange(n, dtype=torch.int64, device=flat.device)
-    _, payload = ops.sort_by_key(flat.contiguous(), idx)
+    _, payload = ops.sort_by_key(_canonical_keys(flat).contiguous(), idx)
     ranks = torch.empty_like(flat)
     ops.scatter_ranks(payload, 0.0, ranks)
     return ranks
@@ -423,7 +478,7 @@ def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor
     world, me = dist.get_world_size(group), dist.get_rank(group)
     N, C = x.shape
     dev = x.device
-    flat = x.t().contiguous().reshape(-1)
+    flat = _canonical_keys(x.t().contiguous().reshape(-1))
     S_local = flat.numel()
     sizes = _all_gather_counts(S_local, dev, group)
     ends = torch.cumsum(torch.tensor(sizes, dtype=torch.int64, device=dev), 0)
@@ -437,8 +492,7 @@ def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor
         k = min(s, S_local)
         pos = ((torch.arange(k, dtype=torch.float64, device=dev) + 0.5) * (S_local / k)).to(torch.int64).clamp_(max=S_local - 1)
         samp[:k] = keys[pos]
-    parts = [torch.empty_like(samp) for _ in range(world)]
-    dist.all_gather(parts, samp, group=group)
+    parts = _bkdist.all_gather(samp, group)
     allsamp = torch.sort(torch.cat(parts)).values          # world*s values: tiny
     nreal = int(torch.isfinite(allsamp).sum().item())
     cut_pos = [(nreal * (r + 1)) // world for r in range(world - 1)]
@@ -449,14 +503,14 @@ def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor
     bounds = torch.cummax(bounds, 0).values                # (monotone even if splitters repeat)
     send_counts = (bounds[1:] - bounds[:-1])
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
+    _bkdist.all_to_all_single(recv_counts, send_counts, group=group)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
     # 4. the buckets travel
     R = sum(rc)
     rk = torch.empty(R, dtype=torch.float64, device=dev)
     rp = torch.empty(R, dtype=torch.int64, device=dev)
-    dist.all_to_all_single(rk, keys, rc, sc, group=group)
-    dist.all_to_all_single(rp, pay, rc, sc, group=group)
+    _bkdist.all_to_all_single(rk, keys, rc, sc, group=group)
+    _bkdist.all_to_all_single(rp, pay, rc, sc, group=group)
     # 5. ranks inside my bucket
     _, ps = ops.sort_by_key(rk, rp)
     bsz = _all_gather_counts(R, dev, group)
@@ -468,8 +522,8 @@ def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor
     back_rank = (my_base + (order + 1).to(torch.float64)).contiguous()
     hi = torch.empty(S_local, dtype=torch.int64, device=dev)
     hr = torch.empty(S_local, dtype=torch.float64, device=dev)
-    dist.all_to_all_single(hi, back_idx, sc, rc, group=group)
-    dist.all_to_all_single(hr, back_rank, sc, rc, group=group)
+    _bkdist.all_to_all_single(hi, back_idx, sc, rc, group=group)
+    _bkdist.all_to_all_single(hr, back_rank, sc, rc, group=group)
     ranks = torch.empty(S_local, dtype=torch.float64, device=dev)
     ranks[hi - first] = hr
     return ranks.reshape(C, N).t()
@@ -525,9 +579,7 @@ def _all_gather_counts(n: int, device, group=None):
     uneven split to the first ranks, so shard widths may differ by one)."""
     world = dist.get_world_size(group)
     mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    return [int(p.item()) for p in parts]
+    return [int(p.item()) for p in _bkdist.all_gather(mine, group)]
 
 
 def _all_gather_columns(x: torch.Tensor, group=None):
@@ -541,8 +593,7 @@ def _all_gather_columns(x: torch.Tensor, group=None):
     if x.shape[1] != cmax:
         send = torch.zeros((x.shape[0], cmax), dtype=x.dtype, device=x.device)
         send[:, : x.shape[1]] = x
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send, group=group)
+    parts = _bkdist.all_gather(send, group)
     full = torch.cat([p[:, :c] for p, c in zip(parts, counts)], dim=1)
     return full, sum(counts[: dist.get_rank(group)])
 

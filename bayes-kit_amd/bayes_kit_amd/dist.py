@@ -46,10 +46,63 @@ def init_from_env(backend: str = None):
     return rank, local_rank, world
 
 
+# Collectives issued through this module and diagnostics.py since import, by kind: lets a caller state how
+# many a summary cost (bench.py: `collectives_per_summary`) from calls that really happened.
+collective_calls = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
+
+
+def host_staged(t: torch.Tensor, group=None) -> torch.Tensor:
+    """`t` as the process group can move it.  RCCL moves device memory; gloo implements all_gather /
+    all_to_all for host memory only, so a device tensor is staged through the host there (the CPU tests,
+    and bench.py's ranks-share-one-GPU mode)."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return t.cpu()
+    return t
+
+
+def all_gather(t: torch.Tensor, group=None):
+    """Every rank's `t` (same shape on all ranks), as a list in rank order, on t's device."""
+    world = dist.get_world_size(group)
+    send = host_staged(t.contiguous(), group)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    collective_calls["all_gather"] += 1
+    return parts if send.device == t.device else [p.to(t.device) for p in parts]
+
+
+def all_to_all_single(recv: torch.Tensor, send: torch.Tensor, recv_counts=None, send_counts=None, group=None):
+    """dist.all_to_all_single into `recv` (rows split by the count lists, or evenly)."""
+    s_ = host_staged(send.contiguous(), group)
+    if s_.device == send.device:
+        dist.all_to_all_single(recv, s_, recv_counts, send_counts, group=group)
+    else:
+        r_ = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r_, s_, recv_counts, send_counts, group=group)
+        recv.copy_(r_)
+    collective_calls["all_to_all"] += 1
+    return recv
+
+
+def gather_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of `t` over the ranks of `group`, accumulated in rank order (deterministic: the result does
+    not depend on the collective's reduction order).  ONE all_gather.  No-op without a process group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    world = dist.get_world_size(group)
+    if world == 1:
+        return t
+    parts = all_gather(t, group)
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out += p
+    return out
+
+
 def sum_over_ranks(value: float, device=None, group=None) -> float:
     """Scalar sum over ranks (e.g. total ESS, accepted counts)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, group=group)
+    collective_calls["all_reduce"] += 1
     return float(t.item())

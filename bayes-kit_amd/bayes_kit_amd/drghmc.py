@@ -122,12 +122,19 @@ class DrGhmcDiag(ManyChainSampler):
         self._host_stats = (0, 0, [])   # (grad evals, lane steps, [(tag, lanes)]) of the last host-sized draw
         self._first_eval = 0
         if self._dev_counts:
-            # the fixed schedule of trajectories (slot order = launch order) and its lane counters
-            self._schedule = []
-            self._plan(int(max_proposals))
-            self._slot_lanes = torch.zeros(len(self._schedule), dtype=torch.int32, device=dev)
-            self._slot_steps = torch.tensor([st for _, st in self._schedule], dtype=torch.float64, device=dev)
-            self._slot_lanes_total = torch.zeros(len(self._schedule), dtype=torch.int64, device=dev)
+            self._steps_total_base = 0.0
+            self._make_schedule()
+
+    def _make_schedule(self):
+        """The fixed schedule of trajectories (slot order = launch order) and its lane counters, for the
+        step counts as they stand (plain attributes in the reference: they may be assigned between draws)."""
+        dev = self._ops.device
+        self._schedule = []
+        self._plan(int(self._max_proposals))
+        self._schedule_counts = tuple(int(n) for n in self._leapfrog_step_counts)
+        self._slot_lanes = torch.zeros(len(self._schedule), dtype=torch.int32, device=dev)
+        self._slot_steps = torch.tensor([st for _, st in self._schedule], dtype=torch.float64, device=dev)
+        self._slot_lanes_total = torch.zeros(len(self._schedule), dtype=torch.int64, device=dev)
 
     def _plan(self, K):
         """Tags and step counts of the trajectories of one draw in launch order, e.g. for K = 3:
@@ -303,6 +310,10 @@ class DrGhmcDiag(ManyChainSampler):
         ops.dr_accept_prob(P.H, cur_H, P.h, cur_h, cur_idx, 1.0 if self._prob_retry else 0.0, P.live, P.a, n)
         return P.a
 
+    def _graph_key(self):
+        return (float(self._damping), float(self._rho_sign), bool(self._prob_retry),
+                tuple(float(h) for h in self._leapfrog_step_sizes), tuple(int(n) for n in self._leapfrog_step_counts))
+
     # -- one draw for every chain -----------------------------------------------------------------------------
     def sample(self):
         if self._dev_counts:
@@ -312,6 +323,11 @@ class DrGhmcDiag(ManyChainSampler):
                 self._first_eval = 1
             else:
                 self._first_eval = 0
+            if tuple(int(n) for n in self._leapfrog_step_counts) != self._schedule_counts:
+                # the trajectories change length: close the books of the old schedule (one host read, rare)
+                self._steps_total_base = float(self.lane_steps_total.item())
+                self._make_schedule()
+                self._drop_graphs()
             self._run_draw(self._draw_dev)
             self._rho_sign = -1.0  # drghmc.py:388, applied lazily
             self._draws += 1
@@ -423,7 +439,7 @@ class DrGhmcDiag(ManyChainSampler):
     def lane_steps_total(self):
         """Chain-steps run since construction (0-d device tensor; the per-trajectory lane counts are
         accumulated by the proposal launches themselves)."""
-        return (self._slot_lanes_total.to(torch.float64) * self._slot_steps).sum()
+        return (self._slot_lanes_total.to(torch.float64) * self._slot_steps).sum() + self._steps_total_base
 
 
 class _View:

@@ -311,6 +311,9 @@ class HMCDiag(ManyChainSampler):
             ev.record(self._side)
         self._pf_event, self._pf_slot, self._pf_ready = ev, nxt, True
 
+    def _graph_key(self):
+        return (float(self._stepsize), int(self._steps))
+
     # -- one draw for every chain ------------------------------------------------------------------
     def sample(self):
         self._run_draw(self._draw)

@@ -244,6 +244,9 @@ class MALA(ManyChainSampler):
     def _log_p_grad_theta(self):
         return self._grad.t() if self._batched else self._grad[:, 0].cpu().numpy()
 
+    def _graph_key(self):
+        return float(self._epsilon)
+
     def sample(self):
         self._run_draw(self._draw2 if self._two_pass else self._draw)
         self._join_side_stream()

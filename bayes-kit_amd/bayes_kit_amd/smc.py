@@ -251,6 +251,7 @@ class TemperedLikelihoodSMC:
         import torch.distributed as dist
 
         ops, g = self._ops, self._group
+        from . import dist as _bkdist
         from .diagnostics import _all_gather_counts
 
         world, M = dist.get_world_size(g), w.shape[0]
@@ -260,8 +261,7 @@ class TemperedLikelihoodSMC:
         counts = _all_gather_counts(M, w.device, g)
         mmax = max(counts)
         send_w = w if M == mmax else torch.cat([w, torch.zeros(mmax - M, dtype=w.dtype, device=w.device)])
-        wparts = [torch.empty_like(send_w) for _ in range(world)]
-        dist.all_gather(wparts, send_w.contiguous(), group=g)
+        wparts = _bkdist.all_gather(send_w, g)
         w_all = torch.cat([p[:c] for p, c in zip(wparts, counts)])
         self.last_ess = float((w_all.sum() ** 2 / (w_all * w_all).sum()).item())
         ops.resample_indices(w_all, self._u, torch.empty_like(w_all), self._idx)  # global ancestors
@@ -272,11 +272,11 @@ class TemperedLikelihoodSMC:
         order = torch.sort(owner, stable=True).indices       # my slots grouped by the rank that owns their ancestor
         want = torch.bincount(owner, minlength=world)         # how many columns I need from each rank
         give = torch.empty_like(want)
-        dist.all_to_all_single(give, want, group=g)           # how many each rank needs from me
+        _bkdist.all_to_all_single(give, want, group=g)         # how many each rank needs from me
         want_l, give_l = want.tolist(), give.tolist()
         req_out = (idx[order] - first[owner[order]]).contiguous()
         req_in = torch.empty(sum(give_l), dtype=torch.int64, device=idx.device)
-        dist.all_to_all_single(req_in, req_out, give_l, want_l, group=g)
+        _bkdist.all_to_all_single(req_in, req_out, give_l, want_l, group=g)
         # the requested columns, particle-major so that each destination's block is contiguous
         D, n_send = th.shape[0], req_in.shape[0]
         send_pm = torch.empty((n_send, D), dtype=th.dtype, device=th.device)
@@ -285,7 +285,7 @@ class TemperedLikelihoodSMC:
             ops.gather_columns(req_in.to(self._idx.dtype), th, cols)
             ops.relayout(cols, send_pm.t())
         recv_pm = torch.empty((M, D), dtype=th.dtype, device=th.device)
-        dist.all_to_all_single(recv_pm, send_pm, want_l, give_l, group=g)
+        _bkdist.all_to_all_single(recv_pm, send_pm, want_l, give_l, group=g)
         # arrival k belongs to slot order[k]
         self._prop_dc[:, order] = recv_pm.t()
 

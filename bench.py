@@ -46,6 +46,7 @@ EPS_CFG3 = 0.006
 SEED_CFG3 = 20241
 C_CFG3 = 65536
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_MFMA_PEAK_TFLOPS = 78.6  # dense fp64 matrix-core peak (AMD datasheet; the local guide lists no fp64 figure)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # spec, counts an FMA as 2 flop; kernels here may not contract: ceiling 39.3
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "cfg3_traffic.json")
 KD_SOURCE = os.path.join(ROOT, "bayes-kit_amd", "csrc", "bk_integrator.hip")
@@ -110,12 +111,40 @@ def launch_ranks(n, child_argv, extra_env=None, timeout=3000.0, out=None):
 
 
 def _visible_gpus():
-    """Number of GPUs visible to this process WITHOUT initialising any (device_count() only
-    enumerates on this image; the launcher must not touch the GPU before its children do)."""
+    """Number of GPUs this process's children will see, found WITHOUT loading the HIP runtime here: the
+    launcher must not touch the GPU before its ranks do.  Order: an explicit visibility list in the
+    environment; the kernel driver's topology (KFD nodes that have SIMDs are GPUs); render nodes; and, if
+    none of that is readable, a child process that asks PyTorch (the child, not the launcher, loads HIP)."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip()])
     try:
-        import torch
+        import glob
 
-        return int(torch.cuda.device_count())
+        n, seen = 0, 0
+        for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            with open(path) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            seen += 1
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        if seen:
+            return n
+    except (OSError, ValueError):
+        pass
+    try:
+        import glob
+
+        n = len(glob.glob("/dev/dri/renderD*"))
+        if n:
+            return n
+    except OSError:
+        pass
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
     except Exception:
         return 0
 
@@ -166,10 +195,27 @@ def _pmc_traffic(C, D):
     return None
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(seconds_hint=12.0):
     """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler
     object per chain, chains spread over P processes, config-3 shape, bounded sample."""
-    P = max(1, min(os.cpu_count() or 1, 32))
+    # P = os.cpu_count() (BASELINE.md): every hardware thread the host exposes to this process
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))  # (a container may be pinned to fewer)
+    except (AttributeError, OSError):
+        usable = total
+    P = max(1, usable)
     chains_per_proc, draws = 8, 400  # 8*400*64 = 205k leapfrog steps per process (~1.5 s each)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
 
@@ -193,6 +239,8 @@ def cpu_baseline(seconds_hint=12.0):
         "value": rate,
         "unit": "leapfrog steps/sec",
         "cores": P,
+        "host_cores_total": total,
+        "cpu_model": _cpu_model(),
         "kind": "port",
         "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
                   f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s",
@@ -259,6 +307,19 @@ class RankContext:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def collective_ranks(self):
+        """The number of ranks, as counted by a collective that actually completed on the process group
+        (an all_reduce of ones on the device; RCCL when the backend is nccl); 0 without a group."""
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return 0
+        one = torch.ones(1, dtype=torch.float64, device=self.device)
+        dist.all_reduce(one)
+        torch.cuda.synchronize()
+        return int(round(float(one.item())))
+
     def timed_loop(self, fn, steps):
         """EXACTLY `steps` calls of fn bracketed by barrier + synchronize; max over ranks."""
         self.barrier()
@@ -302,8 +363,10 @@ def bench_cfg2(ctx, steps=60, warmup=6, chains=4096):
     return res
 
 
-def bench_cfg4(ctx, draws=40, warmup=3, chains=32768):
-    """configs[3]: Neal's funnel D=101, DRGHMC K=3, 32,768 chains per GPU + R-hat / ESS."""
+def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
+    """configs[3]: Neal's funnel D=101, DRGHMC K=3, 32,768 chains PER RANK (chain ids rank*C ..), R-hat over
+    ALL ranks' chains and the summed ESS through the process group (bayes_kit/rhat.py:163-171: the
+    cross-chain reduction north_star assigns to RCCL)."""
     import torch
 
     import bayes_kit_amd as bk
@@ -328,20 +391,35 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768):
 
     el = ctx.timed_loop(one, draws)
     lane_steps = float(s.lane_steps_total.item()) - base if on_device else state["lane_steps"]
+    # the summary: R-hat of every dimension over the chains of ALL ranks (two all_gathers of 3*D+1 doubles,
+    # summed in rank order), ESS and lane totals (one all_reduce each) -- timed on its own
+    calls0 = dict(bk.dist.collective_calls)
+    ctx.barrier()
+    t0 = time.perf_counter()
     rh = mom.rhat()
     ess = rec.ess()
     ess = torch.where(ess > 0, ess, torch.full_like(ess, float(draws))).clamp(max=float(draws)).min(dim=0).values
     ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), ctx.device)
     lane_total = bk.dist.sum_over_ranks(float(lane_steps), ctx.device)
+    torch.cuda.synchronize()
+    summary_s = time.perf_counter() - t0
+    calls = {k: bk.dist.collective_calls[k] - calls0[k] for k in calls0}
     flop_per_eval = 13.0 * D  # see DESIGN.md section 3: funnel gradient + kick + drift, per chain-step
-    return {"workload": "BASELINE.json configs[3]: Neal's funnel D=101, DRGHMC K=3 eps=(0.2,0.05,0.0125) L=(10,40,160) "
-                        "damping 0.1, 32,768 chains per GPU, Welford R-hat over all dims + ESS of 3 dims and logp",
-            "bound": "fp64 VALU + exp latency (state register-resident inside a proposal; 26 MB arrays are cache-resident)",
-            "ms_per_draw": 1e3 * el / draws, "draws_per_sec": C * ctx.world * draws / el,
-            "grad_evals_per_sec": lane_total / el, "mean_grad_evals_per_draw": lane_total / (C * ctx.world * draws),
-            "fp64_tflops": lane_total * flop_per_eval / el / 1e12, "flop_model": "13*D flop per gradient evaluation",
-            "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "draws": draws,
-            "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False))}
+    out = {"workload": "BASELINE.json configs[3]: Neal's funnel D=101, DRGHMC K=3 eps=(0.2,0.05,0.0125) L=(10,40,160) "
+                       f"damping 0.1, {C} chains per GPU (global chain ids rank*{C}..), Welford R-hat over all dims and "
+                       "ALL ranks' chains + ESS of 3 dims and logp",
+           "bound": "fp64 VALU + exp latency (state register-resident inside a proposal; 26 MB arrays are cache-resident)",
+           "chains_per_gpu": C, "chains_total": C * ctx.world,
+           "ms_per_draw": 1e3 * el / draws, "draws_per_sec": C * ctx.world * draws / el,
+           "grad_evals_per_sec": lane_total / el, "mean_grad_evals_per_draw": lane_total / (C * ctx.world * draws),
+           "fp64_tflops": lane_total * flop_per_eval / el / 1e12, "flop_model": "13*D flop per gradient evaluation",
+           "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "draws": draws,
+           "rhat_over_chains": C * ctx.world, "collectives_per_summary": calls, "summary_ms": 1e3 * summary_s,
+           "collective_backend": ctx.backend, "collective_ranks": ctx.collective_ranks(),
+           "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False))}
+    if full_rhat:
+        out["rhat"] = [float(v) for v in rh]
+    return out
 
 
 def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
@@ -388,15 +466,67 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
             "path_hbm_frac_56D_model": C * L / per * 56.0 * D / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate()}
 
 
-def run_secondary(ctx, which):
+def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
+    """configs[4]: synthetic logistic regression N=1e6, D=512, 2,048 chains: the gradient for all chains
+    (two fp64 MFMA GEMMs + one elementwise pass), one HMC draw with a dense metric, one temperature of the
+    likelihood-annealed SMC (smc.py:47-75).  No reference oracle (parity by tolerance in tests/); priced
+    against the dense fp64 MFMA peak."""
     import torch
 
-    table = {"cfg2": bench_cfg2, "cfg4": bench_cfg4, "mala": bench_mala, "torch_model": bench_torch_model}
+    import bayes_kit_amd as bk
+
+    dev, C = ctx.device, chains
+    g = torch.Generator(device=dev)
+    g.manual_seed(20243)
+    X = torch.randn((N, D), dtype=torch.float64, device=dev, generator=g) / D ** 0.5
+    tstar = torch.randn(D, dtype=torch.float64, device=dev, generator=g)
+    y = (torch.rand(N, dtype=torch.float64, device=dev, generator=g) < torch.sigmoid(X @ tstar)).to(torch.float64)
+    model = bk.LogisticRegression(X, y, prior_scale=1.0)
+    th = torch.randn((D, C), dtype=torch.float64, device=dev, generator=g) * 0.1
+    grad, lp = torch.empty_like(th), torch.empty(C, dtype=torch.float64, device=dev)
+    model.bk_eval(th, grad, lp)  # warm-up: uploads X^T, sizes the scratch
+    el = ctx.timed_loop(lambda: model.bk_eval(th, grad, lp), grad_reps) / grad_reps
+    flop = 2 * 2.0 * N * D * C  # Z = X Theta and G = X^T R
+    out = {"workload": f"BASELINE.json configs[4]: logistic regression N={N} D={D}, {C} chains per GPU (synthetic, torch "
+                       "seed 20243), gradient = 2 fp64 MFMA GEMMs + residual pass",
+           "bound": "mfma", "gradient_ms": 1e3 * el, "gradient_evals_per_sec": C * ctx.world / el,
+           "achieved": flop / el / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS, "flop_model": "4*N*D flop per chain-gradient"}
+    # one draw of HMC with a dense metric (velocity covariance ~ the posterior scale 4 D / N)
+    L = 4
+    Md = torch.eye(D, dtype=torch.float64) * (4.0 * D / N)
+    s = bk.HMCDiag(model, 0.3, L, chains=C, chain_id0=ctx.rank * C, seed=20243, metric_dense=Md,
+                   init=th.t().contiguous().cpu())
+    s.sample()
+    el = ctx.timed_loop(s.sample, 1)
+    # per step: the gradient (4 N D) + M @ grad (2 D^2); per draw also chol(M) z and M^-1 rho twice
+    hflop = C * (L * (4.0 * N * D + 2.0 * D * D) + 3 * 2.0 * D * D)
+    out["hmc_dense_metric"] = {"leapfrog_steps": L, "ms_per_draw": 1e3 * el, "steps_per_sec": C * ctx.world * L / el,
+                               "tflops_fp64": hflop / el / 1e12, "frac_of_mfma_peak": hflop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                               "accept_rate": s.accept_rate()}
+    del s
+    # one SMC temperature: reweight, resample, one HMC move (L = 2) of every particle
+    init = torch.randn((C, D), dtype=torch.float64, device=dev, generator=g)
+    smc = bk.TemperedLikelihoodSMC(model, C, 1, init, bk.hmc_kernel(0.5, 2, metric_dense=Md), seed=20243)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    smc.run()
+    ctx.barrier()
+    out["annealed_smc_temperature"] = {"particles": C, "move": "HMC L=2, dense metric", "seconds": time.perf_counter() - t0,
+                                       "ess_after_reweighting": float(smc.last_ess)}
+    return out
+
+
+def run_secondary(ctx, which, **kw):
+    import torch
+
+    table = {"cfg2": bench_cfg2, "cfg4": bench_cfg4, "mala": bench_mala, "torch_model": bench_torch_model,
+             "cfg5": bench_cfg5}
     out = {}
     for name in which:
         t0 = time.perf_counter()
         try:
-            out[name] = table[name](ctx)
+            out[name] = table[name](ctx, **kw)
         except Exception as e:  # a secondary figure must never cost the headline line
             out[name] = {"error": repr(e)}
         out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 2)
@@ -425,7 +555,11 @@ def run_rank(args):
     device = ctx.device
 
     if args.only is not None:  # one secondary workload on its own (profiling runs)
-        out = run_secondary(ctx, [args.only])[args.only]
+        kw = {}
+        if args.only == "cfg4":
+            kw = dict(full_rhat=True, **({"chains": args.chains} if args.chains else {}),
+                      **({"draws": args.steps} if args.steps_given else {}))
+        out = run_secondary(ctx, [args.only], **kw)[args.only]
         out.update({"n_gpus": world, "secondary_only": args.only})
         if rank == 0:
             print(json.dumps(out), flush=True)
@@ -475,7 +609,8 @@ def run_rank(args):
             "chain_tile": Ct,
         },
         "comm_backend": ctx.backend,
-        "rccl_ranks": world if ctx.backend == "nccl" else 0,
+        # ranks counted by an all_reduce that completed on the group, reported as RCCL's only when it ran on nccl
+        "rccl_ranks": ctx.collective_ranks() if ctx.backend == "nccl" else 0,
         "shared_gpu": ctx.shared_gpu,
         "value_weak": value,
         "accept_rate": accept,
@@ -628,8 +763,10 @@ def run_rank(args):
         except Exception as e:  # the extra must never cost the headline line
             ops.timed = None
             out["fused_builtin"] = {"error": repr(e)}
-    if world == 1 and not args.no_secondary:
-        out["secondary"] = run_secondary(ctx, ["cfg2", "cfg4", "mala", "torch_model"])
+    if not args.no_secondary:
+        # N = 1: every other BASELINE.json config.  N > 1: config 4, the one north_star shards with a
+        # cross-rank reduction (32,768 chains per rank, R-hat / ESS over the process group).
+        out["secondary"] = run_secondary(ctx, ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"])
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if rank == 0:
@@ -643,7 +780,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (default: 65,536)")
-    ap.add_argument("--only", choices=["cfg2", "cfg4", "mala", "torch_model"], default=None,
+    ap.add_argument("--only", choices=["cfg2", "cfg4", "mala", "torch_model", "cfg5"], default=None,
                     help="run ONE secondary workload alone and print its record (profiling runs)")
     ap.add_argument("--chain-tile", type=int, default=None,
                     help="chains per Infinity-Cache tile (default: no tiling)")
@@ -657,7 +794,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' records (N=1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N>1 only)")
     ap.add_argument("--ess-draws", type=int, default=50, help="extra draws for the ESS/sec figure (0 = skip)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in (sys.argv[1:] if argv is None else argv))
+    return args
 
 
 def main(argv=None):

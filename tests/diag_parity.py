@@ -9,7 +9,33 @@ import bayes_kit_amd as bk
 from tests.helpers import GOLDEN
 
 
+def check_special_values_in_ranks(ops):
+    """rhat.py:51-52 ranks with numpy's comparison order: a NaN (whatever its sign bit) ranks LAST, -0.0 and
+    +0.0 are one value.  The device sorts raw bit patterns (radix), so the keys are canonicalised first."""
+    from bayes_kit_amd.rhat import rank_chains
+    from oracle import diagnostics as od
+
+    neg_nan = np.frombuffer(np.uint64(0xFFF8000000000001).tobytes(), dtype=np.float64)[0]
+    assert np.isnan(neg_nan) and np.signbit(neg_nan)
+    # (a) no ties: the oracle (numpy's default argsort) is the reference's behaviour
+    a = np.array([[3.5, -0.0, 1.0, -2.0], [neg_nan, 7.0, -np.inf, 0.5], [np.inf, -1.0, 2.0, 9.0]])
+    want = od.rank_chains([r for r in a])
+    got = rank_chains([r for r in a], ops=ops)
+    assert [list(r) for r in got] == [list(r) for r in want]
+    assert got[1][0] == 12.0  # the NaN is last
+    x = torch.from_numpy(np.ascontiguousarray(a.T)).to(ops.device)
+    np.testing.assert_allclose(bk.rank_normalized_rhat(x, ops=ops), od.rank_normalized_rhat([r for r in a]), rtol=1e-12)
+    # (b) ties: -0.0 / +0.0 rank in pooled order (numpy leaves tie order to its sort; the stable one is taken)
+    b = np.array([[0.0, -0.0, 5.0], [-0.0, 0.0, -1.0], [1.0, -0.0, 0.0]])
+    pooled = b.reshape(-1)
+    stable = (np.argsort(np.argsort(pooled, kind="stable"), kind="stable") + 1).astype(np.float64).reshape(b.shape)
+    got = rank_chains([r for r in b], ops=ops)
+    assert [list(r) for r in got] == [list(r) for r in stable]
+    assert sorted(np.asarray(got).reshape(-1)[pooled == 0.0]) == [2.0, 3.0, 4.0, 5.0, 6.0, 7.0]
+
+
 def check_diagnostics(ops, ess_rtol):
+    check_special_values_in_ranks(ops)
     z = np.load(os.path.join(GOLDEN, "diagnostics.npz"))
     chains = list(z["rhat_chains"])
     # reference-style inputs (list of 1-D chains)
@@ -146,3 +172,39 @@ def check_checkpoint_of_sampler_and_diagnostics(ops, tmpdir, chains=40, D=12, dr
         assert np.array_equal(want[k], got[k]), k
     # the stored series of a coordinate is what ess / rhat of the recorder saw
     assert np.array_equal(want["store0"], want["series"][0])
+    # the chunk files the interrupted run wrote after the checkpoint were set aside, not deleted
+    assert any(f.startswith("superseded_0_chunk_") for f in os.listdir(os.path.join(tmpdir, "b")))
+    check_square_draws_and_reader(ops, os.path.join(tmpdir, "sq"))
+
+
+def check_square_draws_and_reader(ops, path):
+    """C == D: the (C, D) view sample() returns and a [D, C] buffer have the same shape; the store and the
+    moments tell them apart by strides (or are told).  A reader never allocates the staging buffer."""
+    import bayes_kit_amd as bk
+
+    n = 6
+    lam = np.logspace(0, 0.5, n)
+    s = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.2, 3, chains=n, seed=5, ops=ops)
+    store = bk.DrawStore.create(path, n, n, chunk=4, ops=ops)
+    assert store._buf_t is None  # nothing staged yet
+    mom_view, mom_buf, mom_told = (bk.RunningMoments(n, n, ops=ops) for _ in range(3))
+    kept = []
+    for i in range(6):
+        th, _ = s.sample()                       # (C, D) view, chain stride 1
+        assert th.stride(0) == 1 or n == 1
+        kept.append(np.array(th.cpu().numpy()))
+        store.append(th) if i % 2 == 0 else store.append(th.t().contiguous().t(), layout="cd")
+        mom_view.update(th)
+        mom_buf.update(th.t())                   # the [D, C] buffer itself
+        mom_told.update(th.contiguous(), layout="cd")  # a row-major copy: strides say nothing, the caller does
+        with pytest.raises(ValueError):
+            mom_told.update(torch.zeros((n, n), dtype=torch.float64, device=ops.device)[:, :1].expand(n, n))
+    store.close()
+    rd = bk.DrawStore.open(path, ops=ops)
+    for d in (0, n - 1):
+        want = np.stack([k[:, d] for k in kept])   # [N, C]: coordinate d of every chain
+        assert np.array_equal(rd.series(d).cpu().numpy(), want), d
+    assert rd._buf_t is None  # the reader read 6 draws without a staging buffer
+    assert torch.equal(mom_view.mean, mom_buf.mean) and torch.equal(mom_view.mean, mom_told.mean)
+    assert np.array_equal(mom_view.mean.cpu().numpy(), np.mean(np.stack(kept), axis=0).T) or np.allclose(
+        mom_view.mean.cpu().numpy(), np.mean(np.stack(kept), axis=0).T, rtol=1e-13)

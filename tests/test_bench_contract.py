@@ -71,3 +71,32 @@ def test_bench_refuses_multi_gpu_launch_without_any_gpu():
 
     if torch.cuda.device_count() == 0:
         assert out.returncode != 0 and "needs a GPU" in out.stderr
+
+
+def test_launcher_counts_gpus_without_loading_hip(tmp_path, monkeypatch):
+    """The launcher must not touch the GPU before its ranks do: the GPU count comes from the environment or
+    from the kernel driver's topology files, never from torch / HIP in the launcher process."""
+    code = (
+        "import sys, os; sys.path.insert(0, %r); import bench\n"
+        "os.environ['HIP_VISIBLE_DEVICES'] = '0,1,2'\n"
+        "assert bench._visible_gpus() == 3\n"
+        "os.environ['HIP_VISIBLE_DEVICES'] = ''\n"
+        "assert bench._visible_gpus() == 0\n"
+        "assert 'torch' not in sys.modules\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    # the topology reader: nodes with SIMDs are GPUs, CPU nodes have simd_count 0
+    sys.path.insert(0, ROOT)
+    import glob as globmod
+
+    import bench
+
+    for i, simd in enumerate([0, 256, 256, 0]):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real = globmod.glob
+    monkeypatch.setattr(globmod, "glob", lambda pat: real(str(tmp_path / "*" / "properties")) if "kfd" in pat else real(pat))
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench._visible_gpus() == 2

@@ -993,3 +993,36 @@ def test_full_size_cfg5_properties(ops):
     smc = bk.TemperedLikelihoodSMC(model, C, 1, init, bk.hmc_kernel(0.5, 1, metric_dense=Md), seed=20243)
     smc.run()
     assert torch.isfinite(smc.thetas).all() and 1.0 <= smc.last_ess <= C
+
+
+def test_scalars_assigned_between_draws_reach_a_replayed_graph(ops):
+    """Step sizes, step counts and damping are plain attributes in the reference (hmc.py:18-19, mala.py:23,
+    drghmc.py:60-66): a step-size adaptation assigns them between draws.  A captured hipGraph bakes them into
+    its launches, so they are compared before every replay and a change -- assignment or an in-place edit of
+    the list -- captures again.  Graph samplers must follow the eager ones bit for bit through such edits."""
+    lam = np.logspace(0, 1, 16)
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=512, seed=3, graph=True)
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=512, seed=3, graph=False, prefetch_rng=False)
+    ma = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=512, seed=4, graph=True)
+    mb = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=512, seed=4, graph=False, prefetch_rng=False)
+    da = bk.DrGhmcDiag(bk.Funnel(21), 3, [0.3, 0.1, 0.03], [3, 6, 12], 0.3, chains=700, seed=5)  # device counts + graph
+    db = bk.DrGhmcDiag(bk.Funnel(21), 3, [0.3, 0.1, 0.03], [3, 6, 12], 0.3, chains=700, seed=5, device_counts=False)
+    assert da._use_graph and not db._use_graph
+    for n in range(12):
+        if n == 4:
+            a._stepsize = b._stepsize = 0.07
+            ma._epsilon = mb._epsilon = 0.03
+            for d in (da, db):
+                d._damping = 0.5
+                d._leapfrog_step_sizes[0] = 0.25   # in place: no assignment to intercept
+        if n == 8:
+            a._steps = b._steps = 3
+            for d in (da, db):
+                d._leapfrog_step_counts = [2, 6, 10]
+        for x, y in ((a, b), (ma, mb), (da, db)):
+            tx, lx = x.sample()
+            ty, ly = y.sample()
+            assert torch.equal(tx, ty) and torch.equal(lx, ly), (type(x).__name__, n)
+        assert da.last_stage_lanes == db.last_stage_lanes and da.last_lane_steps == db.last_lane_steps, n
+    assert a._graph is not None and ma._graph is not None and da._graph is not None
+    np.testing.assert_array_equal(da.rng_state(), db.rng_state())
