@@ -607,7 +607,7 @@ def rank_normalized_rhat(chains, *, ops=None, group=None):
     into normal scores and joins the usual cross-rank split R-hat."""
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not multi:
-        return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops)
+        return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops, group=group)  # (a one-rank group stays local)
     if not _is_matrix(chains):
         raise ValueError("across ranks rank_normalized_rhat takes this rank's [N, C_local] device tensor")
     ops = _ops(ops)

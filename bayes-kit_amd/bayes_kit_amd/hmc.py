@@ -116,6 +116,11 @@ class HMCDiag(ManyChainSampler):
             self._mv_rng = torch.empty((D, C), **f64)  # M @ rho of the (possibly prefetched) momentum
         self._have_cache = False
         self._draws = 0
+        # `self._theta = theta_prop` (hmc.py:61) as a REBIND: with a batched model and eager launches the
+        # blend of state and proposal is written to a fresh array that becomes the state and is what sample()
+        # returns (never written again): one array written instead of the in-place select's two
+        # (bk_blend_columns).  A replayed hipGraph needs fixed addresses and keeps the in-place select.
+        self._rebind = self._batched and not self._use_graph
         # Randomness of draw n+1 (momentum, its kinetic energy, the accept uniform) does not
         # depend on draw n, and the reference consumes it in a fixed order (D normals, then one
         # uniform: hmc.py:56,60).  With prefetch_rng it is generated on a second HIP stream
@@ -214,7 +219,7 @@ class HMCDiag(ManyChainSampler):
         return self._rng_state
 
     def load_state_dict(self, sd):
-        if self._fused_draw and not self._use_graph:
+        if self._rebind:
             # the state array is the last draw handed out (see _draw): restore into a fresh one
             self._theta_dc = torch.empty_like(self._theta_dc)
         super().load_state_dict(sd)
@@ -343,15 +348,7 @@ class HMCDiag(ManyChainSampler):
             m_draw = None if (m is None or self._metric_identity) else m
             self._model.bk_hmc_draw(th, thp, rho, zt, m_draw, eps, L, self._part, kin0, self._kin1, self._lp_p,
                                     accept=(self._lp, logu, self._mask, self._ret, self._accepted))  # [hmc.py:56-63]
-            if self._use_graph:
-                self._select(self._mask, th, thp)
-            else:
-                # `self._theta = theta_prop` [hmc.py:61] as a REBIND: the blend of state and proposal is
-                # written to a fresh array that becomes the state and is what sample() returns (never
-                # written again) -- one array written instead of two (bk_blend_columns)
-                self._out = torch.empty_like(th)
-                ops.blend_columns(self._mask, th, thp, self._out)
-                self._theta_dc = self._out
+            self._take(th, thp)
             return
         if self._fused:
             if not self._have_cache:
@@ -362,7 +359,7 @@ class HMCDiag(ManyChainSampler):
             self._eval_logp(thp, self._lp_p)
             ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
                           self._mask, self._ret, self._accepted)
-            self._select(self._mask, th, thp)
+            self._take(th, thp)
             return
 
         if mirror:
@@ -420,7 +417,15 @@ class HMCDiag(ManyChainSampler):
             self._select(self._mask, th, thp)
         else:
             gp = self._materialize(g_last, self._grad_p) if L > 0 else None
-            if gp is not None:
-                self._select(self._mask, th, thp, self._grad, gp)
-            else:
-                self._select(self._mask, th, thp)
+            self._take(th, thp, self._grad if gp is not None else None, gp)
+
+    def _take(self, th, thp, g=None, gp=None):
+        """The accepted chains take their proposal [hmc.py:61] (and its cached gradient)."""
+        if not self._rebind:
+            self._select(self._mask, th, thp, g, gp)
+            return
+        self._out = torch.empty_like(th)
+        self._ops.blend_columns(self._mask, th, thp, self._out)
+        self._theta_dc = self._out
+        if gp is not None:
+            self._ops.select_columns(self._mask, g, gp)

@@ -211,22 +211,37 @@ class MALA(ManyChainSampler):
             self._gen_unit(cur)  # first draw after a (re)start: nothing generated ahead yet
         elif self._pf_event is not None:
             main.wait_event(self._pf_event)
-        # slot nxt was last read by the previous draw's kernel, already queued on `main`; the RNG
-        # table is shared, so the side stream also starts after anything generated in line above
+        self._pf_slot, self._unit_ready, self._cur_slot = nxt, True, cur
+        if self.generate_with == "grad":
+            self._start_unit(nxt)
+        return self._logu_bufs[cur], self._zt_bufs[cur]
+
+    def _start_unit(self, nxt, recorded=False):
+        """Queue the generator of the next unit on the side stream, behind everything queued on the main
+        stream so far (or up to where the caller recorded the slot's ready event).  Slot nxt was last read by
+        the previous draw's kernel, already queued on `main`; the RNG table is shared, so the side stream also
+        starts after anything generated in line."""
+        main = torch.cuda.current_stream()
         ready, ev = self._ev_ready[nxt], self._ev_done[nxt]
-        ready.record(main)
+        if not recorded:
+            ready.record(main)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             self._gen_unit(nxt)
             ev.record(self._side)
-        self._pf_event, self._pf_slot, self._unit_ready, self._cur_slot = ev, nxt, True, cur
-        return self._logu_bufs[cur], self._zt_bufs[cur]
+        self._pf_event = ev
 
     # bk_mala_step's workgroups each take a whole CU's register file: next to the generator's
     # wavefronts they cannot be scheduled, and the two kernels only slow each other down (1.52 ms per
     # draw at 65,536 x 1024 against 1.3 when the generator overlaps the model's gradient op alone).
     # With serialize_step the step kernel starts after the generator of the next unit has finished.
     serialize_step = True
+    # When the generator of the next unit starts: "grad" = with the model's gradient op (then, with
+    # serialize_step, the step kernel waits for it), "step" = together with the step kernel, behind the
+    # gradient op (the step kernel's workgroups are queued first and take one slot per CU; a generator
+    # workgroup fits beside each: 160 of the 256 free registers per SIMD lane, 6 of the 27 free KB of LDS).
+    generate_with = "grad"
+    step_first = True  # (experiments: with generate_with = "step", which of the two is queued first)
 
     def accept_rate(self) -> float:
         n = self._draws * self._C
@@ -269,10 +284,19 @@ class MALA(ManyChainSampler):
         logu, zt_next = self._take_unit()
         gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)   # mala.py:46-48
         out = th if self._use_graph else torch.empty_like(th)
-        if self._prefetch and self.serialize_step and self._pf_event is not None:
+        with_step = self._prefetch and self.generate_with == "step"
+        if self._prefetch and self.serialize_step and self._pf_event is not None and not with_step:
             torch.cuda.current_stream().wait_event(self._pf_event)
+        if with_step:
+            # both become runnable when the gradient op has finished; the step kernel's launch is handed to
+            # the hardware first
+            self._ev_ready[self._pf_slot].record(torch.cuda.current_stream())
+            if not self.step_first:
+                self._start_unit(self._pf_slot, recorded=True)
         ops.mala_step(th, out, self._grad, thp, gp, self._lp, self._lp_p, logu, zt_next, eps, s2,
                       self._mask, self._ret, self._accepted)                                   # mala.py:50-66
+        if with_step and self.step_first:
+            self._start_unit(self._pf_slot, recorded=True)
         self._theta_dc = out
 
     def _draw(self):

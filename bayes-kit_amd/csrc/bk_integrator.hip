@@ -238,6 +238,66 @@ __global__ __launch_bounds__(RED_BLOCK) void k_finish(const double* rho_in, doub
   if (w == 0 && c < C) kin_out[c] = 0.5 * s;
 }
 
+// The same with two chains (16 B) per lane: 128 chains per workgroup, 1 KiB per wavefront and row instead
+// of 512 B (8-byte-per-lane streams reach 0.5-0.7x the rate of 16-byte ones on gfx950: 344 us for the
+// 1.07 GB of a config-3 launch).  Each component runs the scalar kernel's operation sequence: same values.
+__global__ __launch_bounds__(RED_BLOCK) void k_finish_v2(const double* rho_in, double* rho_out, i64 ld,
+                                                         const double* grad, i64 ldg, const double* metric,
+                                                         double half, int negate, double* kin_out, i64 C2, i64 D) {
+  __shared__ dvec2 part[RED_WAVES][BK_WAVE];
+  constexpr int U = FIN_UNROLL;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 c2 = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
+  dvec2 kin = {0.0, 0.0};
+  if (c2 < C2) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += U) {
+      dvec2 r[U], g[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) {
+          r[u] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(rho_in + (d0 + u) * ld + 2 * c2));
+          if (grad) g[u] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(grad + (d0 + u) * ldg + 2 * c2));
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) {
+          const double m = metric ? metric[d0 + u] : 1.0;
+          dvec2 v;
+          {
+            double t = metric ? m * g[u].x : g[u].x;
+            v.x = grad ? r[u].x + half * t : r[u].x;
+            t = metric ? m * g[u].y : g[u].y;
+            v.y = grad ? r[u].y + half * t : r[u].y;
+          }
+          if (negate) {
+            v.x = -v.x;
+            v.y = -v.y;
+          }
+          if (rho_out) *reinterpret_cast<dvec2*>(rho_out + (d0 + u) * ld + 2 * c2) = v;
+          const double mx = metric ? m * v.x : v.x, my = metric ? m * v.y : v.y;
+          kin.x = kin.x + v.x * mx;
+          kin.y = kin.y + v.y * my;
+        }
+    }
+  }
+  if (!kin_out) return;  // uniform: no barrier needed without the reduction
+  part[w][lane] = kin;
+  __syncthreads();
+  if (w == 0 && c2 < C2) {
+    dvec2 s = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < RED_WAVES; ++k) {
+      s.x = s.x + part[k][lane].x;
+      s.y = s.y + part[k][lane].y;
+    }
+    s.x = 0.5 * s.x;
+    s.y = 0.5 * s.y;
+    *reinterpret_cast<dvec2*>(kin_out + 2 * c2) = s;
+  }
+}
+
 // ---- accept ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mh_accept(int mode, double* lp_cur, const double* a_cur,
                                                    const double* lp_prop, const double* a_prop,
@@ -522,8 +582,15 @@ int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld, const 
   if (!rho_in || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_finish<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
-      rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D);
+  const bool vec = C % 2 == 0 && ld % 2 == 0 && C >= 2 * BK_WAVE && bk_aligned16(rho_in) &&
+                   (!rho_out || bk_aligned16(rho_out)) && (!kin_out || bk_aligned16(kin_out)) &&
+                   (!grad || (ldg_c == 1 && ldg_d % 2 == 0 && bk_aligned16(grad)));
+  if (vec)
+    k_finish_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
+        rho_in, rho_out, ld, grad, ldg_d, metric, half, negate, kin_out, C / 2, D);
+  else
+    k_finish<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
+        rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D);
   BK_RETURN_LAUNCH_STATUS();
 }
 

@@ -98,6 +98,52 @@ __global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp(const double* th, doub
   }
 }
 
+// ... two chains (16 B) per lane: 128 chains per workgroup, 1 KiB per wavefront and row (the 8-byte form
+// streams at 5.2 TB/s, 207 us per config-3 launch).  Per component the scalar kernel's operation sequence.
+__global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp_v2(const double* th, double* g, double* logp, i64 ld,
+                                                             const double* lam, i64 C2, i64 D) {
+  __shared__ dvec2 part[RED_WAVES][BK_WAVE];
+  constexpr int U = 8;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 c2 = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
+  dvec2 s = {0.0, 0.0};
+  if (c2 < C2) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += U) {
+      dvec2 t[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) t[u] = __builtin_nontemporal_load(reinterpret_cast<const dvec2*>(th + (d0 + u) * ld + 2 * c2));
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (d0 + u < dhi) {
+          const double l = lam ? lam[d0 + u] : 1.0;
+          const double lx = lam ? l * t[u].x : t[u].x, ly = lam ? l * t[u].y : t[u].y;
+          s.x = s.x + t[u].x * lx;
+          s.y = s.y + t[u].y * ly;
+          if (g) {
+            dvec2 o = {-lx, -ly};
+            __builtin_nontemporal_store(o, reinterpret_cast<dvec2*>(g + (d0 + u) * ld + 2 * c2));
+          }
+        }
+    }
+  }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c2 < C2) {
+    dvec2 tot = part[0][lane];
+#pragma unroll
+    for (int k = 1; k < RED_WAVES; ++k) {
+      tot.x = tot.x + part[k][lane].x;
+      tot.y = tot.y + part[k][lane].y;
+    }
+    tot.x = -0.5 * tot.x;
+    tot.y = -0.5 * tot.y;
+    *reinterpret_cast<dvec2*>(logp + 2 * c2) = tot;
+  }
+}
+
 // Neal's funnel, any D: one lane per chain, sequential in d
 __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g, double* logp, i64 ld,
                                                      i64 C, i64 D) {
@@ -133,8 +179,7 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
 }
 
 // Neal's funnel.  The only coupling between the coordinates of a chain is s = sum_{d>=1}
-// theta_d^2, so a workgroup splits the ROWS of its chains over wavefronts (and lane groups) and
-// reduces s through LDS.
+// theta_d^2, so the ROWS of a chain are split over lanes and s is reduced across them.
 //
 // Canonical summation order (every funnel kernel below; results do not depend on how many chains
 // are in flight, on the grid, or on which geometry runs).  Row d belongs to class c = (d-1) mod 16,
@@ -142,14 +187,19 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
 //     cs[c] = sum over i, in order, of x[1 + c + 16 i]^2              (16 class sums)
 //     q[g]  = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12],  g = 0..3     (4 group sums)
 //     s     = ((q[0] + q[1]) + q[2]) + q[3]
-// Two geometries of a 4-wavefront workgroup produce exactly these values:
-//   * WIDE (throughput: a large lane set).  64 chains, lane = chain; wavefront w owns the four
-//     classes of group w (up to 32 rows in registers) and contributes q[w].
-//   * NARROW (latency: small lane sets, long trajectories).  16 chains; lane = (chain, h), h = lane/16;
-//     wavefront w, lane group h own class w + 4h (up to 8 rows); q[w] is formed across the four
-//     lane groups by shuffles, in order.  A leapfrog step then has a quarter of the dependent work per
-//     lane and a set of n chains spreads over 4x as many CUs -- the sparse 40- and 160-step stages
-//     of config 4 (a few per cent of the chains) are latency bound: 170 -> 94 us for the 160-step launch.
+// Geometries that produce exactly these values:
+//   * the gradient op (k_funnel_coop): a 4-wavefront workgroup, 64 chains, lane = chain; wavefront w owns
+//     the four classes of group w and contributes q[w] through LDS.
+//   * the trajectory kernel (k_funnel_traj): LPC adjacent lanes of ONE wavefront serve a chain, and s is
+//     reduced with DPP moves inside the wavefront -- no LDS, no workgroup barrier in the leapfrog loop
+//     (round 2 reduced through LDS with a 4-wavefront barrier per step: 0.59 us per step).
+//       LPC = 4  (throughput: the first stage, every chain): 16 chains per wavefront; lane p of a chain's
+//                quad holds the classes of group p (p, p+4, p+8, p+12: up to 32 rows), forms q[p] by itself,
+//                and s is ((q0 + q1) + q2) + q3 over the quad (four quad_perm broadcasts).
+//       LPC = 16 (latency: the sparse, long later stages -- a few per cent of the chains, 40 / 160 steps):
+//                4 chains per wavefront, one 16-lane DPP row each; lane p holds class p (up to 8 rows).
+//                Lanes 0..3 of the row fetch cs[p+4], cs[p+8], cs[p+12] with row_shl, form q[p], the quad
+//                sums it to s, and two masked row_shr moves hand s to the other twelve lanes.
 // Every lane integrates v = theta_0 redundantly (it needs exp(-v) for its own rows); one lane per
 // chain writes it.
 constexpr int FN_WAVES = 4;
@@ -159,43 +209,28 @@ constexpr int FN_MAX_ROWS = FN_CLASSES * FN_MAX_SLOTS;
 constexpr int FN_BLOCK = FN_WAVES * BK_WAVE;
 
 struct FunnelLds {
-  double part[2][FN_WAVES][BK_WAVE];
+  double part[FN_WAVES][BK_WAVE];
 };
 
-// Geometry: which rows live in a lane's registers and which chain a lane serves.
-//   NARROW = false: register slot u = k*SL + i holds class w + 4k, slot i; chain = lane.
-//   NARROW = true : u = i holds class w + 4*(lane/16), slot i;          chain = lane % 16.
-template <bool NARROW, int SL>
+// Geometry of the gradient op: register slot u = k*SL + i holds class w + 4k, slot i; chain = lane.
+template <int SL>
 struct FunnelGeo {
-  static constexpr int KC = NARROW ? 1 : 4;   // classes per lane
-  static constexpr int NU = KC * SL;          // register slots per lane
-  static constexpr int CHAINS = NARROW ? 16 : BK_WAVE;
+  static constexpr int KC = 4;        // classes per lane
+  static constexpr int NU = KC * SL;  // register slots per lane
   __device__ static __forceinline__ i64 row(int w, int lane, int u) {
-    const int k = NARROW ? (lane >> 4) : (u / SL), i = NARROW ? u : (u % SL);
-    return 1 + (w + 4 * k) + (i64)FN_CLASSES * i;
+    return 1 + (w + 4 * (u / SL)) + (i64)FN_CLASSES * (u % SL);
   }
-  __device__ static __forceinline__ int chain(int lane) { return NARROW ? (lane & 15) : lane; }
 };
 
-// s (canonical order) for this lane's chain from the lane's class sums cs[KC]; buf alternates per call
-template <bool NARROW>
-__device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, int lane, const double* cs) {
-  double q;
-  if (NARROW) {
-    // the four lane groups of this wavefront hold classes w, w+4, w+8, w+12 of the same 16 chains
-    const int cl = lane & 15;
-    const double c0 = __shfl(cs[0], cl), c1 = __shfl(cs[0], cl + 16), c2 = __shfl(cs[0], cl + 32),
-                 c3 = __shfl(cs[0], cl + 48);
-    q = ((c0 + c1) + c2) + c3;
-  } else {
-    q = ((cs[0] + cs[1]) + cs[2]) + cs[3];
-  }
-  lds.part[buf][w][lane] = q;
+// s (canonical order) for this lane's chain from the lane's class sums cs[4] (one use per launch)
+__device__ __forceinline__ double funnel_reduce_lds(FunnelLds& lds, int w, int lane, const double* cs) {
+  lds.part[w][lane] = ((cs[0] + cs[1]) + cs[2]) + cs[3];
   __syncthreads();
-  return ((lds.part[buf][0][lane] + lds.part[buf][1][lane]) + lds.part[buf][2][lane]) + lds.part[buf][3][lane];
+  return ((lds.part[0][lane] + lds.part[1][lane]) + lds.part[2][lane]) + lds.part[3][lane];
 }
 
 // class sums of `expr` over this lane's rows < D, each class sequential in its slots
+// (G::row(w, lane, u) with u = k*SL + i is the row of class slot (k, i))
 #define BK_FN_CLASS_SUMS(cs, expr)                                   \
   _Pragma("unroll") for (int k = 0; k < G::KC; ++k) {                \
     double acc_ = 0.0;                                               \
@@ -210,7 +245,7 @@ __device__ __forceinline__ double funnel_reduce(FunnelLds& lds, int buf, int w, 
 template <int SL>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
                                                           i64 n, i64 D) {
-  using G = FunnelGeo<false, SL>;
+  using G = FunnelGeo<SL>;
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
@@ -224,7 +259,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
   double cs[G::KC];
   BK_FN_CLASS_SUMS(cs, x[u] * x[u])
   double v = on ? th[j] : 0.0;
-  double s = funnel_reduce<false>(lds, 0, w, lane, cs);
+  double s = funnel_reduce_lds(lds, w, lane, cs);
   if (!on) return;
   double ev = exp(-v);
   double hn = 0.5 * (double)(D - 1);
@@ -242,23 +277,93 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
   }
 }
 
+// ---- lanes of one wavefront serving one chain: geometry and the DPP reduction ------------------------
+// DPP move of a double (two 32-bit halves).  Lanes the control does not reach (row / bank masks, a shift
+// whose source lies outside the 16-lane row) keep `old`.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double bk_dpp_f64(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int BK_DPP_ROW_SHL = 0x100;  // + n: lane i reads lane i + n of its row
+constexpr int BK_DPP_ROW_SHR = 0x110;  // + n: lane i reads lane i - n of its row
+template <int K>
+__device__ __forceinline__ double bk_quad_bcast(double x) {  // lane K of every quad, to the whole quad
+  return bk_dpp_f64<K * 0x55, 0xF, 0xF>(x, x);
+}
+
+//   LPC = 4 : p = lane % 4 is the class GROUP; register slot u = k*SL + i holds class p + 4k, slot i.
+//   LPC = 16: p = lane % 16 is the CLASS;      register slot u = i     holds class p,      slot i.
+// A lane's rows are 1 + p + off(u) with a lane-independent off(u): row addresses are a per-lane 32-bit
+// offset (row 1 + p of the lane's chain) on top of a wavefront-uniform row base, and only the LAST slot
+// of a class can run past D (SL is exactly ceil((D-1)/16)): every other row needs no guard.
+template <int LPC, int SL>
+struct FunnelLanes {
+  static_assert(LPC == 4 || LPC == 16, "a chain is served by a quad or by a DPP row");
+  static constexpr int KC = FN_CLASSES / LPC;     // classes per lane
+  static constexpr int NU = KC * SL;              // register slots per lane
+  static constexpr int CHAINS = BK_WAVE / LPC;    // chains per wavefront
+  __host__ __device__ static constexpr int off(int u) {  // row of slot u, relative to the lane's first row
+    return LPC == 4 ? 4 * (u / SL) + FN_CLASSES * (u % SL) : FN_CLASSES * u;
+  }
+  __host__ __device__ static constexpr bool last_slot(int u) { return (LPC == 4 ? u % SL : u) == SL - 1; }
+};
+
+// s (canonical order) of the chain this lane serves, from the lane's class sums; valid in EVERY lane
+// of the chain.  All 64 lanes must be active.
+template <int LPC>
+__device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
+  double q;
+  if (LPC == 4) {
+    q = ((cs[0] + cs[1]) + cs[2]) + cs[3];  // this lane holds classes p, p+4, p+8, p+12
+  } else {
+    // lane p of the row holds cs[p]; in lanes 0..3: q[p] = ((cs[p] + cs[p+4]) + cs[p+8]) + cs[p+12]
+    // (the other twelve lanes compute something nobody reads)
+    const double b = bk_dpp_f64<BK_DPP_ROW_SHL + 4, 0xF, 0xF>(cs[0], cs[0]);
+    const double c = bk_dpp_f64<BK_DPP_ROW_SHL + 8, 0xF, 0xF>(cs[0], cs[0]);
+    const double d = bk_dpp_f64<BK_DPP_ROW_SHL + 12, 0xF, 0xF>(cs[0], cs[0]);
+    q = ((cs[0] + b) + c) + d;
+  }
+  // lane p of the quad holds q[p]
+  double s = ((bk_quad_bcast<0>(q) + bk_quad_bcast<1>(q)) + bk_quad_bcast<2>(q)) + bk_quad_bcast<3>(q);
+  if (LPC == 16) {
+    // s is right in lanes 0..3 of the row: hand it to lanes 4..7, then lanes 0..7 hand it to 8..15
+    s = bk_dpp_f64<BK_DPP_ROW_SHR + 4, 0xF, 0x2>(s, s);
+    s = bk_dpp_f64<BK_DPP_ROW_SHR + 8, 0xF, 0xC>(s, s);
+  }
+  return s;
+}
+
+// class sums of `expr` over this lane's rows (tail_ok[k]: the last slot of class k exists), each class
+// sequential in its slots
+#define BK_FL_CLASS_SUMS(cs, expr)                                   \
+  _Pragma("unroll") for (int k = 0; k < G::KC; ++k) {                \
+    double acc_ = 0.0;                                               \
+    _Pragma("unroll") for (int i = 0; i < SL; ++i) {                 \
+      const int u = k * SL + i;                                      \
+      if (!G::last_slot(u) || tail_ok[k]) acc_ = acc_ + (expr);      \
+    }                                                                \
+    cs[k] = acc_;                                                    \
+  }
+
 // One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE
 // launch: gather chain idx[j] of the source point, first half-kick with the source's cached
 // gradient + drift, (steps-1) x {gradient, kick, drift}, final gradient + log density,
-// last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers.
-// NARROW: geometry (above); SL = slots per class kept in registers (>= ceil((D-1)/16)); HM = a
-// metric is given.  All compile-time: with generic sizes and a run-time metric flag the kernel
-// needed 330 registers (one wavefront per SIMD, AGPR spills).
-template <bool NARROW, int SL, bool HM>
+// last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers, and the sum over a
+// chain's coordinates never leaves the wavefront.
+// LPC: lanes per chain (above); SL = slots per class = ceil((D-1)/16) exactly; HM = a metric is given.
+// All compile-time: with generic sizes and a run-time metric flag the kernel needed 330 registers (one
+// wavefront per SIMD, AGPR spills).
+template <int LPC, int SL, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
     unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out) {
-  using G = FunnelGeo<NARROW, SL>;
+  using G = FunnelLanes<LPC, SL>;
   constexpr int NU = G::NU;
-  __shared__ FunnelLds lds;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
   // lanes actually in the set: read from device memory when the host only knows an upper bound
   i64 n = n_host;
   if (n_dev) {
@@ -269,24 +374,37 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     if (lanes_out) *lanes_out = (uint32_t)n;
     if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
   }
-  if ((i64)blockIdx.x * G::CHAINS >= n) return;  // whole workgroup past the set (uniform: before any barrier)
-  const i64 j = (i64)blockIdx.x * G::CHAINS + G::chain(lane);
+  const i64 j0 = ((i64)blockIdx.x * FN_WAVES + wave) * G::CHAINS;  // first chain of this wavefront
+  if (j0 >= n) return;  // whole wavefront past the set (uniform; the wavefronts of a workgroup are independent)
+  const int pos = lane & (LPC - 1);
+  const i64 j = j0 + lane / LPC;
   const bool on = j < n;
-  const bool writer = on && w == 0 && (!NARROW || lane < 16);  // the lane that owns theta_0 / the scalars
+  const bool writer = on && pos == 0;  // the lane that owns theta_0 / the scalars
   const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
   const double half = 0.5 * h;
   const double hn = 0.5 * (double)(D - 1);
   constexpr bool hm = HM;
-  double x[NU], r[NU];
+  // this lane's rows: d(u) = 1 + pos + off(u).  Byte offsets of its first row (host checked: < 2^32)
+  const uint32_t bo_in = (uint32_t)(((i64)(1 + pos) * ld_in + src) * 8);
+  const uint32_t bo_out = (uint32_t)(((i64)(1 + pos) * ld_out + (on ? j : 0)) * 8);
+#define BK_FL_IN(p, u) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>((p) + (i64)G::off(u) * ld_in) + bo_in))
+#define BK_FL_OUT(p, u) (*reinterpret_cast<double*>(reinterpret_cast<char*>((p) + (i64)G::off(u) * ld_out) + bo_out))
+  bool tail_ok[G::KC];  // does the last slot of class k exist for this lane?
+#pragma unroll
+  for (int k = 0; k < G::KC; ++k) tail_ok[k] = 1 + pos + G::off(k * SL + SL - 1) < D;
+#define BK_FL_OK(u) (!G::last_slot(u) || tail_ok[(u) / SL])
+  double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
   // gather + first half-kick + drift (drghmc.py:276-278)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const i64 d = G::row(w, lane, u);
-    bool ok = on && d < D;
-    x[u] = ok ? th_in[d * ld_in + src] : 0.0;
-    r[u] = ok ? rho_in[d * ld_in + src] : 0.0;
-    double g0 = ok ? g_in[d * ld_in + src] : 0.0;
-    const double mi = (hm && d < D) ? metric[d] : 1.0;
+    // (lanes past the set read chain 0 -- src = 0 -- and compute on it; they store nothing.  No branch
+    // around the loads of rows that exist for every lane.)
+    const bool ok = BK_FL_OK(u);
+    x[u] = ok ? BK_FL_IN(th_in, u) : 0.0;
+    r[u] = ok ? BK_FL_IN(rho_in, u) : 0.0;
+    double g0 = ok ? BK_FL_IN(g_in, u) : 0.0;
+    const double mi = (hm && BK_FL_OK(u)) ? metric[1 + pos + G::off(u)] : 1.0;
+    if (HM && LPC == 16) mt[u] = mi;
     double t = hm ? mi * g0 : g0;
     r[u] = r[u] + half * t;
     x[u] = x[u] + h * r[u];
@@ -294,21 +412,21 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     // kernel's register count (and so its occupancy for the whole trajectory)
     if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
   }
-  double v = on ? th_in[src] : 0.0, rv = on ? rho_in[src] : 0.0;
+  double v = th_in[src], rv = rho_in[src];
   const double mv = hm ? metric[0] : 1.0;
   {
-    double g0 = on ? g_in[src] : 0.0;
+    double g0 = g_in[src];
     double t = hm ? mv * g0 : g0;
     rv = rv + half * t;
     v = v + h * rv;
   }
-  int buf = 0;
+  // the metric entry of row u: held in registers by the 16-lane geometry (<= 8 rows), re-read (L1) by the quad one
+#define BK_FL_METRIC(u) ((HM && LPC == 16) ? mt[(HM && LPC == 16) ? (u) : 0] : metric[1 + pos + G::off(u)])
   double cs[G::KC];
   // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283)
   for (int step = 0; step + 1 < steps; ++step) {
-    BK_FN_CLASS_SUMS(cs, x[u] * x[u])
-    const double s = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
-    buf ^= 1;
+    BK_FL_CLASS_SUMS(cs, x[u] * x[u])
+    const double s = funnel_reduce_lanes<LPC>(cs);
     const double ev = exp(-v);
     const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
     {
@@ -318,22 +436,20 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const i64 d = G::row(w, lane, u);
-      if (d < D) {
+      if (BK_FL_OK(u)) {
         double gi = -(ev * x[u]);
-        double t = hm ? metric[d] * gi : gi;
+        double t = hm ? BK_FL_METRIC(u) * gi : gi;
         r[u] = r[u] + h * t;
         x[u] = x[u] + h * r[u];
       }
-      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
+      if (LPC == 4 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
     }
   }
   // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
   double logp_j = 0.0;
   {
-    BK_FN_CLASS_SUMS(cs, x[u] * x[u])
-    const double s = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
-    buf ^= 1;
+    BK_FL_CLASS_SUMS(cs, x[u] * x[u])
+    const double s = funnel_reduce_lanes<LPC>(cs);
     const double ev = exp(-v);
     const double he = 0.5 * ev;
     const double gv = ((-v / 9.0) - hn) + he * s;
@@ -343,12 +459,11 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const i64 d = G::row(w, lane, u);
-      if (d < D) {
+      if (BK_FL_OK(u)) {
         double gi = -(ev * x[u]);
-        double t = hm ? metric[d] * gi : gi;
+        double t = hm ? BK_FL_METRIC(u) * gi : gi;
         r[u] = r[u] + half * t;
-        if (on) g_out[d * ld_out + j] = gi;
+        if (on) BK_FL_OUT(g_out, u) = gi;
       }
     }
     logp_j = ((-(v * v) / 18.0) - hn * v) - he * s;
@@ -360,17 +475,16 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250; same canonical order), outputs
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const i64 d = G::row(w, lane, u);
-    if (d < D) {
+    if (BK_FL_OK(u)) {
       r[u] = -r[u];
       if (on) {
-        rho_out[d * ld_out + j] = r[u];
-        th_out[d * ld_out + j] = x[u];
+        BK_FL_OUT(rho_out, u) = r[u];
+        BK_FL_OUT(th_out, u) = x[u];
       }
     }
   }
-  BK_FN_CLASS_SUMS(cs, r[u] * (hm ? metric[G::row(w, lane, u)] * r[u] : r[u]))
-  double ksum = funnel_reduce<NARROW>(lds, buf, w, lane, cs);
+  BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
+  double ksum = funnel_reduce_lanes<LPC>(cs);
   if (writer) {
     double rr = -rv;
     double mr = hm ? mv * rr : rr;
@@ -387,6 +501,10 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
       live_out[j] = 1;
     }
   }
+#undef BK_FL_IN
+#undef BK_FL_OUT
+#undef BK_FL_OK
+#undef BK_FL_METRIC
 }
 
 // Whole HMC trajectory of the separable Gaussians in registers (hmc.py:40-53 with
@@ -586,7 +704,12 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
   if (C == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
   if (logp) {
-    k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D);
+    if (C % 2 == 0 && ld % 2 == 0 && C >= 2 * BK_WAVE && bk_aligned16(theta) && bk_aligned16(logp) &&
+        (!grad || bk_aligned16(grad)))
+      k_gauss_logp_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam,
+                                                                                          C / 2, D);
+    else
+      k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D);
     BK_RETURN_LAUNCH_STATUS();
   }
   if (D == 0) return BK_OK;
@@ -728,6 +851,8 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
   if (D - 1 > FN_MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (H_out && (!h_out || !live_out)) return BK_E_ARG;
   if (ld_out < n) return BK_E_ALIGN;
+  // the kernel addresses a lane's rows with 32-bit byte offsets from wavefront-uniform row bases
+  if ((ld_in > ld_out ? ld_in : ld_out) >= ((i64)1 << 32) / (8 * (FN_CLASSES + 1))) return BK_E_ARG;
   if (n == 0) {
     if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
     return BK_OK;
@@ -735,34 +860,41 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
   const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
   hipStream_t s = bk_stream(stream);
   // Geometry.  A set that is small, or whose size only the device knows (every set after the first
-  // stage: a few per cent of the chains) -> NARROW, 16 chains per workgroup; a set known to be large ->
-  // WIDE, 64 chains per workgroup.  Same values either way.  BK_FUNNEL_GEOMETRY=wide|narrow overrides.
+  // stage: a few per cent of the chains) -> 16 lanes per chain, 16 chains per workgroup; a set known to be
+  // large -> 4 lanes per chain, 64 chains per workgroup.  Same values either way.
+  // BK_FUNNEL_GEOMETRY=wide|narrow overrides (wide = 4 lanes per chain).
   static const int forced = []() {
     const char* e = getenv("BK_FUNNEL_GEOMETRY");
     return !e ? 0 : (e[0] == 'n' ? 2 : 1);
   }();
   const bool narrow = forced ? forced == 2 : (n_dev != nullptr || n < 8192);
-  dim3 grid((unsigned)bk_cdiv(n, narrow ? 16 : BK_WAVE));
-#define BK_FT(NW, R, M)                                                                                           \
-  k_funnel_traj<NW, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out,  \
-                                                          rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
-                                                          (int)steps, n, D, n_dev, lanes_out,                      \
-                                                          reinterpret_cast<unsigned long long*>(lanes_total),     \
-                                                          H_out, h_out, live_out)
-#define BK_FT_ROWS(R)                     \
-  do {                                    \
-    if (narrow) {                         \
-      if (metric) BK_FT(true, R, true);   \
-      else BK_FT(true, R, false);         \
-    } else {                              \
-      if (metric) BK_FT(false, R, true);  \
-      else BK_FT(false, R, false);        \
-    }                                     \
+  dim3 grid((unsigned)bk_cdiv(n, FN_WAVES * (narrow ? BK_WAVE / 16 : BK_WAVE / 4)));
+#define BK_FT(LPC, R, M)                                                                                          \
+  k_funnel_traj<LPC, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, \
+                                                           rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
+                                                           (int)steps, n, D, n_dev, lanes_out,                     \
+                                                           reinterpret_cast<unsigned long long*>(lanes_total),    \
+                                                           H_out, h_out, live_out)
+#define BK_FT_ROWS(R)                   \
+  do {                                  \
+    if (narrow) {                       \
+      if (metric) BK_FT(16, R, true);   \
+      else BK_FT(16, R, false);         \
+    } else {                            \
+      if (metric) BK_FT(4, R, true);    \
+      else BK_FT(4, R, false);          \
+    }                                   \
   } while (0)
-  if (need <= 2) BK_FT_ROWS(2);
-  else if (need <= 4) BK_FT_ROWS(4);
-  else if (need <= 7) BK_FT_ROWS(7);
-  else BK_FT_ROWS(8);
+  switch (need < 1 ? 1 : need) {  // slots per class, exactly: only a class's last slot can run past D
+    case 1: BK_FT_ROWS(1); break;
+    case 2: BK_FT_ROWS(2); break;
+    case 3: BK_FT_ROWS(3); break;
+    case 4: BK_FT_ROWS(4); break;
+    case 5: BK_FT_ROWS(5); break;
+    case 6: BK_FT_ROWS(6); break;
+    case 7: BK_FT_ROWS(7); break;
+    default: BK_FT_ROWS(8); break;
+  }
 #undef BK_FT_ROWS
 #undef BK_FT
   BK_RETURN_LAUNCH_STATUS();

@@ -16,6 +16,10 @@ import bayes_kit_amd as bk
 
 
 def main():
+    import faulthandler
+
+    # a rank stuck in a collective says where (every thread's stack) and exits, instead of hanging the test
+    faulthandler.dump_traceback_later(float(os.environ.get("BK_TEST_WATCHDOG", "150")), exit=True)
     backend = os.environ.get("BK_TEST_BACKEND", "nccl")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ["LOCAL_RANK"]) if backend == "nccl" else 0
