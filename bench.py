@@ -105,7 +105,10 @@ def launch_ranks(n, child_argv, extra_env=None, timeout=3000.0, out=None):
     for r in range(1, n):
         if outputs.get(r):
             sys.stderr.write(outputs[r])
-    out.write(outputs.get(0) or "")
+    # rank 0's JSON line(s) are the launcher's stdout; anything else a library printed there (gloo
+    # announces its connections on stdout) goes to stderr, so that stdout stays one JSON line
+    for line in (outputs.get(0) or "").splitlines():
+        (out if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     out.flush()
     return rc
 
