@@ -49,6 +49,9 @@ SIGNATURES = {
     "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_test": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost": [P, P, P, P, P, F, P, P, I, P, P, P, P],
+    "bk_dr_begin_retry": [c_int, P, I, P, P, P, P, P, P, F, P, I, I, P],
+    "bk_dr_accept_prob_test_next": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P, P, P],
+    "bk_dr_accept_prob_ghost_next": [P, P, P, P, P, F, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
@@ -62,6 +65,7 @@ SIGNATURES = {
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
+    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
@@ -91,6 +95,12 @@ _RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sor
 
 class BkHipError(RuntimeError):
     pass
+
+
+class ScatterJob(ctypes.Structure):
+    """bk_scatter_job of include/bkhip.h: the arguments of one bk_scatter_columns call."""
+    _fields_ = [("mask", P), ("index", P), ("n", I), ("D", I), ("dst0", P), ("src0", P), ("dst1", P), ("src1", P),
+                ("dst2", P), ("src2", P), ("ld_dst", I), ("ld_src", I), ("sdst", P), ("ssrc", P), ("n_dev", P)]
 
 
 _lib = None
@@ -302,6 +312,26 @@ class Ops:
         self._call("bk_dr_accept_prob_ghost", ptr(H), ptr(parent_H), ptr(h), ptr(parent_h), ptr(sub_index),
                    float(prob_retry), ptr(live), ptr(a), n, ptr(n_dev), ptr(parent_live), ptr(parent_a), self._s())
 
+    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters):
+        """dr_begin + the first stage's dr_retry_test + zeroing of the draw's lane counters, one launch."""
+        self._call("bk_dr_begin_retry", kind, ptr(state), state.stride(0), ptr(logp), ptr(kin), ptr(cur_H), ptr(cur_h),
+                   ptr(rej), ptr(alive), float(prob_retry), ptr(counters), 0 if counters is None else counters.numel(),
+                   logp.shape[0], self._s())
+
+    def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
+                                 accepted, next_index, next_count, n_dev=None):
+        """dr_accept_prob_test + the next stage's retry test + the list of chains that propose again."""
+        self._call("bk_dr_accept_prob_test_next", kind, ptr(state), state.stride(0), ptr(chain_index), ptr(H), ptr(h),
+                   ptr(live), ptr(a), float(prob_retry), n, ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive),
+                   ptr(accepted), ptr(n_dev), ptr(next_index), ptr(next_count), self._s())
+
+    def dr_accept_prob_ghost_next(self, H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, parent_live,
+                                  parent_a, next_index, next_count, n_dev=None):
+        """dr_accept_prob_ghost + the list of parent lanes that go on to their next ghost."""
+        self._call("bk_dr_accept_prob_ghost_next", ptr(H), ptr(parent_H), ptr(h), ptr(parent_h), ptr(sub_index),
+                   float(prob_retry), ptr(live), ptr(a), n, ptr(n_dev), ptr(parent_live), ptr(parent_a),
+                   ptr(next_index), ptr(next_count), self._s())
+
     def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         """dsts/srcs: up to three [D, *] tensors each (same ld within each list)."""
         d = list(dsts) + [None] * (3 - len(dsts))
@@ -403,19 +433,31 @@ class Ops:
                    ptr(metric), eps, steps, ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), ptr(lp_cur), ptr(log_u),
                    ptr(mask), ptr(ret), ptr(count), C, D, self._s())
 
+    def scatter_job(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
+        """The arguments of scatter_columns(...) as a job for dr_proposal_funnel(job=...)."""
+        d = list(dsts) + [None] * (3 - len(dsts))
+        s_ = list(srcs) + [None] * (3 - len(srcs))
+        return ScatterJob(ptr(mask) or None, ptr(index) or None, n, dsts[0].shape[0], ptr(d[0]) or None, ptr(s_[0]) or None,
+                          ptr(d[1]) or None, ptr(s_[1]) or None, ptr(d[2]) or None, ptr(s_[2]) or None, _ld(dsts[0]),
+                          _ld(srcs[0]), ptr(sdst) or None, ptr(ssrc) or None, ptr(n_dev) or None)
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None):
         """level: optional (H, h, live) tensors of the destination level -- its bk_dr_level_begin is then
-        done by the same launch."""
+        done by the same launch.  job: optional scatter_job(...) run by surplus workgroups of the launch."""
         D, n = theta_out.shape
         H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
         ld_out = _ld(theta_out)
         assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
-        self._call("bk_dr_proposal_funnel", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
-                   ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
-                   h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live), self._s())
+        args = (ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
+                ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
+                h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live))
+        if job is None:
+            self._call("bk_dr_proposal_funnel", *args, self._s())
+        else:
+            self._call("bk_dr_proposal_funnel_job", *args, ctypes.byref(job), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape

@@ -46,6 +46,7 @@ class _Level:
         self.a = torch.empty(C, **f64)
         self.live = torch.empty(C, dtype=torch.uint8, device=dev)
         self.idx = torch.empty(C, dtype=torch.int32, device=dev)
+        self.idx_alt = torch.empty(C, dtype=torch.int32, device=dev)  # (a list is built while the previous one is read)
         self.count = torch.zeros(1, dtype=torch.int32, device=dev)
         self.accepted = torch.empty(C, dtype=torch.uint8, device=dev)
 
@@ -95,6 +96,7 @@ class DrGhmcDiag(ManyChainSampler):
         self._rej = torch.empty(C, **f64)
         self._alive = torch.empty(C, dtype=torch.uint8, device=dev)
         self._levels = [_Level(D, C, dev) for _ in range(int(max_proposals))]
+        self._level0_alt = None  # a second level-0 buffer set (device-count path: stages alternate, see _draw_dev)
         self._have_cache = False
         self._draws = 0
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
@@ -124,6 +126,8 @@ class DrGhmcDiag(ManyChainSampler):
         if self._dev_counts:
             self._steps_total_base = 0.0
             self._make_schedule()
+            if int(max_proposals) > 1:
+                self._level0_alt = _Level(D, C, dev)
 
     def _make_schedule(self):
         """The fixed schedule of trajectories (slot order = launch order) and its lane counters, for the
@@ -135,6 +139,10 @@ class DrGhmcDiag(ManyChainSampler):
         self._slot_lanes = torch.zeros(len(self._schedule), dtype=torch.int32, device=dev)
         self._slot_steps = torch.tensor([st for _, st in self._schedule], dtype=torch.float64, device=dev)
         self._slot_lanes_total = torch.zeros(len(self._schedule), dtype=torch.int64, device=dev)
+        # one lane counter per list the draw builds (stage lists + ghost lists), zeroed by the draw's first launch
+        K = int(self._max_proposals)
+        n_lists = (K - 1) + sum(max(0, k - 1) * (2 ** 0) for k in range(K)) + 64
+        self._counters = torch.zeros(min(64, n_lists), dtype=torch.int32, device=dev)
 
     def _plan(self, K):
         """Tags and step counts of the trajectories of one draw in launch order, e.g. for K = 3:
@@ -374,8 +382,9 @@ class DrGhmcDiag(ManyChainSampler):
         return self._draw_out(self._theta_dc, self._cur_H)
 
     # -- the same draw with lane counts on the device: a fixed launch sequence ----------------------------
-    def _proposal_dev(self, src, idx, n_dev, k, lvl):
-        """Proposal k from lanes idx (count n_dev; None = all C chains) of `src` into level lvl."""
+    def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None):
+        """Proposal k from lanes idx (count n_dev; None = all C chains) of `src` into level lvl; `job`: a
+        scatter job the launch carries along."""
         h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
         dst = self._levels[lvl]
         slot = self._slot
@@ -385,29 +394,46 @@ class DrGhmcDiag(ManyChainSampler):
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
                                         lanes_out=self._slot_lanes[slot:slot + 1],
                                         lanes_total=self._slot_lanes_total[slot:slot + 1],
-                                        level=(dst.H, dst.h, dst.live))
+                                        level=(dst.H, dst.h, dst.live), job=job)
         assert ok
 
-    def _accept_dev(self, lvl, n_dev, k, parent=None, sub=None):
+    def _new_list(self):
+        """The next unused lane counter of this draw (zeroed by bk_dr_begin_retry)."""
+        i = self._list
+        self._list += 1
+        if i >= self._counters.numel():
+            raise RuntimeError("max_proposals too large for the device-side lane lists")
+        return self._counters[i:i + 1]
+
+    def _accept_dev(self, lvl, n_dev, k, parent=None, sub=None, parent_next=None):
         """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains): the ghost
         proposals of level `lvl` and their recursive accepts.  For a ghost level (`parent` given: the level
         its lanes belong to, paired by `sub`) the level's own accept probability and the update of the
         parent are one launch (bk_dr_accept_prob_ghost); for the stage's proposal itself (level 0) the
-        probability is evaluated by the accept test's launch (bk_dr_accept_prob_test, in _draw_dev)."""
+        probability is evaluated by the accept test's launch (bk_dr_accept_prob_test, in _draw_dev).
+        The lane set of ghost i >= 1 -- the lanes of this level that are still live -- is listed by the launch
+        that updates the level after ghost i - 1 (`parent_next` = (list, counter) handed down to it)."""
         ops, C = self._ops, self._C
         P = self._levels[lvl]  # (H, h, live of the level were set by the proposal's own launch)
+        nxt = self._levels[lvl + 1] if lvl + 1 < len(self._levels) else None
+        m_dev, gsub = n_dev, None  # ghost 0: every lane of the level is still live
         for i in range(k):
-            if i == 0:
-                m_dev, gsub = n_dev, None  # every lane of the level is still live
-            else:
-                nxt = self._levels[lvl + 1]
-                ops.compact_indices(P.live, C, nxt.idx, nxt.count, n_dev=n_dev)
-                m_dev, gsub = nxt.count, nxt.idx
+            following = None
+            if i + 1 < k:  # the list ghost i + 1 will run over, built while ghost i's result is applied
+                buf = nxt.idx if (i % 2 == 0) else nxt.idx_alt
+                following = (buf, self._new_list())
             self._proposal_dev(P, gsub, m_dev, i, lvl + 1)
-            self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub)
+            self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following)
+            if following is not None:
+                gsub, m_dev = following
         if parent is not None:
-            ops.dr_accept_prob_ghost(P.H, parent.H, P.h, parent.h, sub, 1.0 if self._prob_retry else 0.0, P.live, P.a,
-                                     C, parent.live, parent.a, n_dev=n_dev)                   # :426-446
+            pr = 1.0 if self._prob_retry else 0.0
+            if parent_next is None:
+                ops.dr_accept_prob_ghost(P.H, parent.H, P.h, parent.h, sub, pr, P.live, P.a, C, parent.live, parent.a,
+                                         n_dev=n_dev)                                         # :426-446
+            else:
+                ops.dr_accept_prob_ghost_next(P.H, parent.H, P.h, parent.h, sub, pr, P.live, P.a, C, parent.live,
+                                              parent.a, parent_next[0], parent_next[1], n_dev=n_dev)
 
     def _draw_dev(self):
         ops = self._ops
@@ -415,25 +441,43 @@ class DrGhmcDiag(ManyChainSampler):
         ops.momentum_refresh(self._rng_kind, self._rng_state, self._rho_dc,
                              self._rho_sign * math.sqrt(1 - damping), math.sqrt(damping), self._rho_dc, m,
                              self._kin, None, self._rng_work)                                     # :360-364
-        ops.dr_begin(self._lp, self._kin, self._cur_H, self._cur_h, self._rej, self._alive)
-        cur = _Cur(self)
         pr = 1.0 if self._prob_retry else 0.0
-        P0 = self._levels[0]
+        # start of the draw + the first stage's retry test (always passed, its uniform drawn) :365-371
+        ops.dr_begin_retry(self._rng_kind, self._rng_state, self._lp, self._kin, self._cur_H, self._cur_h, self._rej,
+                           self._alive, pr, self._counters)
+        cur = _Cur(self)
         self._slot = 0
-        for k in range(int(self._max_proposals)):
-            ops.dr_retry_test(self._rng_kind, self._rng_state, self._rej, pr, self._alive)        # :369-371
-            if k == 0:
-                n_dev, idx = None, None  # every chain proposes at the first stage
-            else:
-                ops.compact_indices(self._alive, C, P0.idx, P0.count)
-                n_dev, idx = P0.count, P0.idx
-            self._proposal_dev(cur, idx, n_dev, k, 0)                                             # :373
+        self._list = 0
+        K = int(self._max_proposals)
+        n_dev, idx = None, None  # every chain proposes at the first stage
+        # The stages alternate between two level-0 buffer sets, so that the scatter of stage k's accepted
+        # proposals into the chains' current point can run INSIDE stage k+1's proposal launch (surplus
+        # workgroups beside a sparse, latency-bound lane set): it reads stage k's buffers and writes columns
+        # of accepted chains, the proposal reads columns of rejected chains and writes the other set.
+        level0 = [self._levels[0], self._level0_alt]
+        job = None
+        for k in range(K):
+            P0 = self._levels[0] = level0[k % 2]
+            self._proposal_dev(cur, idx, n_dev, k, 0, job=job)                                    # :373
             self._accept_dev(0, n_dev, k)                                                         # :374-376
-            ops.dr_accept_prob_test(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
-                                    self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted,
-                                    n_dev=n_dev)                                                  # :441-446, :378-385
-            ops.scatter_columns(P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad],
-                                [P0.theta, P0.rho, P0.grad], self._lp, P0.logp, n_dev=n_dev)
+            if k + 1 < K:
+                # accept test :441-446, :378-385; for the rejected chains the next stage's retry test :369-371;
+                # the chains that propose again are listed for the next stage
+                nidx, ncount = (P0.idx if k % 2 == 0 else P0.idx_alt), self._new_list()
+                ops.dr_accept_prob_test_next(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
+                                             self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, nidx, ncount,
+                                             n_dev=n_dev)
+            else:
+                ops.dr_accept_prob_test(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
+                                        self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, n_dev=n_dev)
+            scatter = (P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad], [P0.theta, P0.rho, P0.grad],
+                       self._lp, P0.logp)                                                          # :379-381
+            if k + 1 < K:
+                job = ops.scatter_job(*scatter, n_dev=n_dev)   # rides on the next stage's proposal launch
+                idx, n_dev = nidx, ncount
+            else:
+                ops.scatter_columns(*scatter, n_dev=n_dev)
+        self._levels[0] = level0[0]
 
     @property
     def lane_steps_total(self):

@@ -112,14 +112,14 @@ class Funnel(_BuiltinTarget):
     _FUSED_MAX_D = 129  # bk_dr_proposal_funnel keeps a chain's coordinates in one workgroup's registers
 
     def bk_dr_proposal(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                       kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):
+                       kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None):
         """Whole delayed-rejection proposal in one launch; False if the shape is unsupported.
-        n_dev / lanes_out: device-side lane count in / out (include/bkhip.h)."""
-        if self._D > self._FUSED_MAX_D:
+        n_dev / lanes_out: device-side lane count in / out; job: a scatter job carried along (include/bkhip.h)."""
+        if self._D > self._FUSED_MAX_D or max(theta_in.stride(0), theta_out.stride(0)) * 17 * 8 >= 2 ** 32:
             return False
         self._get_ops().dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
                                            logp_out, kin_out, metric, h, steps, n_dev=n_dev, lanes_out=lanes_out,
-                                           lanes_total=lanes_total, level=level)
+                                           lanes_total=lanes_total, level=level, job=job)
         return True
 
     def bk_dr_proposal_supported(self) -> bool:

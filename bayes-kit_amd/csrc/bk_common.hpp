@@ -29,3 +29,35 @@ static inline bool bk_streams_past_llc(i64 elems) { return elems * 8 > ((i64)192
 // all 64 lanes, but the compiler only knows that if told -- otherwise every loop bound, row guard and
 // address derived from it is per-lane vector work (selects, 64-bit VGPR address math).
 __device__ __forceinline__ int bk_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)); }
+
+// ---- accepted columns -> the chains' current point (bk_scatter_columns) -----------------------------------
+// One unit = 64 lanes (lane = chain of the compacted set) x BK_SCT_ROWS dimensions: the copy of an accepted
+// column is spread over D / BK_SCT_ROWS units (one lane walking all D rows with dependent load -> store pairs
+// took 22 us per launch at D = 101, whatever the number of accepted lanes).  Shared by k_scatter and by the
+// trajectory kernel, whose surplus workgroups run the PREVIOUS stage's scatter beside the trajectories.
+constexpr int BK_SCT_ROWS = 8;
+__device__ __forceinline__ void bk_scatter_unit(i64 ux, i64 uy, int lane, const uint8_t* mask, const int32_t* idx, i64 n,
+                                                i64 D, double* d0, const double* s0, double* d1, const double* s1,
+                                                double* d2, const double* s2, i64 ldd, i64 lds, double* sd,
+                                                const double* ss) {
+  const i64 j = ux * 64 + lane;
+  if (j >= n || !mask[j]) return;
+  const i64 g = idx ? (i64)idx[j] : j;
+  if (sd && uy == 0) sd[g] = ss[j];
+  const i64 b = uy * BK_SCT_ROWS;
+  double x0[BK_SCT_ROWS], x1[BK_SCT_ROWS], x2[BK_SCT_ROWS];
+#pragma unroll
+  for (int u = 0; u < BK_SCT_ROWS; ++u)
+    if (b + u < D) {
+      x0[u] = s0[(b + u) * lds + j];
+      if (d1) x1[u] = s1[(b + u) * lds + j];
+      if (d2) x2[u] = s2[(b + u) * lds + j];
+    }
+#pragma unroll
+  for (int u = 0; u < BK_SCT_ROWS; ++u)
+    if (b + u < D) {
+      d0[(b + u) * ldd + g] = x0[u];
+      if (d1) d1[(b + u) * ldd + g] = x1[u];
+      if (d2) d2[(b + u) * ldd + g] = x2[u];
+    }
+}

@@ -97,6 +97,44 @@ __global__ __launch_bounds__(64) void k_dr_retry(uint64_t* st, i64 ldr, const do
   if (!(lu < retry)) alive[c] = 0;  // drghmc.py:370-371
 }
 
+// Append `value` to list[0 .. *count) for the lanes with `take` set: one atomic per wavefront (ballot +
+// popcount), positions inside the wavefront in lane order.  Every lane of the wavefront must call it.
+// The ORDER of a list built this way depends on which wavefront's atomic lands first, so it differs from
+// run to run; the lane sets, and every chain's values, do not (a chain's trajectory does not depend on the
+// lane that integrates it, and the coordinate sums have a canonical order).
+__device__ __forceinline__ void bk_append(bool take, int32_t value, int32_t* list, uint32_t* count) {
+  const unsigned long long b = __ballot(take);
+  if (b == 0) return;  // wavefront-uniform
+  const int lane = threadIdx.x & (BK_WAVE - 1);
+  const int leader = __ffsll((long long)b) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(b));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  if (take) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = value;
+}
+
+// Start of a draw + the first stage's retry test in one launch (k_dr_begin, then k_dr_retry for every
+// chain: rej = 0, so the test always passes -- drghmc.py:366-371 -- but its uniform is drawn), and the
+// draw's lane counters are zeroed for the appending kernels below.
+template <typename G>
+__global__ __launch_bounds__(64) void k_dr_begin_retry(uint64_t* st, i64 ldr, const double* logp, const double* kin,
+                                                       double* H, double* h, double* rej, uint8_t* alive, double pr,
+                                                       uint32_t* counters, int n_counters, i64 C) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_counters) counters[threadIdx.x] = 0;
+  i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  H[c] = joint(logp[c], kin[c]);
+  h[c] = 0.0;
+  const double r0 = 0.0;
+  rej[c] = r0;
+  G g;
+  g.load(st, ldr, c);
+  double lu = log(bk::next_double(g));
+  g.store(st, ldr, c);
+  double retry = pr * r0;             // drghmc.py:317
+  alive[c] = (lu < retry) ? 1 : 0;    // drghmc.py:370-371
+}
+
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const int32_t* sub, i64 m,
                                                        double* h, uint8_t* live, double* a,
                                                        const uint32_t* n_dev) {
@@ -125,23 +163,31 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob_ghost(const double*
                                                                    const int32_t* sub, double pr,
                                                                    const uint8_t* live, double* a, i64 n,
                                                                    const uint32_t* n_dev, uint8_t* par_live,
-                                                                   double* par_a) {
+                                                                   double* par_a, int32_t* next_idx,
+                                                                   uint32_t* next_count) {
   i64 j = (i64)blockIdx.x * SC_BLOCK + threadIdx.x;
-  if (j >= bk_lanes(n, n_dev)) return;
-  i64 p = sub ? (i64)sub[j] : j;
-  double g;
-  if (live[j]) {
-    g = dr_accept_logprob(H[j], par_H[p], h[j], par_h[p], pr);
-    a[j] = g;
-  } else {
-    g = a[j];  // (-inf: set when one of this lane's own ghosts was accepted with probability one)
+  const bool on = j < bk_lanes(n, n_dev);
+  bool still_live = false;
+  i64 p = 0;
+  if (on) {
+    p = sub ? (i64)sub[j] : j;
+    double g;
+    if (live[j]) {
+      g = dr_accept_logprob(H[j], par_H[p], h[j], par_h[p], pr);
+      a[j] = g;
+    } else {
+      g = a[j];  // (-inf: set when one of this lane's own ghosts was accepted with probability one)
+    }
+    if (g == 0.0) {  // drghmc.py:430-432
+      par_a[p] = -INFINITY;
+      par_live[p] = 0;
+    } else {
+      par_h[p] = par_h[p] + log1p(-exp(g));  // drghmc.py:434-435
+      still_live = true;
+    }
   }
-  if (g == 0.0) {  // drghmc.py:430-432
-    par_a[p] = -INFINITY;
-    par_live[p] = 0;
-  } else {
-    par_h[p] = par_h[p] + log1p(-exp(g));  // drghmc.py:434-435
-  }
+  // the parent lanes that go on to their next ghost (drghmc.py:424): the lane set of that trajectory
+  if (next_idx) bk_append(still_live, (int32_t)p, next_idx, next_count);
 }
 
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, const double* cur_H,
@@ -162,56 +208,50 @@ __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, co
                                                        double* a, const double* H, i64 n,
                                                        double* cur_H, double* cur_h, double* rej,
                                                        uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev,
-                                                       const double* h, const uint8_t* live, double pr) {
+                                                       const double* h, const uint8_t* live, double pr,
+                                                       int32_t* next_idx, uint32_t* next_count) {
   i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
-  if (j >= bk_lanes(n, n_dev)) return;
-  i64 c = cidx ? (i64)cidx[j] : j;
-  G g;
-  g.load(st, ldr, c);
-  double lu = log(bk::next_double(g));
-  g.store(st, ldr, c);
-  if (h && live[j]) a[j] = dr_accept_logprob(H[j], cur_H[c], h[j], cur_h[c], pr);
-  double aj = a[j];
-  if (lu < aj) {  // drghmc.py:378-381
-    accepted[j] = 1;
-    cur_H[c] = H[j];
-    alive[c] = 0;
-  } else {  // drghmc.py:383-384
-    accepted[j] = 0;
-    double r = log1p(-exp(aj));
-    rej[c] = r;
-    cur_h[c] = cur_h[c] + r;
+  const bool on = j < bk_lanes(n, n_dev);
+  bool again = false;
+  i64 c = 0;
+  if (on) {
+    c = cidx ? (i64)cidx[j] : j;
+    G g;
+    g.load(st, ldr, c);
+    double lu = log(bk::next_double(g));
+    if (h && live[j]) a[j] = dr_accept_logprob(H[j], cur_H[c], h[j], cur_h[c], pr);
+    double aj = a[j];
+    if (lu < aj) {  // drghmc.py:378-381
+      accepted[j] = 1;
+      cur_H[c] = H[j];
+      alive[c] = 0;
+    } else {  // drghmc.py:383-384
+      accepted[j] = 0;
+      double r = log1p(-exp(aj));
+      rej[c] = r;
+      cur_h[c] = cur_h[c] + r;
+      if (next_idx) {
+        // the NEXT stage's retry test for this chain (k_dr_retry; drghmc.py:369-371): its uniform is the
+        // next value of the chain's stream, drawn here instead of by a launch of its own
+        double lu2 = log(bk::next_double(g));
+        double retry = pr * r;  // drghmc.py:317 (bool * float)
+        if (lu2 < retry) again = true;
+        else alive[c] = 0;
+      }
+    }
+    g.store(st, ldr, c);
   }
+  // the chains that propose again: the lane set of the next stage
+  if (next_idx) bk_append(again, (int32_t)c, next_idx, next_count);
 }
 
-// lane = chain of the compacted set, blockIdx.y = a block of SCT_ROWS dimensions: the copy of an
-// accepted column is spread over D / SCT_ROWS workgroups (one lane walking all D rows with dependent
-// load -> store pairs took 22 us per launch at D = 101, whatever the number of accepted lanes)
-constexpr int SCT_ROWS = 8;
+// lane = chain of the compacted set, blockIdx.y = a block of BK_SCT_ROWS dimensions (bk_scatter_unit)
 __global__ __launch_bounds__(64) void k_scatter(const uint8_t* mask, const int32_t* idx, i64 n, i64 D,
                                                 double* d0, const double* s0, double* d1, const double* s1,
                                                 double* d2, const double* s2, i64 ldd, i64 lds, double* sd,
                                                 const double* ss, const uint32_t* n_dev) {
-  i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
-  if (j >= bk_lanes(n, n_dev) || !mask[j]) return;
-  i64 g = idx ? (i64)idx[j] : j;
-  if (sd && blockIdx.y == 0) sd[g] = ss[j];
-  const i64 b = (i64)blockIdx.y * SCT_ROWS;
-  double x0[SCT_ROWS], x1[SCT_ROWS], x2[SCT_ROWS];
-#pragma unroll
-  for (int u = 0; u < SCT_ROWS; ++u)
-    if (b + u < D) {
-      x0[u] = s0[(b + u) * lds + j];
-      if (d1) x1[u] = s1[(b + u) * lds + j];
-      if (d2) x2[u] = s2[(b + u) * lds + j];
-    }
-#pragma unroll
-  for (int u = 0; u < SCT_ROWS; ++u)
-    if (b + u < D) {
-      d0[(b + u) * ldd + g] = x0[u];
-      if (d1) d1[(b + u) * ldd + g] = x1[u];
-      if (d2) d2[(b + u) * ldd + g] = x2[u];
-    }
+  bk_scatter_unit(blockIdx.x, blockIdx.y, threadIdx.x, mask, idx, bk_lanes(n, n_dev), D, d0, s0, d1, s1, d2, s2, ldd,
+                  lds, sd, ss);
 }
 
 }  // namespace
@@ -279,16 +319,18 @@ int bk_dr_accept_prob(const double* H, const double* cur_H, const double* h, con
 static int dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, double* a,
                           const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
                           uint8_t* accepted, const uint32_t* n_dev, const double* h, const uint8_t* live, double pr,
-                          void* stream) {
+                          int32_t* next_idx, uint32_t* next_count, void* stream) {
   if (!state || !a || !H || !cur_H || !cur_h || !rej || !alive || !accepted || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   dim3 grid((unsigned)bk_cdiv(n, 64)), block(64);
   if (rng_kind == BK_RNG_PHILOX)
     k_dr_accept_test<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                       cur_h, rej, alive, accepted, n_dev, h, live, pr);
+                                                                       cur_h, rej, alive, accepted, n_dev, h, live, pr,
+                                                                       next_idx, next_count);
   else if (rng_kind == BK_RNG_PCG64)
     k_dr_accept_test<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
-                                                                      cur_h, rej, alive, accepted, n_dev, h, live, pr);
+                                                                      cur_h, rej, alive, accepted, n_dev, h, live, pr,
+                                                                      next_idx, next_count);
   else
     return BK_E_ARG;
   BK_RETURN_LAUNCH_STATUS();
@@ -298,7 +340,7 @@ int bk_dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t*
                       const double* H, int64_t n, double* cur_H, double* cur_h, double* rej, uint8_t* alive,
                       uint8_t* accepted, const uint32_t* n_dev, void* stream) {
   return dr_accept_test(rng_kind, state, ldr, chain_index, const_cast<double*>(a), H, n, cur_H, cur_h, rej, alive,
-                        accepted, n_dev, nullptr, nullptr, 0.0, stream);
+                        accepted, n_dev, nullptr, nullptr, 0.0, nullptr, nullptr, stream);
 }
 
 int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* H,
@@ -307,7 +349,38 @@ int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int
                            const uint32_t* n_dev, void* stream) {
   if (!h || !live) return BK_E_ARG;
   return dr_accept_test(rng_kind, state, ldr, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev, h,
-                        live, prob_retry, stream);
+                        live, prob_retry, nullptr, nullptr, stream);
+}
+
+int bk_dr_accept_prob_test_next(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index, const double* H,
+                                const double* h, const uint8_t* live, double* a, double prob_retry, int64_t n,
+                                double* cur_H, double* cur_h, double* rej, uint8_t* alive, uint8_t* accepted,
+                                const uint32_t* n_dev, int32_t* next_index, uint32_t* next_count, void* stream) {
+  if (!h || !live || !next_index || !next_count || next_index == chain_index) return BK_E_ARG;
+  return dr_accept_test(rng_kind, state, ldr, chain_index, a, H, n, cur_H, cur_h, rej, alive, accepted, n_dev, h,
+                        live, prob_retry, next_index, next_count, stream);
+}
+
+int bk_dr_begin_retry(int rng_kind, uint64_t* state, int64_t ldr, const double* logp, const double* kin,
+                      double* cur_H, double* cur_h, double* rej, uint8_t* alive, double prob_retry,
+                      uint32_t* counters, int64_t n_counters, int64_t C, void* stream) {
+  if (!state || !logp || !kin || !cur_H || !cur_h || !rej || !alive || C < 0 || ldr < C || n_counters < 0 ||
+      n_counters > 64 || (n_counters > 0 && !counters))
+    return BK_E_ARG;
+  if (C == 0) {
+    if (n_counters) return (int)hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), bk_stream(stream));
+    return BK_OK;
+  }
+  dim3 grid((unsigned)bk_cdiv(C, 64)), block(64);
+  if (rng_kind == BK_RNG_PHILOX)
+    k_dr_begin_retry<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, logp, kin, cur_H, cur_h, rej, alive,
+                                                                       prob_retry, counters, (int)n_counters, C);
+  else if (rng_kind == BK_RNG_PCG64)
+    k_dr_begin_retry<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, logp, kin, cur_H, cur_h, rej, alive,
+                                                                      prob_retry, counters, (int)n_counters, C);
+  else
+    return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_dr_accept_prob_ghost(const double* H, const double* parent_H, const double* h, double* parent_h,
@@ -316,7 +389,20 @@ int bk_dr_accept_prob_ghost(const double* H, const double* parent_H, const doubl
   if (!H || !parent_H || !h || !parent_h || !live || !a || !parent_live || !parent_a || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
   k_dr_accept_prob_ghost<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(
-      H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev, parent_live, parent_a);
+      H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev, parent_live, parent_a, nullptr, nullptr);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_accept_prob_ghost_next(const double* H, const double* parent_H, const double* h, double* parent_h,
+                                 const int32_t* sub_index, double prob_retry, const uint8_t* live, double* a, int64_t n,
+                                 const uint32_t* n_dev, uint8_t* parent_live, double* parent_a, int32_t* next_index,
+                                 uint32_t* next_count, void* stream) {
+  if (!H || !parent_H || !h || !parent_h || !live || !a || !parent_live || !parent_a || n < 0 || !next_index ||
+      !next_count || next_index == sub_index)
+    return BK_E_ARG;
+  if (n == 0) return BK_OK;
+  k_dr_accept_prob_ghost<<<dim3((unsigned)bk_cdiv(n, SC_BLOCK)), dim3(SC_BLOCK), 0, bk_stream(stream)>>>(
+      H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev, parent_live, parent_a, next_index, next_count);
   BK_RETURN_LAUNCH_STATUS();
 }
 
@@ -327,7 +413,7 @@ int bk_scatter_columns(const uint8_t* mask, const int32_t* index, int64_t n, int
   if (!mask || !dst0 || !src0 || (dst1 && !src1) || (dst2 && !src2) || (sdst && !ssrc) || n < 0 || D < 0)
     return BK_E_ARG;
   if (n == 0) return BK_OK;
-  k_scatter<<<dim3((unsigned)bk_cdiv(n, 64), (unsigned)bk_cdiv(D > 0 ? D : 1, SCT_ROWS)), dim3(64), 0, bk_stream(stream)>>>(
+  k_scatter<<<dim3((unsigned)bk_cdiv(n, 64), (unsigned)bk_cdiv(D > 0 ? D : 1, BK_SCT_ROWS)), dim3(64), 0, bk_stream(stream)>>>(
       mask, index, n, D, dst0, src0, dst1, src1, dst2, src2, ld_dst, ld_src, sdst, ssrc, n_dev);
   BK_RETURN_LAUNCH_STATUS();
 }

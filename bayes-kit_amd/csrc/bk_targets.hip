@@ -360,10 +360,26 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
-    unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out) {
+    unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out, unsigned traj_blocks,
+    bk_scatter_job job) {
   using G = FunnelLanes<LPC, SL>;
   constexpr int NU = G::NU;
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
+  if (blockIdx.x >= traj_blocks) {
+    // surplus workgroups: the previous stage's scatter (bk_scatter_job), one 64-lane unit per wavefront
+    i64 jn = job.n;
+    if (job.n_dev) {
+      const i64 m = (i64)*job.n_dev;
+      jn = m < jn ? m : jn;
+    }
+    const i64 ux_count = (job.n + 63) / 64;  // (units are laid out for the host-side bound)
+    const i64 unit = ((i64)blockIdx.x - traj_blocks) * FN_WAVES + wave;
+    const i64 ux = unit % ux_count, uy = unit / ux_count;
+    if (uy * BK_SCT_ROWS < job.D)
+      bk_scatter_unit(ux, uy, lane, job.mask, job.index, jn, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
+                      job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc);
+    return;
+  }
   // lanes actually in the set: read from device memory when the host only knows an upper bound
   i64 n = n_host;
   if (n_dev) {
@@ -704,7 +720,7 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
   if (C == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
   if (logp) {
-    if (C % 2 == 0 && ld % 2 == 0 && C >= 2 * BK_WAVE && bk_aligned16(theta) && bk_aligned16(logp) &&
+    if (C % 2 == 0 && ld % 2 == 0 && C * D >= ((i64)1 << 22) && bk_aligned16(theta) && bk_aligned16(logp) &&
         (!grad || bk_aligned16(grad)))
       k_gauss_logp_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam,
                                                                                           C / 2, D);
@@ -840,20 +856,36 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
-                          const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
-                          double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
-                          int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
-                          uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
+int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                              const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                              double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                              int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                              uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
+                              const bk_scatter_job* job_in, void* stream) {
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
   if (D - 1 > FN_MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (H_out && (!h_out || !live_out)) return BK_E_ARG;
   if (ld_out < n) return BK_E_ALIGN;
+  bk_scatter_job job = {};
+  unsigned job_blocks = 0;
+  if (job_in) {
+    job = *job_in;
+    if (!job.mask || !job.dst0 || !job.src0 || (job.dst1 && !job.src1) || (job.dst2 && !job.src2) ||
+        (job.sdst && !job.ssrc) || job.n < 0 || job.D < 0)
+      return BK_E_ARG;
+    if (job.n > 0 && job.D > 0)
+      job_blocks = (unsigned)bk_cdiv(bk_cdiv(job.n, 64) * bk_cdiv(job.D, BK_SCT_ROWS), FN_WAVES);
+  }
   // the kernel addresses a lane's rows with 32-bit byte offsets from wavefront-uniform row bases
   if ((ld_in > ld_out ? ld_in : ld_out) >= ((i64)1 << 32) / (8 * (FN_CLASSES + 1))) return BK_E_ARG;
   if (n == 0) {
+    if (job_blocks) {  // nothing to propose: the job still runs
+      int rc = bk_scatter_columns(job.mask, job.index, job.n, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
+                                  job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc, job.n_dev, stream);
+      if (rc != BK_OK) return rc;
+    }
     if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
     return BK_OK;
   }
@@ -868,13 +900,14 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
     return !e ? 0 : (e[0] == 'n' ? 2 : 1);
   }();
   const bool narrow = forced ? forced == 2 : (n_dev != nullptr || n < 8192);
-  dim3 grid((unsigned)bk_cdiv(n, FN_WAVES * (narrow ? BK_WAVE / 16 : BK_WAVE / 4)));
+  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (narrow ? BK_WAVE / 16 : BK_WAVE / 4));
+  dim3 grid(traj_blocks + job_blocks);
 #define BK_FT(LPC, R, M)                                                                                          \
   k_funnel_traj<LPC, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, \
                                                            rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
                                                            (int)steps, n, D, n_dev, lanes_out,                     \
                                                            reinterpret_cast<unsigned long long*>(lanes_total),    \
-                                                           H_out, h_out, live_out)
+                                                           H_out, h_out, live_out, traj_blocks, job)
 #define BK_FT_ROWS(R)                   \
   do {                                  \
     if (narrow) {                       \
@@ -898,6 +931,17 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
 #undef BK_FT_ROWS
 #undef BK_FT
   BK_RETURN_LAUNCH_STATUS();
+}
+
+
+int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                          const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                          double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                          int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                          uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
+  return bk_dr_proposal_funnel_job(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                                   kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out, lanes_total, H_out, h_out,
+                                   live_out, nullptr, stream);
 }
 
 }  // extern "C"

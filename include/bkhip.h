@@ -233,6 +233,34 @@ int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int
                            double prob_retry, int64_t n, double* cur_H, double* cur_h, double* rej,
                            uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev, void* stream);
 
+/* Start of a draw and the first stage's retry test in one launch: bk_dr_begin, then bk_dr_retry_test for every
+ * chain (drghmc.py:365-371: reject_logp = 0 at the first stage, the test passes, its uniform is drawn all the
+ * same).  Also zeroes `n_counters` (<= 64) lane counters -- the `next_count` words of the two entry points below --
+ * so that a whole draw needs no separate memset. */
+int bk_dr_begin_retry(int rng_kind, uint64_t* state, int64_t ldr, const double* logp, const double* kin,
+                      double* cur_H, double* cur_h, double* rej, uint8_t* alive, double prob_retry,
+                      uint32_t* counters, int64_t n_counters, int64_t C, void* stream);
+
+/* bk_dr_accept_prob_test, then -- for the lanes it rejects -- the NEXT stage's retry test (bk_dr_retry_test: the
+ * chain's next uniform, drghmc.py:369-371) and the compaction of the chains that propose again: chain g is
+ * appended to next_index[0 .. *next_count) (one atomic per wavefront; *next_count must be zero beforehand).  The
+ * list holds the same chains bk_compact_indices would give, in an order that depends on wavefront timing: lane
+ * order carries no meaning (every chain's values are independent of the lane that computes them).
+ * next_index must not be chain_index.  drghmc.py:378-385 and :369-371. */
+int bk_dr_accept_prob_test_next(int rng_kind, uint64_t* state, int64_t ldr, const int32_t* chain_index,
+                                const double* H, const double* h, const uint8_t* live, double* a,
+                                double prob_retry, int64_t n, double* cur_H, double* cur_h, double* rej,
+                                uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev, int32_t* next_index,
+                                uint32_t* next_count, void* stream);
+
+/* bk_dr_accept_prob_ghost, then the parent lanes that are still live -- the lane set of the parent's NEXT ghost
+ * (drghmc.py:424) -- are appended to next_index[0 .. *next_count) as above (instead of a bk_compact_indices
+ * launch over parent_live).  next_index must not be sub_index. */
+int bk_dr_accept_prob_ghost_next(const double* H, const double* parent_H, const double* h, double* parent_h,
+                                 const int32_t* sub_index, double prob_retry, const uint8_t* live, double* a,
+                                 int64_t n, const uint32_t* n_dev, uint8_t* parent_live, double* parent_a,
+                                 int32_t* next_index, uint32_t* next_count, void* stream);
+
 /* bk_dr_accept_prob of a GHOST level (against its parent level's H / h, lanes paired by sub_index) followed
  * by bk_dr_ghost_update of the parent (parent_h, parent_live, parent_a), in one launch: every ghost lane has
  * exactly one parent lane.  drghmc.py:426-446. */
@@ -390,6 +418,32 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
                           int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
                           double* H_out, double* h_out, uint8_t* live_out, void* stream);
+
+/* The arguments of one bk_scatter_columns call, as a job a trajectory launch can carry along. */
+typedef struct bk_scatter_job {
+  const uint8_t* mask;
+  const int32_t* index;
+  int64_t n, D;
+  double* dst0; const double* src0;
+  double* dst1; const double* src1;
+  double* dst2; const double* src2;
+  int64_t ld_dst, ld_src;
+  double* sdst; const double* ssrc;
+  const uint32_t* n_dev;
+} bk_scatter_job;
+
+/* bk_dr_proposal_funnel with a scatter job (may be NULL) run by surplus workgroups of the SAME launch: the
+ * previous stage's accepted columns move into the chains' current point (drghmc.py:379-381) while this stage's
+ * trajectories -- a sparse, latency-bound lane set -- integrate.  The caller guarantees that the job and the
+ * proposal touch disjoint memory: the job writes columns of accepted chains and reads the previous stage's
+ * proposal buffers, the proposal reads columns of rejected chains and writes its own buffers. */
+int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in,
+                          int64_t ld_in, const int32_t* src_index, double* theta_out,
+                          double* rho_out, double* grad_out, double* logp_out, double* kin_out,
+                          int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
+                          int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
+                          double* H_out, double* h_out, uint8_t* live_out, const bk_scatter_job* job,
+                              void* stream);
 
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix

@@ -312,7 +312,15 @@ class FakeOps:
         return n if n_dev is None else min(int(n), int(n_dev[0]))
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None):
+        # a scatter job runs BESIDE the trajectories on the device (disjoint memory): do it afterwards here, so
+        # that a job which overlapped the proposal's inputs or outputs would be noticed
+        if job is not None:
+            try:
+                return self.dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
+                                               logp_out, kin_out, metric, h, steps, n_dev, lanes_out, lanes_total, level)
+            finally:
+                self.scatter_columns(*job["args"], **job["kw"])
         n = self._lanes(theta_out.shape[1], n_dev)
         if lanes_out is not None:
             lanes_out[0] = n
@@ -560,6 +568,48 @@ class FakeOps:
         # (every parent lane has one ghost lane)
         self.dr_accept_prob(H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, n_dev)
         self.dr_ghost_update(a, sub_index, n, parent_h, parent_live, parent_a, n_dev)
+
+    # The appending forms build their lists in REVERSE lane order here: on the device the order depends on
+    # wavefront timing, and nothing may depend on it.
+    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters):
+        self.dr_begin(logp, kin, cur_H, cur_h, rej, alive)
+        self.dr_retry_test(kind, state, rej, prob_retry, alive)
+        if counters is not None:
+            counters.zero_()
+
+    def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
+                                 accepted, next_index, next_count, n_dev=None):
+        assert int(next_count[0]) == 0
+        self.dr_accept_prob_test(kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
+                                 accepted, n_dev)
+        again = []
+        for j in range(self._lanes(n, n_dev)):
+            if accepted[j]:
+                continue
+            c = j if chain_index is None else int(chain_index[j])
+            g = self._gen(kind, state, c)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                lu = np.log(g.uniform())
+                if lu < prob_retry * rej.numpy()[c]:
+                    again.append(c)
+                else:
+                    alive[c] = 0
+            self._put(kind, state, c, g)
+        next_index.numpy()[: len(again)] = again[::-1]
+        next_count.numpy()[0] = len(again)
+
+    def dr_accept_prob_ghost_next(self, H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, parent_live,
+                                  parent_a, next_index, next_count, n_dev=None):
+        assert int(next_count[0]) == 0
+        self.dr_accept_prob_ghost(H, parent_H, h, parent_h, sub_index, prob_retry, live, a, n, parent_live, parent_a, n_dev)
+        m = self._lanes(n, n_dev)
+        keep = [j if sub_index is None else int(sub_index[j]) for j in range(m)]
+        keep = [p for p in keep if parent_live[p]]
+        next_index.numpy()[: len(keep)] = keep[::-1]
+        next_count.numpy()[0] = len(keep)
+
+    def scatter_job(self, *args, **kw):
+        return {"args": args, "kw": kw}
 
     def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         n = self._lanes(n, n_dev)

@@ -65,7 +65,9 @@ def main():
         assert torch.equal(rrec.series[0, :N, first:first + n], rec.series[0, :N])  # my shard, bit for bit
     dist.barrier()
     dist.destroy_process_group()
-    print(f"rank {rank} ok backend {backend} gpu {local}", flush=True)
+    import json
+
+    print(json.dumps({"rank": rank, "ok": True, "backend": backend, "gpu": local}), flush=True)
 
 
 if __name__ == "__main__":

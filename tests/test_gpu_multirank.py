@@ -25,7 +25,8 @@ def _run_ranks(backend, world=2):
     rc = bench.launch_ranks(world, [sys.executable, os.path.join(ROOT, "tests", "rank_worker_gpu.py")],
                             {"BK_TEST_BACKEND": backend, "OMP_NUM_THREADS": "1"}, timeout=240, out=buf)
     assert rc == 0, buf.getvalue()
-    assert f"rank 0 ok backend {backend}" in buf.getvalue()
+    r0 = json.loads(buf.getvalue().strip().splitlines()[-1])  # (the launcher relays rank 0's JSON lines)
+    assert r0["ok"] and r0["rank"] == 0 and r0["backend"] == backend
 
 
 def test_two_ranks_share_one_gpu_over_gloo():

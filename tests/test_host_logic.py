@@ -419,3 +419,26 @@ def test_checkpoint_of_sampler_moments_recorder_and_draw_store(tmp_path):
     from tests.diag_parity import check_checkpoint_of_sampler_and_diagnostics
 
     check_checkpoint_of_sampler_and_diagnostics(FakeOps(), str(tmp_path), chains=6, D=5, draws=24, at=11)
+
+
+@pytest.mark.parametrize("K", [2, 3, 4])
+def test_drghmc_device_side_lists_equal_host_sized_launches(K):
+    """Lane lists built by the appending entry points (bk_dr_accept_prob_test_next / _ghost_next: here in
+    REVERSE lane order, on the device in wavefront-timing order) against stable compaction sized by host
+    reads: same draws, momenta, stream positions and lane sets -- lane order carries no meaning.  K = 4
+    exercises the alternating list buffers of a level (ghost lists two deep)."""
+    sizes, counts = [0.5, 0.2, 0.08, 0.03][:K], [2, 3, 5, 7][:K]
+    ops_a, ops_b = FakeOps(), FakeOps()
+    a = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_a), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=False, ops=ops_a)
+    b = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_b), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True, ops=ops_b)
+    assert b._dev_counts and not a._dev_counts
+    seen = set()
+    for n in range(10):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert np.array_equal(ta.numpy(), tb.numpy()) and np.array_equal(la.numpy(), lb.numpy()), (K, n)
+        assert a.last_stage_lanes == b.last_stage_lanes and a.last_lane_steps == b.last_lane_steps
+        seen.update(t for t, _ in a.last_stage_lanes)
+    assert np.array_equal(a._rho.numpy(), b._rho.numpy())
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    assert len(seen) >= min(4, 2 ** (K - 1))
