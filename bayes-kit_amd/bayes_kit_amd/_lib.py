@@ -65,7 +65,7 @@ SIGNATURES = {
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
-    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P],
+    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
@@ -95,6 +95,12 @@ _RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sor
 
 class BkHipError(RuntimeError):
     pass
+
+
+class GhostLink(ctypes.Structure):
+    """bk_ghost_link of include/bkhip.h: what a ghost proposal without ghosts of its own owes its parent level."""
+    _fields_ = [("parent_H", P), ("parent_h", P), ("parent_live", P), ("parent_a", P), ("a_out", P),
+                ("prob_retry", F), ("next_index", P), ("next_count", P)]
 
 
 class ScatterJob(ctypes.Structure):
@@ -441,10 +447,18 @@ class Ops:
                           ptr(d[1]) or None, ptr(s_[1]) or None, ptr(d[2]) or None, ptr(s_[2]) or None, _ld(dsts[0]),
                           _ld(srcs[0]), ptr(sdst) or None, ptr(ssrc) or None, ptr(n_dev) or None)
 
+    def ghost_link(self, parent_H, parent_h, parent_live, parent_a, a_out, prob_retry, next_index=None, next_count=None):
+        """dr_accept_prob_ghost[_next] of a ghost level without ghosts of its own, as a part of its proposal
+        launch (dr_proposal_funnel(ghost=...))."""
+        return GhostLink(ptr(parent_H), ptr(parent_h), ptr(parent_live), ptr(parent_a), ptr(a_out), float(prob_retry),
+                         ptr(next_index) or None, ptr(next_count) or None)
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
+                           ghost=None):
         """level: optional (H, h, live) tensors of the destination level -- its bk_dr_level_begin is then
-        done by the same launch.  job: optional scatter_job(...) run by surplus workgroups of the launch."""
+        done by the same launch.  job: optional scatter_job(...) run by surplus workgroups of the launch.
+        ghost: optional ghost_link(...), the level's accept probability + parent update in the same launch."""
         D, n = theta_out.shape
         H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
@@ -454,10 +468,11 @@ class Ops:
         args = (ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                 ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                 h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live))
-        if job is None:
+        if job is None and ghost is None:
             self._call("bk_dr_proposal_funnel", *args, self._s())
         else:
-            self._call("bk_dr_proposal_funnel_job", *args, ctypes.byref(job), self._s())
+            self._call("bk_dr_proposal_funnel_job", *args, None if job is None else ctypes.byref(job),
+                       None if ghost is None else ctypes.byref(ghost), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape

@@ -382,9 +382,10 @@ class DrGhmcDiag(ManyChainSampler):
         return self._draw_out(self._theta_dc, self._cur_H)
 
     # -- the same draw with lane counts on the device: a fixed launch sequence ----------------------------
-    def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None):
+    def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None, ghost=None):
         """Proposal k from lanes idx (count n_dev; None = all C chains) of `src` into level lvl; `job`: a
-        scatter job the launch carries along."""
+        scatter job the launch carries along; `ghost`: the level's accept probability + parent update, done by
+        the same launch (a ghost without ghosts of its own)."""
         h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
         dst = self._levels[lvl]
         slot = self._slot
@@ -394,7 +395,7 @@ class DrGhmcDiag(ManyChainSampler):
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
                                         lanes_out=self._slot_lanes[slot:slot + 1],
                                         lanes_total=self._slot_lanes_total[slot:slot + 1],
-                                        level=(dst.H, dst.h, dst.live), job=job)
+                                        level=(dst.H, dst.h, dst.live), job=job, ghost=ghost)
         assert ok
 
     def _new_list(self):
@@ -422,8 +423,15 @@ class DrGhmcDiag(ManyChainSampler):
             if i + 1 < k:  # the list ghost i + 1 will run over, built while ghost i's result is applied
                 buf = nxt.idx if (i % 2 == 0) else nxt.idx_alt
                 following = (buf, self._new_list())
-            self._proposal_dev(P, gsub, m_dev, i, lvl + 1)
-            self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following)
+            if i == 0:
+                # a ghost of the first proposal kind has no ghosts of its own: its acceptance probability and the
+                # update of this level (:426-446) are done by its proposal's launch
+                pr = 1.0 if self._prob_retry else 0.0
+                link = ops.ghost_link(P.H, P.h, P.live, P.a, nxt.a, pr, *(following or (None, None)))
+                self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=link)
+            else:
+                self._proposal_dev(P, gsub, m_dev, i, lvl + 1)
+                self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following)
             if following is not None:
                 gsub, m_dev = following
         if parent is not None:

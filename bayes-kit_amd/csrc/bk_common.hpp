@@ -61,3 +61,28 @@ __device__ __forceinline__ void bk_scatter_unit(i64 ux, i64 uy, int lane, const 
       if (d2) d2[(b + u) * ldd + g] = x2[u];
     }
 }
+
+// ---- delayed rejection: helpers shared by bk_dr.hip and the trajectory kernel -----------------------------
+// Append `value` to list[0 .. *count) for the lanes with `take` set: one atomic per wavefront (ballot +
+// popcount), positions inside the wavefront in lane order.  Every lane of the wavefront must call it.
+// The ORDER of a list built this way depends on which wavefront's atomic lands first, so it differs from
+// run to run; the lane sets, and every chain's values, do not (a chain's trajectory does not depend on the
+// lane that integrates it, and the coordinate sums have a canonical order).
+__device__ __forceinline__ void bk_append(bool take, int32_t value, int32_t* list, uint32_t* count) {
+  const unsigned long long b = __ballot(take);
+  if (b == 0) return;  // wavefront-uniform
+  const int lane = threadIdx.x & (BK_WAVE - 1);
+  const int leader = __ffsll((long long)b) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(b));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+  if (take) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = value;
+}
+
+
+// the acceptance log-probability of lane j against its current point p (drghmc.py:441-446)
+__device__ __forceinline__ double dr_accept_logprob(double Hj, double cH, double ph, double ch, double pr) {
+  const double frac = ((Hj - cH) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
+  return frac < 0.0 ? frac : 0.0;                                      // min(0, frac), :446
+}
+

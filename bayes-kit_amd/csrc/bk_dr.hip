@@ -97,22 +97,6 @@ __global__ __launch_bounds__(64) void k_dr_retry(uint64_t* st, i64 ldr, const do
   if (!(lu < retry)) alive[c] = 0;  // drghmc.py:370-371
 }
 
-// Append `value` to list[0 .. *count) for the lanes with `take` set: one atomic per wavefront (ballot +
-// popcount), positions inside the wavefront in lane order.  Every lane of the wavefront must call it.
-// The ORDER of a list built this way depends on which wavefront's atomic lands first, so it differs from
-// run to run; the lane sets, and every chain's values, do not (a chain's trajectory does not depend on the
-// lane that integrates it, and the coordinate sums have a canonical order).
-__device__ __forceinline__ void bk_append(bool take, int32_t value, int32_t* list, uint32_t* count) {
-  const unsigned long long b = __ballot(take);
-  if (b == 0) return;  // wavefront-uniform
-  const int lane = threadIdx.x & (BK_WAVE - 1);
-  const int leader = __ffsll((long long)b) - 1;
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(b));
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-  if (take) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = value;
-}
-
 // Start of a draw + the first stage's retry test in one launch (k_dr_begin, then k_dr_retry for every
 // chain: rej = 0, so the test always passes -- drghmc.py:366-371 -- but its uniform is drawn), and the
 // draw's lane counters are zeroed for the appending kernels below.
@@ -148,12 +132,6 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_ghost(const double* ga, const i
   } else {
     h[p] = h[p] + log1p(-exp(g));  // drghmc.py:434-435
   }
-}
-
-// the acceptance log-probability of lane j against its current point p (drghmc.py:441-446)
-__device__ __forceinline__ double dr_accept_logprob(double Hj, double cH, double ph, double ch, double pr) {
-  const double frac = ((Hj - cH) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445
-  return frac < 0.0 ? frac : 0.0;                                      // min(0, frac), :446
 }
 
 // accept probability of a GHOST level followed by the update of its parent level (k_dr_accept_prob +

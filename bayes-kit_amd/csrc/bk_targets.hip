@@ -288,9 +288,17 @@ __device__ __forceinline__ double bk_dpp_f64(double old, double src) {
 }
 constexpr int BK_DPP_ROW_SHL = 0x100;  // + n: lane i reads lane i + n of its row
 constexpr int BK_DPP_ROW_SHR = 0x110;  // + n: lane i reads lane i - n of its row
+// the same for controls under which every lane that matters has a source lane: no `old` operand, so no copy
+// of the source in front of the move (lanes without a source read 0)
+template <int CTRL>
+__device__ __forceinline__ double bk_dpp_f64_all(double src) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 template <int K>
 __device__ __forceinline__ double bk_quad_bcast(double x) {  // lane K of every quad, to the whole quad
-  return bk_dpp_f64<K * 0x55, 0xF, 0xF>(x, x);
+  return bk_dpp_f64_all<K * 0x55>(x);
 }
 
 //   LPC = 4 : p = lane % 4 is the class GROUP; register slot u = k*SL + i holds class p + 4k, slot i.
@@ -320,9 +328,9 @@ __device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
   } else {
     // lane p of the row holds cs[p]; in lanes 0..3: q[p] = ((cs[p] + cs[p+4]) + cs[p+8]) + cs[p+12]
     // (the other twelve lanes compute something nobody reads)
-    const double b = bk_dpp_f64<BK_DPP_ROW_SHL + 4, 0xF, 0xF>(cs[0], cs[0]);
-    const double c = bk_dpp_f64<BK_DPP_ROW_SHL + 8, 0xF, 0xF>(cs[0], cs[0]);
-    const double d = bk_dpp_f64<BK_DPP_ROW_SHL + 12, 0xF, 0xF>(cs[0], cs[0]);
+    const double b = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[0]);
+    const double c = bk_dpp_f64_all<BK_DPP_ROW_SHL + 8>(cs[0]);
+    const double d = bk_dpp_f64_all<BK_DPP_ROW_SHL + 12>(cs[0]);
     q = ((cs[0] + b) + c) + d;
   }
   // lane p of the quad holds q[p]
@@ -355,15 +363,25 @@ __device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
 // LPC: lanes per chain (above); SL = slots per class = ceil((D-1)/16) exactly; HM = a metric is given.
 // All compile-time: with generic sizes and a run-time metric flag the kernel needed 330 registers (one
 // wavefront per SIMD, AGPR spills).
+// LPC_ARG = 4 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows --
+// sets of FN_AUTO_WIDE lanes and more take 4 lanes per chain (69 cycles of a SIMD per chain-step instead of
+// 145: above ~8,000 lanes the 16-lane form has two wavefronts on every SIMD and costs more than it saves),
+// smaller ones 16 lanes per chain.  The grid is sized for the 16-lane form of the bound n_host.
+constexpr i64 FN_AUTO_WIDE = 8192;
 template <int LPC, int SL, bool HM>
+__device__ __forceinline__ void funnel_traj_body(
+    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
+    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
+    const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
+    const bk_ghost_link& ghost, int lane, int wave);
+
+template <int LPC_ARG, int SL, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
     unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out, unsigned traj_blocks,
-    bk_scatter_job job) {
-  using G = FunnelLanes<LPC, SL>;
-  constexpr int NU = G::NU;
+    bk_scatter_job job, bk_ghost_link ghost) {
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
   if (blockIdx.x >= traj_blocks) {
     // surplus workgroups: the previous stage's scatter (bk_scatter_job), one 64-lane unit per wavefront
@@ -390,6 +408,22 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     if (lanes_out) *lanes_out = (uint32_t)n;
     if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
   }
+#define BK_FT_BODY(L)                                                                                              \
+  funnel_traj_body<L, SL, HM>(th_in, rho_in, g_in, ld_in, idx, th_out, rho_out, g_out, logp_out, kin_out, ld_out, \
+                              metric, h, steps, n, D, H_out, hh_out, live_out, ghost, lane, wave)
+  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= FN_AUTO_WIDE)) BK_FT_BODY(4);
+  else BK_FT_BODY(16);
+#undef BK_FT_BODY
+}
+
+template <int LPC, int SL, bool HM>
+__device__ __forceinline__ void funnel_traj_body(
+    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
+    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
+    const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
+    const bk_ghost_link& ghost, int lane, int wave) {
+  using G = FunnelLanes<LPC, SL>;
+  constexpr int NU = G::NU;
   const i64 j0 = ((i64)blockIdx.x * FN_WAVES + wave) * G::CHAINS;  // first chain of this wavefront
   if (j0 >= n) return;  // whole wavefront past the set (uniform; the wavefronts of a workgroup are independent)
   const int pos = lane & (LPC - 1);
@@ -501,6 +535,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   }
   BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
   double ksum = funnel_reduce_lanes<LPC>(cs);
+  bool parent_goes_on = false;
   if (writer) {
     double rr = -rv;
     double mr = hm ? mv * rr : rr;
@@ -512,11 +547,28 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
       // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
       // H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0, live = 1
       const double potential = -logp_j;
-      H_out[j] = -(potential + kin);
+      const double Hj = -(potential + kin);
+      H_out[j] = Hj;
       hh_out[j] = 0.0;
       live_out[j] = 1;
+      if (ghost.parent_H) {
+        // a ghost with no ghosts of its own: its acceptance probability against the parent lane it came from
+        // and the parent's update (bk_dr_accept_prob_ghost; drghmc.py:426-446), here instead of in a launch of
+        // their own.  One ghost lane per parent lane: nobody else touches lane `src` of the parent level.
+        const double g = dr_accept_logprob(Hj, ghost.parent_H[src], 0.0, ghost.parent_h[src], ghost.prob_retry);
+        ghost.a_out[j] = g;
+        if (g == 0.0) {  // drghmc.py:430-432
+          ghost.parent_a[src] = -INFINITY;
+          ghost.parent_live[src] = 0;
+        } else {
+          ghost.parent_h[src] = ghost.parent_h[src] + log1p(-exp(g));  // drghmc.py:434-435
+          parent_goes_on = true;
+        }
+      }
     }
   }
+  // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
+  if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
 #undef BK_FL_IN
 #undef BK_FL_OUT
 #undef BK_FL_OK
@@ -861,13 +913,20 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                               double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
                               int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
                               uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
-                              const bk_scatter_job* job_in, void* stream) {
+                              const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, void* stream) {
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
   if (D - 1 > FN_MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
   if (H_out && (!h_out || !live_out)) return BK_E_ARG;
   if (ld_out < n) return BK_E_ALIGN;
+  bk_ghost_link ghost = {};
+  if (ghost_in) {
+    ghost = *ghost_in;
+    if (!H_out || !ghost.parent_H || !ghost.parent_h || !ghost.parent_live || !ghost.parent_a || !ghost.a_out ||
+        (ghost.next_index && (!ghost.next_count || ghost.next_index == src_index)))
+      return BK_E_ARG;
+  }
   bk_scatter_job job = {};
   unsigned job_blocks = 0;
   if (job_in) {
@@ -891,31 +950,35 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
   }
   const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
   hipStream_t s = bk_stream(stream);
-  // Geometry.  A set that is small, or whose size only the device knows (every set after the first
-  // stage: a few per cent of the chains) -> 16 lanes per chain, 16 chains per workgroup; a set known to be
-  // large -> 4 lanes per chain, 64 chains per workgroup.  Same values either way.
+  // Geometry.  A set known to be small -> 16 lanes per chain, 16 chains per workgroup; known to be large -> 4
+  // lanes per chain, 64 chains per workgroup; a set whose size only the device knows (every set after the first
+  // stage) -> decided by the kernel from *n_dev when the bound allows a large one.  Same values either way.
   // BK_FUNNEL_GEOMETRY=wide|narrow overrides (wide = 4 lanes per chain).
   static const int forced = []() {
     const char* e = getenv("BK_FUNNEL_GEOMETRY");
     return !e ? 0 : (e[0] == 'n' ? 2 : 1);
   }();
-  const bool narrow = forced ? forced == 2 : (n_dev != nullptr || n < 8192);
-  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (narrow ? BK_WAVE / 16 : BK_WAVE / 4));
+  // 16: 16 lanes per chain; 4: 4 lanes per chain; 0: the kernel decides from *n_dev
+  const int geo = forced ? (forced == 2 ? 16 : 4) : (n_dev != nullptr ? (n >= FN_AUTO_WIDE ? 0 : 16) : (n < FN_AUTO_WIDE ? 16 : 4));
+  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (geo == 4 ? BK_WAVE / 4 : BK_WAVE / 16));
   dim3 grid(traj_blocks + job_blocks);
 #define BK_FT(LPC, R, M)                                                                                          \
   k_funnel_traj<LPC, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, \
                                                            rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
                                                            (int)steps, n, D, n_dev, lanes_out,                     \
                                                            reinterpret_cast<unsigned long long*>(lanes_total),    \
-                                                           H_out, h_out, live_out, traj_blocks, job)
+                                                           H_out, h_out, live_out, traj_blocks, job, ghost)
 #define BK_FT_ROWS(R)                   \
   do {                                  \
-    if (narrow) {                       \
+    if (geo == 16) {                    \
       if (metric) BK_FT(16, R, true);   \
       else BK_FT(16, R, false);         \
-    } else {                            \
+    } else if (geo == 4) {              \
       if (metric) BK_FT(4, R, true);    \
       else BK_FT(4, R, false);          \
+    } else {                            \
+      if (metric) BK_FT(0, R, true);    \
+      else BK_FT(0, R, false);          \
     }                                   \
   } while (0)
   switch (need < 1 ? 1 : need) {  // slots per class, exactly: only a class's last slot can run past D
@@ -941,7 +1004,7 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
                           uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
   return bk_dr_proposal_funnel_job(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
                                    kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out, lanes_total, H_out, h_out,
-                                   live_out, nullptr, stream);
+                                   live_out, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

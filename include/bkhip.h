@@ -432,18 +432,34 @@ typedef struct bk_scatter_job {
   const uint32_t* n_dev;
 } bk_scatter_job;
 
+/* What a GHOST proposal without ghosts of its own (the first proposal kind: drghmc.py:424 with k = 0) owes its
+ * parent level, so that the proposal's launch can do bk_dr_accept_prob_ghost[_next] itself: lane j's parent lane is
+ * src_index[j] (the lane it was gathered from).  a_out: the ghost level's `a`; next_index / next_count may be NULL. */
+typedef struct bk_ghost_link {
+  const double* parent_H;
+  double* parent_h;
+  uint8_t* parent_live;
+  double* parent_a;
+  double* a_out;
+  double prob_retry;
+  int32_t* next_index;
+  uint32_t* next_count;
+} bk_ghost_link;
+
 /* bk_dr_proposal_funnel with a scatter job (may be NULL) run by surplus workgroups of the SAME launch: the
  * previous stage's accepted columns move into the chains' current point (drghmc.py:379-381) while this stage's
  * trajectories -- a sparse, latency-bound lane set -- integrate.  The caller guarantees that the job and the
  * proposal touch disjoint memory: the job writes columns of accepted chains and reads the previous stage's
- * proposal buffers, the proposal reads columns of rejected chains and writes its own buffers. */
+ * proposal buffers, the proposal reads columns of rejected chains and writes its own buffers.
+ * ghost (may be NULL; needs H_out): the launch also evaluates each produced lane's acceptance probability against
+ * its parent lane and applies it to the parent (bk_ghost_link): one launch instead of two per such ghost. */
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
                           int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
                           double* H_out, double* h_out, uint8_t* live_out, const bk_scatter_job* job,
-                              void* stream);
+                              const bk_ghost_link* ghost, void* stream);
 
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix

@@ -312,15 +312,27 @@ class FakeOps:
         return n if n_dev is None else min(int(n), int(n_dev[0]))
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None):
+                           kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
+                           ghost=None):
         # a scatter job runs BESIDE the trajectories on the device (disjoint memory): do it afterwards here, so
         # that a job which overlapped the proposal's inputs or outputs would be noticed
-        if job is not None:
+        if job is not None or ghost is not None:
             try:
-                return self.dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
-                                               logp_out, kin_out, metric, h, steps, n_dev, lanes_out, lanes_total, level)
+                self.dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
+                                        logp_out, kin_out, metric, h, steps, n_dev, lanes_out, lanes_total, level)
+                if ghost is not None:
+                    gl = ghost
+                    n_l = theta_out.shape[1]
+                    args = (level[0], gl["parent_H"], level[1], gl["parent_h"], src_index, gl["prob_retry"], level[2],
+                            gl["a_out"], n_l, gl["parent_live"], gl["parent_a"])
+                    if gl["next_index"] is None:
+                        self.dr_accept_prob_ghost(*args, n_dev=n_dev)
+                    else:
+                        self.dr_accept_prob_ghost_next(*args, gl["next_index"], gl["next_count"], n_dev=n_dev)
+                return
             finally:
-                self.scatter_columns(*job["args"], **job["kw"])
+                if job is not None:
+                    self.scatter_columns(*job["args"], **job["kw"])
         n = self._lanes(theta_out.shape[1], n_dev)
         if lanes_out is not None:
             lanes_out[0] = n
@@ -610,6 +622,10 @@ class FakeOps:
 
     def scatter_job(self, *args, **kw):
         return {"args": args, "kw": kw}
+
+    def ghost_link(self, parent_H, parent_h, parent_live, parent_a, a_out, prob_retry, next_index=None, next_count=None):
+        return dict(parent_H=parent_H, parent_h=parent_h, parent_live=parent_live, parent_a=parent_a, a_out=a_out,
+                    prob_retry=prob_retry, next_index=next_index, next_count=next_count)
 
     def scatter_columns(self, mask, index, n, dsts, srcs, sdst=None, ssrc=None, n_dev=None):
         n = self._lanes(n, n_dev)
