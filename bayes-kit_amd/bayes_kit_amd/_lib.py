@@ -75,6 +75,7 @@ SIGNATURES = {
     "bk_gather_columns": [P, P, I, P, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
+    "bk_record_series": [P, I, P, I, P, P, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
     "bk_end_pos_pairs": [P, I, I, P, I, P],
@@ -522,6 +523,13 @@ class Ops:
         ld = _ld(theta)
         assert _ld(mean) == ld and _ld(m2) == ld
         self._call("bk_welford_update", ptr(mean), ptr(m2), ptr(theta), ld, n, C, D, self._s())
+
+    def record_series(self, theta, dims, logp, series, row):
+        """series[k, row, :] = theta[dims[k], :] (k < K), series[K, row, :] = logp: one launch."""
+        D, C = theta.shape
+        assert series.is_contiguous() and series.shape[2] == C
+        self._call("bk_record_series", ptr(theta), _ld(theta), ptr(dims), 0 if dims is None else dims.numel(), ptr(logp),
+                   ptr(series), series.shape[1], row, C, self._s())
 
     def rhat_partials(self, mean, m2, n, center, out):
         D, C = mean.shape

@@ -148,16 +148,26 @@ class DrawRecorder:
         self.with_logp = bool(with_logp)
         K = len(self.dims) + (1 if with_logp else 0)
         self.series = torch.empty((K, int(capacity), int(chains)), dtype=torch.float64, device=self._ops.device)
+        self._dims_dev = torch.tensor(self.dims, dtype=torch.int32, device=self._ops.device)
         self.n = 0
 
     def record(self, theta, logp=None) -> None:
-        """theta: the (C, D) draw returned by ``sample()``; logp: its (C,) log density."""
+        """theta: the (C, D) draw returned by ``sample()`` (or the [D, C] buffer behind it); logp: its (C,) log
+        density.  One launch (bk_record_series) for all tracked series."""
         if self.n >= self.series.shape[1]:
             raise IndexError("DrawRecorder is full")
-        for k, d in enumerate(self.dims):
-            self.series[k, self.n].copy_(theta[:, d])
+        C = self.series.shape[2]
+        t = theta.t() if (theta.dim() == 2 and theta.shape[0] == C and (theta.shape[1] != C or theta.stride(0) == 1)) else theta
+        lp = None
         if self.with_logp:
-            self.series[-1, self.n].copy_(logp)
+            lp = logp if (logp.dtype == torch.float64 and logp.is_contiguous()) else logp.to(torch.float64).contiguous()
+        if t.dim() == 2 and t.shape[1] == C and (C == 1 or t.stride(1) == 1) and t.dtype == torch.float64:
+            self._ops.record_series(t, self._dims_dev, lp, self.series, self.n)
+        else:  # a draw in some other layout: one strided copy per series
+            for k, d in enumerate(self.dims):
+                self.series[k, self.n].copy_(theta[:, d])
+            if self.with_logp:
+                self.series[-1, self.n].copy_(logp)
         self.n += 1
 
     def names(self):

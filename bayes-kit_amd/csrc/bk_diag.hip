@@ -417,6 +417,18 @@ __global__ __launch_bounds__(256) void k_rank_normalize(const double* rank, doub
   out[i] = bk_ndtri((rank[i] - 0.325) / (S - 0.25));
 }
 
+// ---- tracked series of a draw recorder ---------------------------------------------------------------------
+// series[k][row][c] = theta[dims[k]][c] for k < K, series[K][row][c] = logp[c] (if given): one launch per draw
+// instead of one strided copy per tracked coordinate.
+__global__ __launch_bounds__(256) void k_record_series(const double* theta, i64 ld, const int32_t* dims, int K,
+                                                       const double* logp, double* series, i64 cap, i64 row, i64 C) {
+  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
+  const int k = blockIdx.y;
+  if (c >= C) return;
+  const double v = k < K ? theta[(i64)dims[k] * ld + c] : logp[c];
+  series[((i64)k * cap + row) * C + c] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -539,6 +551,18 @@ int bk_ess(const double* x, int64_t ld, int64_t N, int estimator, double* ess_ou
   if (r == 0)
     k_ess<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(x, ld, N, estimator,
                                                                                        ess_out, iat_out, C);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_record_series(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
+                     double* series, int64_t capacity, int64_t row, int64_t C, void* stream) {
+  if (!theta || !series || (K > 0 && !dims) || K < 0 || capacity < 1 || row < 0 || row >= capacity || C < 0)
+    return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  const int rows = (int)K + (logp ? 1 : 0);
+  if (C == 0 || rows == 0) return BK_OK;
+  k_record_series<<<dim3((unsigned)bk_cdiv(C, 256), (unsigned)rows), dim3(256), 0, bk_stream(stream)>>>(
+      theta, ld, dims, (int)K, logp, series, capacity, row, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 

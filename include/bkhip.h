@@ -518,6 +518,12 @@ int bk_relayout(const double* src, int64_t lds_d, int64_t lds_c, double* dst, in
 int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n,
                       int64_t C, int64_t D, void* stream);
 
+/* Draw storage for ess / rhat post-processing: row `row` of the K (+1) tracked series,
+ * series[k][row][c] = theta[dims[k]][c] (k < K) and series[K][row][c] = logp[c] (logp may be NULL); series is
+ * [K (+1)][capacity][C], chain-contiguous -- the [N, C] layout bk_ess / bk_chain_mean_var consume.  dims: device. */
+int bk_record_series(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
+                     double* series, int64_t capacity, int64_t row, int64_t C, void* stream);
+
 /* Per-dimension partial sums over this rank's C chains for R-hat (rhat.py:163-171):
  * out[0*D + d] = sum_c mean ; out[1*D + d] = sum_c var_c (var_c = m2/(n-1)).
  * With `center` != NULL also out[2*D + d] = sum_c (mean - center[d])^2  (second pass of

@@ -620,6 +620,12 @@ class FakeOps:
         next_index.numpy()[: len(keep)] = keep[::-1]
         next_count.numpy()[0] = len(keep)
 
+    def record_series(self, theta, dims, logp, series, row):
+        for k, d in enumerate([] if dims is None else dims.tolist()):
+            series[k, row].copy_(theta[d])
+        if logp is not None:
+            series[-1, row].copy_(logp)
+
     def scatter_job(self, *args, **kw):
         return {"args": args, "kw": kw}
 
