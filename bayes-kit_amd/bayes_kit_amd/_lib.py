@@ -56,6 +56,7 @@ SIGNATURES = {
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
     "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P, P],
+    "bk_normals_chain_major_bg": [c_int, P, I, P, I, I, I, P, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_mala_step_supported": [I, I, I],
     "bk_mala_step": [P, P, P, P, P, I, P, P, P, P, I, F, F, P, P, P, I, I, P],
@@ -365,14 +366,19 @@ class Ops:
         self._call("bk_mala_propose_from_normals", ptr(theta), ptr(grad), ptr(z), z.stride(0), z.stride(1),
                    ptr(theta_prop), ld, eps, sqrt2eps, C, D, self._s())
 
-    def normals_chain_major(self, kind, state, zt, D, snapshot=None):
+    def normals_chain_major(self, kind, state, zt, D, snapshot=None, max_workgroups=0):
         """zt[c, :D] = the next D standard normals of chain c; `snapshot` (optional, a table like
-        `state`) receives the stream table as it was before the call."""
+        `state`) receives the stream table as it was before the call; max_workgroups > 0: a background launch
+        of at most that many workgroups (bk_normals_chain_major_bg)."""
         C = zt.shape[0]
         assert zt.stride(1) == 1 and zt.shape[1] >= D
         assert snapshot is None or (snapshot.shape == state.shape and snapshot.stride(0) == state.stride(0))
-        self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
-                   ptr(snapshot), self._s())
+        if max_workgroups:
+            self._call("bk_normals_chain_major_bg", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
+                       ptr(snapshot), int(max_workgroups), self._s())
+        else:
+            self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
+                       ptr(snapshot), self._s())
 
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         D, C = theta.shape

@@ -196,7 +196,8 @@ class MALA(ManyChainSampler):
         ops.log_uniform(self._rng_kind, self._rng_state, self._logu_bufs[slot])     # U_n   [metropolis.py:74]
         # Z_{n+1} [mala.py:44]; the generator leaves the table as it found it -- the position after draw n
         # -- in snap[slot]
-        ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim, self._snap[slot])
+        ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[slot], self._dim, self._snap[slot],
+                                max_workgroups=self.generator_workgroups if self._prefetch else 0)
 
     def _take_unit(self):
         """(log u of this draw, chain-major normals of the next); with prefetch also starts the
@@ -241,6 +242,9 @@ class MALA(ManyChainSampler):
     # gradient op (the step kernel's workgroups are queued first and take one slot per CU; a generator
     # workgroup fits beside each: 160 of the 256 free registers per SIMD lane, 6 of the 27 free KB of LDS).
     generate_with = "grad"
+    # Workgroups of the side-stream generator (0 = one per 16 chains, the kernel's own grid).  A bound of one per CU
+    # turns it into a background kernel with one wavefront per SIMD, beside which a step workgroup still fits.
+    generator_workgroups = 0
     step_first = True  # (experiments: with generate_with = "step", which of the two is queued first)
 
     def accept_rate(self) -> float:

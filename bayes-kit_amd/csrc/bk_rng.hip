@@ -214,14 +214,31 @@ __device__ SlowRes zig_slow_at(WordWindow& win, int k, int idx, uint64_t rabs, d
 // wavefront-wide with LPC = 64 (ballots, ranks, the covered range) is per SEGMENT of LPC lanes.
 constexpr int ZP_WAVES = 4;  // wavefronts per workgroup
 template <int LPC>
+__device__ __forceinline__ void zig_parallel_wave(uint64_t* st, i64 ldr, double* zt, i64 ldz, i64 C, i64 D,
+                                                  uint64_t* snap, const ZigLds& tab, i64 wave_index);
+
+// The grid may be SMALLER than the number of chain groups (a "background" launch: bk_normals_chain_major with
+// a bound on the workgroups): every workgroup then walks the groups blockIdx.x, blockIdx.x + gridDim.x, ...
+// With one workgroup per CU the generator keeps one wavefront per SIMD and leaves the rest of every CU --
+// registers, LDS, wavefront slots -- to a kernel that streams beside it.
+template <int LPC>
 __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st, i64 ldr, double* zt, i64 ldz,
                                                                     i64 C, i64 D, uint64_t* snap) {
   constexpr int G = BK_WAVE / LPC;  // chains per wavefront
   __shared__ ZigLds tab;
   load_tables(tab);
+  const i64 n_wg = (C + (i64)ZP_WAVES * G - 1) / ((i64)ZP_WAVES * G);
+  for (i64 wg = blockIdx.x; wg < n_wg; wg += gridDim.x)
+    zig_parallel_wave<LPC>(st, ldr, zt, ldz, C, D, snap, tab, wg * ZP_WAVES + bk_wave_id());
+}
+
+template <int LPC>
+__device__ __forceinline__ void zig_parallel_wave(uint64_t* st, i64 ldr, double* zt, i64 ldz, i64 C, i64 D,
+                                                  uint64_t* snap, const ZigLds& tab, i64 wave_index) {
+  constexpr int G = BK_WAVE / LPC;  // chains per wavefront
   const int lane = threadIdx.x & (BK_WAVE - 1);
   const int seg = lane / LPC, l = lane % LPC;
-  const i64 c = ((i64)blockIdx.x * ZP_WAVES + bk_wave_id()) * G + seg;
+  const i64 c = wave_index * G + seg;
   if ((c - seg) >= C) return;  // whole wavefront
   const bool live = c < C;     // (a wavefront's last segments may have no chain)
   const i64 cs = live ? c : C - 1;
@@ -393,10 +410,12 @@ static int zp_lanes_per_chain(i64 C, i64 D) {
 }
 
 static void zig_parallel_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, uint64_t* snap,
-                                hipStream_t s) {
+                                hipStream_t s, i64 max_workgroups = 0) {
   const int lpc = zp_lanes_per_chain(C, D);
   const i64 chains_per_wg = (i64)ZP_WAVES * (BK_WAVE / lpc);
-  dim3 grid((unsigned)bk_cdiv(C, chains_per_wg)), block(ZP_WAVES * BK_WAVE);
+  i64 n_wg = bk_cdiv(C, chains_per_wg);
+  if (max_workgroups > 0 && n_wg > max_workgroups) n_wg = max_workgroups;
+  dim3 grid((unsigned)n_wg), block(ZP_WAVES * BK_WAVE);
   if (lpc == 16) k_zig_parallel<16><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
   else if (lpc == 32) k_zig_parallel<32><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
   else k_zig_parallel<64><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, snap);
@@ -599,7 +618,12 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
 
 int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
                            int64_t D, uint64_t* snapshot, void* stream) {
-  if (!state || !zt || C < 0 || D < 0 || ldr < C || ldz < D) return BK_E_ARG;
+  return bk_normals_chain_major_bg(rng_kind, state, ldr, zt, ldz, C, D, snapshot, 0, stream);
+}
+
+int bk_normals_chain_major_bg(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
+                              int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream) {
+  if (!state || !zt || C < 0 || D < 0 || ldr < C || ldz < D || max_workgroups < 0) return BK_E_ARG;
   if (rng_kind != BK_RNG_PHILOX) return BK_E_ARG;
   if (C == 0) return BK_OK;
   if (D == 0) {
@@ -608,7 +632,7 @@ int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* z
                                    BK_RNG_WORDS, hipMemcpyDeviceToDevice, bk_stream(stream));
     return BK_OK;
   }
-  zig_parallel_launch(state, ldr, zt, ldz, C, D, snapshot, bk_stream(stream));
+  zig_parallel_launch(state, ldr, zt, ldz, C, D, snapshot, bk_stream(stream), max_workgroups);
   BK_RETURN_LAUNCH_STATUS();
 }
 

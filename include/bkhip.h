@@ -303,6 +303,12 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
 int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz,
                            int64_t C, int64_t D, uint64_t* snapshot, void* stream);
 
+/* The same as a BACKGROUND launch: at most max_workgroups workgroups (0 = no bound), each walking several groups
+ * of chains.  With one workgroup per CU (256 on MI355X) the generator keeps one wavefront per SIMD and the rest of
+ * every CU stays free for a bandwidth-bound kernel running beside it on another stream.  Same stream of normals. */
+int bk_normals_chain_major_bg(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
+                              int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream);
+
 /* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
  * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */
 int bk_mala_logq(const double* theta, const double* grad, const double* theta_prop,

@@ -174,7 +174,7 @@ class FakeOps:
             theta_prop.numpy()[:, c] = (theta.numpy()[:, c] + eps * grad.numpy()[:, c]) + sqrt2eps * z
             self._put(kind, state, c, g)
 
-    def normals_chain_major(self, kind, state, zt, D, snapshot=None):
+    def normals_chain_major(self, kind, state, zt, D, snapshot=None, max_workgroups=0):
         self._count("normals_chain_major")
         if snapshot is not None:
             snapshot.numpy()[...] = state.numpy()

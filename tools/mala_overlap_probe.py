@@ -15,8 +15,9 @@ lam = torch.logspace(0, 4, D, dtype=torch.float64)
 print("stream priority range (least, greatest):", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None)
 
 
-def run(tag, serialize, gen_with, step_first, high):
+def run(tag, serialize, gen_with, step_first, high, gen_wgs=0):
     bk.MALA.serialize_step, bk.MALA.generate_with, bk.MALA.step_first = serialize, gen_with, step_first
+    bk.MALA.generator_workgroups = gen_wgs
     stream = torch.cuda.Stream(priority=-1) if high else torch.cuda.current_stream()
     with torch.cuda.stream(stream):
         s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7)
@@ -40,7 +41,13 @@ for rep in range(2):
     for tag, a in [("V0 grad+wait", (True, "grad", True, False)), ("V1 grad no wait", (False, "grad", True, False)),
                    ("V2 step, step first", (False, "step", True, False)), ("V2 HIGH", (False, "step", True, True)),
                    ("V3 step, gen first", (False, "step", False, False)), ("V3 HIGH", (False, "step", False, True)),
-                   ("V0 HIGH", (True, "grad", True, True))]:
+                   ("V0 HIGH", (True, "grad", True, True)),
+                   # the generator as a background kernel of N workgroups (one wavefront per SIMD at 256), started with
+                   # the gradient op, the step kernel not waiting for it
+                   ("BG256", (False, "grad", True, False, 256)), ("BG512", (False, "grad", True, False, 512)),
+                   ("BG768", (False, "grad", True, False, 768)), ("BG256 HIGH", (False, "grad", True, True, 256)),
+                   ("BG512 HIGH", (False, "grad", True, True, 512)),
+                   ("BG256 with step", (False, "step", False, False, 256)), ("BG512 wait", (True, "grad", True, False, 512))]:
         r = run(tag, *a)
         res.append(r)
         print(json.dumps(r), flush=True)
