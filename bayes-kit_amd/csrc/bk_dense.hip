@@ -26,22 +26,34 @@ typedef double dvec2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LDP = 144;  // padded panel pitch (doubles): 1152 B = 128 B mod 256 B
 
-struct DenseLds {
+struct alignas(16) DenseLds {
   double a[2][BK][LDP];  // [k][row of M]
   double b[2][BK][LDP];  // [k][chain]
 };
 
+// Thread -> panel elements (the same for the global loads and the LDS stores):
+//   A (128 rows of M x 16 k, k contiguous in global): thread t holds row (t & 127), k = 8 (t >> 7) .. + 8.
+//     Its eight LDS stores go to a[k][row]: 16 consecutive lanes = 16 consecutive rows = 32 distinct banks
+//     (the k pitch of 288 dwords is a multiple of the 32 store banks, so lanes must not differ in k only:
+//     round 2's (row = t >> 1, k = 8 (t & 1)) mapping made every store a 2-way conflict).
+//   B (16 k x 128 chains, chain contiguous): thread t holds k = t >> 4 and, for i = 0..3, the chain pair
+//     32 i + 2 (t & 15): a global load instruction reads 256 contiguous bytes per k, and the 16-byte LDS
+//     store of 8 consecutive lanes covers 32 consecutive dwords (round 2 stored 8 consecutive chains per
+//     thread with 8-byte stores: lanes 128 B apart, an 8-way conflict; SQ_LDS_BANK_CONFLICT was 57 % of the
+//     LDS cycles of the kernel, profiles/r3_dense_mfma.md).
 template <bool FULL>
 __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const double* X, i64 ld, i64 r0,
                                             i64 c0, i64 k0, i64 R, i64 D, i64 C, double (&ra)[8],
                                             double (&rb)[8]) {
   const int t = threadIdx.x;
+  const int row = t & 127, ka = (t >> 7) * 8;
+  const int kb = t >> 4, q = (t & 15) * 2;
   if (FULL) {  // whole tiles, 16-B aligned rows: four 16-B loads per panel, no bounds checks
-    const dvec2* pa = reinterpret_cast<const dvec2*>(M + (r0 + (t >> 1)) * ldm + k0 + (t & 1) * 8);
-    const dvec2* pb = reinterpret_cast<const dvec2*>(X + (k0 + (t >> 4)) * ld + c0 + (t & 15) * 8);
+    const dvec2* pa = reinterpret_cast<const dvec2*>(M + (r0 + row) * ldm + k0 + ka);
+    const double* pb = X + (k0 + kb) * ld + c0 + q;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      dvec2 va = pa[i], vb = pb[i];
+      dvec2 va = pa[i], vb = *reinterpret_cast<const dvec2*>(pb + 32 * i);
       ra[2 * i] = va.x;
       ra[2 * i + 1] = va.y;
       rb[2 * i] = vb.x;
@@ -49,23 +61,19 @@ __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const doub
     }
     return;
   }
-  // A panel: 128 rows x 16 k, row-major in global (k contiguous): thread -> (row, 8 consecutive k)
   {
-    int row = t >> 1, kk = (t & 1) * 8;
     i64 r = r0 + row;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      i64 k = k0 + kk + i;
+      i64 k = k0 + ka + i;
       ra[i] = (r < R && k < D) ? M[r * ldm + k] : 0.0;
     }
   }
-  // B panel: 16 k x 128 chains (chain contiguous): thread -> (k, 8 consecutive chains)
   {
-    int kk = t >> 4, cc = (t & 15) * 8;
-    i64 k = k0 + kk;
+    i64 k = k0 + kb;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      i64 c = c0 + cc + i;
+      i64 c = c0 + 32 * (i >> 1) + q + (i & 1);
       rb[i] = (k < D && c < C) ? X[k * ld + c] : 0.0;
     }
   }
@@ -74,14 +82,17 @@ __device__ __forceinline__ void load_panels(const double* M, i64 ldm, const doub
 __device__ __forceinline__ void store_panels(DenseLds& lds, int buf, const double (&ra)[8], const double (&rb)[8]) {
   const int t = threadIdx.x;
   {
-    int row = t >> 1, kk = (t & 1) * 8;
+    const int row = t & 127, ka = (t >> 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lds.a[buf][kk + i][row] = ra[i];
+    for (int i = 0; i < 8; ++i) lds.a[buf][ka + i][row] = ra[i];
   }
   {
-    int kk = t >> 4, cc = (t & 15) * 8;
+    const int kb = t >> 4, q = (t & 15) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) lds.b[buf][kk][cc + i] = rb[i];
+    for (int i = 0; i < 4; ++i) {
+      dvec2 v = {rb[2 * i], rb[2 * i + 1]};
+      *reinterpret_cast<dvec2*>(&lds.b[buf][kb][32 * i + q]) = v;
+    }
   }
 }
 
@@ -127,23 +138,34 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
   for (i64 kb = 0; kb < nk; ++kb) {
     const int buf = (int)(kb & 1);
     if (kb + 1 < nk) load_panels<FULL>(M, ldm, X, ld, r0, c0, k_lo + (kb + 1) * BK, R, D, C, ra, rb);  // in flight under the MFMAs
+    // fragments of k-slice ks + 4 are read while the MFMAs of slice ks run (two register sets)
+    double a[2][4], b[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[0][i] = lds.a[buf][l4][wr + 16 * i + l15];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[0][j] = lds.b[buf][l4][wc + 16 * j + l15];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 4) {
-      double a[4], b[4];
+      const int cur = (ks / 4) & 1;
+      if (ks + 4 < BK) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = lds.a[buf][ks + l4][wr + 16 * i + l15];
+        for (int i = 0; i < 4; ++i) a[cur ^ 1][i] = lds.a[buf][ks + 4 + l4][wr + 16 * i + l15];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = lds.b[buf][ks + l4][wc + 16 * j + l15];
+        for (int j = 0; j < 4; ++j) b[cur ^ 1][j] = lds.b[buf][ks + 4 + l4][wc + 16 * j + l15];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+      if (ks == BK / 2 - 4 && kb + 1 < nk) {
+        // the next panels go to the other LDS buffer (last read one iteration ago, behind a barrier) while
+        // the matrix pipe still has half of this panel's MFMAs queued: the stores and the wait for the global
+        // loads overlap matrix work instead of following it
+        store_panels(lds, buf ^ 1, ra, rb);
+      }
     }
-    if (kb + 1 < nk) {
-      store_panels(lds, buf ^ 1, ra, rb);
-      __syncthreads();
-    }
+    if (kb + 1 < nk) __syncthreads();
   }
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
