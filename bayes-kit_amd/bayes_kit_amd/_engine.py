@@ -346,8 +346,22 @@ class ManyChainSampler:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             self._graph_scalars = self._graph_key()
-            with torch.cuda.graph(g):
-                draw_fn()
+            # No garbage collection while the stream is capturing: a collection that happens to run inside the
+            # capture may finalise GPU objects of OTHER samplers (graphs, events, streams held in reference
+            # cycles), and destroying those is not a capturable operation -- the runtime aborts the process
+            # (seen in the full GPU test run, never in a single file: it takes earlier tests' garbage plus a draw
+            # that allocates enough Python objects to trigger a collection).  torch.cuda.graph() collects once
+            # before the capture begins.
+            import gc
+
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    draw_fn()
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self._graph = g
         elif self._graph_key() != self._graph_scalars:
             self._drop_graphs()
@@ -517,5 +531,8 @@ class ManyChainSampler:
         """What sample() hands back: stable copies, shaped like the reference's return."""
         if self._batched:
             out, self._out = self._out, None
-            return (out.t() if out is not None else theta_dc.t().clone()), logp.clone()
+            if out is None:
+                out = torch.empty(tuple(theta_dc.shape), dtype=theta_dc.dtype, device=theta_dc.device)
+                out.copy_(theta_dc)  # (a dense [D, C] copy also when the state's rows are padded)
+            return out.t(), logp.clone()
         return np.array(theta_dc[:, 0].cpu().numpy()), np.float64(logp[0].item())

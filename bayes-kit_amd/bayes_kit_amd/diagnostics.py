@@ -114,8 +114,8 @@ class RunningMoments:
         """theta: the sampler's draw, either the engine's [D, C] buffer or the (C, D) view
         returned by ``sample()`` (told apart by shape, for C == D by strides: see _as_dc)."""
         t = _as_dc(theta, self.mean.shape[0], self.mean.shape[1], layout)
-        if t.stride(1) != 1:
-            t = t.contiguous()
+        if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) != self.mean.stride(0)):
+            t = t.contiguous()  # (the kernel walks theta, mean and M2 with one row pitch)
         self.n += 1
         self._ops.welford_update(self.mean, self.m2, t, self.n)
 

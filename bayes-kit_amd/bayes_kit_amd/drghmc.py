@@ -34,11 +34,11 @@ from ._engine import ManyChainSampler
 class _Level:
     """Dense buffers of one recursion level."""
 
-    def __init__(self, D, C, dev):
+    def __init__(self, D, C, dev, pad=0):
         f64 = dict(dtype=torch.float64, device=dev)
-        self.theta = torch.empty((D, C), **f64)
-        self.rho = torch.empty((D, C), **f64)
-        self.grad = torch.empty((D, C), **f64)
+        self.theta = torch.empty((D, C + pad), **f64)[:, :C]
+        self.rho = torch.empty((D, C + pad), **f64)[:, :C]
+        self.grad = torch.empty((D, C + pad), **f64)[:, :C]
         self.logp = torch.empty(C, **f64)
         self.kin = torch.empty(C, **f64)
         self.H = torch.empty(C, **f64)
@@ -95,7 +95,7 @@ class DrGhmcDiag(ManyChainSampler):
         self._cur_h = torch.empty(C, **f64)
         self._rej = torch.empty(C, **f64)
         self._alive = torch.empty(C, dtype=torch.uint8, device=dev)
-        self._levels = [_Level(D, C, dev) for _ in range(int(max_proposals))]
+        self._levels = None      # (allocated below, once the path is known)
         self._level0_alt = None  # a second level-0 buffer set (device-count path: stages alternate, see _draw_dev)
         self._have_cache = False
         self._draws = 0
@@ -118,6 +118,18 @@ class DrGhmcDiag(ManyChainSampler):
         self._init_graph(graph)
         self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
             max(0, k - 1) for k in range(int(max_proposals)))
+        # Row padding (one-launch-proposal path).  The proposal kernel walks the ROWS of a few chains: with a
+        # row pitch that is a multiple of 4 KiB -- 32,768 chains: 256 KiB -- every row of a chain sits on the same
+        # memory channel, and the gather / store phase of the first stage (all chains, 160 MB) queues up there:
+        # 48 -> 34 us with the rows 576 bytes further apart (tools/funnel_traj_bench.py, PAD=72).
+        pad = 72 if (self._dev_counts and C >= 4096 and (C * 8) % 4096 == 0) else 0
+        if pad:
+            def padded(t):
+                p = torch.empty((D, C + pad), **f64)[:, :C]
+                p.copy_(t)
+                return p
+            self._theta_dc, self._rho_dc, self._grad = padded(self._theta_dc), padded(self._rho_dc), padded(self._grad)
+        self._levels = [_Level(D, C, dev, pad) for _ in range(int(max_proposals))]
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._fused:
             self._tune_placement()
@@ -127,7 +139,7 @@ class DrGhmcDiag(ManyChainSampler):
             self._steps_total_base = 0.0
             self._make_schedule()
             if int(max_proposals) > 1:
-                self._level0_alt = _Level(D, C, dev)
+                self._level0_alt = _Level(D, C, dev, pad)
 
     def _make_schedule(self):
         """The fixed schedule of trajectories (slot order = launch order) and its lane counters, for the

@@ -419,7 +419,7 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
         th, lp = s.sample()
         if not on_device:
             state["lane_steps"] += s.last_lane_steps
-        mom.update(s._theta_dc)
+        mom.update(th)
         rec.record(th, lp)
 
     el = ctx.timed_loop(one, draws)
