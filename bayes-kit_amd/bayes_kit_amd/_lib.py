@@ -49,7 +49,7 @@ SIGNATURES = {
     "bk_dr_accept_test": [c_int, P, I, P, P, P, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_test": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost": [P, P, P, P, P, F, P, P, I, P, P, P, P],
-    "bk_dr_begin_retry": [c_int, P, I, P, P, P, P, P, P, F, P, I, I, P],
+    "bk_dr_begin_retry": [c_int, P, I, P, P, P, P, P, P, F, P, I, P, I, P],
     "bk_dr_accept_prob_test_next": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost_next": [P, P, P, P, P, F, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
@@ -77,6 +77,8 @@ SIGNATURES = {
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
     "bk_record_series": [P, I, P, I, P, P, I, I, I, P],
+    "bk_record_series_dev": [P, I, P, I, P, P, I, P, I, I, P],
+    "bk_welford_update_dev": [P, P, I, P, I, P, I, I, I, P],
     "bk_rhat_partials": [P, P, I, I, P, P, I, I, P],
     "bk_chain_mean_var": [P, I, P, I, P, P, I, P],
     "bk_end_pos_pairs": [P, I, I, P, I, P],
@@ -320,11 +322,12 @@ class Ops:
         self._call("bk_dr_accept_prob_ghost", ptr(H), ptr(parent_H), ptr(h), ptr(parent_h), ptr(sub_index),
                    float(prob_retry), ptr(live), ptr(a), n, ptr(n_dev), ptr(parent_live), ptr(parent_a), self._s())
 
-    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters):
-        """dr_begin + the first stage's dr_retry_test + zeroing of the draw's lane counters, one launch."""
+    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters, draw_counter=None):
+        """dr_begin + the first stage's dr_retry_test + zeroing of the draw's lane counters (+ the sampler's
+        device-side draw counter incremented), one launch."""
         self._call("bk_dr_begin_retry", kind, ptr(state), state.stride(0), ptr(logp), ptr(kin), ptr(cur_H), ptr(cur_h),
                    ptr(rej), ptr(alive), float(prob_retry), ptr(counters), 0 if counters is None else counters.numel(),
-                   logp.shape[0], self._s())
+                   ptr(draw_counter), logp.shape[0], self._s())
 
     def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
                                  accepted, next_index, next_count, n_dev=None):
@@ -536,6 +539,20 @@ class Ops:
         assert series.is_contiguous() and series.shape[2] == C
         self._call("bk_record_series", ptr(theta), _ld(theta), ptr(dims), 0 if dims is None else dims.numel(), ptr(logp),
                    ptr(series), series.shape[1], row, C, self._s())
+
+    def record_series_dev(self, theta, dims, logp, series, row_dev, row_offset):
+        """record_series with the row index read on the device: row = row_dev[0] - row_offset."""
+        D, C = theta.shape
+        assert series.is_contiguous() and series.shape[2] == C and row_dev.dtype == torch.int64
+        self._call("bk_record_series_dev", ptr(theta), _ld(theta), ptr(dims), 0 if dims is None else dims.numel(),
+                   ptr(logp), ptr(series), series.shape[1], ptr(row_dev), int(row_offset), C, self._s())
+
+    def welford_update_dev(self, mean, m2, theta, n_dev, n_offset):
+        """welford_update with n = n_dev[0] - n_offset read on the device; theta may have its own row pitch."""
+        D, C = theta.shape
+        assert _ld(m2) == _ld(mean) and n_dev.dtype == torch.int64
+        self._call("bk_welford_update_dev", ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), ptr(n_dev),
+                   int(n_offset), C, D, self._s())
 
     def rhat_partials(self, mean, m2, n, center, out):
         D, C = mean.shape

@@ -119,6 +119,11 @@ class RunningMoments:
         self.n += 1
         self._ops.welford_update(self.mean, self.m2, t, self.n)
 
+    def _update_dev(self, theta_dc, n_dev, n_offset) -> None:
+        """update() as a part of a sampler's draw (DrGhmcDiag.attach): the update count is read on the device,
+        n = n_dev[0] - n_offset; the caller keeps self.n in step."""
+        self._ops.welford_update_dev(self.mean, self.m2, theta_dc, n_dev, n_offset)
+
     def rhat(self, group=None) -> np.ndarray:
         return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
 
@@ -169,6 +174,12 @@ class DrawRecorder:
             if self.with_logp:
                 self.series[-1, self.n].copy_(logp)
         self.n += 1
+
+    def _record_dev(self, theta_dc, logp, row_dev, row_offset) -> None:
+        """record() as a part of a sampler's draw (DrGhmcDiag.attach): row = row_dev[0] - row_offset, read on the
+        device; the caller keeps self.n in step."""
+        self._ops.record_series_dev(theta_dc, self._dims_dev, logp if self.with_logp else None, self.series, row_dev,
+                                    row_offset)
 
     def names(self):
         return [f"theta[{d}]" for d in self.dims] + (["logp"] if self.with_logp else [])

@@ -99,6 +99,8 @@ class DrGhmcDiag(ManyChainSampler):
         self._level0_alt = None  # a second level-0 buffer set (device-count path: stages alternate, see _draw_dev)
         self._have_cache = False
         self._draws = 0
+        self._draws_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # the draw count, kept on the device as well
+        self._attached = []  # (RunningMoments / DrawRecorder objects fed by the draw itself: attach())
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
         # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
@@ -274,6 +276,7 @@ class DrGhmcDiag(ManyChainSampler):
 
     def _load_extra(self, extra):
         self._rho_sign = float(extra.get("rho_sign", 1.0))
+        self._draws_dev.fill_(int(self._draws))
 
     # -- views ----------------------------------------------------------------------------------------
     @property
@@ -330,12 +333,56 @@ class DrGhmcDiag(ManyChainSampler):
         ops.dr_accept_prob(P.H, cur_H, P.h, cur_h, cur_idx, 1.0 if self._prob_retry else 0.0, P.live, P.a, n)
         return P.a
 
+    # -- diagnostics fed by the draw itself ------------------------------------------------------------------
+    def attach(self, moments=None, recorder=None):
+        """Feed a ``RunningMoments`` and / or a ``DrawRecorder`` from inside every draw: their updates become part
+        of the draw's launch sequence -- with device-side lane counts, of the ONE hipGraph a draw replays as -- and
+        take their draw index from the sampler's device-side draw counter.  The objects are then up to date after
+        every ``sample()`` / ``advance()`` without calls of their own (do not also call update() / record())."""
+        for obj, kind in ((moments, "moments"), (recorder, "recorder")):
+            if obj is not None:
+                self._attached.append((kind, obj, self._draws - obj.n))
+        self._drop_graphs()
+
+    def detach(self):
+        """Stop feeding the attached diagnostics (they keep what they have)."""
+        self._attached = []
+        self._drop_graphs()
+
+    def _feed_attached(self, theta_dc, logp, on_device):
+        """Inside the draw: the attached diagnostics see the new state (theta_dc [D, C], joint log density)."""
+        for kind, obj, off in self._attached:
+            if on_device:
+                if kind == "moments":
+                    obj._update_dev(theta_dc, self._draws_dev, off)
+                else:
+                    obj._record_dev(theta_dc, logp, self._draws_dev, off + 1)
+            elif kind == "moments":
+                obj.update(theta_dc, layout="dc")
+            else:
+                obj.record(theta_dc, logp)
+
+    def _count_attached(self):
+        for kind, obj, off in self._attached:
+            if kind == "recorder" and obj.n >= obj.series.shape[1]:
+                raise IndexError("DrawRecorder is full")
+
+    def advance(self):
+        """One draw of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed
+        by attached diagnostics only.  ``sample()`` = ``advance()`` + the returned (theta, logp) copies."""
+        self._step()
+
     def _graph_key(self):
         return (float(self._damping), float(self._rho_sign), bool(self._prob_retry),
                 tuple(float(h) for h in self._leapfrog_step_sizes), tuple(int(n) for n in self._leapfrog_step_counts))
 
     # -- one draw for every chain -----------------------------------------------------------------------------
     def sample(self):
+        self._step()
+        return self._draw_out(self._theta_dc, self._cur_H)
+
+    def _step(self):
+        self._count_attached()
         if self._dev_counts:
             if not self._have_cache:  # drghmc.py:243-245 (first draw only; outside any capture)
                 self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
@@ -351,7 +398,13 @@ class DrGhmcDiag(ManyChainSampler):
             self._run_draw(self._draw_dev)
             self._rho_sign = -1.0  # drghmc.py:388, applied lazily
             self._draws += 1
-            return self._draw_out(self._theta_dc, self._cur_H)
+            for kind, obj, off in self._attached:
+                obj.n += 1
+            return
+        self._step_host()
+        self._feed_attached(self._theta_dc, self._cur_H, False)
+
+    def _step_host(self):
         ops = self._ops
         C, m = self._C, self._metric_dev
         self._h_evals, self._h_lane_steps, self._h_stages = 0, 0, []
@@ -390,8 +443,8 @@ class DrGhmcDiag(ManyChainSampler):
                                 [P0.theta[:, :n], P0.rho[:, :n], P0.grad[:, :n]], self._lp, P0.logp)
         self._rho_sign = -1.0  # drghmc.py:388, applied lazily
         self._draws += 1
+        self._draws_dev.fill_(self._draws)
         self._host_stats = (self._h_evals, self._h_lane_steps, self._h_stages)
-        return self._draw_out(self._theta_dc, self._cur_H)
 
     # -- the same draw with lane counts on the device: a fixed launch sequence ----------------------------
     def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None, ghost=None):
@@ -464,7 +517,7 @@ class DrGhmcDiag(ManyChainSampler):
         pr = 1.0 if self._prob_retry else 0.0
         # start of the draw + the first stage's retry test (always passed, its uniform drawn) :365-371
         ops.dr_begin_retry(self._rng_kind, self._rng_state, self._lp, self._kin, self._cur_H, self._cur_h, self._rej,
-                           self._alive, pr, self._counters)
+                           self._alive, pr, self._counters, self._draws_dev)
         cur = _Cur(self)
         self._slot = 0
         self._list = 0
@@ -498,6 +551,7 @@ class DrGhmcDiag(ManyChainSampler):
             else:
                 ops.scatter_columns(*scatter, n_dev=n_dev)
         self._levels[0] = level0[0]
+        self._feed_attached(self._theta_dc, self._cur_H, True)
 
     @property
     def lane_steps_total(self):

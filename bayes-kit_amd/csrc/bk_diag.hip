@@ -16,17 +16,18 @@ __device__ __forceinline__ void welford_elem(double x, double& mu, double& q, do
   q = q + delta * (x - mu);
 }
 
-__global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const double* th, i64 ld,
-                                                 double n, i64 C, i64 D) {
+__global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const double* th, i64 ld, i64 ld_th,
+                                                 double n, const int64_t* n_dev, i64 n_off, i64 C, i64 D) {
   i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
   i64 d0 = (i64)blockIdx.y * EL_ROWS;
   if (c >= C) return;
+  if (n_dev) n = (double)(*n_dev - n_off);
 #pragma unroll
   for (int i = 0; i < EL_ROWS; ++i)
     if (d0 + i < D) {
       i64 o = (d0 + i) * ld + c;
       double mu = mean[o], q = m2[o];
-      welford_elem(th[o], mu, q, n);
+      welford_elem(th[(d0 + i) * ld_th + c], mu, q, n);
       mean[o] = mu;
       m2[o] = q;
     }
@@ -35,18 +36,21 @@ __global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const
 // two chains (16 B) per lane, 40 algorithmic bytes per element (R theta, mean, M2; W mean, M2);
 // non-temporal when the three arrays stream past the Infinity Cache
 typedef double dvec2 __attribute__((ext_vector_type(2)));
+// (ld_th: theta's own row pitch; n_dev != NULL: the update count is read from device memory -- n = *n_dev -
+// n_off -- so that the launch can sit inside a sampler's captured draw)
 template <bool NT>
-__global__ __launch_bounds__(256) void k_welford_v2(double* mean, double* m2, const double* th, i64 ld,
-                                                    double n, i64 C2, i64 D) {
+__global__ __launch_bounds__(256) void k_welford_v2(double* mean, double* m2, const double* th, i64 ld, i64 ld_th,
+                                                    double n, const int64_t* n_dev, i64 n_off, i64 C2, i64 D) {
   i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
   i64 d0 = (i64)blockIdx.y * EL_ROWS;
   if (c2 >= C2) return;
+  if (n_dev) n = (double)(*n_dev - n_off);
   dvec2 x[EL_ROWS], mu[EL_ROWS], q[EL_ROWS];
 #pragma unroll
   for (int i = 0; i < EL_ROWS; ++i)
     if (d0 + i < D) {
       i64 o = (d0 + i) * ld + 2 * c2;
-      const dvec2 *px = reinterpret_cast<const dvec2*>(th + o), *pm = reinterpret_cast<const dvec2*>(mean + o),
+      const dvec2 *px = reinterpret_cast<const dvec2*>(th + (d0 + i) * ld_th + 2 * c2), *pm = reinterpret_cast<const dvec2*>(mean + o),
                   *pq = reinterpret_cast<const dvec2*>(m2 + o);
       x[i] = NT ? __builtin_nontemporal_load(px) : *px;
       mu[i] = NT ? __builtin_nontemporal_load(pm) : *pm;
@@ -421,10 +425,13 @@ __global__ __launch_bounds__(256) void k_rank_normalize(const double* rank, doub
 // series[k][row][c] = theta[dims[k]][c] for k < K, series[K][row][c] = logp[c] (if given): one launch per draw
 // instead of one strided copy per tracked coordinate.
 __global__ __launch_bounds__(256) void k_record_series(const double* theta, i64 ld, const int32_t* dims, int K,
-                                                       const double* logp, double* series, i64 cap, i64 row, i64 C) {
+                                                       const double* logp, double* series, i64 cap, i64 row,
+                                                       const int64_t* row_dev, i64 row_off, i64 C) {
   const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
   const int k = blockIdx.y;
   if (c >= C) return;
+  if (row_dev) row = *row_dev - row_off;  // (the row index kept by the sampler's device-side draw counter)
+  if (row < 0 || row >= cap) return;
   const double v = k < K ? theta[(i64)dims[k] * ld + c] : logp[c];
   series[((i64)k * cap + row) * C + c] = v;
 }
@@ -433,22 +440,35 @@ __global__ __launch_bounds__(256) void k_record_series(const double* theta, i64 
 
 extern "C" {
 
-int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n, int64_t C,
-                      int64_t D, void* stream) {
-  if (!mean || !m2 || !theta || n < 1 || C < 0 || D < 0) return BK_E_ARG;
-  if (ld < C) return BK_E_ALIGN;
+static int welford_launch(double* mean, double* m2, i64 ld, const double* theta, i64 ld_th, i64 n, const int64_t* n_dev,
+                          i64 n_off, i64 C, i64 D, void* stream) {
+  if (!mean || !m2 || !theta || (!n_dev && n < 1) || C < 0 || D < 0) return BK_E_ARG;
+  if (ld < C || ld_th < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(mean) && bk_aligned16(m2) && bk_aligned16(theta)) {
+  if (C % 2 == 0 && ld % 2 == 0 && ld_th % 2 == 0 && bk_aligned16(mean) && bk_aligned16(m2) && bk_aligned16(theta)) {
     dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, EL_ROWS));
     if (bk_streams_past_llc(3 * C * D))
-      k_welford_v2<true><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C / 2, D);
+      k_welford_v2<true><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, ld_th, (double)n, n_dev, n_off,
+                                                                    C / 2, D);
     else
-      k_welford_v2<false><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C / 2, D);
+      k_welford_v2<false><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, ld_th, (double)n, n_dev, n_off,
+                                                                     C / 2, D);
   } else {
     dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)bk_cdiv(D, EL_ROWS));
-    k_welford<<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, (double)n, C, D);
+    k_welford<<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, ld_th, (double)n, n_dev, n_off, C, D);
   }
   BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n, int64_t C,
+                      int64_t D, void* stream) {
+  return welford_launch(mean, m2, ld, theta, ld, n, nullptr, 0, C, D, stream);
+}
+
+int bk_welford_update_dev(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
+                          const int64_t* n_dev, int64_t n_offset, int64_t C, int64_t D, void* stream) {
+  if (!n_dev) return BK_E_ARG;
+  return welford_launch(mean, m2, ld, theta, ld_theta, 0, n_dev, n_offset, C, D, stream);
 }
 
 int bk_rhat_partials(const double* mean, const double* m2, int64_t ld, int64_t n, const double* center,
@@ -554,16 +574,28 @@ int bk_ess(const double* x, int64_t ld, int64_t N, int estimator, double* ess_ou
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_record_series(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
-                     double* series, int64_t capacity, int64_t row, int64_t C, void* stream) {
-  if (!theta || !series || (K > 0 && !dims) || K < 0 || capacity < 1 || row < 0 || row >= capacity || C < 0)
-    return BK_E_ARG;
+static int record_launch(const double* theta, i64 ld, const int32_t* dims, i64 K, const double* logp, double* series,
+                         i64 capacity, i64 row, const int64_t* row_dev, i64 row_off, i64 C, void* stream) {
+  if (!theta || !series || (K > 0 && !dims) || K < 0 || capacity < 1 || C < 0) return BK_E_ARG;
+  if (!row_dev && (row < 0 || row >= capacity)) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   const int rows = (int)K + (logp ? 1 : 0);
   if (C == 0 || rows == 0) return BK_OK;
   k_record_series<<<dim3((unsigned)bk_cdiv(C, 256), (unsigned)rows), dim3(256), 0, bk_stream(stream)>>>(
-      theta, ld, dims, (int)K, logp, series, capacity, row, C);
+      theta, ld, dims, (int)K, logp, series, capacity, row, row_dev, row_off, C);
   BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_record_series(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
+                     double* series, int64_t capacity, int64_t row, int64_t C, void* stream) {
+  return record_launch(theta, ld, dims, K, logp, series, capacity, row, nullptr, 0, C, stream);
+}
+
+int bk_record_series_dev(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
+                         double* series, int64_t capacity, const int64_t* row_dev, int64_t row_offset, int64_t C,
+                         void* stream) {
+  if (!row_dev) return BK_E_ARG;
+  return record_launch(theta, ld, dims, K, logp, series, capacity, 0, row_dev, row_offset, C, stream);
 }
 
 }  // extern "C"

@@ -103,8 +103,10 @@ __global__ __launch_bounds__(64) void k_dr_retry(uint64_t* st, i64 ldr, const do
 template <typename G>
 __global__ __launch_bounds__(64) void k_dr_begin_retry(uint64_t* st, i64 ldr, const double* logp, const double* kin,
                                                        double* H, double* h, double* rej, uint8_t* alive, double pr,
-                                                       uint32_t* counters, int n_counters, i64 C) {
+                                                       uint32_t* counters, int n_counters, int64_t* draw_counter,
+                                                       i64 C) {
   if (blockIdx.x == 0 && (int)threadIdx.x < n_counters) counters[threadIdx.x] = 0;
+  if (draw_counter && blockIdx.x == 0 && threadIdx.x == 0) *draw_counter += 1;  // (one writer; launches are stream-ordered)
   i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
   H[c] = joint(logp[c], kin[c]);
@@ -341,21 +343,18 @@ int bk_dr_accept_prob_test_next(int rng_kind, uint64_t* state, int64_t ldr, cons
 
 int bk_dr_begin_retry(int rng_kind, uint64_t* state, int64_t ldr, const double* logp, const double* kin,
                       double* cur_H, double* cur_h, double* rej, uint8_t* alive, double prob_retry,
-                      uint32_t* counters, int64_t n_counters, int64_t C, void* stream) {
+                      uint32_t* counters, int64_t n_counters, int64_t* draw_counter, int64_t C, void* stream) {
   if (!state || !logp || !kin || !cur_H || !cur_h || !rej || !alive || C < 0 || ldr < C || n_counters < 0 ||
       n_counters > 64 || (n_counters > 0 && !counters))
     return BK_E_ARG;
-  if (C == 0) {
-    if (n_counters) return (int)hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), bk_stream(stream));
-    return BK_OK;
-  }
+  if (C == 0) return BK_OK;  // (no chain: no draw)
   dim3 grid((unsigned)bk_cdiv(C, 64)), block(64);
   if (rng_kind == BK_RNG_PHILOX)
     k_dr_begin_retry<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, logp, kin, cur_H, cur_h, rej, alive,
-                                                                       prob_retry, counters, (int)n_counters, C);
+                                                                       prob_retry, counters, (int)n_counters, draw_counter, C);
   else if (rng_kind == BK_RNG_PCG64)
     k_dr_begin_retry<bk::Pcg64><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, logp, kin, cur_H, cur_h, rej, alive,
-                                                                      prob_retry, counters, (int)n_counters, C);
+                                                                      prob_retry, counters, (int)n_counters, draw_counter, C);
   else
     return BK_E_ARG;
   BK_RETURN_LAUNCH_STATUS();

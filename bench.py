@@ -411,16 +411,18 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
     rec = bk.DrawRecorder([0, 1, D - 1], draws, C)
     for _ in range(warmup):
         s.sample()
+    # The Welford moments of all 101 dims and the tracked series (3 dims + joint log density) are fed from
+    # INSIDE every draw (DrGhmcDiag.attach): their two launches are part of the draw's replayed hipGraph and read
+    # the draw index from the sampler's device-side counter; advance() is a draw without returned copies.
+    s.attach(moments=mom, recorder=rec)
     state = {"lane_steps": 0}
     on_device = hasattr(s, "lane_steps_total") and s._dev_counts  # counted on the device: no host read per draw
     base = float(s.lane_steps_total.item()) if on_device else 0.0
 
     def one():
-        th, lp = s.sample()
+        s.advance()
         if not on_device:
             state["lane_steps"] += s.last_lane_steps
-        mom.update(th)
-        rec.record(th, lp)
 
     el = ctx.timed_loop(one, draws)
     lane_steps = float(s.lane_steps_total.item()) - base if on_device else state["lane_steps"]
@@ -449,9 +451,29 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
            "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "draws": draws,
            "rhat_over_chains": C * ctx.world, "collectives_per_summary": calls, "summary_ms": 1e3 * summary_s,
            "collective_backend": ctx.backend, "collective_ranks": ctx.collective_ranks(),
-           "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False))}
+           "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False)),
+           "diagnostics": "Welford moments + tracked series updated inside the draw's hipGraph (attach), no returned copies "
+                          "(advance)", "timed_draws_follow_warmup_draws": warmup}
     if full_rhat:
         out["rhat"] = [float(v) for v in rh]
+    try:
+        # The same sampler further into its run: the timed draws above are draws 4..43 from N(0, I) starts, where the
+        # chains are still finding the funnel and the delayed-rejection stages run over 2-3x the lanes of the
+        # stationary regime (mean_grad_evals_per_draw above against the one below).
+        s.detach()
+        mom2 = bk.RunningMoments(D, C)
+        s.attach(moments=mom2)
+        for _ in range(60):
+            s.advance()
+        b0 = float(s.lane_steps_total.item()) if on_device else 0.0
+        n2 = 100
+        el2 = ctx.timed_loop(s.advance, n2)
+        ls2 = bk.dist.sum_over_ranks((float(s.lane_steps_total.item()) - b0) if on_device else float("nan"), ctx.device)
+        out["after_100_draws"] = {"ms_per_draw": 1e3 * el2 / n2, "draws": n2,
+                                  "mean_grad_evals_per_draw": ls2 / (C * ctx.world * n2),
+                                  "grad_evals_per_sec": ls2 / el2, "diagnostics": "Welford moments inside the draw"}
+    except Exception as e:  # context only
+        out["after_100_draws"] = {"error": repr(e)}
     return out
 
 

@@ -236,10 +236,11 @@ int bk_dr_accept_prob_test(int rng_kind, uint64_t* state, int64_t ldr, const int
 /* Start of a draw and the first stage's retry test in one launch: bk_dr_begin, then bk_dr_retry_test for every
  * chain (drghmc.py:365-371: reject_logp = 0 at the first stage, the test passes, its uniform is drawn all the
  * same).  Also zeroes `n_counters` (<= 64) lane counters -- the `next_count` words of the two entry points below --
- * so that a whole draw needs no separate memset. */
+ * so that a whole draw needs no separate memset -- and adds 1 to *draw_counter (may be NULL): the sampler's draw
+ * count in device memory, which bk_welford_update_dev / bk_record_series_dev launched later in the same draw read. */
 int bk_dr_begin_retry(int rng_kind, uint64_t* state, int64_t ldr, const double* logp, const double* kin,
                       double* cur_H, double* cur_h, double* rej, uint8_t* alive, double prob_retry,
-                      uint32_t* counters, int64_t n_counters, int64_t C, void* stream);
+                      uint32_t* counters, int64_t n_counters, int64_t* draw_counter, int64_t C, void* stream);
 
 /* bk_dr_accept_prob_test, then -- for the lanes it rejects -- the NEXT stage's retry test (bk_dr_retry_test: the
  * chain's next uniform, drghmc.py:369-371) and the compaction of the chains that propose again: chain g is
@@ -524,11 +525,22 @@ int bk_relayout(const double* src, int64_t lds_d, int64_t lds_c, double* dst, in
 int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n,
                       int64_t C, int64_t D, void* stream);
 
+/* bk_welford_update with the update count in device memory: n = *n_dev - n_offset (e.g. a sampler's draw counter), and
+ * with theta's own row pitch.  A launch like this can be part of a captured draw (hipGraph): nothing of it changes
+ * from one replay to the next on the host side. */
+int bk_welford_update_dev(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
+                          const int64_t* n_dev, int64_t n_offset, int64_t C, int64_t D, void* stream);
+
 /* Draw storage for ess / rhat post-processing: row `row` of the K (+1) tracked series,
  * series[k][row][c] = theta[dims[k]][c] (k < K) and series[K][row][c] = logp[c] (logp may be NULL); series is
  * [K (+1)][capacity][C], chain-contiguous -- the [N, C] layout bk_ess / bk_chain_mean_var consume.  dims: device. */
 int bk_record_series(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
                      double* series, int64_t capacity, int64_t row, int64_t C, void* stream);
+
+/* The same with row = *row_dev - row_offset read on the device (rows outside [0, capacity) are not written). */
+int bk_record_series_dev(const double* theta, int64_t ld, const int32_t* dims, int64_t K, const double* logp,
+                         double* series, int64_t capacity, const int64_t* row_dev, int64_t row_offset, int64_t C,
+                         void* stream);
 
 /* Per-dimension partial sums over this rank's C chains for R-hat (rhat.py:163-171):
  * out[0*D + d] = sum_c mean ; out[1*D + d] = sum_c var_c (var_c = m2/(n-1)).

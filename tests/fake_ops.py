@@ -583,11 +583,21 @@ class FakeOps:
 
     # The appending forms build their lists in REVERSE lane order here: on the device the order depends on
     # wavefront timing, and nothing may depend on it.
-    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters):
+    def dr_begin_retry(self, kind, state, logp, kin, cur_H, cur_h, rej, alive, prob_retry, counters, draw_counter=None):
         self.dr_begin(logp, kin, cur_H, cur_h, rej, alive)
         self.dr_retry_test(kind, state, rej, prob_retry, alive)
         if counters is not None:
             counters.zero_()
+        if draw_counter is not None:
+            draw_counter += 1
+
+    def record_series_dev(self, theta, dims, logp, series, row_dev, row_offset):
+        row = int(row_dev[0]) - int(row_offset)
+        if 0 <= row < series.shape[1]:
+            self.record_series(theta, dims, logp, series, row)
+
+    def welford_update_dev(self, mean, m2, theta, n_dev, n_offset):
+        self.welford_update(mean, m2, theta, int(n_dev[0]) - int(n_offset))
 
     def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
                                  accepted, next_index, next_count, n_dev=None):

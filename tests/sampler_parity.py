@@ -283,3 +283,38 @@ def check_logistic_target(ops, N=700, D=24, C=50):
             np.testing.assert_allclose(np.asarray(th[c].cpu()), oth, rtol=1e-8, atol=1e-10)
             np.testing.assert_allclose(lp[c].item(), olp, rtol=1e-9)
     return model, tstar
+
+
+def check_attached_diagnostics(ops, C=40, D=7, draws=12, **kw):
+    """DrGhmcDiag.attach(): moments and recorder fed from inside the draw (device-side draw counter, part of the
+    captured launch sequence) against update() / record() called after every sample(): same moments, same series."""
+    import torch
+
+    args = (3, [0.5, 0.2, 0.08], [2, 3, 5], 0.4)
+    a = bk.DrGhmcDiag(bk.Funnel(D, ops=ops), *args, chains=C, seed=11, ops=ops, **kw)
+    b = bk.DrGhmcDiag(bk.Funnel(D, ops=ops), *args, chains=C, seed=11, ops=ops, **kw)
+    ma, mb = bk.RunningMoments(D, C, ops=ops), bk.RunningMoments(D, C, ops=ops)
+    ra, rb = bk.DrawRecorder([0, D - 1], draws, C, ops=ops), bk.DrawRecorder([0, D - 1], draws, C, ops=ops)
+    for _ in range(3):  # attach after a few draws: the offsets between the sampler's draw count and n matter
+        a.sample()
+        b.sample()
+    b.attach(moments=mb, recorder=rb)
+    for n in range(draws):
+        th, lp = a.sample()
+        ma.update(th)
+        ra.record(th, lp)
+        if n % 3 == 0:
+            tb, lb = b.sample()
+            assert torch.equal(th, tb) and torch.equal(lp, lb)
+        else:
+            b.advance()
+        assert (mb.n, rb.n) == (ma.n, ra.n) == (n + 1, n + 1)
+    assert torch.equal(ma.mean, mb.mean) and torch.equal(ma.m2, mb.m2)
+    assert torch.equal(ra.series, rb.series)
+    np.testing.assert_array_equal(ma.rhat(), mb.rhat())
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    import pytest
+
+    with pytest.raises(IndexError):
+        b.advance()  # the recorder is full
+    return b

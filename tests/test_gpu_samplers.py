@@ -1026,3 +1026,16 @@ def test_scalars_assigned_between_draws_reach_a_replayed_graph(ops):
         assert da.last_stage_lanes == db.last_stage_lanes and da.last_lane_steps == db.last_lane_steps, n
     assert a._graph is not None and ma._graph is not None and da._graph is not None
     np.testing.assert_array_equal(da.rng_state(), db.rng_state())
+
+
+def test_drghmc_attached_diagnostics_equal_manual_updates(ops):
+    """attach(): Welford moments and tracked series updated by launches INSIDE the replayed hipGraph of a draw
+    (update count / row index read from the sampler's device-side draw counter) == update() / record() after
+    every sample(); advance() draws without returned copies."""
+    from tests.sampler_parity import check_attached_diagnostics
+
+    g = check_attached_diagnostics(ops, C=700, D=21, draws=15)
+    assert g._use_graph and g._graph is not None
+    check_attached_diagnostics(ops, C=700, D=21, draws=8, graph=False)
+    check_attached_diagnostics(ops, C=130, D=11, draws=8, device_counts=False)
+    check_attached_diagnostics(ops, C=4096, D=21, draws=6)  # padded rows: theta's row pitch differs from the moments'

@@ -442,3 +442,10 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
     assert np.array_equal(a._rho.numpy(), b._rho.numpy())
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
     assert len(seen) >= min(4, 2 ** (K - 1))
+
+
+def test_drghmc_attached_diagnostics_equal_manual_updates():
+    from tests.sampler_parity import check_attached_diagnostics
+
+    check_attached_diagnostics(FakeOps())                         # device-side lists (eager on the CPU stand-in)
+    check_attached_diagnostics(FakeOps(), device_counts=False)    # host-sized path: fed after the draw
