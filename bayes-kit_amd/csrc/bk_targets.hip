@@ -302,20 +302,21 @@ __device__ __forceinline__ double bk_quad_bcast(double x) {  // lane K of every 
 }
 
 //   LPC = 4 : p = lane % 4 is the class GROUP; register slot u = k*SL + i holds class p + 4k, slot i.
+//   LPC = 8 : p = lane % 8;                    register slot u = k*SL + i holds class p + 8k, slot i (k = 0, 1).
 //   LPC = 16: p = lane % 16 is the CLASS;      register slot u = i     holds class p,      slot i.
 // A lane's rows are 1 + p + off(u) with a lane-independent off(u): row addresses are a per-lane 32-bit
 // offset (row 1 + p of the lane's chain) on top of a wavefront-uniform row base, and only the LAST slot
 // of a class can run past D (SL is exactly ceil((D-1)/16)): every other row needs no guard.
 template <int LPC, int SL>
 struct FunnelLanes {
-  static_assert(LPC == 4 || LPC == 16, "a chain is served by a quad or by a DPP row");
+  static_assert(LPC == 4 || LPC == 8 || LPC == 16, "a chain is served by a quad, half a DPP row or a DPP row");
   static constexpr int KC = FN_CLASSES / LPC;     // classes per lane
   static constexpr int NU = KC * SL;              // register slots per lane
   static constexpr int CHAINS = BK_WAVE / LPC;    // chains per wavefront
   __host__ __device__ static constexpr int off(int u) {  // row of slot u, relative to the lane's first row
-    return LPC == 4 ? 4 * (u / SL) + FN_CLASSES * (u % SL) : FN_CLASSES * u;
+    return LPC * (u / SL) + FN_CLASSES * (u % SL);  // (LPC = 16: one class per lane, u / SL = 0)
   }
-  __host__ __device__ static constexpr bool last_slot(int u) { return (LPC == 4 ? u % SL : u) == SL - 1; }
+  __host__ __device__ static constexpr bool last_slot(int u) { return u % SL == SL - 1; }
 };
 
 // s (canonical order) of the chain this lane serves, from the lane's class sums; valid in EVERY lane
@@ -325,6 +326,11 @@ __device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
   double q;
   if (LPC == 4) {
     q = ((cs[0] + cs[1]) + cs[2]) + cs[3];  // this lane holds classes p, p+4, p+8, p+12
+  } else if (LPC == 8) {
+    // lane p of the 8-lane group holds cs[p] and cs[p+8]; lanes 0..3 fetch cs[p+4], cs[p+12] from lane p + 4
+    const double b = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[0]);
+    const double d = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[1]);
+    q = ((cs[0] + b) + cs[1]) + d;
   } else {
     // lane p of the row holds cs[p]; in lanes 0..3: q[p] = ((cs[p] + cs[p+4]) + cs[p+8]) + cs[p+12]
     // (the other twelve lanes compute something nobody reads)
@@ -339,6 +345,9 @@ __device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
     // s is right in lanes 0..3 of the row: hand it to lanes 4..7, then lanes 0..7 hand it to 8..15
     s = bk_dpp_f64<BK_DPP_ROW_SHR + 4, 0xF, 0x2>(s, s);
     s = bk_dpp_f64<BK_DPP_ROW_SHR + 8, 0xF, 0xC>(s, s);
+  } else if (LPC == 8) {
+    // s is right in lanes 0..3 of each 8-lane group: hand it to lanes 4..7 (banks 1 and 3 of the row)
+    s = bk_dpp_f64<BK_DPP_ROW_SHR + 4, 0xF, 0xA>(s, s);
   }
   return s;
 }
@@ -363,11 +372,12 @@ __device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
 // LPC: lanes per chain (above); SL = slots per class = ceil((D-1)/16) exactly; HM = a metric is given.
 // All compile-time: with generic sizes and a run-time metric flag the kernel needed 330 registers (one
 // wavefront per SIMD, AGPR spills).
-// LPC_ARG = 4 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows --
-// sets of FN_AUTO_WIDE lanes and more take 4 lanes per chain (69 cycles of a SIMD per chain-step instead of
-// 145: above ~8,000 lanes the 16-lane form has two wavefronts on every SIMD and costs more than it saves),
-// smaller ones 16 lanes per chain.  The grid is sized for the 16-lane form of the bound n_host.
-constexpr i64 FN_AUTO_WIDE = 8192;
+// LPC_ARG = 4, 8 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows.
+// A wavefront-step costs ~580 / ~700 / ~1100 cycles with 16 / 8 / 4 lanes per chain and serves 4 / 8 / 16
+// chains; up to one wavefront per SIMD (1024 of them) the fewest cycles win, beyond that the fewest cycles per
+// chain: 16 lanes per chain below FN_AUTO_MID lanes, 8 below FN_AUTO_WIDE, 4 from there on.  The grid is sized
+// for the 16-lane form of the bound n_host.
+constexpr i64 FN_AUTO_MID = 4608, FN_AUTO_WIDE = 12288;
 template <int LPC, int SL, bool HM>
 __device__ __forceinline__ void funnel_traj_body(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
@@ -412,6 +422,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   funnel_traj_body<L, SL, HM>(th_in, rho_in, g_in, ld_in, idx, th_out, rho_out, g_out, logp_out, kin_out, ld_out, \
                               metric, h, steps, n, D, H_out, hh_out, live_out, ghost, lane, wave)
   if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= FN_AUTO_WIDE)) BK_FT_BODY(4);
+  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= FN_AUTO_MID)) BK_FT_BODY(8);
   else BK_FT_BODY(16);
 #undef BK_FT_BODY
 }
@@ -492,7 +503,7 @@ __device__ __forceinline__ void funnel_traj_body(
         r[u] = r[u] + h * t;
         x[u] = x[u] + h * r[u];
       }
-      if (LPC == 4 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
+      if (LPC != 16 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
     }
   }
   // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
@@ -956,11 +967,14 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
   // BK_FUNNEL_GEOMETRY=wide|narrow overrides (wide = 4 lanes per chain).
   static const int forced = []() {
     const char* e = getenv("BK_FUNNEL_GEOMETRY");
-    return !e ? 0 : (e[0] == 'n' ? 2 : 1);
+    return !e ? 0 : (e[0] == 'n' ? 2 : e[0] == 'm' ? 3 : 1);  // wide | mid (8 lanes per chain) | narrow
   }();
   // 16: 16 lanes per chain; 4: 4 lanes per chain; 0: the kernel decides from *n_dev
-  const int geo = forced ? (forced == 2 ? 16 : 4) : (n_dev != nullptr ? (n >= FN_AUTO_WIDE ? 0 : 16) : (n < FN_AUTO_WIDE ? 16 : 4));
-  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (geo == 4 ? BK_WAVE / 4 : BK_WAVE / 16));
+  int geo;
+  if (forced) geo = forced == 2 ? 16 : (forced == 3 ? 8 : 4);
+  else if (n_dev) geo = n >= FN_AUTO_MID ? 0 : 16;
+  else geo = n >= FN_AUTO_WIDE ? 4 : (n >= FN_AUTO_MID ? 8 : 16);
+  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
   dim3 grid(traj_blocks + job_blocks);
 #define BK_FT(LPC, R, M)                                                                                          \
   k_funnel_traj<LPC, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, \
@@ -976,6 +990,9 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
     } else if (geo == 4) {              \
       if (metric) BK_FT(4, R, true);    \
       else BK_FT(4, R, false);          \
+    } else if (geo == 8) {              \
+      if (metric) BK_FT(8, R, true);    \
+      else BK_FT(8, R, false);          \
     } else {                            \
       if (metric) BK_FT(0, R, true);    \
       else BK_FT(0, R, false);          \

@@ -751,3 +751,51 @@ def test_sample_sort_and_rhat_collectives_run_on_rccl(ops):
         assert bk.dist.sum_over_ranks(2.5, ops.device) == 2.5
     finally:
         dist.destroy_process_group()
+
+
+def test_funnel_proposal_geometries_give_the_same_values():
+    """bk_dr_proposal_funnel picks 4, 8 or 16 lanes of a wavefront per chain from the size of the lane set (on the
+    host when it knows the size, on the device otherwise); the sum over a chain's coordinates has one canonical
+    order, so the same chains integrated in sets of different sizes give the same bits -- and the same as the
+    gradient op + kick/drift launches (step-by-step)."""
+    ops = bk._lib.default_ops()
+    dev = ops.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    for D, steps, h in ((101, 7, 0.05), (18, 5, 0.1), (129, 3, 0.02)):
+        C = 13000
+        g = torch.Generator(device=dev)
+        g.manual_seed(D)
+        th = torch.randn((D, C), generator=g, **f64)
+        th[0] *= 2.0
+        rho = torch.randn((D, C), generator=g, **f64)
+        grad, lp = torch.empty_like(th), torch.empty(C, **f64)
+        ops.target_grad("funnel", None, th, grad, lp)
+        metric = torch.linspace(0.8, 1.2, D, **f64) if D == 18 else None
+
+        def run(n, n_on_device):
+            idx = None if n == C else torch.arange(n, dtype=torch.int32, device=dev)
+            out = [torch.full((D, C), float("nan"), **f64) for _ in range(3)]
+            lpo, kin = torch.empty(C, **f64), torch.empty(C, **f64)
+            n_dev = torch.tensor([n], dtype=torch.int32, device=dev) if n_on_device else None
+            views = [o if n_on_device else o[:, :n] for o in out]
+            ops.dr_proposal_funnel(th, rho, grad, idx, views[0], views[1], views[2], lpo if n_on_device else lpo[:n],
+                                   kin if n_on_device else kin[:n], metric, h, steps, n_dev=n_dev)
+            return [o[:, :n].clone() for o in out] + [lpo[:n].clone(), kin[:n].clone()]
+
+        ref = run(C, False)  # 13,000 lanes known on the host: 4 lanes per chain
+        for n, on_dev in ((C, True), (6000, False), (6000, True), (1000, False), (1000, True), (4608, True), (12288, True)):
+            got = run(n, on_dev)
+            for a, b in zip(got, ref):
+                assert torch.equal(a, b[..., :n]), (D, n, on_dev)
+        # ... and the step-by-step launches (first_step_gather, gradient op, kick + drift, finish)
+        tho, rhoo, go = (torch.empty((D, 1000), **f64) for _ in range(3))
+        lpo, kin = torch.empty(1000, **f64), torch.empty(1000, **f64)
+        ops.first_step_gather(th, rho, grad, None, tho, rhoo, metric, h, 0.5 * h)
+        for _ in range(steps - 1):
+            ops.target_grad("funnel", None, tho, go, None)
+            ops.kick_drift(tho, tho, rhoo, rhoo, go, metric, h, False, 0.0, True, h)
+        ops.target_grad("funnel", None, tho, go, lpo)
+        ops.leapfrog_finish(rhoo, rhoo, go, metric, 0.5 * h, True, kin)
+        assert torch.equal(tho, ref[0][:, :1000]) and torch.equal(rhoo, ref[1][:, :1000]) and torch.equal(go, ref[2][:, :1000])
+        assert torch.equal(lpo, ref[3][:1000])
+        np.testing.assert_allclose(kin.cpu().numpy(), ref[4][:1000].cpu().numpy(), rtol=1e-12)
