@@ -799,3 +799,21 @@ def test_funnel_proposal_geometries_give_the_same_values():
         assert torch.equal(tho, ref[0][:, :1000]) and torch.equal(rhoo, ref[1][:, :1000]) and torch.equal(go, ref[2][:, :1000])
         assert torch.equal(lpo, ref[3][:1000])
         np.testing.assert_allclose(kin.cpu().numpy(), ref[4][:1000].cpu().numpy(), rtol=1e-12)
+
+
+def test_background_generator_launch_gives_the_same_stream():
+    """bk_normals_chain_major_bg: a bounded number of workgroups, each walking several groups of chains
+    (a background kernel beside a streaming one), against the one-workgroup-per-group launch."""
+    ops = bk._lib.default_ops()
+    for C, D in ((1000, 70), (4096, 128), (333, 1000)):
+        st_a = torch.zeros((bk._lib.RNG_WORDS, C), dtype=torch.int64, device=ops.device)
+        ops.rng_init_philox(st_a, 99, 5)
+        st_b = st_a.clone()
+        dp = (D + 7) // 8 * 8
+        za = torch.full((C, dp), float("nan"), dtype=torch.float64, device=ops.device)
+        zb = za.clone()
+        sa, sb = torch.empty_like(st_a), torch.empty_like(st_a)
+        for rep in range(3):  # (resumes mid-buffer on the later calls)
+            ops.normals_chain_major(bk._lib.RNG_PHILOX, st_a, za, D, sa)
+            ops.normals_chain_major(bk._lib.RNG_PHILOX, st_b, zb, D, sb, max_workgroups=7)
+            assert torch.equal(za[:, :D], zb[:, :D]) and torch.equal(st_a, st_b) and torch.equal(sa, sb), (C, D, rep)
