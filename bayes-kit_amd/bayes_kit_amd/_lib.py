@@ -50,6 +50,7 @@ SIGNATURES = {
     "bk_dr_accept_prob_test": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost": [P, P, P, P, P, F, P, P, I, P, P, P, P],
     "bk_dr_begin_retry": [c_int, P, I, P, P, P, P, P, P, F, P, I, P, I, P],
+    "bk_dr_refresh_begin": [c_int, P, I, P, F, F, P, I, P, P, I, I, P, I, P, P, P, P, P, F, P, I, P, P],
     "bk_dr_accept_prob_test_next": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost_next": [P, P, P, P, P, F, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
@@ -66,7 +67,7 @@ SIGNATURES = {
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
-    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P],
+    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
@@ -105,6 +106,12 @@ class GhostLink(ctypes.Structure):
     """bk_ghost_link of include/bkhip.h: what a ghost proposal without ghosts of its own owes its parent level."""
     _fields_ = [("parent_H", P), ("parent_h", P), ("parent_live", P), ("parent_a", P), ("a_out", P),
                 ("prob_retry", F), ("next_index", P), ("next_count", P)]
+
+
+class Ghost0(ctypes.Structure):
+    """bk_ghost0 of include/bkhip.h: the first ghost of the proposals a launch produces, run by that launch."""
+    _fields_ = [("h", F), ("steps", I), ("parent_a", P), ("prob_retry", F), ("next_index", P), ("next_count", P),
+                ("lanes_out", P), ("lanes_total", P)]
 
 
 class ScatterJob(ctypes.Structure):
@@ -329,6 +336,15 @@ class Ops:
                    ptr(rej), ptr(alive), float(prob_retry), ptr(counters), 0 if counters is None else counters.numel(),
                    ptr(draw_counter), logp.shape[0], self._s())
 
+    def dr_refresh_begin(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, work, logp, cur_H, cur_h, rej,
+                         alive, prob_retry, counters, draw_counter=None):
+        """momentum_refresh(..., kin_out) + dr_begin_retry(...): the generator's launch + one more."""
+        D, C = out.shape
+        self._call("bk_dr_refresh_begin", kind, ptr(state), state.stride(0), ptr(loc_in), loc_mul, scale, ptr(out),
+                   _ld(out), ptr(metric), ptr(kin_out), C, D, ptr(work), 0 if work is None else work.numel(), ptr(logp),
+                   ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), float(prob_retry), ptr(counters),
+                   0 if counters is None else counters.numel(), ptr(draw_counter), self._s())
+
     def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
                                  accepted, next_index, next_count, n_dev=None):
         """dr_accept_prob_test + the next stage's retry test + the list of chains that propose again."""
@@ -463,12 +479,19 @@ class Ops:
         return GhostLink(ptr(parent_H), ptr(parent_h), ptr(parent_live), ptr(parent_a), ptr(a_out), float(prob_retry),
                          ptr(next_index) or None, ptr(next_count) or None)
 
+    def ghost0(self, h, steps, parent_a, prob_retry, next_index=None, next_count=None, lanes_out=None, lanes_total=None):
+        """The first ghost of the proposals a dr_proposal_funnel launch produces, integrated and applied to the
+        produced level by that launch (dr_proposal_funnel(ghost0=...))."""
+        return Ghost0(float(h), int(steps), ptr(parent_a), float(prob_retry), ptr(next_index) or None,
+                      ptr(next_count) or None, ptr(lanes_out) or None, ptr(lanes_total) or None)
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
-                           ghost=None):
+                           ghost=None, ghost0=None):
         """level: optional (H, h, live) tensors of the destination level -- its bk_dr_level_begin is then
         done by the same launch.  job: optional scatter_job(...) run by surplus workgroups of the launch.
-        ghost: optional ghost_link(...), the level's accept probability + parent update in the same launch."""
+        ghost: optional ghost_link(...), the level's accept probability + parent update in the same launch.
+        ghost0: optional ghost0(...), the produced level's first ghost in the same launch."""
         D, n = theta_out.shape
         H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
@@ -478,11 +501,12 @@ class Ops:
         args = (ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                 ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                 h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live))
-        if job is None and ghost is None:
+        if job is None and ghost is None and ghost0 is None:
             self._call("bk_dr_proposal_funnel", *args, self._s())
         else:
             self._call("bk_dr_proposal_funnel_job", *args, None if job is None else ctypes.byref(job),
-                       None if ghost is None else ctypes.byref(ghost), self._s())
+                       None if ghost is None else ctypes.byref(ghost),
+                       None if ghost0 is None else ctypes.byref(ghost0), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape

@@ -70,6 +70,7 @@ class DrGhmcDiag(ManyChainSampler):
         tune_placement: Optional[bool] = None,
         device_counts: Optional[bool] = None,
         graph: Optional[bool] = None,
+        fuse_first_ghost: bool = True,
         ops=None,
     ):
         self._max_proposals = max_proposals
@@ -117,6 +118,9 @@ class DrGhmcDiag(ManyChainSampler):
             graph = self._dev_counts and dev.type == "cuda"
         if graph and not self._dev_counts:
             raise ValueError("graph=True needs device_counts (the host-sized path reads lane counts back every draw)")
+        # (device-count path) a proposal's launch also runs the first ghost of the lanes it produces; False keeps
+        # that ghost a launch of its own -- same results, for A/B timing and the tests
+        self._fuse_first_ghost = bool(fuse_first_ghost)
         self._init_graph(graph)
         self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
             max(0, k - 1) for k in range(int(max_proposals)))
@@ -447,21 +451,37 @@ class DrGhmcDiag(ManyChainSampler):
         self._host_stats = (self._h_evals, self._h_lane_steps, self._h_stages)
 
     # -- the same draw with lane counts on the device: a fixed launch sequence ----------------------------
-    def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None, ghost=None):
+    def _proposal_dev(self, src, idx, n_dev, k, lvl, job=None, ghost=None, own_ghosts=0):
         """Proposal k from lanes idx (count n_dev; None = all C chains) of `src` into level lvl; `job`: a
         scatter job the launch carries along; `ghost`: the level's accept probability + parent update, done by
-        the same launch (a ghost without ghosts of its own)."""
+        the same launch (a ghost without ghosts of its own).  own_ghosts >= 1: the produced level has ghosts of
+        its own, and the launch runs the first of them as well (every produced lane has one, it starts from the
+        registers the proposal ends in; bk_ghost0).  Returns then (True, list of the lanes that go on to ghost 1
+        or None), else (False, None)."""
         h, steps = float(self._leapfrog_step_sizes[k]), int(self._leapfrog_step_counts[k])
         dst = self._levels[lvl]
         slot = self._slot
         self._slot += 1
+        g0, fused, following = None, False, None
+        if own_ghosts >= 1 and self._fuse_first_ghost:
+            fused = True
+            gslot = self._slot  # (the schedule lists G0(X) right after X)
+            self._slot += 1
+            if own_ghosts >= 2:
+                following = (self._levels[lvl + 1].idx, self._new_list())
+            g0 = self._ops.ghost0(self._leapfrog_step_sizes[0], self._leapfrog_step_counts[0], dst.a,
+                                  1.0 if self._prob_retry else 0.0, *(following or (None, None)),
+                                  lanes_out=self._slot_lanes[gslot:gslot + 1],
+                                  lanes_total=self._slot_lanes_total[gslot:gslot + 1])
         # the launch also counts its lanes (per draw and in total) and sets up its level for accept()
+        kw = {} if g0 is None else {"ghost0": g0}
         ok = self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, dst.theta, dst.rho, dst.grad, dst.logp,
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
                                         lanes_out=self._slot_lanes[slot:slot + 1],
                                         lanes_total=self._slot_lanes_total[slot:slot + 1],
-                                        level=(dst.H, dst.h, dst.live), job=job, ghost=ghost)
+                                        level=(dst.H, dst.h, dst.live), job=job, ghost=ghost, **kw)
         assert ok
+        return fused, following
 
     def _new_list(self):
         """The next unused lane counter of this draw (zeroed by bk_dr_begin_retry)."""
@@ -471,20 +491,25 @@ class DrGhmcDiag(ManyChainSampler):
             raise RuntimeError("max_proposals too large for the device-side lane lists")
         return self._counters[i:i + 1]
 
-    def _accept_dev(self, lvl, n_dev, k, parent=None, sub=None, parent_next=None):
+    def _accept_dev(self, lvl, n_dev, k, parent=None, sub=None, parent_next=None, first=(False, None)):
         """_accept() over lane sets whose sizes live on the device (n_dev None = all C chains): the ghost
         proposals of level `lvl` and their recursive accepts.  For a ghost level (`parent` given: the level
         its lanes belong to, paired by `sub`) the level's own accept probability and the update of the
         parent are one launch (bk_dr_accept_prob_ghost); for the stage's proposal itself (level 0) the
         probability is evaluated by the accept test's launch (bk_dr_accept_prob_test, in _draw_dev).
         The lane set of ghost i >= 1 -- the lanes of this level that are still live -- is listed by the launch
-        that updates the level after ghost i - 1 (`parent_next` = (list, counter) handed down to it)."""
+        that updates the level after ghost i - 1 (`parent_next` = (list, counter) handed down to it).
+        `first`: what _proposal_dev returned for this level -- ghost 0 already run by the level's own launch."""
         ops, C = self._ops, self._C
         P = self._levels[lvl]  # (H, h, live of the level were set by the proposal's own launch)
         nxt = self._levels[lvl + 1] if lvl + 1 < len(self._levels) else None
         m_dev, gsub = n_dev, None  # ghost 0: every lane of the level is still live
         for i in range(k):
             following = None
+            if i == 0 and first[0]:
+                if first[1] is not None:
+                    gsub, m_dev = first[1]
+                continue
             if i + 1 < k:  # the list ghost i + 1 will run over, built while ghost i's result is applied
                 buf = nxt.idx if (i % 2 == 0) else nxt.idx_alt
                 following = (buf, self._new_list())
@@ -495,8 +520,8 @@ class DrGhmcDiag(ManyChainSampler):
                 link = ops.ghost_link(P.H, P.h, P.live, P.a, nxt.a, pr, *(following or (None, None)))
                 self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=link)
             else:
-                self._proposal_dev(P, gsub, m_dev, i, lvl + 1)
-                self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following)
+                done = self._proposal_dev(P, gsub, m_dev, i, lvl + 1, own_ghosts=i)
+                self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following, first=done)
             if following is not None:
                 gsub, m_dev = following
         if parent is not None:
@@ -511,13 +536,12 @@ class DrGhmcDiag(ManyChainSampler):
     def _draw_dev(self):
         ops = self._ops
         C, m, damping = self._C, self._metric_dev, self._damping
-        ops.momentum_refresh(self._rng_kind, self._rng_state, self._rho_dc,
-                             self._rho_sign * math.sqrt(1 - damping), math.sqrt(damping), self._rho_dc, m,
-                             self._kin, None, self._rng_work)                                     # :360-364
         pr = 1.0 if self._prob_retry else 0.0
-        # start of the draw + the first stage's retry test (always passed, its uniform drawn) :365-371
-        ops.dr_begin_retry(self._rng_kind, self._rng_state, self._lp, self._kin, self._cur_H, self._cur_h, self._rej,
-                           self._alive, pr, self._counters, self._draws_dev)
+        # partial momentum refresh + its kinetic energy :360-364, start of the draw + the first stage's retry test
+        # (always passed, its uniform drawn) :365-371: the generator's launch + one more
+        ops.dr_refresh_begin(self._rng_kind, self._rng_state, self._rho_dc, self._rho_sign * math.sqrt(1 - damping),
+                             math.sqrt(damping), self._rho_dc, m, self._kin, self._rng_work, self._lp, self._cur_H,
+                             self._cur_h, self._rej, self._alive, pr, self._counters, self._draws_dev)
         cur = _Cur(self)
         self._slot = 0
         self._list = 0
@@ -531,8 +555,8 @@ class DrGhmcDiag(ManyChainSampler):
         job = None
         for k in range(K):
             P0 = self._levels[0] = level0[k % 2]
-            self._proposal_dev(cur, idx, n_dev, k, 0, job=job)                                    # :373
-            self._accept_dev(0, n_dev, k)                                                         # :374-376
+            done = self._proposal_dev(cur, idx, n_dev, k, 0, job=job, own_ghosts=k)               # :373
+            self._accept_dev(0, n_dev, k, first=done)                                             # :374-376
             if k + 1 < K:
                 # accept test :441-446, :378-385; for the rejected chains the next stage's retry test :369-371;
                 # the chains that propose again are listed for the next stage

@@ -113,15 +113,17 @@ class Funnel(_BuiltinTarget):
 
     def bk_dr_proposal(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                        kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
-                       ghost=None):
+                       ghost=None, ghost0=None):
         """Whole delayed-rejection proposal in one launch; False if the shape is unsupported.
         n_dev / lanes_out: device-side lane count in / out; job: a scatter job carried along; ghost: the level's
-        accept probability and parent update done by the same launch (include/bkhip.h)."""
+        accept probability and parent update done by the same launch; ghost0: the produced level's first ghost run
+        by the same launch (include/bkhip.h)."""
         if self._D > self._FUSED_MAX_D or max(theta_in.stride(0), theta_out.stride(0)) * 17 * 8 >= 2 ** 32:
             return False
         self._get_ops().dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
                                            logp_out, kin_out, metric, h, steps, n_dev=n_dev, lanes_out=lanes_out,
-                                           lanes_total=lanes_total, level=level, job=job, ghost=ghost)
+                                           lanes_total=lanes_total, level=level, job=job, ghost=ghost,
+                                           ghost0=ghost0)
         return True
 
     def bk_dr_proposal_supported(self) -> bool:

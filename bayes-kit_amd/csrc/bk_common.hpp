@@ -80,6 +80,12 @@ __device__ __forceinline__ void bk_append(bool take, int32_t value, int32_t* lis
 }
 
 
+// joint log density of (theta, rho) from log p(theta) and the kinetic energy (drghmc.py:249-251)
+__device__ __forceinline__ double dr_joint(double logp, double kin) {
+  double potential = -logp;
+  return -(potential + kin);
+}
+
 // the acceptance log-probability of lane j against its current point p (drghmc.py:441-446)
 __device__ __forceinline__ double dr_accept_logprob(double Hj, double cH, double ph, double ch, double pr) {
   const double frac = ((Hj - cH) + (ph - ch)) + (pr * ph - pr * ch);  // drghmc.py:441-445

@@ -68,10 +68,7 @@ __global__ __launch_bounds__(CP_BLOCK) void k_compact(const uint8_t* mask, i64 n
   if (threadIdx.x == 0) *count = base;
 }
 
-__device__ __forceinline__ double joint(double logp, double kin) {
-  double potential = -logp;  // drghmc.py:249-251
-  return -(potential + kin);
-}
+__device__ __forceinline__ double joint(double logp, double kin) { return dr_joint(logp, kin); }
 
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_begin(const double* logp, const double* kin, double* H,
                                                        double* h, double* rej, uint8_t* alive, i64 C,

@@ -448,6 +448,93 @@ __global__ __launch_bounds__(256) void k_refresh_apply(const double* zt, i64 ldz
   }
 }
 
+// The same + the kinetic energy of the result (bk_leapfrog_finish with no kick: the four-quarter order of
+// bk_integrator.hip) in ONE pass, optionally followed by the start of a DRGHMC draw for the chain
+// (bk_dr_begin_retry): one launch and one sweep over rho instead of three launches and two sweeps.
+// A workgroup serves 64 chains; wavefront w owns the quarter [w*Dq, (w+1)*Dq) of the dimensions, brings its
+// [64 chains x 16 dims] pieces of the chain-major zt through a private LDS tile (lanes along d when reading zt,
+// along the chains when writing rho) and sums v*(m*v) sequentially in d, as k_finish does.
+struct DrBegin {
+  const double* logp;
+  double *H, *h, *rej;
+  uint8_t* alive;
+  double pr;
+  uint32_t* counters;
+  int n_counters;
+  int64_t* draw_counter;
+  uint64_t* state;
+  i64 ldr;
+};
+
+constexpr int RK_CH = 16;  // dimensions per piece
+
+template <bool BEGIN>
+__global__ __launch_bounds__(256) void k_refresh_apply_kin(const double* zt, i64 ldz, const double* loc_in,
+                                                           double loc_mul, double scale, double* out, i64 ld,
+                                                           const double* metric, double* kin_out, i64 C, i64 D,
+                                                           DrBegin b) {
+  __shared__ double tile[4][64][RK_CH + 1];
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, w = bk_wave_id();
+  const i64 c0 = (i64)blockIdx.x * 64, c = c0 + lane;
+  const i64 Dq = (D + 3) / 4;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
+  if (BEGIN) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < b.n_counters) b.counters[threadIdx.x] = 0;
+    if (b.draw_counter && blockIdx.x == 0 && threadIdx.x == 0) *b.draw_counter += 1;
+  }
+  const int sub = lane >> 4, dl = lane & 15;  // zt side: 4 chains x 16 dims per instruction
+  double kin = 0.0;
+  for (i64 p0 = 0; p0 < Dq; p0 += RK_CH) {  // (the same trip count in every wavefront: barriers inside)
+    const i64 d0 = dlo + p0;
+    double z[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      i64 cc = c0 + 4 * i + sub, d = d0 + dl;
+      z[i] = (cc < C && d < dhi) ? zt[cc * ldz + d] : 0.0;
+    }
+    double loc[RK_CH];
+#pragma unroll
+    for (int u = 0; u < RK_CH; ++u)
+      loc[u] = (loc_in && c < C && d0 + u < dhi) ? loc_in[(d0 + u) * ld + c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tile[w][4 * i + sub][dl] = z[i];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < RK_CH; ++u) {
+      if (c < C && d0 + u < dhi) {
+        double lo = loc_in ? loc[u] * loc_mul : 0.0;
+        double v = lo + scale * tile[w][lane][u];
+        out[(d0 + u) * ld + c] = v;
+        double mv = metric ? metric[d0 + u] * v : v;
+        kin = kin + v * mv;
+      }
+    }
+    __syncthreads();
+  }
+  part[w][lane] = kin;
+  __syncthreads();
+  if (w != 0 || c >= C) return;
+  double s = part[0][lane];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) s = s + part[k][lane];
+  const double kc = 0.5 * s;
+  kin_out[c] = kc;
+  if (BEGIN) {
+    // bk_dr_begin_retry for this chain (drghmc.py:365-371): the retry uniform comes after the chain's normals
+    b.H[c] = dr_joint(b.logp[c], kc);
+    b.h[c] = 0.0;
+    const double r0 = 0.0;
+    b.rej[c] = r0;
+    bk::Philox g;
+    g.load(b.state, b.ldr, c);
+    double lu = log(bk::next_double(g));
+    g.store(b.state, b.ldr, c);
+    double retry = b.pr * r0;
+    b.alive[c] = (lu < retry) ? 1 : 0;
+  }
+}
+
 // theta' = (theta + eps*grad) + s*z with z already drawn (mala.py:41-45), two rows per thread
 __global__ __launch_bounds__(256) void k_mala_propose_z(const double* th, const double* g, const double* z,
                                                         double* prop, i64 ld, double eps, double s, i64 C, i64 D) {
@@ -531,12 +618,14 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr, const double
     if (work && !active && D >= 32 && work_elems >= bk_refresh_work_elems(C, D)) {
       i64 dp = (D + 7) / 8 * 8;
       zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
-      dim3 g2((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
-      k_refresh_apply<<<g2, dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out, ld, C, D);
-      hipError_t e = hipGetLastError();
-      if (e != hipSuccess) return (int)e;
-      if (kin_out) return bk_leapfrog_finish(out, nullptr, ld, nullptr, 0, 0, metric, 0.0, 0, kin_out, C, D, stream);
-      return BK_OK;
+      if (kin_out) {
+        k_refresh_apply_kin<false><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), 0, s>>>(
+            work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, DrBegin{});
+      } else {
+        dim3 g2((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
+        k_refresh_apply<<<g2, dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out, ld, C, D);
+      }
+      BK_RETURN_LAUNCH_STATUS();
     }
     k_refresh<bk::Philox><<<grid, block, 0, s>>>(state, ldr, loc_in, loc_mul, scale, out, ld, metric, kin_out, active,
                                                  C, D);
@@ -547,6 +636,31 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr, const double
     return BK_E_ARG;
   }
   BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double* loc_in, double loc_mul, double scale,
+                        double* out, int64_t ld, const double* metric, double* kin_out, int64_t C, int64_t D,
+                        double* work, int64_t work_elems, const double* logp, double* cur_H, double* cur_h,
+                        double* rej, uint8_t* alive, double prob_retry, uint32_t* counters, int64_t n_counters,
+                        int64_t* draw_counter, void* stream) {
+  if (!state || !out || !kin_out || !logp || !cur_H || !cur_h || !rej || !alive || C < 0 || D < 0 || ld < C ||
+      ldr < C || n_counters < 0 || n_counters > 64 || (n_counters > 0 && !counters))
+    return BK_E_ARG;
+  if (C == 0) return BK_OK;
+  if (rng_kind == BK_RNG_PHILOX && work && D >= 32 && work_elems >= bk_refresh_work_elems(C, D)) {
+    hipStream_t s = bk_stream(stream);
+    i64 dp = (D + 7) / 8 * 8;
+    zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
+    DrBegin b = {logp, cur_H, cur_h, rej, alive, prob_retry, counters, (int)n_counters, draw_counter, state, ldr};
+    k_refresh_apply_kin<true><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out,
+                                                                                  ld, metric, kin_out, C, D, b);
+    BK_RETURN_LAUNCH_STATUS();
+  }
+  int rc = bk_momentum_refresh(rng_kind, state, ldr, loc_in, loc_mul, scale, out, ld, metric, kin_out, nullptr, C, D,
+                               work, work_elems, stream);
+  if (rc != BK_OK) return rc;
+  return bk_dr_begin_retry(rng_kind, state, ldr, logp, kin_out, cur_H, cur_h, rej, alive, prob_retry, counters,
+                           n_counters, draw_counter, C, stream);
 }
 
 int bk_log_uniform(int rng_kind, uint64_t* state, int64_t ldr, double* out, const uint8_t* active,

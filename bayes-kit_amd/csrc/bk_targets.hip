@@ -383,7 +383,7 @@ __device__ __forceinline__ void funnel_traj_body(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
-    const bk_ghost_link& ghost, int lane, int wave);
+    const bk_ghost_link& ghost, const bk_ghost0& g0, int lane, int wave);
 
 template <int LPC_ARG, int SL, bool HM>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
     unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out, unsigned traj_blocks,
-    bk_scatter_job job, bk_ghost_link ghost) {
+    bk_scatter_job job, bk_ghost_link ghost, bk_ghost0 g0) {
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
   if (blockIdx.x >= traj_blocks) {
     // surplus workgroups: the previous stage's scatter (bk_scatter_job), one 64-lane unit per wavefront
@@ -417,10 +417,14 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (lanes_out) *lanes_out = (uint32_t)n;
     if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
+    if (g0.steps > 0) {  // the fused first ghost runs over the same lanes
+      if (g0.lanes_out) *g0.lanes_out = (uint32_t)n;
+      if (g0.lanes_total) *reinterpret_cast<unsigned long long*>(g0.lanes_total) += (unsigned long long)n;
+    }
   }
 #define BK_FT_BODY(L)                                                                                              \
   funnel_traj_body<L, SL, HM>(th_in, rho_in, g_in, ld_in, idx, th_out, rho_out, g_out, logp_out, kin_out, ld_out, \
-                              metric, h, steps, n, D, H_out, hh_out, live_out, ghost, lane, wave)
+                              metric, h, steps, n, D, H_out, hh_out, live_out, ghost, g0, lane, wave)
   if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= FN_AUTO_WIDE)) BK_FT_BODY(4);
   else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= FN_AUTO_MID)) BK_FT_BODY(8);
   else BK_FT_BODY(16);
@@ -432,7 +436,7 @@ __device__ __forceinline__ void funnel_traj_body(
     const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
     double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
     const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
-    const bk_ghost_link& ghost, int lane, int wave) {
+    const bk_ghost_link& ghost, const bk_ghost0& g0, int lane, int wave) {
   using G = FunnelLanes<LPC, SL>;
   constexpr int NU = G::NU;
   const i64 j0 = ((i64)blockIdx.x * FN_WAVES + wave) * G::CHAINS;  // first chain of this wavefront
@@ -507,13 +511,15 @@ __device__ __forceinline__ void funnel_traj_body(
     }
   }
   // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
-  double logp_j = 0.0;
+  double logp_j = 0.0, ev_end = 0.0, gv_end = 0.0;
   {
     BK_FL_CLASS_SUMS(cs, x[u] * x[u])
     const double s = funnel_reduce_lanes<LPC>(cs);
     const double ev = exp(-v);
     const double he = 0.5 * ev;
     const double gv = ((-v / 9.0) - hn) + he * s;
+    ev_end = ev;
+    gv_end = gv;
     {
       double t = hm ? mv * gv : gv;
       rv = rv + half * t;
@@ -547,6 +553,7 @@ __device__ __forceinline__ void funnel_traj_body(
   BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
   double ksum = funnel_reduce_lanes<LPC>(cs);
   bool parent_goes_on = false;
+  double H_own = 0.0;
   if (writer) {
     double rr = -rv;
     double mr = hm ? mv * rr : rr;
@@ -559,9 +566,12 @@ __device__ __forceinline__ void funnel_traj_body(
       // H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0, live = 1
       const double potential = -logp_j;
       const double Hj = -(potential + kin);
+      H_own = Hj;
       H_out[j] = Hj;
-      hh_out[j] = 0.0;
-      live_out[j] = 1;
+      if (g0.steps <= 0) {  // (with a fused first ghost h and live are written after it, below)
+        hh_out[j] = 0.0;
+        live_out[j] = 1;
+      }
       if (ghost.parent_H) {
         // a ghost with no ghosts of its own: its acceptance probability against the parent lane it came from
         // and the parent's update (bk_dr_accept_prob_ghost; drghmc.py:426-446), here instead of in a launch of
@@ -580,6 +590,97 @@ __device__ __forceinline__ void funnel_traj_body(
   }
   // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
   if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
+
+  // ---- the proposal's FIRST GHOST, in the same wavefront (drghmc.py:424-436 with i = 0) ----------------------
+  // Every lane of a level gets ghost 0, lane for lane, and a ghost of the first proposal kind has no ghosts of its
+  // own: the wavefront that has just produced proposal P integrates P's ghost straight from its registers
+  // (theta_P, the flipped momentum, the gradient at theta_P = -(e^-v x) with the e^-v of the last evaluation) --
+  // no store + gather of the ghost's source, no ghost arrays at all (only its joint log density is ever used),
+  // one launch instead of two.  Same operation sequence as a launch of its own.
+  if (g0.steps > 0) {
+    const double h2 = g0.h, half2 = 0.5 * g0.h;
+    // first half-kick + drift from the proposal's end point (drghmc.py:276-278)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (BK_FL_OK(u)) {
+        double gi = -(ev_end * x[u]);
+        double t = hm ? BK_FL_METRIC(u) * gi : gi;
+        r[u] = r[u] + half2 * t;
+        x[u] = x[u] + h2 * r[u];
+      }
+    }
+    double rv2 = -rv;
+    {
+      double t = hm ? mv * gv_end : gv_end;
+      rv2 = rv2 + half2 * t;
+      v = v + h2 * rv2;
+    }
+    for (int step = 0; step + 1 < g0.steps; ++step) {
+      BK_FL_CLASS_SUMS(cs, x[u] * x[u])
+      const double s = funnel_reduce_lanes<LPC>(cs);
+      const double ev = exp(-v);
+      const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
+      {
+        double t = hm ? mv * gv : gv;
+        rv2 = rv2 + h2 * t;
+        v = v + h2 * rv2;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (BK_FL_OK(u)) {
+          double gi = -(ev * x[u]);
+          double t = hm ? BK_FL_METRIC(u) * gi : gi;
+          r[u] = r[u] + h2 * t;
+          x[u] = x[u] + h2 * r[u];
+        }
+        if (LPC != 16 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    double logp_g = 0.0;
+    {
+      BK_FL_CLASS_SUMS(cs, x[u] * x[u])
+      const double s = funnel_reduce_lanes<LPC>(cs);
+      const double ev = exp(-v);
+      const double he = 0.5 * ev;
+      const double gv = ((-v / 9.0) - hn) + he * s;
+      {
+        double t = hm ? mv * gv : gv;
+        rv2 = rv2 + half2 * t;
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        if (BK_FL_OK(u)) {
+          double gi = -(ev * x[u]);
+          double t = hm ? BK_FL_METRIC(u) * gi : gi;
+          r[u] = r[u] + half2 * t;
+          r[u] = -r[u];
+        }
+      }
+      logp_g = ((-(v * v) / 18.0) - hn * v) - he * s;
+    }
+    BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
+    const double ksum_g = funnel_reduce_lanes<LPC>(cs);
+    bool goes_on = false;
+    if (writer) {
+      const double rr = -rv2;
+      const double mr = hm ? mv * rr : rr;
+      const double kin_g = 0.5 * (rr * mr + ksum_g);
+      const double H_g = -((-logp_g) + kin_g);
+      // the ghost against the proposal it came from (parent h = 0: this is the proposal's first ghost), then the
+      // proposal's level entry: bk_dr_level_begin + bk_dr_accept_prob_ghost in one
+      const double g = dr_accept_logprob(H_g, H_own, 0.0, 0.0, g0.prob_retry);
+      if (g == 0.0) {  // drghmc.py:430-432
+        hh_out[j] = 0.0;
+        live_out[j] = 0;
+        g0.parent_a[j] = -INFINITY;
+      } else {
+        hh_out[j] = 0.0 + log1p(-exp(g));  // drghmc.py:434-435
+        live_out[j] = 1;
+        goes_on = true;
+      }
+    }
+    if (g0.next_index) bk_append(goes_on, (int32_t)j, g0.next_index, g0.next_count);
+  }
 #undef BK_FL_IN
 #undef BK_FL_OUT
 #undef BK_FL_OK
@@ -924,7 +1025,8 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                               double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
                               int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
                               uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
-                              const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, void* stream) {
+                              const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, const bk_ghost0* g0_in,
+                              void* stream) {
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
     return BK_E_ARG;
@@ -936,6 +1038,13 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
     ghost = *ghost_in;
     if (!H_out || !ghost.parent_H || !ghost.parent_h || !ghost.parent_live || !ghost.parent_a || !ghost.a_out ||
         (ghost.next_index && (!ghost.next_count || ghost.next_index == src_index)))
+      return BK_E_ARG;
+  }
+  bk_ghost0 g0 = {};
+  if (g0_in) {
+    g0 = *g0_in;
+    if (g0.steps < 1 || g0.steps > 0x7fffffff || !H_out || !g0.parent_a || ghost_in ||
+        (g0.next_index && (!g0.next_count || g0.next_index == src_index)))
       return BK_E_ARG;
   }
   bk_scatter_job job = {};
@@ -955,6 +1064,10 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
       int rc = bk_scatter_columns(job.mask, job.index, job.n, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
                                   job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc, job.n_dev, stream);
       if (rc != BK_OK) return rc;
+    }
+    if (g0.steps > 0 && g0.lanes_out) {
+      int rc = (int)hipMemsetAsync(g0.lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
+      if (rc != 0) return rc;
     }
     if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
     return BK_OK;
@@ -981,7 +1094,7 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                                                            rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
                                                            (int)steps, n, D, n_dev, lanes_out,                     \
                                                            reinterpret_cast<unsigned long long*>(lanes_total),    \
-                                                           H_out, h_out, live_out, traj_blocks, job, ghost)
+                                                           H_out, h_out, live_out, traj_blocks, job, ghost, g0)
 #define BK_FT_ROWS(R)                   \
   do {                                  \
     if (geo == 16) {                    \
@@ -1021,7 +1134,7 @@ int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const do
                           uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
   return bk_dr_proposal_funnel_job(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
                                    kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out, lanes_total, H_out, h_out,
-                                   live_out, nullptr, nullptr, stream);
+                                   live_out, nullptr, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

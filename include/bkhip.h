@@ -72,6 +72,16 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
                         const uint8_t* active, int64_t C, int64_t D, double* work,
                         int64_t work_elems, void* stream);
 
+/* DRGHMC: the partial momentum refresh with its kinetic energy (bk_momentum_refresh, no mask) followed by the
+ * start of the draw (bk_dr_begin_retry with kin = kin_out) -- drghmc.py:360-371.  With `work` (Philox, D >= 32) the
+ * transpose of the normals into the state layout, the kinetic energy and the start of the draw are ONE launch after
+ * the generator's; otherwise the two calls in sequence.  Same values, same stream positions either way. */
+int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double* loc_in, double loc_mul,
+                        double scale, double* out, int64_t ld, const double* metric, double* kin_out, int64_t C,
+                        int64_t D, double* work, int64_t work_elems, const double* logp, double* cur_H,
+                        double* cur_h, double* rej, uint8_t* alive, double prob_retry, uint32_t* counters,
+                        int64_t n_counters, int64_t* draw_counter, void* stream);
+
 /* out[c] = log(u), u = next double of chain c's stream: `np.log(self._rng.uniform())`
  * (hmc.py:60, metropolis.py:74, drghmc.py:370,378).  Inactive chains draw nothing and
  * keep out[c]. */
@@ -453,20 +463,38 @@ typedef struct bk_ghost_link {
   uint32_t* next_count;
 } bk_ghost_link;
 
+/* The FIRST GHOST of the produced proposals (drghmc.py:424 with i = 0), integrated by the proposal's own launch from its
+ * registers: h / steps of the first proposal kind.  Every produced lane gets one, lane for lane; only the ghost's joint
+ * log density is used, so no ghost arrays exist.  The launch then writes the level's h (= log1p(-exp(g)), or 0) and live
+ * (g != 0) itself, parent_a[j] = -inf where g == 0, and appends the lanes that go on to their next ghost to
+ * next_index (may be NULL).  lanes_out / lanes_total (may be NULL): the ghost trajectory's lane statistics. */
+typedef struct bk_ghost0 {
+  double h;
+  int64_t steps;
+  double* parent_a;
+  double prob_retry;
+  int32_t* next_index;
+  uint32_t* next_count;
+  uint32_t* lanes_out;
+  uint64_t* lanes_total;
+} bk_ghost0;
+
 /* bk_dr_proposal_funnel with a scatter job (may be NULL) run by surplus workgroups of the SAME launch: the
  * previous stage's accepted columns move into the chains' current point (drghmc.py:379-381) while this stage's
  * trajectories -- a sparse, latency-bound lane set -- integrate.  The caller guarantees that the job and the
  * proposal touch disjoint memory: the job writes columns of accepted chains and reads the previous stage's
  * proposal buffers, the proposal reads columns of rejected chains and writes its own buffers.
  * ghost (may be NULL; needs H_out): the launch also evaluates each produced lane's acceptance probability against
- * its parent lane and applies it to the parent (bk_ghost_link): one launch instead of two per such ghost. */
+ * its parent lane and applies it to the parent (bk_ghost_link): one launch instead of two per such ghost.
+ * ghost0 (may be NULL; needs H_out, excludes `ghost`): the launch also integrates the first ghost of every produced
+ * lane (bk_ghost0) and applies it to the produced level. */
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
                           int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
                           double* H_out, double* h_out, uint8_t* live_out, const bk_scatter_job* job,
-                              const bk_ghost_link* ghost, void* stream);
+                              const bk_ghost_link* ghost, const bk_ghost0* ghost0, void* stream);
 
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix

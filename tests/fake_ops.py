@@ -313,13 +313,29 @@ class FakeOps:
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
-                           ghost=None):
+                           ghost=None, ghost0=None):
         # a scatter job runs BESIDE the trajectories on the device (disjoint memory): do it afterwards here, so
         # that a job which overlapped the proposal's inputs or outputs would be noticed
-        if job is not None or ghost is not None:
+        if job is not None or ghost is not None or ghost0 is not None:
             try:
                 self.dr_proposal_funnel(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out,
                                         logp_out, kin_out, metric, h, steps, n_dev, lanes_out, lanes_total, level)
+                if ghost0 is not None:
+                    # the produced level's first ghost as a launch of its own into scratch arrays, then
+                    # dr_accept_prob_ghost[_next] against the produced level
+                    assert ghost is None and level is not None
+                    g0 = ghost0
+                    n_l = theta_out.shape[1]
+                    th, rh, gr = (torch.empty_like(t) for t in (theta_out, rho_out, grad_out))
+                    lp, kn, gH, gh, ga = (torch.empty(n_l, dtype=torch.float64) for _ in range(5))
+                    glive = torch.empty(n_l, dtype=torch.uint8)
+                    self.dr_proposal_funnel(theta_out, rho_out, grad_out, None, th, rh, gr, lp, kn, metric, g0["h"],
+                                            g0["steps"], n_dev, g0["lanes_out"], g0["lanes_total"], (gH, gh, glive))
+                    args = (gH, level[0], gh, level[1], None, g0["prob_retry"], glive, ga, n_l, level[2], g0["parent_a"])
+                    if g0["next_index"] is None:
+                        self.dr_accept_prob_ghost(*args, n_dev=n_dev)
+                    else:
+                        self.dr_accept_prob_ghost_next(*args, g0["next_index"], g0["next_count"], n_dev=n_dev)
                 if ghost is not None:
                     gl = ghost
                     n_l = theta_out.shape[1]
@@ -591,6 +607,11 @@ class FakeOps:
         if draw_counter is not None:
             draw_counter += 1
 
+    def dr_refresh_begin(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, work, logp, cur_H, cur_h, rej,
+                         alive, prob_retry, counters, draw_counter=None):
+        self.momentum_refresh(kind, state, loc_in, loc_mul, scale, out, metric, kin_out, None, work)
+        self.dr_begin_retry(kind, state, logp, kin_out, cur_H, cur_h, rej, alive, prob_retry, counters, draw_counter)
+
     def record_series_dev(self, theta, dims, logp, series, row_dev, row_offset):
         row = int(row_dev[0]) - int(row_offset)
         if 0 <= row < series.shape[1]:
@@ -638,6 +659,10 @@ class FakeOps:
 
     def scatter_job(self, *args, **kw):
         return {"args": args, "kw": kw}
+
+    def ghost0(self, h, steps, parent_a, prob_retry, next_index=None, next_count=None, lanes_out=None, lanes_total=None):
+        return dict(h=float(h), steps=int(steps), parent_a=parent_a, prob_retry=prob_retry, next_index=next_index,
+                    next_count=next_count, lanes_out=lanes_out, lanes_total=lanes_total)
 
     def ghost_link(self, parent_H, parent_h, parent_live, parent_a, a_out, prob_retry, next_index=None, next_count=None):
         return dict(parent_H=parent_H, parent_h=parent_h, parent_live=parent_live, parent_a=parent_a, a_out=a_out,

@@ -432,6 +432,41 @@ def test_wave_per_chain_refresh_resumes_anywhere(ops, D):
             assert np.array_equal(a[:, c].cpu().numpy(), want), (D, rep, c)
 
 
+@pytest.mark.parametrize("C,D,with_metric", [(67, 101, True), (4096, 101, False), (1000, 33, True), (130, 129, False),
+                                              (64, 400, True), (50, 8, True)])
+def test_dr_refresh_begin_equals_refresh_then_begin(ops, C, D, with_metric):
+    """bk_dr_refresh_begin (generator launch + ONE launch: transpose, partial refresh in place, kinetic energy,
+    start of the draw, first retry uniform) against bk_momentum_refresh with one lane per chain followed by
+    bk_dr_begin_retry: momenta, energies, H / h / rej / alive, counters, draw counter and stream positions.
+    (D = 8: below the wavefront-per-chain threshold -- the entry point falls back to the two calls.)"""
+    kind, st_a = make_state(4242, C, ops)
+    _, st_b = make_state(4242, C, ops)
+    f64 = dict(dtype=torch.float64, device=ops.device)
+    g = torch.Generator(device=ops.device)
+    g.manual_seed(C + D)
+    rho_a = torch.randn((D, C), generator=g, **f64)
+    rho_b = rho_a.clone()
+    logp = torch.randn(C, generator=g, **f64)
+    m = dev(np.linspace(0.5, 1.5, D), ops) if with_metric else None
+    work = ops.refresh_work(C, D)
+
+    def outs():
+        return (torch.empty(C, **f64), torch.empty(C, **f64), torch.empty(C, **f64), torch.empty(C, **f64),
+                torch.empty(C, dtype=torch.uint8, device=ops.device),
+                torch.full((5,), 9, dtype=torch.int32, device=ops.device),
+                torch.full((1,), 3, dtype=torch.int64, device=ops.device))
+
+    for rep in range(3):
+        ka, Ha, ha, ra, la, ca, na = outs()
+        kb, Hb, hb, rb, lb, cb, nb = outs()
+        ops.dr_refresh_begin(kind, st_a, rho_a, -0.9, 0.4, rho_a, m, ka, work, logp, Ha, ha, ra, la, 1.0, ca, na)
+        ops.momentum_refresh(kind, st_b, rho_b, -0.9, 0.4, rho_b, m, kb, None, None)
+        ops.dr_begin_retry(kind, st_b, logp, kb, Hb, hb, rb, lb, 1.0, cb, nb)
+        for x, y in zip((rho_a, ka, Ha, ha, ra, la, ca, na, st_a), (rho_b, kb, Hb, hb, rb, lb, cb, nb, st_b)):
+            assert torch.equal(x, y), (C, D, rep)
+        assert int(na) == 4 and int(ca.abs().sum()) == 0 and int(la.sum()) == C
+
+
 @pytest.mark.parametrize("C,D", [(1, 1), (64, 9), (129, 17), (130, 8), (1024, 33)])
 def test_select_with_fused_output_copy(ops, C, D):
     """copy0 = array 0 after the select, for every chain; with and without the second pair; the
@@ -799,6 +834,65 @@ def test_funnel_proposal_geometries_give_the_same_values():
         assert torch.equal(tho, ref[0][:, :1000]) and torch.equal(rhoo, ref[1][:, :1000]) and torch.equal(go, ref[2][:, :1000])
         assert torch.equal(lpo, ref[3][:1000])
         np.testing.assert_allclose(kin.cpu().numpy(), ref[4][:1000].cpu().numpy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("D,n,prob_retry", [(101, 13000, 1.0), (101, 5000, 0.0), (18, 900, 1.0), (129, 13000, 1.0), (2, 300, 1.0)])
+def test_funnel_proposal_with_its_first_ghost_equals_two_launches(D, n, prob_retry):
+    """bk_ghost0: a proposal launch that also integrates the first ghost of every lane it produces (from its
+    registers) and applies it to the produced level, against the ghost as a launch of its own with a bk_ghost_link
+    -- same level H / h / live / a, same list of lanes that go on (as a set), same lane statistics; for every
+    lanes-per-chain geometry (13,000 / 5,000 / fewer lanes), sizes known on the host or on the device."""
+    ops = bk._lib.default_ops()
+    dev = ops.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    C = 13000
+    g = torch.Generator(device=dev)
+    g.manual_seed(D + n)
+    th = torch.randn((D, C), generator=g, **f64)
+    th[0] *= 2.0
+    rho = torch.randn((D, C), generator=g, **f64)
+    grad, lp = torch.empty_like(th), torch.empty(C, **f64)
+    ops.target_grad("funnel", None, th, grad, lp)
+    metric = torch.linspace(0.8, 1.2, D, **f64) if D == 18 else None
+    idx = torch.randperm(C, generator=torch.Generator().manual_seed(3))[:n].to(torch.int32).to(dev)
+    h, steps, gh, gsteps = 0.3, 4, 0.9, 3   # a long first-kind step: many ghosts are accepted outright (g == 0)
+
+    def level():
+        out = [torch.full((D, n), float("nan"), **f64) for _ in range(3)]
+        return out, torch.empty(n, **f64), torch.empty(n, **f64), (torch.empty(n, **f64), torch.empty(n, **f64),
+                                                                  torch.empty(n, dtype=torch.uint8, device=dev))
+
+    for on_dev in (False, True):
+        n_dev = torch.tensor([n], dtype=torch.int32, device=dev) if on_dev else None
+        # two launches: the proposal, then its ghost with a link to it
+        oa, lpa, kina, lva = level()
+        a_par = torch.full((n,), 7.0, **f64)
+        lanes_a = torch.zeros(2, dtype=torch.int32, device=dev)
+        tot_a = torch.full((2,), 5, dtype=torch.int64, device=dev)
+        ops.dr_proposal_funnel(th, rho, grad, idx, *oa, lpa, kina, metric, h, steps, n_dev=n_dev, lanes_out=lanes_a[0:1],
+                               lanes_total=tot_a[0:1], level=lva)
+        og, lpg, king, lvg = level()
+        a_g = torch.empty(n, **f64)
+        list_a, cnt_a = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        link = ops.ghost_link(lva[0], lva[1], lva[2], a_par, a_g, prob_retry, list_a, cnt_a)
+        ops.dr_proposal_funnel(oa[0], oa[1], oa[2], None, *og, lpg, king, metric, gh, gsteps, n_dev=n_dev,
+                               lanes_out=lanes_a[1:2], lanes_total=tot_a[1:2], level=lvg, ghost=link)
+        # one launch
+        ob, lpb, kinb, lvb = level()
+        b_par = torch.full((n,), 7.0, **f64)
+        lanes_b = torch.zeros(2, dtype=torch.int32, device=dev)
+        tot_b = torch.full((2,), 5, dtype=torch.int64, device=dev)
+        list_b, cnt_b = torch.full((n,), -1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+        g0 = ops.ghost0(gh, gsteps, b_par, prob_retry, list_b, cnt_b, lanes_b[1:2], tot_b[1:2])
+        ops.dr_proposal_funnel(th, rho, grad, idx, *ob, lpb, kinb, metric, h, steps, n_dev=n_dev, lanes_out=lanes_b[0:1],
+                               lanes_total=tot_b[0:1], level=lvb, ghost0=g0)
+        for x, y in zip(oa + [lpa, kina] + list(lva) + [a_par, lanes_a, tot_a, cnt_a],
+                        ob + [lpb, kinb] + list(lvb) + [b_par, lanes_b, tot_b, cnt_b]):
+            assert torch.equal(x, y), (D, n, on_dev)
+        m = int(cnt_a)
+        assert torch.equal(list_a[:m].sort().values, list_b[:m].sort().values)
+        live = lva[2].bool()
+        assert 0 < m == int(live.sum()) < n and torch.isinf(a_par[~live]).all() and (lva[1][live] <= 0).all() and (lva[1][live] < 0).any()
 
 
 def test_background_generator_launch_gives_the_same_stream():

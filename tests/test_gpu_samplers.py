@@ -852,15 +852,18 @@ def test_drghmc_device_side_lane_counts_equal_host_sized_launches(ops, D, K):
         a = mk(device_counts=False)
         b = mk(device_counts=True, graph=False)
         g = mk()  # default: device counts + hipGraph replay
+        u = mk(graph=False, fuse_first_ghost=False)  # every ghost a launch of its own
         assert g._dev_counts and g._use_graph and not a._dev_counts and g.host_syncs_per_draw == 0
         seen = set()
         for n in range(12):
             ta, la = a.sample()
             tb, lb = b.sample()
             tg, lg = g.sample()
+            tu, lu = u.sample()
             assert torch.equal(ta, tb) and torch.equal(la, lb), (D, K, C, n)
             assert torch.equal(ta, tg) and torch.equal(la, lg), (D, K, C, n, "graph")
-            assert a.last_stage_lanes == b.last_stage_lanes == g.last_stage_lanes
+            assert torch.equal(ta, tu) and torch.equal(la, lu), (D, K, C, n, "unfused ghosts")
+            assert a.last_stage_lanes == b.last_stage_lanes == g.last_stage_lanes == u.last_stage_lanes
             assert a.last_lane_steps == b.last_lane_steps == g.last_lane_steps
             assert a.last_grad_evals == b.last_grad_evals == g.last_grad_evals
             seen.update(t for t, _ in a.last_stage_lanes)

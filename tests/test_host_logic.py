@@ -431,13 +431,18 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
     ops_a, ops_b = FakeOps(), FakeOps()
     a = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_a), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=False, ops=ops_a)
     b = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_b), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True, ops=ops_b)
+    ops_u = FakeOps()
+    u = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_u), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,
+                      fuse_first_ghost=False, ops=ops_u)   # every ghost a launch of its own
     assert b._dev_counts and not a._dev_counts
     seen = set()
     for n in range(10):
         ta, la = a.sample()
         tb, lb = b.sample()
+        tu, lu = u.sample()
         assert np.array_equal(ta.numpy(), tb.numpy()) and np.array_equal(la.numpy(), lb.numpy()), (K, n)
-        assert a.last_stage_lanes == b.last_stage_lanes and a.last_lane_steps == b.last_lane_steps
+        assert np.array_equal(ta.numpy(), tu.numpy()) and np.array_equal(la.numpy(), lu.numpy()), (K, n)
+        assert a.last_stage_lanes == b.last_stage_lanes == u.last_stage_lanes and a.last_lane_steps == b.last_lane_steps
         seen.update(t for t, _ in a.last_stage_lanes)
     assert np.array_equal(a._rho.numpy(), b._rho.numpy())
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())

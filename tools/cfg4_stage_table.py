@@ -22,7 +22,9 @@ def short(n):
 starts = [i for i, r in enumerate(rows) if "k_zig_parallel" in r["Kernel_Name"]]
 starts = starts[-(want + 1):]
 draws = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
-tags = ["P0", "P1", "G0(P1)", "P2", "G0(P2)", "G1(P2)", "G0(G1(P2))"]
+TAGS = {7: ["P0", "P1", "G0(P1)", "P2", "G0(P2)", "G1(P2)", "G0(G1(P2))"],
+        4: ["P0", "P1+G0(P1)", "P2+G0(P2)", "G1(P2)+G0(G1(P2))"]}  # (a launch runs its lanes' first ghost too)
+tags = TAGS.get(sum("k_funnel_traj" in r["Kernel_Name"] for r in draws[-1]), TAGS[7])
 per_kernel, per_traj, spans, busy, launches = defaultdict(float), defaultdict(float), [], [], []
 for d in draws:
     t = 0
