@@ -513,12 +513,13 @@ class DrGhmcDiag(ManyChainSampler):
             if i + 1 < k:  # the list ghost i + 1 will run over, built while ghost i's result is applied
                 buf = nxt.idx if (i % 2 == 0) else nxt.idx_alt
                 following = (buf, self._new_list())
-            if i == 0:
-                # a ghost of the first proposal kind has no ghosts of its own: its acceptance probability and the
-                # update of this level (:426-446) are done by its proposal's launch
+            if i == 0 or (i == 1 and self._fuse_first_ghost):
+                # a ghost of the first proposal kind has no ghosts of its own, one of the second kind has one and
+                # its launch runs it: the ghost's acceptance probability and the update of this level (:426-446)
+                # are done by the ghost's launch
                 pr = 1.0 if self._prob_retry else 0.0
                 link = ops.ghost_link(P.H, P.h, P.live, P.a, nxt.a, pr, *(following or (None, None)))
-                self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=link)
+                self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=link, own_ghosts=i)
             else:
                 done = self._proposal_dev(P, gsub, m_dev, i, lvl + 1, own_ghosts=i)
                 self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following, first=done)
@@ -555,15 +556,15 @@ class DrGhmcDiag(ManyChainSampler):
         job = None
         for k in range(K):
             P0 = self._levels[0] = level0[k % 2]
+            nidx, ncount = (None, None) if k + 1 == K else ((P0.idx if k % 2 == 0 else P0.idx_alt), self._new_list())
             done = self._proposal_dev(cur, idx, n_dev, k, 0, job=job, own_ghosts=k)               # :373
             self._accept_dev(0, n_dev, k, first=done)                                             # :374-376
+            # accept test :441-446, :378-385; for the rejected chains the next stage's retry test :369-371;
+            # the chains that propose again are listed for the next stage
             if k + 1 < K:
-                # accept test :441-446, :378-385; for the rejected chains the next stage's retry test :369-371;
-                # the chains that propose again are listed for the next stage
-                nidx, ncount = (P0.idx if k % 2 == 0 else P0.idx_alt), self._new_list()
                 ops.dr_accept_prob_test_next(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
-                                             self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, nidx, ncount,
-                                             n_dev=n_dev)
+                                             self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, nidx,
+                                             ncount, n_dev=n_dev)
             else:
                 ops.dr_accept_prob_test(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
                                         self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, n_dev=n_dev)

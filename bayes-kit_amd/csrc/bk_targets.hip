@@ -552,7 +552,6 @@ __device__ __forceinline__ void funnel_traj_body(
   }
   BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
   double ksum = funnel_reduce_lanes<LPC>(cs);
-  bool parent_goes_on = false;
   double H_own = 0.0;
   if (writer) {
     double rr = -rv;
@@ -563,33 +562,15 @@ __device__ __forceinline__ void funnel_traj_body(
     kin_out[j] = kin;
     if (H_out) {
       // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
-      // H = -((-logp) + kin) (drghmc.py:421 -> :249-251), h = 0, live = 1
+      // H = -((-logp) + kin) (drghmc.py:421 -> :249-251); h and live follow below
       const double potential = -logp_j;
       const double Hj = -(potential + kin);
       H_own = Hj;
       H_out[j] = Hj;
-      if (g0.steps <= 0) {  // (with a fused first ghost h and live are written after it, below)
-        hh_out[j] = 0.0;
-        live_out[j] = 1;
-      }
-      if (ghost.parent_H) {
-        // a ghost with no ghosts of its own: its acceptance probability against the parent lane it came from
-        // and the parent's update (bk_dr_accept_prob_ghost; drghmc.py:426-446), here instead of in a launch of
-        // their own.  One ghost lane per parent lane: nobody else touches lane `src` of the parent level.
-        const double g = dr_accept_logprob(Hj, ghost.parent_H[src], 0.0, ghost.parent_h[src], ghost.prob_retry);
-        ghost.a_out[j] = g;
-        if (g == 0.0) {  // drghmc.py:430-432
-          ghost.parent_a[src] = -INFINITY;
-          ghost.parent_live[src] = 0;
-        } else {
-          ghost.parent_h[src] = ghost.parent_h[src] + log1p(-exp(g));  // drghmc.py:434-435
-          parent_goes_on = true;
-        }
-      }
     }
   }
-  // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
-  if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
+  double h_own = 0.0;    // the produced level's h / live for this lane (h = 0, live = 1 unless its first ghost
+  bool live_own = true;  // is run here as well)
 
   // ---- the proposal's FIRST GHOST, in the same wavefront (drghmc.py:424-436 with i = 0) ----------------------
   // Every lane of a level gets ghost 0, lane for lane, and a ghost of the first proposal kind has no ghosts of its
@@ -670,16 +651,42 @@ __device__ __forceinline__ void funnel_traj_body(
       // proposal's level entry: bk_dr_level_begin + bk_dr_accept_prob_ghost in one
       const double g = dr_accept_logprob(H_g, H_own, 0.0, 0.0, g0.prob_retry);
       if (g == 0.0) {  // drghmc.py:430-432
-        hh_out[j] = 0.0;
-        live_out[j] = 0;
+        live_own = false;
         g0.parent_a[j] = -INFINITY;
       } else {
-        hh_out[j] = 0.0 + log1p(-exp(g));  // drghmc.py:434-435
-        live_out[j] = 1;
+        h_own = 0.0 + log1p(-exp(g));  // drghmc.py:434-435
         goes_on = true;
       }
     }
     if (g0.next_index) bk_append(goes_on, (int32_t)j, g0.next_index, g0.next_count);
+  }
+  if (writer && H_out) {
+    hh_out[j] = h_own;
+    live_out[j] = live_own ? 1 : 0;
+  }
+
+  // ---- a GHOST level that is complete here (no ghosts of its own, or one and it ran above): its acceptance
+  // probability against the parent lane it came from and the parent's update (bk_dr_accept_prob_ghost;
+  // drghmc.py:426-446), instead of a launch of their own.  One ghost lane per parent lane: nobody else touches
+  // lane `src` of the parent level.
+  if (ghost.parent_H) {
+    bool parent_goes_on = false;
+    if (writer) {
+      double g = -INFINITY;  // (a dead lane: one of its own ghosts was accepted with probability one)
+      if (live_own) {
+        g = dr_accept_logprob(H_own, ghost.parent_H[src], h_own, ghost.parent_h[src], ghost.prob_retry);
+        ghost.a_out[j] = g;
+      }
+      if (g == 0.0) {  // drghmc.py:430-432
+        ghost.parent_a[src] = -INFINITY;
+        ghost.parent_live[src] = 0;
+      } else {
+        ghost.parent_h[src] = ghost.parent_h[src] + log1p(-exp(g));  // drghmc.py:434-435
+        parent_goes_on = true;
+      }
+    }
+    // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
+    if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
   }
 #undef BK_FL_IN
 #undef BK_FL_OUT
@@ -1043,8 +1050,9 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
   bk_ghost0 g0 = {};
   if (g0_in) {
     g0 = *g0_in;
-    if (g0.steps < 1 || g0.steps > 0x7fffffff || !H_out || !g0.parent_a || ghost_in ||
-        (g0.next_index && (!g0.next_count || g0.next_index == src_index)))
+    // (a level that has further ghosts is not complete in this launch: no link)
+    if (g0.steps < 1 || g0.steps > 0x7fffffff || !H_out || !g0.parent_a ||
+        (g0.next_index && (!g0.next_count || g0.next_index == src_index || ghost_in)))
       return BK_E_ARG;
   }
   bk_scatter_job job = {};

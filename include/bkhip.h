@@ -486,8 +486,9 @@ typedef struct bk_ghost0 {
  * proposal buffers, the proposal reads columns of rejected chains and writes its own buffers.
  * ghost (may be NULL; needs H_out): the launch also evaluates each produced lane's acceptance probability against
  * its parent lane and applies it to the parent (bk_ghost_link): one launch instead of two per such ghost.
- * ghost0 (may be NULL; needs H_out, excludes `ghost`): the launch also integrates the first ghost of every produced
- * lane (bk_ghost0) and applies it to the produced level. */
+ * ghost0 (may be NULL; needs H_out): the launch also integrates the first ghost of every produced lane (bk_ghost0) and
+ * applies it to the produced level; together with `ghost` only for a level whose ONLY ghost it is
+ * (ghost0->next_index NULL) -- the link then sees the level after that ghost. */
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,

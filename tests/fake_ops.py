@@ -323,7 +323,7 @@ class FakeOps:
                 if ghost0 is not None:
                     # the produced level's first ghost as a launch of its own into scratch arrays, then
                     # dr_accept_prob_ghost[_next] against the produced level
-                    assert ghost is None and level is not None
+                    assert level is not None and (ghost0["next_index"] is None or ghost is None)
                     g0 = ghost0
                     n_l = theta_out.shape[1]
                     th, rh, gr = (torch.empty_like(t) for t in (theta_out, rho_out, grad_out))

@@ -895,6 +895,58 @@ def test_funnel_proposal_with_its_first_ghost_equals_two_launches(D, n, prob_ret
         assert 0 < m == int(live.sum()) < n and torch.isinf(a_par[~live]).all() and (lva[1][live] <= 0).all() and (lva[1][live] < 0).any()
 
 
+@pytest.mark.parametrize("D,n", [(101, 5000), (18, 13000), (40, 600)])
+def test_funnel_ghost_with_its_own_ghost_applies_itself_to_its_parent(D, n):
+    """A ghost level with ONE ghost of its own: proposal + that ghost (bk_ghost0) + the level's acceptance probability
+    against its parent lanes and the parent's update (bk_ghost_link) in one launch, against the link as
+    bk_dr_accept_prob_ghost_next in a launch of its own."""
+    ops = bk._lib.default_ops()
+    dev = ops.device
+    f64 = dict(dtype=torch.float64, device=dev)
+    C = 13000
+    g = torch.Generator(device=dev)
+    g.manual_seed(D * 11 + n)
+    th = torch.randn((D, C), generator=g, **f64)
+    th[0] *= 2.0
+    rho = torch.randn((D, C), generator=g, **f64)
+    grad, lp = torch.empty_like(th), torch.empty(C, **f64)
+    ops.target_grad("funnel", None, th, grad, lp)
+    metric = torch.linspace(0.8, 1.2, D, **f64) if D == 18 else None
+    sub = torch.randperm(C, generator=torch.Generator().manual_seed(8))[:n].to(torch.int32).to(dev)
+    kin0 = torch.empty(C, **f64)
+    ops.leapfrog_finish(rho, None, None, metric, 0.0, False, kin0)
+    h, steps, gh, gsteps, pr = 0.25, 4, 0.7, 3, 1.0
+
+    def run(fused):
+        par_H = (lp - kin0).clone() + 0.5
+        par_h = -torch.rand(C, generator=torch.Generator().manual_seed(2), dtype=torch.float64).to(dev)
+        par_live = torch.ones(C, dtype=torch.uint8, device=dev)
+        par_a = torch.full((C,), 3.0, **f64)
+        out = [torch.full((D, n), float("nan"), **f64) for _ in range(3)]
+        lpo, kino = torch.empty(n, **f64), torch.empty(n, **f64)
+        lv = (torch.empty(n, **f64), torch.empty(n, **f64), torch.empty(n, dtype=torch.uint8, device=dev))
+        a = torch.full((n,), 5.0, **f64)
+        nlist = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ncnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        g0 = ops.ghost0(gh, gsteps, a, pr)
+        n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+        kw = dict(n_dev=n_dev, level=lv, ghost0=g0)
+        if fused:
+            link = ops.ghost_link(par_H, par_h, par_live, par_a, a, pr, nlist, ncnt)
+            ops.dr_proposal_funnel(th, rho, grad, sub, *out, lpo, kino, metric, h, steps, ghost=link, **kw)
+        else:
+            ops.dr_proposal_funnel(th, rho, grad, sub, *out, lpo, kino, metric, h, steps, **kw)
+            ops.dr_accept_prob_ghost_next(lv[0], par_H, lv[1], par_h, sub, pr, lv[2], a, n, par_live, par_a, nlist, ncnt,
+                                          n_dev=n_dev)
+        m = int(ncnt)
+        return out + [lpo, kino, *lv, a, par_H, par_h, par_live, par_a, ncnt, nlist[:m].sort().values]
+
+    one, two = run(True), run(False)
+    for i, (x, y) in enumerate(zip(one, two)):
+        assert torch.equal(x, y), (D, n, i)
+    assert 0 < int(one[-2]) < n and 0 < int(one[7].sum()) < n
+
+
 def test_background_generator_launch_gives_the_same_stream():
     """bk_normals_chain_major_bg: a bounded number of workgroups, each walking several groups of chains
     (a background kernel beside a streaming one), against the one-workgroup-per-group launch."""

@@ -6,7 +6,8 @@ import torch
 import bayes_kit_amd as bk
 C, D, N = int(os.environ.get("C", 32768)), 101, int(os.environ.get("N", 200))
 s = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
-                  device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None))
+                  device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
+                  fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1")
 for _ in range(100):
     s.sample()
 torch.cuda.synchronize()
@@ -16,5 +17,5 @@ for _ in range(N):
     s.sample()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print({"ms_per_draw": 1e3 * el / N, "device_counts": s._dev_counts, "graph": s._use_graph, "lane_steps_last": s.last_lane_steps,
+print({"ms_per_draw": 1e3 * el / N, "fuse_first_ghost": s._fuse_first_ghost, "device_counts": s._dev_counts, "graph": s._use_graph, "lane_steps_last": s.last_lane_steps,
        "stages_last": s.last_stage_lanes})
