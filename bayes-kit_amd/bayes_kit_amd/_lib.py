@@ -86,6 +86,8 @@ SIGNATURES = {
     "bk_ess": [P, I, I, c_int, P, P, I, P],
     "bk_iat_from_acor": [P, I, I, c_int, P, P, I, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
+    "bk_autocorr_fft_work_bytes": [I, I],
+    "bk_autocorr_fft": [P, I, I, P, I, I, P, I, P],
     "bk_rank_normalize": [P, F, P, I, P],
     "bk_sort_by_key_work_bytes": [I],
     "bk_sort_by_key": [P, P, P, P, I, P, I, P],
@@ -95,7 +97,8 @@ SIGNATURES = {
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
 }
-_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64}
+_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64,
+             "bk_autocorr_fft_work_bytes": c_int64}
 
 
 class BkHipError(RuntimeError):
@@ -616,6 +619,12 @@ class Ops:
     def autocorr(self, x, out):
         N, C = x.shape
         self._call("bk_autocorr", ptr(x), _ld(x), N, ptr(out), _ld(out), C, self._s())
+
+    def autocorr_fft(self, x, out):
+        """autocorr(x, out) by FFT (long chains): the library's own Stockham passes, scratch allocated here."""
+        N, C = x.shape
+        work = torch.empty(max(16, self.lib.bk_autocorr_fft_work_bytes(N, C)), dtype=torch.uint8, device=x.device)
+        self._call("bk_autocorr_fft", ptr(x), _ld(x), N, ptr(out), _ld(out), C, ptr(work), work.numel(), self._s())
 
     def end_pos_pairs(self, acor, out):
         N, C = acor.shape

@@ -654,28 +654,23 @@ def _len(chain) -> int:
     return chain.shape[0] if _is_matrix(chain) else len(chain)
 
 
-# Chains up to FFT_MIN_DRAWS draws: the library's own kernels (series staged in LDS, direct lag sums:
-# N steps per 64 lags, only the lags the Geyer truncation needs).  Longer chains: the reference's own
-# FFT formulation (autocorr.py:26-32) through torch.fft (rocFFT), O(N log N) per chain, followed by
-# the library's scan kernel (bk_iat_from_acor) -- the direct sums are O(N^2 / 64) for ALL lags.
+# Chains up to FFT_MIN_DRAWS draws: series staged in LDS, direct lag sums (N steps per 64 lags, only the lags the
+# Geyer truncation needs).  Longer chains: the reference's own FFT formulation (autocorr.py:26-32), O(N log N)
+# per chain, by the library's Stockham passes over the [N, C] layout (bk_autocorr_fft: one lane per pair of
+# chains, two real series per complex transform), followed by the scan kernel (bk_iat_from_acor) -- the direct
+# sums are O(N^2 / 64) for ALL lags.
 FFT_MIN_DRAWS = 16384
-_FFT_CHAIN_BLOCK = 4096  # chains per FFT batch (bounds the complex scratch)
+_FFT_SCRATCH_BYTES = 2 << 30  # chains per FFT batch are chosen to keep the two complex scratch arrays below this
 
 
-def _autocorr_fft(x: torch.Tensor) -> torch.Tensor:
-    """autocorr.py:23-33 for every column of x [N, C]: zero-padded to 2**ceil(log2(2N-1)), |fft|^2,
-    inverse, / np.var (ddof=0) / N, first N lags."""
+def _autocorr_fft(x: torch.Tensor, ops) -> torch.Tensor:
+    """autocorr.py:23-33 for every column of x [N, C]."""
     N, C = x.shape
     size = 1 << int(np.ceil(np.log2(2 * N - 1)))
+    block = max(128, (_FFT_SCRATCH_BYTES // (size * 16)) // 128 * 128)  # (2 buffers x size x block/2 x 16 B)
     out = torch.empty_like(x)
-    for c0 in range(0, C, _FFT_CHAIN_BLOCK):
-        xb = x[:, c0:c0 + _FFT_CHAIN_BLOCK]
-        xc = xb - xb.mean(dim=0)
-        f = torch.fft.rfft(xc, n=size, dim=0)
-        pw = f.real * f.real + f.imag * f.imag
-        ac = torch.fft.irfft(pw, n=size, dim=0)[:N]
-        var = xb.var(dim=0, unbiased=False)
-        out[:, c0:c0 + _FFT_CHAIN_BLOCK] = ac / var / N
+    for c0 in range(0, C, block):
+        ops.autocorr_fft(x[:, c0:c0 + block], out[:, c0:c0 + block])
     return out
 
 
@@ -686,7 +681,7 @@ def autocorr(chain, *, ops=None):
     ops = _ops(ops)
     x, one = _series(chain, ops)
     if x.shape[0] >= FFT_MIN_DRAWS:
-        out = _autocorr_fft(x)
+        out = _autocorr_fft(x, ops)
     else:
         out = torch.empty_like(x)
         ops.autocorr(x, out)
@@ -700,7 +695,7 @@ def _iat_ess(chain, estimator, want, ops):
     ess_out = torch.empty(C, dtype=torch.float64, device=x.device)
     iat_out = torch.empty(C, dtype=torch.float64, device=x.device)
     if N >= FFT_MIN_DRAWS:
-        ops.iat_from_acor(_autocorr_fft(x), estimator, ess_out, iat_out)
+        ops.iat_from_acor(_autocorr_fft(x, ops), estimator, ess_out, iat_out)
     else:
         ops.ess(x, estimator, ess_out, iat_out)
     r = ess_out if want == "ess" else iat_out

@@ -610,8 +610,16 @@ int bk_scatter_ranks(const int64_t* payload, int64_t n, double base, double* out
 int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C,
                 void* stream);
 
+/* The same by FFT, as the reference computes it (autocorr.py:23-33: zero-padded to S = 2**ceil(log2(2N-1)), |fft|^2,
+ * inverse, / var / N), for chains too long for the LDS-staged direct sums: O(N log N) per chain.  Stockham radix-8
+ * passes across the rows of the [N, C] layout, one lane per column pair (two real series per complex transform);
+ * work: caller-owned scratch of bk_autocorr_fft_work_bytes(N, C) bytes, 16-byte aligned. */
+int64_t bk_autocorr_fft_work_bytes(int64_t N, int64_t C);
+int bk_autocorr_fft(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo, int64_t C, void* work,
+                    int64_t work_bytes, void* stream);
+
 /* IAT / ESS of each chain from an autocorrelation array acor[n*ld + c], n < N (iat.py:46-135: the
- * Geyer scan alone) -- for autocorrelations obtained elsewhere, e.g. by an FFT for very long chains. */
+ * Geyer scan alone) -- for autocorrelations obtained elsewhere (bk_autocorr_fft for very long chains). */
 int bk_iat_from_acor(const double* acor, int64_t ld, int64_t N, int estimator, double* ess_out,
                      double* iat_out, int64_t C, void* stream);
 

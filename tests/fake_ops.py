@@ -461,6 +461,9 @@ class FakeOps:
         for c in range(x.shape[1]):
             out.numpy()[:, c] = od.autocorr(x.numpy()[:, c])
 
+    def autocorr_fft(self, x, out):
+        self.autocorr(x, out)
+
     def end_pos_pairs(self, acor, out):
         a = acor.numpy()
         for c in range(a.shape[1]):

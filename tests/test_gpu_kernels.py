@@ -691,7 +691,7 @@ def test_lds_staged_ess_and_autocorr_vs_oracle(ops, N, C):
 
 
 def test_long_chains_take_the_fft_formulation(ops):
-    """N >= FFT_MIN_DRAWS: autocorrelation by the reference's own FFT formula (rocFFT) + the library's
+    """N >= FFT_MIN_DRAWS: autocorrelation by the reference's own FFT formula (bk_autocorr_fft) + the library's
     Geyer scan kernel; against the oracle, and against the direct-sum kernel at the switch-over."""
     from oracle import diagnostics as od
     from bayes_kit_amd import diagnostics as dg
@@ -713,8 +713,46 @@ def test_long_chains_take_the_fft_formulation(ops):
     short = xd[:12000].contiguous()
     direct = bk.ess(short).cpu().numpy()
     e2 = torch.empty(C, dtype=torch.float64, device=ops.device)
-    ops.iat_from_acor(dg._autocorr_fft(short), 0, e2, None)
+    ops.iat_from_acor(dg._autocorr_fft(short, ops), 0, e2, None)
     np.testing.assert_allclose(direct, e2.cpu().numpy(), rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,C", [(2, 1), (3, 2), (4, 5), (5, 64), (17, 3), (64, 129), (100, 7), (257, 66), (1000, 130),
+                                 (4096, 9), (4097, 2), (16384, 5), (40000, 3)])
+def test_autocorr_fft_against_numpy(ops, N, C):
+    """bk_autocorr_fft (Stockham radix-8/4/2 passes across the rows, two real series per complex column, unit-variance
+    scaling on the way in) against autocorr.py:23-33 evaluated with numpy.fft, for every transform size from 4 to
+    131,072, odd and even column counts, columns of very different scale side by side, a strided input view."""
+    rng = np.random.default_rng(N * 1000 + C)
+    x = np.empty((N, C))
+    for c in range(C):
+        phi = [0.0, 0.5, 0.95, 0.999][c % 4]
+        e = rng.normal(size=N)
+        x[0, c] = e[0]
+        for t in range(1, N):
+            x[t, c] = phi * x[t - 1, c] + e[t]
+        x[:, c] = (x[:, c] + 10.0 * (c % 3)) * 10.0 ** (3 * (c % 5) - 6)   # scales 1e-6 .. 1e6, offsets
+    wide = torch.zeros((N, C + 3), dtype=torch.float64, device=ops.device)
+    wide[:, :C] = torch.from_numpy(x).to(ops.device)
+    out = torch.full((N, C + 1), float("nan"), dtype=torch.float64, device=ops.device)
+    ops.autocorr_fft(wide[:, :C], out[:, :C])
+    got = out[:, :C].cpu().numpy()
+    assert torch.isnan(out[:, C]).all()
+    size = 1 << int(np.ceil(np.log2(2 * N - 1)))
+    for c in range(C):
+        nd = x[:, c] - x[:, c].mean()
+        want = np.fft.ifft(np.abs(np.fft.fft(nd, size)) ** 2).real[:N] / np.var(x[:, c]) / N
+        np.testing.assert_allclose(got[:, c], want, rtol=0, atol=2e-12, err_msg=str((N, C, c)))
+    assert np.allclose(got[0], 1.0, rtol=0, atol=1e-13)
+
+
+def test_autocorr_fft_constant_series_gives_nan_like_the_reference(ops):
+    """np.var == 0: the reference divides 0 by 0 (autocorr.py:32); so does the kernel, for that column only."""
+    x = torch.randn((50, 4), dtype=torch.float64, device=ops.device)
+    x[:, 2] = 3.0
+    out = torch.empty_like(x)
+    ops.autocorr_fft(x, out)
+    assert torch.isnan(out[:, 2]).all() and torch.isfinite(out[:, [0, 1, 3]]).all()
 
 
 def test_sort_entry_points_and_pooled_ranks(ops):
