@@ -514,7 +514,8 @@ def _ranks_pooled_across_ranks(x: torch.Tensor, ops, group=None) -> torch.Tensor
         pos = ((torch.arange(k, dtype=torch.float64, device=dev) + 0.5) * (S_local / k)).to(torch.int64).clamp_(max=S_local - 1)
         samp[:k] = keys[pos]
     parts = _bkdist.all_gather(samp, group)
-    allsamp = torch.sort(torch.cat(parts)).values          # world*s values: tiny
+    cat = torch.cat(parts)                                  # world*s values: tiny
+    allsamp, _ = ops.sort_by_key(cat, torch.arange(cat.numel(), dtype=torch.int64, device=dev))
     nreal = int(torch.isfinite(allsamp).sum().item())
     cut_pos = [(nreal * (r + 1)) // world for r in range(world - 1)]
     splitters = allsamp[torch.tensor(cut_pos, dtype=torch.int64, device=dev).clamp_(max=max(nreal - 1, 0))]

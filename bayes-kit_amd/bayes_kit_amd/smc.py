@@ -269,7 +269,8 @@ class TemperedLikelihoodSMC:
         ends = torch.cumsum(torch.tensor(counts, dtype=torch.int64, device=idx.device), 0)
         owner = torch.searchsorted(ends, idx, right=True)     # rank whose block holds global particle idx
         first = ends - torch.tensor(counts, dtype=torch.int64, device=idx.device)
-        order = torch.sort(owner, stable=True).indices       # my slots grouped by the rank that owns their ancestor
+        # my slots grouped by the rank that owns their ancestor (stable: bk_sort_by_key)
+        _, order = ops.sort_by_key(owner.to(torch.float64), torch.arange(owner.numel(), dtype=torch.int64, device=idx.device))
         want = torch.bincount(owner, minlength=world)         # how many columns I need from each rank
         give = torch.empty_like(want)
         _bkdist.all_to_all_single(give, want, group=g)         # how many each rank needs from me

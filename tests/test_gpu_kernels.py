@@ -759,15 +759,18 @@ def test_sort_entry_points_and_pooled_ranks(ops):
     """bk_sort_by_key (stable, -0.0 < +0.0, duplicates, infinities), bk_count_below, bk_scatter_ranks and
     the pooled ranks built on them, against torch's stable sort / NumPy."""
     rng = np.random.default_rng(17)
-    for n in (1, 2, 63, 1000, 3_000_001):
+    for n in (1, 2, 63, 1000, 4095, 4096, 4097, 70_000, 3_000_001):
         v = rng.normal(size=n)
-        if n >= 63:
+        if n == 70_000:
+            v = rng.integers(0, 8, size=n).astype(np.float64)   # a few distinct keys: most passes see ONE digit
+        elif n >= 63:
             v[::7] = np.round(v[::7])          # many exact ties
             v[3], v[5], v[11], v[12] = 0.0, -0.0, np.inf, -np.inf
         keys = torch.from_numpy(v).to(ops.device)
         pay = torch.arange(n, dtype=torch.int64, device=ops.device)
         ks, ps = ops.sort_by_key(keys, pay)
         ref = torch.sort(keys, stable=True)
+        assert torch.equal(torch.sort(ps).values, pay) and torch.equal(keys[ps], ks)   # a permutation, pairs intact
         assert torch.equal(ks, ref.values) or n < 63
         assert torch.equal(ks.abs(), ref.values.abs()) and bool((ks[1:] >= ks[:-1]).all())
         if n < 63:
