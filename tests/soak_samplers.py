@@ -55,8 +55,46 @@ PROVIDERS_SEEN = {}
 HISTORY = []  # the last few configurations: a corrupted sampler is usually the victim of an earlier one
 
 
+def funnel_paths(rng):
+    """DRGHMC on the built-in funnel (not bit-comparable with the oracle: the kernel sums a chain's coordinates in its
+    own canonical order) -- the device-side lane counts with every launch fusion (a proposal's first ghost, ghost
+    links, the scatter riding on the next stage, refresh + start of the draw in one launch; replayed as a hipGraph
+    or not) against launches sized by host reads with every ghost a launch of its own: bit for bit, with the
+    trajectories run, the momenta and the stream positions."""
+    D = int(rng.choice([2, 3, 11, 17, 18, 33, 34, 50, 65, 101, 129]))
+    C = int(rng.choice([1, 3, 64, 65, 130, 700, 2100, 5000, 13000]))
+    K = int(rng.integers(1, 5))
+    eps = float(rng.uniform(0.05, 0.6))
+    sizes = [eps / (3 ** k) for k in range(K)]
+    counts = [int(rng.integers(1, 5)) * (2 ** k) for k in range(K)]
+    damp = float(rng.uniform(0.05, 1.0))
+    pr = bool(rng.integers(0, 2))
+    metric = np.linspace(0.7, 1.4, D) if rng.random() < 0.4 else None
+    seed = int(rng.integers(1, 2**40))
+    N = int(rng.integers(2, 9))
+    graph = bool(rng.integers(0, 2)) and not NO_GRAPH
+    fuse = bool(rng.integers(0, 4))
+    desc = dict(alg="drfunnel", D=D, C=C, K=K, sizes=sizes, counts=counts, damp=damp, prob_retry=pr, metric=metric is not None,
+                seed=seed, N=N, graph=graph, fuse_first_ghost=fuse)
+    mk = lambda **kw: bk.DrGhmcDiag(bk.Funnel(D), K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed,  # noqa: E731
+                                    prob_retry=pr, **kw)
+    a = mk(device_counts=False)
+    b = mk(device_counts=True, graph=graph, fuse_first_ghost=fuse)
+    for n in range(N):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        same = torch.equal(ta, tb) or (torch.isnan(ta) == torch.isnan(tb)).all() and torch.equal(ta.nan_to_num(), tb.nan_to_num())
+        assert same and torch.equal(la.nan_to_num(), lb.nan_to_num()), ("theta", desc, n)
+        assert a.last_stage_lanes == b.last_stage_lanes and a.last_lane_steps == b.last_lane_steps, ("lanes", desc, n)
+    assert torch.equal(a._rho.nan_to_num(), b._rho.nan_to_num()), ("rho", desc)
+    assert np.array_equal(a.rng_state(), b.rng_state()), ("stream", desc)
+    return "drfunnel"
+
+
 def one(rng, it):
-    alg = rng.choice(os.environ["ALGS"].split(",")) if os.environ.get("ALGS") else rng.choice(["hmc", "mala", "drghmc", "metropolis"])
+    alg = rng.choice(os.environ["ALGS"].split(",")) if os.environ.get("ALGS") else rng.choice(["hmc", "mala", "drghmc", "metropolis", "drfunnel"])
+    if alg == "drfunnel":
+        return funnel_paths(rng)
     if alg == "torchgraph":
         # control: a hipGraph of two plain PyTorch kernels, captured and replayed the way a sampler's draw is
         x = torch.zeros(int(rng.choice([3, 64, 500])), dtype=torch.float64, device="cuda")
