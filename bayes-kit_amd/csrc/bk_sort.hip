@@ -54,11 +54,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const void* keys, i6
   for (int i = t; i < SORT_WAVES * SORT_BINS; i += SORT_THREADS) (&h[0][0])[i] = 0;
   __syncthreads();
   const i64 base = (i64)blockIdx.x * SORT_TILE;
-#pragma unroll 4
+  u64 k[SORT_ITEMS];  // (all of the thread's loads in flight before the first LDS atomic)
+#pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const i64 idx = base + t + (i64)i * SORT_THREADS;
-    if (idx < n) atomicAdd(&h[w][(sort_load<FIRST>(keys, idx) >> shift) & 255], 1u);
+    k[i] = idx < n ? sort_load<FIRST>(keys, idx) : 0;
   }
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i)
+    if (base + t + (i64)i * SORT_THREADS < n) atomicAdd(&h[w][(k[i] >> shift) & 255], 1u);
   __syncthreads();
   tile_hist[(i64)t * n_tiles + blockIdx.x] = ((h[0][t] + h[1][t]) + h[2][t]) + h[3][t];
 }
@@ -121,6 +125,15 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(uint32_t* tile_hist,
   if ((i64)v == n) *same = 1;
 }
 
+// Tile of a workgroup of the scatter: workgroups are handed to the 8 XCDs round-robin, so XCD x takes the x-th
+// contiguous eighth of the tiles.  Consecutive tiles write consecutive runs of every digit; when they run on the
+// same XCD at about the same time, the two partial cache lines where their runs meet merge in that XCD's L2
+// instead of going out to memory as two masked writes.
+__device__ __forceinline__ i64 sort_tile_of_block(i64 n_tiles) {
+  const i64 per = (n_tiles + 7) / 8;
+  return (i64)(blockIdx.x % 8) * per + (i64)(blockIdx.x / 8);
+}
+
 template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const void* kin, const i64* vin, void* kout, i64* vout,
                                                                i64 n, int shift, const uint32_t* tile_off,
@@ -133,7 +146,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const void* kin, 
   __shared__ i64 out_base[SORT_BINS];  // position in the output of the tile's first key of a digit, minus dig_start
   __shared__ uint32_t wtot[SORT_WAVES];
   const int t = threadIdx.x, lane = t & 63, w = bk_wave_id();
-  const i64 base = (i64)blockIdx.x * SORT_TILE;
+  const i64 tile = sort_tile_of_block(n_tiles);
+  if (tile >= n_tiles) return;
+  const i64 base = tile * SORT_TILE;
   const int m = (int)((n - base < SORT_TILE) ? n - base : SORT_TILE);  // keys of this tile
   if (*same) {
     // every key has the same digit in this pass: the pass is the identity
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const void* kin, 
     for (int k = 0; k < w; ++k) before += wtot[k];
     const uint32_t start = before + incl - v;
     dig_start[t] = start;
-    out_base[t] = ((i64)bases[t] + (i64)tile_off[(i64)t * n_tiles + blockIdx.x]) - (i64)start;
+    out_base[t] = ((i64)bases[t] + (i64)tile_off[(i64)t * n_tiles + tile]) - (i64)start;
   }
   __syncthreads();
 #pragma unroll
@@ -292,6 +307,7 @@ int bk_sort_by_key(const double* keys_in, double* keys_out, const int64_t* vals_
   hipError_t e = hipMemsetAsync(done, 0, 2 * sizeof(uint32_t), s);
   if (e != hipSuccess) return (int)e;
   const dim3 tiles((unsigned)p.n_tiles), block(SORT_THREADS);
+  const dim3 tiles8((unsigned)(8 * bk_cdiv(p.n_tiles, 8)));  // (k_sort_scatter: an eighth of the tiles per XCD)
   // in -> tmp -> out -> tmp -> ... : eight passes end in `out`
   const void* kin = keys_in;
   const i64* vin = vals_in;
@@ -303,11 +319,11 @@ int bk_sort_by_key(const double* keys_in, double* keys_out, const int64_t* vals_
     else k_sort_hist<false><<<tiles, block, 0, s>>>(kin, n, shift, hist, p.n_tiles);
     k_sort_scan<<<dim3(SORT_BINS), block, 0, s>>>(hist, p.n_tiles, n, totals, bases, done, same);
     if (pass == 0)
-      k_sort_scatter<true, false><<<tiles, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
+      k_sort_scatter<true, false><<<tiles8, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
     else if (pass == 7)
-      k_sort_scatter<false, true><<<tiles, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
+      k_sort_scatter<false, true><<<tiles8, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
     else
-      k_sort_scatter<false, false><<<tiles, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
+      k_sort_scatter<false, false><<<tiles8, block, 0, s>>>(kin, vin, kout, vout, n, shift, hist, bases, same, p.n_tiles);
     kin = kout;
     vin = vout;
   }
