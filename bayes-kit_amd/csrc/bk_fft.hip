@@ -5,9 +5,9 @@
 //   * The batch dimension is the contiguous one, so the transform runs ACROSS rows with one lane per column:
 //     every lane of a wavefront executes the same butterfly on its own column, all loads and stores are
 //     1-KiB row segments, the twiddles are wavefront-uniform (one table look-up through the scalar unit), no
-//     LDS exchange, no bank conflicts.  Stockham autosort passes of radix 8 (4 / 2 for the remainder)
-//     ping-pong between two scratch arrays: 32 bytes per element and pass -- HBM-bound, as the whole
-//     diagnostic is.
+//     LDS exchange, no bank conflicts.  Stockham autosort passes of radix 16 (8 / 4 / 2 for the remainder:
+//     65,536 points are four passes) ping-pong between two scratch arrays: 32 bytes per element and pass --
+//     HBM-bound, as the whole diagnostic is.
 //   * Two real series per complex column: (x[t, 2c], x[t, 2c+1]) IS a complex number in this layout.  With
 //     z = a + i b:  A[k] = (Z[k] + conj Z[S-k]) / 2,  B[k] = (Z[k] - conj Z[S-k]) / 2i, so the two power
 //     spectra come from one transform, and because both autocovariances are real one inverse transform of
@@ -39,12 +39,34 @@ __device__ __forceinline__ void dft4(dvec2& u0, dvec2& u1, dvec2& u2, dvec2& u3)
   bfly2(u0, u1);
   bfly2(u2, u3);
 }
+// 16 = 4 x 4: input n = n1 + 4 n2, output k = 4 k1 + k2.  y[n1][k2] = DFT4 over n2, times W16^(n1 k2), then DFT4
+// over n1.  With dft4's bit-reversed slots, y[n1][k2] sits at u[n1 + 4 br(k2)] and X[4 k1 + k2] at u[br(k1) + 4 br(k2)].
+__device__ __forceinline__ void dft16(dvec2 (&u)[16]) {
+  const double c1 = 0.92387953251128675613, s1 = 0.38268343236508977173, h = 0.70710678118654752440;
+#pragma unroll
+  for (int n1 = 0; n1 < 4; ++n1) dft4(u[n1], u[n1 + 4], u[n1 + 8], u[n1 + 12]);
+  // slot 4 holds k2 = 2, slot 8 holds k2 = 1, slot 12 holds k2 = 3; W16^m = exp(-2 pi i m / 16)
+  u[1 + 8] = cmul(u[1 + 8], (dvec2){c1, -s1});    // n1 k2 = 1
+  u[2 + 8] = cmul(u[2 + 8], (dvec2){h, -h});      // 2
+  u[3 + 8] = cmul(u[3 + 8], (dvec2){s1, -c1});    // 3
+  u[1 + 4] = cmul(u[1 + 4], (dvec2){h, -h});      // 2
+  u[2 + 4] = mul_mi(u[2 + 4]);                    // 4
+  u[3 + 4] = cmul(u[3 + 4], (dvec2){-h, -h});     // 6
+  u[1 + 12] = cmul(u[1 + 12], (dvec2){s1, -c1});  // 3
+  u[2 + 12] = cmul(u[2 + 12], (dvec2){-h, -h});   // 6
+  u[3 + 12] = cmul(u[3 + 12], (dvec2){-c1, s1});  // 9
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dft4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
+}
+
 template <int R>
 __device__ __forceinline__ void dft(dvec2 (&u)[R]) {
   if constexpr (R == 2) {
     bfly2(u[0], u[1]);
   } else if constexpr (R == 4) {
     dft4(u[0], u[1], u[2], u[3]);
+  } else if constexpr (R == 16) {
+    dft16(u);
   } else {
     const double s = 0.70710678118654752440;
     bfly2(u[0], u[4]);
@@ -62,7 +84,9 @@ template <int R>
 __device__ __forceinline__ int dft_out(int r) {
   if (R == 2) return r;
   if (R == 4) return ((r & 1) << 1) | (r >> 1);
-  return ((r & 1) << 2) | (r & 2) | (r >> 2);
+  if (R == 8) return ((r & 1) << 2) | (r & 2) | (r >> 2);
+  const int k1 = r >> 2, k2 = r & 3;  // 16
+  return (((k1 & 1) << 1) | (k1 >> 1)) + 4 * (((k2 & 1) << 1) | (k2 >> 1));
 }
 
 // mean and 1/sd (ddof = 0) of each column in two sweeps (sum, then sum of squared deviations), each a partial sum
@@ -199,7 +223,9 @@ template <int MODE>
 void launch_pass(int R, const dvec2* in, dvec2* out, const dvec2* W, const FftPlan& p, i64 Ns, const double* x, i64 ldx,
                  i64 N, i64 C, const double* mean, const double* isd, hipStream_t s) {
   const dim3 block(256), grid((unsigned)bk_cdiv(p.S / R, 4), (unsigned)bk_cdiv(p.Cp, 64));
-  if (R == 8)
+  if (R == 16)
+    k_fft_pass<16, MODE><<<grid, block, 0, s>>>(in, out, W, p.S, Ns, p.Cp, p.ldc, x, ldx, N, C, mean, isd);
+  else if (R == 8)
     k_fft_pass<8, MODE><<<grid, block, 0, s>>>(in, out, W, p.S, Ns, p.Cp, p.ldc, x, ldx, N, C, mean, isd);
   else if (R == 4)
     k_fft_pass<4, MODE><<<grid, block, 0, s>>>(in, out, W, p.S, Ns, p.Cp, p.ldc, x, ldx, N, C, mean, isd);
@@ -238,10 +264,10 @@ int bk_autocorr_fft(const double* x, int64_t ld, int64_t N, double* out, int64_t
     k_col_combine<true><<<gc, dim3(64), 0, s>>>(part, p.blocks, N, C, isd);
   }
   k_twiddles<<<dim3((unsigned)bk_cdiv(p.S, 256)), dim3(256), 0, s>>>(W, p.S);
-  // radices of the passes: 8 while three bits remain, then 4 or 2
+  // radices of the passes: 16 while that leaves nothing or at least a factor 2 for a last pass of 8 / 4 / 2
   int radix[64], n_pass = 0;
   for (i64 rem = p.S; rem > 1;) {
-    int R = rem >= 8 ? 8 : (int)rem;
+    int R = rem >= 16 ? 16 : (int)rem;
     radix[n_pass++] = R;
     rem /= R;
   }

@@ -611,7 +611,7 @@ int bk_autocorr(const double* x, int64_t ld, int64_t N, double* out, int64_t ldo
                 void* stream);
 
 /* The same by FFT, as the reference computes it (autocorr.py:23-33: zero-padded to S = 2**ceil(log2(2N-1)), |fft|^2,
- * inverse, / var / N), for chains too long for the LDS-staged direct sums: O(N log N) per chain.  Stockham radix-8
+ * inverse, / var / N), for chains too long for the LDS-staged direct sums: O(N log N) per chain.  Stockham radix-16
  * passes across the rows of the [N, C] layout, one lane per column pair (two real series per complex transform);
  * work: caller-owned scratch of bk_autocorr_fft_work_bytes(N, C) bytes, 16-byte aligned. */
 int64_t bk_autocorr_fft_work_bytes(int64_t N, int64_t C);
