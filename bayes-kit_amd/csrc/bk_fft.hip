@@ -207,7 +207,8 @@ FftPlan fft_plan(i64 N, i64 C) {
   p.S = 1;
   while (p.S < 2 * N - 1) p.S <<= 1;
   p.Cp = (C + 1) / 2;
-  p.ldc = (p.Cp + 255) / 256 * 256 + 36;
+  const i64 mod = p.Cp >= 1024 ? 256 : 64;  // (narrow batches: 576 B off a 1-KiB multiple, less scratch wasted)
+  p.ldc = p.Cp + ((36 - p.Cp % mod) + mod) % mod;
   p.blocks = (int)(N / 64 < 1 ? 1 : (N / 64 > FFT_MOMENT_BLOCKS ? FFT_MOMENT_BLOCKS : N / 64));
   const size_t buf = (size_t)p.S * (size_t)p.ldc * sizeof(dvec2);
   p.off_b = buf;
