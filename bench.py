@@ -520,10 +520,24 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         s.sample()
     el = ctx.timed_loop(s.sample, draws)
     per = el / draws
-    return {"workload": "config-3 shape, gradient = torch autograd of a user log density (TorchModel)",
-            "bound": "hbm (the model's own temporaries and extra passes, not the integrator)",
-            "ms_per_draw": 1e3 * per, "steps_per_sec": C * ctx.world * L / per,
-            "path_hbm_frac_56D_model": C * L / per * 56.0 * D / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate()}
+    out = {"workload": "config-3 shape, gradient = torch autograd of a user log density (TorchModel)",
+           "bound": "hbm (the model's own temporaries and extra passes, not the integrator)",
+           "ms_per_draw": 1e3 * per, "steps_per_sec": C * ctx.world * L / per,
+           "path_hbm_frac_56D_model": C * L / per * 56.0 * D / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate()}
+    # the same density written for the engine's own (D, C) layout: torch's contiguous kernels, a chain-contiguous gradient
+    del s
+    model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), D, layout="dc")
+    s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
+                   metric_diag=torch.ones(D, dtype=torch.float64), tune_placement=False)
+    s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
+    for _ in range(warmup):
+        s.sample()
+    per_dc = ctx.timed_loop(s.sample, draws) / draws
+    out["engine_layout"] = {"what": "TorchModel(fn, D, layout='dc'): fn takes the (D, C) array", "ms_per_draw": 1e3 * per_dc,
+                            "steps_per_sec": C * ctx.world * L / per_dc,
+                            "path_hbm_frac_56D_model": C * L / per_dc * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
+                            "accept_rate": s.accept_rate()}
+    return out
 
 
 def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):

@@ -58,6 +58,29 @@ def test_torch_autograd_model_matches_builtin(ops):
         np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-11)
 
 
+def test_torch_model_written_for_the_engine_layout(ops):
+    """TorchModel(layout="dc"): the user function takes the (D, C) array itself -- same draws as the (C, D) form and as
+    the built-in target, and the gradient comes back chain-contiguous (the streamed kick + drift, no LDS turn)."""
+    lam = torch.logspace(0, 1, 16, dtype=torch.float64, device=ops.device)
+    cd = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), 16)
+    dc = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), 16, layout="dc")
+    for mk in (lambda m: bk.HMCDiag(m, 0.05, 8, chains=300, seed=9), lambda m: bk.MALA(m, 0.01, chains=300, seed=9),
+               lambda m: bk.DrGhmcDiag(m, 2, [0.1, 0.03], [4, 8], 0.3, chains=300, seed=9)):
+        a, b, c = mk(cd), mk(dc), mk(bk.DiagGaussian(lam.cpu()))
+        for _ in range(6):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            tc, lc = c.sample()
+            np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(tb.cpu().numpy(), tc.cpu().numpy(), rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(lb.cpu().numpy(), lc.cpu().numpy(), rtol=1e-11)
+    th = torch.randn((16, 300), dtype=torch.float64, device=ops.device)
+    _, g = dc.log_density_gradient(th.t())
+    assert tuple(g.shape) == (300, 16) and g.stride(0) == 1   # (C, D) view of a chain-contiguous (D, C) array
+    with pytest.raises(ValueError):
+        bk.TorchModel(lambda Th: Th.sum(dim=1), 3, layout="rows")
+
+
 def test_row_major_model_output_goes_through_lds_transpose(ops):
     # a model that returns a fresh row-major (C, D) gradient (dimension-contiguous)
     class RowMajor:

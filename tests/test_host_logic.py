@@ -125,14 +125,21 @@ def test_torch_autograd_model_bridge():
 
     lam = torch.logspace(0, 1, 16, dtype=torch.float64)
     tm = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), 16)
+    tm_dc = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), 16, layout="dc")  # fn on the (D, C) array
     ops = FakeOps()
     a = bk.HMCDiag(tm, 0.05, 8, chains=6, seed=9, ops=ops)
     b = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 8, chains=6, seed=9, ops=ops)
+    c = bk.HMCDiag(tm_dc, 0.05, 8, chains=6, seed=9, ops=ops)
     for _ in range(10):
         ta, la = a.sample()
         tb, lb = b.sample()
+        tc, lc = c.sample()
         np.testing.assert_allclose(ta.numpy(), tb.numpy(), rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(la.numpy(), lb.numpy(), rtol=1e-11)
+        np.testing.assert_allclose(tc.numpy(), tb.numpy(), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(lc.numpy(), lb.numpy(), rtol=1e-11)
+    with pytest.raises(ValueError):
+        bk.TorchModel(lambda Th: Th.sum(dim=1), 3, layout="rows")
 
 
 def test_no_gpu_no_fallback():
