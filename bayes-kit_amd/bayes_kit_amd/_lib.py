@@ -85,6 +85,7 @@ SIGNATURES = {
     "bk_end_pos_pairs": [P, I, I, P, I, P],
     "bk_ess": [P, I, I, c_int, P, P, I, P],
     "bk_iat_from_acor": [P, I, I, c_int, P, P, I, P],
+    "bk_gemm_chains_logistic": [P, I, I, I, P, I, P, I, I, P, P],
     "bk_autocorr": [P, I, I, P, I, I, P],
     "bk_autocorr_fft_work_bytes": [I, I],
     "bk_autocorr_fft": [P, I, I, P, I, I, P, I, P],
@@ -523,15 +524,25 @@ class Ops:
         self._call("bk_gemm_chains", ptr(A), A.stride(0), R, K, ptr(X), _ld(X), ptr(Y), _ld(Y), X.shape[1],
                    ptr(work), 0 if work is None else work.numel(), self._s())
 
-    def logistic_residual(self, Z, y, part):
+    def gemm_chains_logistic(self, A, X, Y, y_rows):
+        """Y[R, C] = y_rows[:, None] - sigmoid(A[R, K] @ X[K, C]): gemm_chains + logistic_residual(part=None) in one launch."""
+        R, K = A.shape
+        assert X.shape[0] == K and Y.shape[0] == R and A.stride(1) == 1 and y_rows.numel() == R
+        self._call("bk_gemm_chains_logistic", ptr(A), A.stride(0), R, K, ptr(X), _ld(X), ptr(Y), _ld(Y), X.shape[1],
+                   ptr(y_rows), self._s())
+
+    def logistic_residual(self, Z, y, part, segments=None):
+        """part None: gradient only (no log likelihood formed); `segments` then still says how many row blocks the
+        launch is cut into (its parallelism over the observations)."""
         N, C = Z.shape
-        self._call("bk_logistic_residual", ptr(Z), _ld(Z), ptr(y), ptr(part), N, C, part.shape[0], self._s())
+        self._call("bk_logistic_residual", ptr(Z), _ld(Z), ptr(y), ptr(part), N, C,
+                   part.shape[0] if part is not None else int(segments or 256), self._s())
 
     def logistic_finish(self, G, theta, part, inv_prior_var, t, grad, logp, loglik):
         D, C = theta.shape
         ld = _ld(theta)
         assert (G is None or _ld(G) == ld) and (grad is None or _ld(grad) == ld)
-        self._call("bk_logistic_finish", ptr(G), ptr(theta), ld, ptr(part), part.shape[0], inv_prior_var, t,
+        self._call("bk_logistic_finish", ptr(G), ptr(theta), ld, ptr(part), 1 if part is None else part.shape[0], inv_prior_var, t,
                    ptr(grad), ptr(logp), ptr(loglik), C, D, self._s())
 
     def dot_columns(self, x, y, scale, out):

@@ -166,9 +166,14 @@ class LogisticRegression(_BuiltinTarget):
         ops = self._get_ops()
         D, C = theta_dc.shape
         b = self._buffers(theta_dc.device, C)
-        Z, part = b["Z"][:, :C], b["part"][:, :C]
-        ops.gemm_chains(b["X"], theta_dc, Z)              # z = X theta          (MFMA)
-        ops.logistic_residual(Z, b["y"], part)            # r = y - sigmoid(z), log-likelihood partials
+        Z = b["Z"][:, :C]
+        # (a leapfrog step wants the gradient alone: the residual pass then skips the log likelihood)
+        part = b["part"][:, :C] if (logp_out is not None or loglik_out is not None) else None
+        if part is None:
+            ops.gemm_chains_logistic(b["X"], theta_dc, Z, b["y"])        # r = y - sigmoid(X theta): residual in the epilogue
+        else:
+            ops.gemm_chains(b["X"], theta_dc, Z)                          # z = X theta          (MFMA)
+            ops.logistic_residual(Z, b["y"], part, b["part"].shape[0])  # r = y - sigmoid(z), log-likelihood partials
         G = None
         if grad_out is not None:
             G = b["G"][:, :C]

@@ -96,15 +96,19 @@ __device__ __forceinline__ void store_panels(DenseLds& lds, int buf, const doubl
   }
 }
 
-template <bool FULL>
+// EPI 1: the result leaves as  y_rows[r] - sigmoid(z)  (the logistic regression's residual, the arithmetic of
+// k_logistic_residual): the elementwise pass between the target's two GEMMs rides on the first one's epilogue --
+// its exp and division run on the vector pipe while the CU's other workgroup keeps the matrix pipe busy.
+template <bool FULL, int EPI>
 __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm, const double* X, double* Y,
                                                         i64 ld, i64 ldy, i64 C, i64 R, i64 Dtot, int row_blocks,
-                                                        int chain_blocks, i64 k_chunk) {
+                                                        int chain_blocks, i64 k_chunk, i64 slab_elems,
+                                                        const double* y_rows) {
   __shared__ DenseLds lds;
   // split-K: blockIdx.y owns the inner-dimension range [k_lo, k_hi) and its own output slab
   const i64 k_lo = (i64)blockIdx.y * k_chunk;
   const i64 D = (k_lo + k_chunk < Dtot) ? k_lo + k_chunk : Dtot;  // exclusive upper bound of k
-  Y += (i64)blockIdx.y * R * ldy;
+  Y += (i64)blockIdx.y * slab_elems;
   // XCD-aware placement: consecutive slots of one XCD walk the row blocks of one chain block
   const int nblk = row_blocks * chain_blocks;
   int id = blockIdx.x;
@@ -176,7 +180,15 @@ __global__ __launch_bounds__(256, 2) void k_dense_apply(const double* M, i64 ldm
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         i64 r = r0 + wr + 16 * i + l4 + 4 * v;
-        if (FULL || (r < R && c < C)) { if (k_chunk >= 0) Y[r * ldy + c] = acc[i][j][v]; }
+        if (FULL || (r < R && c < C)) {
+          double out = acc[i][j][v];
+          if (EPI == 1) {
+            const double e = exp(-fabs(out));
+            const double p = out >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+            out = y_rows[r] - p;
+          }
+          if (k_chunk >= 0) Y[r * ldy + c] = out;
+        }
       }
     }
 }
@@ -216,17 +228,16 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const double* P, i64 slab, in
 namespace {
 
 static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, i64 ldx, double* Y, i64 ldy, i64 C,
-                       double* work, i64 work_elems, void* stream) {
+                       double* work, i64 work_elems, void* stream, const double* y_rows = nullptr) {
   if (!A || !X || !Y || C < 0 || R < 0 || K < 0 || lda < K) return BK_E_ARG;
   if (ldx < C || ldy < C) return BK_E_ALIGN;
   if (C == 0 || R == 0) return BK_OK;
   i64 rb = bk_cdiv(R, BM), cb = bk_cdiv(C, BN);
   i64 per = (cb + 7) / 8;
   if (per * 8 * rb > 0x7fffffff) return BK_E_ARG;
-  unsigned grid = (unsigned)(per * 8 * rb);
   // split the inner dimension when the output has too few tiles to fill 256 CUs x 2 workgroups
   i64 S = 1;
-  if (work && rb * cb < 1024 && K >= 64 * BK) {
+  if (work && !y_rows && rb * cb < 1024 && K >= 64 * BK) {
     S = bk_cdiv(2048, rb * cb);
     i64 maxS = K / (32 * BK);  // keep >= 32 K-panels per split
     if (S > maxS) S = maxS;
@@ -240,15 +251,33 @@ static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, 
     S = bk_cdiv(K, k_chunk);
   }
   double* out = S > 1 ? work : Y;
-  bool full = (R % BM == 0) && (K % BK == 0) && (C % BN == 0) && (lda % 2 == 0) && (ldx % 2 == 0) &&
-              bk_aligned16(A) && bk_aligned16(X);
+  const bool full_but_rows = (K % BK == 0) && (C % BN == 0) && (lda % 2 == 0) && (ldx % 2 == 0) && bk_aligned16(A) &&
+                             bk_aligned16(X);
   hipStream_t st = bk_stream(stream);
-  if (full)
-    k_dense_apply<true><<<dim3(grid, (unsigned)S), dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R, K, (int)rb,
-                                                                      (int)cb, k_chunk);
-  else
-    k_dense_apply<false><<<dim3(grid, (unsigned)S), dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R, K, (int)rb,
-                                                                       (int)cb, k_chunk);
+  // Whole 128-row blocks take the unchecked kernel; a last partial block of rows (R = 10^6 observations: 64 rows)
+  // is a second, small launch of the checked one instead of putting bounds checks into every tile of the first.
+  const i64 R_full = full_but_rows ? R - R % BM : 0;
+  if (R_full > 0) {
+    const i64 rbf = R_full / BM;
+    const dim3 grid((unsigned)(per * 8 * rbf), (unsigned)S);
+    if (y_rows)
+      k_dense_apply<true, 1><<<grid, dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R_full, K, (int)rbf, (int)cb,
+                                                         k_chunk, R * ldy, y_rows);
+    else
+      k_dense_apply<true, 0><<<grid, dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R_full, K, (int)rbf, (int)cb,
+                                                         k_chunk, R * ldy, nullptr);
+  }
+  if (R_full < R) {
+    // rows [R_full, R): its split-K slabs sit at the same row offset inside each slab of R rows
+    const i64 rr = R - R_full, rbr = bk_cdiv(rr, BM);
+    const dim3 grid((unsigned)(per * 8 * rbr), (unsigned)S);
+    if (y_rows)
+      k_dense_apply<false, 1><<<grid, dim3(256), 0, st>>>(A + R_full * lda, lda, X, out + R_full * ldy, ldx, ldy, C, rr, K,
+                                                          (int)rbr, (int)cb, k_chunk, R * ldy, y_rows + R_full);
+    else
+      k_dense_apply<false, 0><<<grid, dim3(256), 0, st>>>(A + R_full * lda, lda, X, out + R_full * ldy, ldx, ldy, C, rr, K,
+                                                          (int)rbr, (int)cb, k_chunk, R * ldy, nullptr);
+  }
   if (S > 1) {
     i64 n = R * ldy;
     k_sum_slabs<<<dim3((unsigned)bk_cdiv(n, 256)), dim3(256), 0, st>>>(work, n, (int)S, Y, n);
@@ -270,6 +299,12 @@ int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const dou
   return gemm_launch(A, lda, R, K, X, ldx, Y, ldy, C, work, work_elems, stream);
 }
 
+int bk_gemm_chains_logistic(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx,
+                            double* Y, int64_t ldy, int64_t C, const double* y_rows, void* stream) {
+  if (!y_rows) return BK_E_ARG;
+  return gemm_launch(A, lda, R, K, X, ldx, Y, ldy, C, nullptr, 0, stream, y_rows);
+}
+
 int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, double* out, int64_t C, int64_t D,
                    void* stream) {
   if (!x || !y || !out || C < 0 || D < 0) return BK_E_ARG;
@@ -285,7 +320,12 @@ int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, d
 namespace {
 
 // Z[n][c] (= x_n . theta_c) -> residual y_n - sigmoid(z) in place; per-segment partial sums of
-// the log likelihood  y z - log(1 + e^z)  (softplus evaluated stably).
+// the log likelihood  y z - log(1 + e^z)  (softplus evaluated stably), summed in row order.  LL false: the caller
+// wants the gradient only (every leapfrog step but the last): no log1p, nothing written to part.
+// The pass is 16 B per element at one exp + one division (+ one log1p) each: RL_ROWS rows are requested before the
+// first is used (one load in flight per thread ran at 2.5 TB/s: 13 ms for the 32.8 GB of config 5).
+constexpr int RL_ROWS = 8;
+template <bool LL>
 __global__ __launch_bounds__(256) void k_logistic_residual(double* Z, i64 ldz, const double* y, double* part,
                                                            i64 N, i64 C, i64 rows_per_seg) {
   i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
@@ -294,16 +334,27 @@ __global__ __launch_bounds__(256) void k_logistic_residual(double* Z, i64 ldz, c
   i64 n0 = seg * rows_per_seg, n1 = n0 + rows_per_seg;
   if (n1 > N) n1 = N;
   double ll = 0.0;
-  for (i64 n = n0; n < n1; ++n) {
-    double z = Z[n * ldz + c];
-    double yn = y[n];
-    double e = exp(-fabs(z));
-    double sp = (z > 0.0 ? z : 0.0) + log1p(e);  // log(1 + e^z)
-    ll = ll + (yn * z - sp);
-    double p = z >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
-    Z[n * ldz + c] = yn - p;
+  for (i64 nb = n0; nb < n1; nb += RL_ROWS) {
+    double zz[RL_ROWS];
+#pragma unroll
+    for (int i = 0; i < RL_ROWS; ++i)
+      if (nb + i < n1) zz[i] = Z[(nb + i) * ldz + c];
+#pragma unroll
+    for (int i = 0; i < RL_ROWS; ++i) {
+      if (nb + i < n1) {
+        const double z = zz[i];
+        const double yn = y[nb + i];
+        const double e = exp(-fabs(z));
+        if (LL) {
+          const double sp = (z > 0.0 ? z : 0.0) + log1p(e);  // log(1 + e^z)
+          ll = ll + (yn * z - sp);
+        }
+        const double p = z >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+        Z[(nb + i) * ldz + c] = yn - p;
+      }
+    }
   }
-  part[seg * C + c] = ll;
+  if (LL) part[seg * C + c] = ll;
 }
 
 // grad = t * G + (-(inv_s2 * theta)); logp = t * sum_s part[s] + (-0.5 * inv_s2 * sum theta^2)
@@ -319,7 +370,8 @@ __global__ __launch_bounds__(64) void k_logistic_finish(const double* G, const d
     if (grad) grad[d * ld + c] = t * G[d * ld + c] + (-(inv_s2 * x));
   }
   double ll = 0.0;
-  for (i64 s = 0; s < S; ++s) ll = ll + part[s * C + c];
+  if (part)
+    for (i64 s = 0; s < S; ++s) ll = ll + part[s * C + c];
   if (ll_out) ll_out[c] = ll;
   if (logp) logp[c] = t * ll + (-0.5 * inv_s2 * s2);
 }
@@ -330,19 +382,20 @@ extern "C" {
 
 int bk_logistic_residual(double* Z, int64_t ldz, const double* y, double* part, int64_t N, int64_t C,
                          int64_t segments, void* stream) {
-  if (!Z || !y || !part || N < 0 || C < 0 || segments < 1 || segments > 65535) return BK_E_ARG;
+  if (!Z || !y || N < 0 || C < 0 || segments < 1 || segments > 65535) return BK_E_ARG;
   if (ldz < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   i64 rows = bk_cdiv(N > 0 ? N : 1, segments);
   dim3 grid((unsigned)bk_cdiv(C, 256), (unsigned)segments);
-  k_logistic_residual<<<grid, dim3(256), 0, bk_stream(stream)>>>(Z, ldz, y, part, N, C, rows);
+  if (part) k_logistic_residual<true><<<grid, dim3(256), 0, bk_stream(stream)>>>(Z, ldz, y, part, N, C, rows);
+  else k_logistic_residual<false><<<grid, dim3(256), 0, bk_stream(stream)>>>(Z, ldz, y, nullptr, N, C, rows);
   BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_logistic_finish(const double* G, const double* theta, int64_t ld, const double* part, int64_t segments,
                        double inv_prior_var, double t, double* grad, double* logp, double* loglik, int64_t C,
                        int64_t D, void* stream) {
-  if (!theta || !part || (grad && !G) || C < 0 || D < 0 || segments < 1) return BK_E_ARG;
+  if (!theta || (!part && (logp || loglik)) || (grad && !G) || C < 0 || D < 0 || segments < 1) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   k_logistic_finish<<<dim3((unsigned)bk_cdiv(C, 64)), dim3(64), 0, bk_stream(stream)>>>(

@@ -560,12 +560,15 @@ def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
     grad, lp = torch.empty_like(th), torch.empty(C, dtype=torch.float64, device=dev)
     model.bk_eval(th, grad, lp)  # warm-up: uploads X^T, sizes the scratch
     el = ctx.timed_loop(lambda: model.bk_eval(th, grad, lp), grad_reps) / grad_reps
+    el_g = ctx.timed_loop(lambda: model.bk_eval(th, grad, None), grad_reps) / grad_reps  # what a leapfrog step asks for
     flop = 2 * 2.0 * N * D * C  # Z = X Theta and G = X^T R
     out = {"workload": f"BASELINE.json configs[4]: logistic regression N={N} D={D}, {C} chains per GPU (synthetic, torch "
                        "seed 20243), gradient = 2 fp64 MFMA GEMMs + residual pass",
            "bound": "mfma", "gradient_ms": 1e3 * el, "gradient_evals_per_sec": C * ctx.world / el,
            "achieved": flop / el / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": flop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS, "flop_model": "4*N*D flop per chain-gradient"}
+           "frac": flop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS, "flop_model": "4*N*D flop per chain-gradient",
+           "gradient_only": {"what": "the same without the log density (a leapfrog step's call)", "ms": 1e3 * el_g,
+                             "achieved": flop / el_g / 1e12, "frac": flop / el_g / 1e12 / FP64_MFMA_PEAK_TFLOPS}}
     # one draw of HMC with a dense metric (velocity covariance ~ the posterior scale 4 D / N)
     L = 4
     Md = torch.eye(D, dtype=torch.float64) * (4.0 * D / N)

@@ -514,10 +514,18 @@ int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double*
 int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx,
                    double* Y, int64_t ldy, int64_t C, double* work, int64_t work_elems, void* stream);
 
+/* bk_gemm_chains whose result leaves as y_rows[r] - sigmoid(Y[r][c]): the logistic regression's first GEMM with the
+ * residual pass (bk_logistic_residual without the log likelihood) in its epilogue -- a gradient-only evaluation is
+ * then two launches.  Same values as the GEMM followed by bk_logistic_residual(part = NULL). */
+int bk_gemm_chains_logistic(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx,
+                            double* Y, int64_t ldy, int64_t C, const double* y_rows, void* stream);
+
 /* Logistic regression target (BASELINE.json config 5; no reference oracle), between the two
  * GEMMs Z = X_data @ Theta and G = X_data^T @ R:
  *   bk_logistic_residual: Z[n*ldz + c] <- y[n] - sigmoid(z) in place, and
- *       part[s*C + c] = sum over the s-th block of observations of  y z - log(1 + e^z);
+ *       part[s*C + c] = sum over the s-th block of observations of  y z - log(1 + e^z)
+ *       (part NULL: gradient only -- no log likelihood is formed; bk_logistic_finish then takes part NULL too
+ *       and writes grad only);
  *   bk_logistic_finish:   grad = t*G + (-(inv_prior_var*theta)),
  *       loglik[c] = sum_s part[s*C + c],  logp[c] = t*loglik + (-0.5*inv_prior_var*|theta|^2)
  *       (t = likelihood temperature of smc.py:47-51; 1 for plain sampling). */

@@ -375,22 +375,27 @@ class FakeOps:
     def gemm_chains(self, A, X, Y, work=None):
         Y.numpy()[...] = A.numpy() @ X.numpy()
 
-    def logistic_residual(self, Z, y, part):
+    def gemm_chains_logistic(self, A, X, Y, y_rows):
+        self.gemm_chains(A, X, Y)
+        self.logistic_residual(Y, y_rows, None)
+
+    def logistic_residual(self, Z, y, part, segments=None):
         z = Z.numpy()
         yv = y.numpy()[:, None]
-        S = part.shape[0]
-        N = z.shape[0]
-        rows = -(-max(N, 1) // S)
-        ll = yv * z - np.logaddexp(0.0, z)
-        for s in range(S):
-            part.numpy()[s] = ll[s * rows:(s + 1) * rows].sum(axis=0)
+        if part is not None:
+            S = part.shape[0]
+            N = z.shape[0]
+            rows = -(-max(N, 1) // S)
+            ll = yv * z - np.logaddexp(0.0, z)
+            for s in range(S):
+                part.numpy()[s] = ll[s * rows:(s + 1) * rows].sum(axis=0)
         from scipy.special import expit
 
         z[...] = yv - expit(z)
 
     def logistic_finish(self, G, theta, part, inv_prior_var, t, grad, logp, loglik):
         th = theta.numpy()
-        ll = part.numpy().sum(axis=0)
+        ll = None if part is None else part.numpy().sum(axis=0)
         if grad is not None:
             grad.numpy()[...] = t * G.numpy() + (-(inv_prior_var * th))
         if loglik is not None:

@@ -1000,6 +1000,11 @@ def test_full_size_cfg5_properties(ops):
     lref = (y[:, None] * z - torch.nn.functional.softplus(z)).sum(dim=0) - 0.5 * (th[:, :16] ** 2).sum(dim=0)
     assert float(((grad[:, :16] - gref).abs().max() / gref.abs().max()).item()) <= 1e-12
     np.testing.assert_allclose(lp[:16].cpu().numpy(), lref.cpu().numpy(), rtol=1e-11)
+    # a gradient-only call (what a leapfrog step makes: no log likelihood formed) gives the same gradient, bit for bit;
+    # N = 1e6 is 7,812 whole 128-row blocks + 64 rows: the last rows go through the checked GEMM launch
+    g_only = torch.full_like(grad, float("nan"))
+    model.bk_eval(th, g_only, None)
+    assert torch.equal(g_only, grad)
     # shard invariance: chains [512, 1024) alone
     # (as views with the full arrays' leading dimension: the target's scratch is laid out for C chains)
     g2 = torch.full((D, C), float("nan"), dtype=torch.float64, device=dev)[:, :512]
