@@ -164,7 +164,8 @@ class ManyChainSampler:
         if metric_diag is not None:
             self._set_metric(metric_diag)
         f64 = dict(dtype=torch.float64, device=dev)
-        self._theta_dc = torch.empty((D, C), **f64)
+        self._state_pad = self._pick_state_pad(C)
+        self._theta_dc = self._new_state()
         if init_t is not None:
             src = init_t.to(dtype=torch.float64)
             if src.dim() == 1:
@@ -481,7 +482,7 @@ class ManyChainSampler:
 
         pool = list(arrays)
         try:
-            pool += [torch.empty_like(arrays[0]) for _ in range(self.TUNE_PLACEMENT_SPARES)]
+            pool += [self._new_state() for _ in range(self.TUNE_PLACEMENT_SPARES)]
         except torch.cuda.OutOfMemoryError:
             pool = list(arrays)  # no room for spare candidates: permute what there is
         for a in pool:
@@ -517,6 +518,24 @@ class ManyChainSampler:
         return e0.elapsed_time(e1) / reps
 
     _out = None
+    _state_pad = 0
+    # Columns of padding in the row pitch of a sampler's [D, C] arrays when C * 8 bytes is a multiple of 4 KiB
+    # (0 = none).  Kernels that walk DOWN the rows of a few chains (per-chain reductions, the one-pass MALA step) then
+    # find every row of those chains on the same memory channels; 1152 bytes off the power-of-two pitch spreads them.
+    # Measured per sampler (the streaming HMC kernels do not care: 39.1 ms per draw with or without), so a class
+    # attribute; BK_STATE_PAD=<columns> overrides it for experiments.
+    STATE_PAD_COLUMNS = 0
+
+    def _pick_state_pad(self, C):
+        env = os.environ.get("BK_STATE_PAD")
+        if env is not None:
+            return max(0, int(env))
+        return self.STATE_PAD_COLUMNS if (self._batched and C >= 4096 and (C * 8) % 4096 == 0) else 0
+
+    def _new_state(self):
+        """A [D, C] state array (rows `_state_pad` columns further apart than C)."""
+        t = torch.empty((self._dim, self._C + self._state_pad), dtype=torch.float64, device=self._ops.device)
+        return t[:, :self._C] if self._state_pad else t
 
     def _select(self, mask, th, thp, g=None, gp=None):
         """theta (and its cached gradient) <- proposal on the accepted chains; in the same pass
@@ -524,7 +543,7 @@ class ManyChainSampler:
         ``_theta`` instead of mutating it, so returned draws must stay valid)."""
         self._out = None
         if self._batched and not self._use_graph:
-            self._out = torch.empty_like(th)
+            self._out = self._new_state()
         self._ops.select_columns(mask, th, thp, g, gp, self._out)
 
     def _draw_out(self, theta_dc, logp):

@@ -58,6 +58,27 @@ def test_torch_autograd_model_matches_builtin(ops):
         np.testing.assert_allclose(la.cpu().numpy(), lb.cpu().numpy(), rtol=1e-11)
 
 
+@pytest.mark.parametrize("two_pass", [True, False])
+def test_mala_padded_row_pitch_gives_the_same_draws(ops, monkeypatch, two_pass):
+    """From 4,096 chains on, MALA keeps its [D, C] arrays with the rows 144 columns further apart than C (rows of a chain
+    off one memory channel); the draws, log densities and stream positions are those of dense arrays."""
+    lam = np.logspace(0, 1, 40)
+    a = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=4096, seed=3, two_pass=two_pass)
+    monkeypatch.setenv("BK_STATE_PAD", "0")
+    b = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=4096, seed=3, two_pass=two_pass)
+    monkeypatch.delenv("BK_STATE_PAD")
+    assert a._state_pad == 144 and b._state_pad == 0 and a._theta_dc.stride(0) == 4096 + 144
+    for _ in range(6):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert tuple(ta.shape) == (4096, 40) and torch.equal(ta, tb) and torch.equal(la, lb)
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    sd = a.state_dict()
+    c = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=4096, seed=99, two_pass=two_pass)
+    c.load_state_dict(sd)
+    assert torch.equal(c.sample()[0], a.sample()[0])
+
+
 def test_torch_model_written_for_the_engine_layout(ops):
     """TorchModel(layout="dc"): the user function takes the (D, C) array itself -- same draws as the (C, D) form and as
     the built-in target, and the gradient comes back chain-contiguous (the streamed kick + drift, no LDS turn)."""
