@@ -59,7 +59,9 @@ __global__ __launch_bounds__(512) void k_tile(double* a0, double* a1, double* a2
 }
 
 int main() {
-  const i64 C = 65536, D = 1024, n = C * D;
+  // PAD=<columns>: rows that many columns further apart than C (the row pitch off a power of two)
+  const i64 C = 65536, D = 1024, LD = C + (getenv("PAD") ? atol(getenv("PAD")) : 0), n = LD * D;
+  printf("row pitch %ld doubles\n", (long)LD);
   double* buf[8]; double* sink;
   for (auto& b : buf) { CK(hipMalloc(&b, n * 8)); CK(hipMemset(b, 0, n * 8)); }
   CK(hipMalloc(&sink, 8));
@@ -76,7 +78,7 @@ int main() {
   const double B = (double)n * 8;
 #define RUN(PA, EE, NA, MO, NTT, XRR, bytes) timeit("P=" #PA " E=" #EE " NA=" #NA " MODE=" #MO " NT=" #NTT " XR=" #XRR, bytes, [&] { \
     constexpr int SLAB = (512 / PA) * EE; const i64 nS = (D + SLAB - 1) / SLAB, nCB = C / (2 * PA); \
-    k_tile<PA, EE, NA, MO, NTT, XRR><<<dim3((unsigned)(nCB * nS)), dim3(512)>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], buf[7], C, C, D, sink); })
+    k_tile<PA, EE, NA, MO, NTT, XRR><<<dim3((unsigned)(nCB * nS)), dim3(512)>>>(buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], buf[7], LD, C, D, sink); })
   // 16 chains x 1024 rows per workgroup (the k_mala_step shape), 2 arrays
   RUN(8, 16, 2, 0, true, false, 2 * B);
   RUN(8, 16, 2, 0, true, true, 2 * B);
@@ -84,6 +86,13 @@ int main() {
   RUN(8, 16, 2, 1, true, true, 2 * B);
   RUN(8, 16, 2, 1, false, true, 2 * B);
   RUN(8, 16, 2, 2, true, true, 4 * B);
+  // 8 chains x 1024 rows per workgroup half the size (64-byte row pieces), two per CU
+  RUN(4, 8, 2, 0, true, false, 2 * B);
+  RUN(4, 8, 2, 1, true, false, 2 * B);
+  RUN(4, 8, 2, 2, true, false, 4 * B);
+  RUN(4, 8, 2, 2, true, true, 4 * B);
+  RUN(4, 8, 4, 2, true, true, 8 * B);
+  RUN(8, 16, 4, 2, true, true, 8 * B);
   // wider tiles with fewer rows (same 16K elements per array per workgroup)
   RUN(16, 16, 2, 1, true, false, 2 * B);
   RUN(32, 16, 2, 1, true, false, 2 * B);
