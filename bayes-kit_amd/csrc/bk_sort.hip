@@ -78,10 +78,16 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(uint32_t* tile_hist,
   uint32_t* row = tile_hist + (i64)blockIdx.x * n_tiles;
   if (t == 0) carry = 0;
   __syncthreads();
-  for (i64 c0 = 0; c0 < n_tiles; c0 += SORT_THREADS) {
-    const i64 i = c0 + t;
-    const uint32_t v = i < n_tiles ? row[i] : 0;
-    uint32_t incl = v;  // inclusive scan inside the wavefront
+  constexpr int PER = 8;  // consecutive entries per thread and round
+  for (i64 c0 = 0; c0 < n_tiles; c0 += SORT_THREADS * PER) {
+    const i64 i0 = c0 + (i64)t * PER;
+    uint32_t v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      v[k] = i0 + k < n_tiles ? row[i0 + k] : 0;
+      mine += v[k];
+    }
+    uint32_t incl = mine;  // inclusive scan of the threads' sums inside the wavefront
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       uint32_t up = __shfl_up(incl, o);
@@ -91,7 +97,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_scan(uint32_t* tile_hist,
     __syncthreads();
     uint32_t before = carry;
     for (int k = 0; k < w; ++k) before += wsum[k];
-    if (i < n_tiles) row[i] = before + incl - v;
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (i0 + k < n_tiles) row[i0 + k] = run;
+      run += v[k];
+    }
     __syncthreads();
     if (t == SORT_THREADS - 1) carry = before + incl;
     __syncthreads();
