@@ -232,6 +232,14 @@ SAMPLER_CASES = [
     dict(name="drghmc_funnel101_cfg4", alg="drghmc", model=dict(kind="funnel", D=101),
          max_proposals=3, leapfrog_step_sizes=[0.2, 0.05, 0.0125],
          leapfrog_step_counts=[10, 40, 160], damping=0.1, chains=4, draws=40, seed=20242),
+    # four proposal kinds: ghosts of ghosts of ghosts (the lane-set recursion three levels deep)
+    dict(name="drghmc_funnel17_k4", alg="drghmc", model=dict(kind="funnel", D=17), max_proposals=4,
+         leapfrog_step_sizes=[0.3, 0.1, 0.033, 0.011], leapfrog_step_counts=[3, 6, 12, 24], damping=0.3,
+         chains=8, draws=40, seed=307),
+    # the funnel with a diagonal metric and without probabilistic retry
+    dict(name="drghmc_funnel33_k2_metric_noretry", alg="drghmc", model=dict(kind="funnel", D=33), max_proposals=2,
+         leapfrog_step_sizes=[0.25, 0.08], leapfrog_step_counts=[4, 12], damping=0.5, prob_retry=False,
+         metric=dict(kind="linspace", lo=0.7, hi=1.4), chains=8, draws=40, seed=308),
     # --- Metropolis / Metropolis-Hastings (bayes_kit/metropolis.py) with seeded user proposals ---
     dict(name="metropolis_rw_iso3", alg="metropolis", model=dict(kind="iso_gaussian", D=3),
          proposal=dict(kind="normal", scale=0.6, seed=9001), chains=6, draws=80, seed=501),

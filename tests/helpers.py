@@ -14,7 +14,8 @@ SAMPLER_CASES = [
     "hmc_diag1024_cfg3", "hmc_pcg_seed",
     "mala_readme_cfg1", "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_diag48", "mala_init",
     "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
-    "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40",
+    "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40", "drghmc_funnel17_k4",
+    "drghmc_funnel33_k2_metric_noretry",
     "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
     "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed",
 ]

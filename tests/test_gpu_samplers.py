@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric", "hmc_diag1024_cfg3",
         "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_diag48", "mala_init",
         "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
-        "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40", "metropolis_rw_iso3", "mh_ar_iso2"]
+        "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40", "drghmc_funnel17_k4",
+        "drghmc_funnel33_k2_metric_noretry", "metropolis_rw_iso3", "mh_ar_iso2"]
 
 
 @pytest.fixture(scope="module")
