@@ -428,15 +428,25 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
     lane_steps = float(s.lane_steps_total.item()) - base if on_device else state["lane_steps"]
     # the summary: R-hat of every dimension over the chains of ALL ranks (two all_gathers of 3*D+1 doubles,
     # summed in rank order), ESS and lane totals (one all_reduce each) -- timed on its own
+    # (evaluated twice -- both are read-only: the first call of a process pays for loading the diagnostics' code
+    # objects, ~0.1-0.2 s; the second is what a summary costs)
+    def summary():
+        rh_ = mom.rhat()
+        e_ = rec.ess()
+        e_ = torch.where(e_ > 0, e_, torch.full_like(e_, float(draws))).clamp(max=float(draws)).min(dim=0).values
+        tot_ = bk.dist.sum_over_ranks(float(e_.sum().item()), ctx.device)
+        lane_ = bk.dist.sum_over_ranks(float(lane_steps), ctx.device)
+        torch.cuda.synchronize()
+        return rh_, tot_, lane_
+
+    ctx.barrier()
+    t0 = time.perf_counter()
+    summary()
+    first_s = time.perf_counter() - t0
     calls0 = dict(bk.dist.collective_calls)
     ctx.barrier()
     t0 = time.perf_counter()
-    rh = mom.rhat()
-    ess = rec.ess()
-    ess = torch.where(ess > 0, ess, torch.full_like(ess, float(draws))).clamp(max=float(draws)).min(dim=0).values
-    ess_total = bk.dist.sum_over_ranks(float(ess.sum().item()), ctx.device)
-    lane_total = bk.dist.sum_over_ranks(float(lane_steps), ctx.device)
-    torch.cuda.synchronize()
+    rh, ess_total, lane_total = summary()
     summary_s = time.perf_counter() - t0
     calls = {k: bk.dist.collective_calls[k] - calls0[k] for k in calls0}
     flop_per_eval = 13.0 * D  # see DESIGN.md section 3: funnel gradient + kick + drift, per chain-step
@@ -450,6 +460,7 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
            "fp64_tflops": lane_total * flop_per_eval / el / 1e12, "flop_model": "13*D flop per gradient evaluation",
            "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "ess_per_sec": ess_total / el, "draws": draws,
            "rhat_over_chains": C * ctx.world, "collectives_per_summary": calls, "summary_ms": 1e3 * summary_s,
+           "summary_first_call_ms": 1e3 * first_s,
            "collective_backend": ctx.backend, "collective_ranks": ctx.collective_ranks(),
            "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False)),
            "diagnostics": "Welford moments + tracked series updated inside the draw's hipGraph (attach), no returned copies "
