@@ -225,7 +225,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <int G>
+// RT (series of ET_RT_MIN_DRAWS draws and more): a block of 64 lags is summed from REGISTER TILES instead of one LDS read
+// per multiply-add.  Lane l owns 9 consecutive draws t = tc + 9 l + b of every chunk of 576 draws and keeps 64
+// accumulators, one per lag of the block; a chunk needs the lane's 9 values x[t..t+8] and the window
+// x[t + n0 .. t + n0 + 71] -- 81 LDS reads (stride 9 doubles between lanes: conflict-free) for 576 fused
+// multiply-adds, against 1,152 reads.  The series is followed by >= 72 zeros in LDS, so draws and lags beyond the end
+// need no masks.  A butterfly of 63 exchanges then leaves the total of lag n0 + l in lane l (the layout the Geyer scan
+// below works on).  Per-lag order of summation: a lane's draws ascending, then a fixed tree over the lanes.
+constexpr int ET_RT_MIN_DRAWS = 288, ET_RT_TAIL = 72;
+
+template <int HALF>
+__device__ __forceinline__ void ess_fold(double (&v)[64], int lane) {
+  // lanes whose bit HALF is set keep the upper half of the first 2*HALF entries, the others the lower half
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const bool up = (lane & HALF) != 0;
+    const double send = up ? v[i] : v[i + HALF];
+    const double mine = up ? v[i + HALF] : v[i];
+    v[i] = mine + __shfl_xor(send, HALF);
+  }
+}
+
+template <int G, bool RT>
 __global__ __launch_bounds__(ET_BLOCK) void k_ess_tile(const double* x, i64 ld, i64 N, int pitch, int estimator,
                                                        double* ess_out, double* iat_out, double* acor_out, i64 ldo,
                                                        i64 C) {
@@ -237,6 +258,8 @@ __global__ __launch_bounds__(ET_BLOCK) void k_ess_tile(const double* x, i64 ld, 
     constexpr int RS = ET_BLOCK / G;
     const bool ok = c0 + cl < C;
     for (i64 r = r0; r < N; r += RS) xs[cl * pitch + r] = ok ? x[r * ld + c0 + cl] : 0.0;
+    if (RT)
+      for (i64 r = N + r0; r < pitch; r += RS) xs[cl * pitch + r] = 0.0;  // (the zeros behind the series)
   }
   __syncthreads();
   for (int cl = w; cl < G; cl += ET_WAVES) {
@@ -260,10 +283,38 @@ __global__ __launch_bounds__(ET_BLOCK) void k_ess_tile(const double* x, i64 ld, 
       const i64 n = n0 + lane;
       double a = 0.0;
       const i64 tmax = N - n0;  // lane 0's term count; lane l stops l terms earlier
+      if (RT) {
+        double acc[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) acc[j] = 0.0;
+        for (i64 tc = 0; tc < tmax; tc += 9 * BK_WAVE) {
+          const i64 t0 = tc + 9 * lane, ty = t0 + n0;
+          const double* px = xc + (t0 < N ? t0 : N);  // (from N on: zeros)
+          const double* py = xc + (ty < N ? ty : N);
+          double X[9], win[16];
+#pragma unroll
+          for (int b = 0; b < 9; ++b) X[b] = px[b];
+#pragma unroll
+          for (int m = 0; m < 12; ++m) win[m] = py[m];
+#pragma unroll
+          for (int j = 0; j < 64; ++j) {
+            if (j + 12 < ET_RT_TAIL) win[(j + 12) & 15] = py[j + 12];
+#pragma unroll
+            for (int b = 0; b < 9; ++b) acc[j] = __builtin_fma(X[b], win[(j + b) & 15], acc[j]);
+          }
+        }
+        ess_fold<32>(acc, lane);
+        ess_fold<16>(acc, lane);
+        ess_fold<8>(acc, lane);
+        ess_fold<4>(acc, lane);
+        ess_fold<2>(acc, lane);
+        ess_fold<1>(acc, lane);
+        a = acc[0];
+      }
       // main part: every lane's index is in range, 8 steps per pass with all 16 LDS reads issued before
       // the (ordered) accumulation -- one read-use dependency per step would cost an LDS latency each
       const i64 tsafe = tmax - (BK_WAVE - 1);  // tt + n0 + 63 < N  for tt < tsafe
-      i64 tt = 0;
+      i64 tt = RT ? tmax : 0;
       for (; tt + 8 <= tsafe; tt += 8) {
         double u[8], v[8];
 #pragma unroll
@@ -504,7 +555,8 @@ static int ess_tile_launch(const double* x, i64 ld, i64 N, int estimator, double
                            double* acor_out, i64 ldo, i64 C, hipStream_t s) {
   static const bool lane_only = []() { const char* e = getenv("BK_ESS_LANE_PER_CHAIN"); return e && e[0] == '1'; }();
   if (lane_only) return 0;  // experiments: the one-lane-per-chain kernels
-  const int pitch = (int)(N | 1);
+  const bool rt = N >= ET_RT_MIN_DRAWS;
+  const int pitch = (int)((rt ? N + ET_RT_TAIL : N) | 1);
   const i64 cap = (i64)(160 * 1024 - 512) / 8;
   int G = 0;
   for (int g : {16, 8, 4, 2, 1})
@@ -515,11 +567,17 @@ static int ess_tile_launch(const double* x, i64 ld, i64 N, int estimator, double
 #define BK_ET(GG)                                                                                                   \
   do {                                                                                                              \
     if (bytes > 64 * 1024) {                                                                                        \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ess_tile<GG>),                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rt ? &k_ess_tile<GG, true>                   \
+                                                                          : &k_ess_tile<GG, false>),                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);                   \
       if (e != hipSuccess) return -(int)e - 1000;                                                                   \
     }                                                                                                               \
-    k_ess_tile<GG><<<grid, block, bytes, s>>>(x, ld, N, pitch, estimator, ess_out, iat_out, acor_out, ldo, C);      \
+    if (rt)                                                                                                         \
+      k_ess_tile<GG, true><<<grid, block, bytes, s>>>(x, ld, N, pitch, estimator, ess_out, iat_out, acor_out, ldo,  \
+                                                      C);                                                           \
+    else                                                                                                            \
+      k_ess_tile<GG, false><<<grid, block, bytes, s>>>(x, ld, N, pitch, estimator, ess_out, iat_out, acor_out, ldo, \
+                                                       C);                                                          \
   } while (0)
   switch (G) {
     case 16: BK_ET(16); break;
