@@ -661,6 +661,9 @@ def _len(chain) -> int:
 # chains, two real series per complex transform), followed by the scan kernel (bk_iat_from_acor) -- the direct
 # sums are O(N^2 / 64) for ALL lags.
 FFT_MIN_DRAWS = 16384
+# autocorr() wants ALL lags, which the direct sums pay O(N^2 / 64) for: the FFT is ahead from 256 draws on (4,096 chains:
+# 0.10 vs 0.13 ms at 256 draws, 0.40 vs 0.66 at 2,048, 0.55 vs 3.2 at 8,192; tools/autocorr_crossover.py)
+AUTOCORR_FFT_MIN_DRAWS = 256
 _FFT_SCRATCH_BYTES = 2 << 30  # chains per FFT batch are chosen to keep the two complex scratch arrays below this
 
 
@@ -681,7 +684,7 @@ def autocorr(chain, *, ops=None):
         raise ValueError(f"autocorr requires len(chain) >= 2, but {len(chain)=}")
     ops = _ops(ops)
     x, one = _series(chain, ops)
-    if x.shape[0] >= FFT_MIN_DRAWS:
+    if x.shape[0] >= AUTOCORR_FFT_MIN_DRAWS:
         out = _autocorr_fft(x, ops)
     else:
         out = torch.empty_like(x)
