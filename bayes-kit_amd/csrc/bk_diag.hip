@@ -111,22 +111,43 @@ __global__ __launch_bounds__(256) void k_rhat_partials(const double* mean, const
   }
 }
 
-// two-pass mean / variance per chain of a stored series (np.mean, np.var(ddof=1))
-__global__ __launch_bounds__(PC_BLOCK) void k_chain_mean_var(const double* x, i64 ld, const int32_t* len,
-                                                             i64 N, double* mean, double* var, i64 C) {
-  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
-  if (c >= C) return;
-  i64 n = len ? (i64)len[c] : N;
+// two-pass mean / variance per chain of a stored series (np.mean, np.var(ddof=1)): a workgroup of four wavefronts
+// serves 64 chains (lane = chain); wavefront w sums the draws t = w, w + 4, w + 8, ... with eight loads in flight,
+// the four partial sums are combined as ((p0 + p1) + p2) + p3.  (One lane walking its chain's N rows alone, one load
+// at a time, ran at 0.5 TB/s: 1.09 ms for 1000 draws x 65,536 chains.)  len: per-chain draw counts (ragged chains).
+__global__ __launch_bounds__(256) void k_chain_mean_var(const double* x, i64 ld, const int32_t* len, i64 N,
+                                                        double* mean, double* var, i64 C) {
+  __shared__ double part[4][BK_WAVE];
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
+  const i64 n = c < C ? (len ? (i64)len[c] : N) : 0;
+  const double* xc = x + (c < C ? c : 0);
   double s = 0.0;
-  for (i64 t = 0; t < n; ++t) s = s + x[t * ld + c];
-  double mu = s / (double)n;
-  double q = 0.0;
-  for (i64 t = 0; t < n; ++t) {
-    double dv = x[t * ld + c] - mu;
-    q = q + dv * dv;
+  for (i64 t0 = w; t0 < N; t0 += 32) {  // (wavefront-uniform trip count; a lane's own draws end at n)
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (t0 + 4 * k < n) ? xc[(t0 + 4 * k) * ld] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = s + v[k];
   }
-  mean[c] = mu;
-  if (var) var[c] = q / (double)(n - 1);
+  part[w][lane] = s;
+  __syncthreads();
+  const double mu = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (double)n;
+  __syncthreads();
+  double q = 0.0;
+  for (i64 t0 = w; t0 < N; t0 += 32) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (t0 + 4 * k < n) ? xc[(t0 + 4 * k) * ld] - mu : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q = q + v[k] * v[k];
+  }
+  part[w][lane] = q;
+  __syncthreads();
+  if (w == 0 && c < C) {
+    mean[c] = mu;
+    if (var) var[c] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (double)(n - 1);
+  }
 }
 
 // ESS per chain, one lane per chain.  acor[n] = (sum_t xc[t]*xc[t+n]) / var0 / N with
@@ -537,8 +558,7 @@ int bk_chain_mean_var(const double* x, int64_t ld, const int32_t* len, int64_t N
   if (!x || !mean || N < 0 || C < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
-  k_chain_mean_var<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
-      x, ld, len, N, mean, var, C);
+  k_chain_mean_var<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(256), 0, bk_stream(stream)>>>(x, ld, len, N, mean, var, C);
   BK_RETURN_LAUNCH_STATUS();
 }
 
