@@ -664,26 +664,35 @@ def test_accept_with_non_finite_log_densities(ops):
 
 
 @pytest.mark.parametrize("N,C", [(4, 3), (5, 70), (63, 17), (64, 33), (65, 16), (130, 100), (1000, 37), (1271, 20),
-                                 (1300, 9), (3000, 5), (6001, 3), (12000, 2)])
+                                 (1300, 9), (3000, 5), (6001, 3), (12000, 2),
+                                 (287, 6), (288, 7), (289, 17), (575, 3), (576, 5), (577, 9), (1151, 4), (1153, 2),
+                                 (5000, 3), (16383, 1)])
 def test_lds_staged_ess_and_autocorr_vs_oracle(ops, N, C):
     """bk_ess / bk_autocorr with the series staged in LDS (16 / 8 / 4 / 2 / 1 chains per workgroup by N,
-    one wavefront per chain, one lane per lag) against oracle/diagnostics.py (the reference's FFT
-    formulation): AR(1) chains of several persistences, antithetic chains (negative first pair), both
-    estimators, ragged last workgroup."""
+    one wavefront per chain; below 288 draws one lane per lag, from 288 on 64 lags per block from register tiles:
+    chunks of 576 draws, so 287 .. 289, 575 .. 577, 1151 / 1153 sit on the seams) against oracle/diagnostics.py
+    (the reference's FFT formulation): AR(1) chains of several persistences up to 0.999 (many 64-lag blocks),
+    antithetic chains (negative first pair), both estimators, ragged last workgroup; autocorr() itself takes the
+    FFT from 256 draws on, so the direct all-lag kernel is called by name as well."""
     from oracle import diagnostics as od
 
     rng = np.random.default_rng(N * 1000 + C)
     x = np.empty((N, C))
     for c in range(C):
-        phi = [-0.6, 0.0, 0.5, 0.9, 0.98][c % 5]
+        phi = [-0.6, 0.0, 0.5, 0.9, 0.98, 0.999][c % 6]
         e = rng.normal(size=N)
         x[0, c] = e[0]
         for t in range(1, N):
             x[t, c] = phi * x[t - 1, c] + e[t]
     xd = torch.from_numpy(x).to(ops.device)
     ac = bk.autocorr(xd).cpu().numpy()
+    direct = torch.empty_like(xd)
+    ops.autocorr(xd, direct)
+    direct = direct.cpu().numpy()
     for c in range(C):
-        np.testing.assert_allclose(ac[:, c], od.autocorr(x[:, c]), rtol=0, atol=1e-12)
+        want = od.autocorr(x[:, c])
+        np.testing.assert_allclose(ac[:, c], want, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(direct[:, c], want, rtol=0, atol=1e-12)
     for fn, ofn in ((bk.ess, od.ess), (bk.ess_ipse, od.ess_ipse), (bk.iat, od.iat), (bk.iat_ipse, od.iat_ipse)):
         got = fn(xd).cpu().numpy()
         want = np.array([ofn(x[:, c]) for c in range(C)])
