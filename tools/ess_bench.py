@@ -11,7 +11,8 @@ args = [int(a) for a in sys.argv[1:]] or [1000, 65536, 1000, 32768, 200, 65536, 
 for N, C in zip(args[::2], args[1::2]):
     g = torch.Generator(device=ops.device)
     g.manual_seed(1)
-    x = torch.randn((N, C), dtype=torch.float64, device=ops.device, generator=g)
+    PAD = int(os.environ.get("PAD", 0))  # extra columns in the row pitch of the series
+    x = torch.randn((N, C + PAD), dtype=torch.float64, device=ops.device, generator=g)[:, :C]
     for t in range(1, N):
         x[t] += 0.8 * x[t - 1]
     e = torch.empty(C, dtype=torch.float64, device=ops.device)
