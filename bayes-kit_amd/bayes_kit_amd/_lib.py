@@ -37,6 +37,9 @@ SIGNATURES = {
     "bk_leapfrog_kick_drift": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P],
     "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P],
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
+    "bk_leapfrog_kick_drift_n": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P, P],
+    "bk_leapfrog_first_step_gather_n": [P, P, P, I, P, P, P, I, P, F, F, I, I, P, P],
+    "bk_leapfrog_finish_level": [P, P, I, P, I, I, P, F, c_int, P, I, I, P, P, P, P, P, P, P, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
     "bk_select_columns": [P, P, P, P, P, P, I, I, I, P],
     "bk_blend_columns": [P, P, P, P, I, I, I, P],
@@ -64,6 +67,9 @@ SIGNATURES = {
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
+    "bk_target_iso_gaussian_grad_n": [P, P, P, I, I, I, P, P],
+    "bk_target_diag_gaussian_grad_n": [P, P, P, I, P, I, I, P, P],
+    "bk_target_funnel_grad_n": [P, P, P, I, I, I, P, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
@@ -246,30 +252,47 @@ class Ops:
                    self._s())
 
     # -- integrator -----------------------------------------------------------------------
+    # n_dev (optional; here and in target_grad): int32 device tensor [1] with the number of lanes really in the
+    # set -- the tensors' chain extent is then only the bound the launch is sized for (bk_*_n entry points)
     def kick_drift(self, theta_in, theta_out, rho_in, rho_out, grad, metric, eps,
-                   use_pre, pre, use_kick, kick):
+                   use_pre, pre, use_kick, kick, n_dev=None):
         D, C = theta_out.shape
         ld = _ld(theta_out)
         assert _ld(theta_in) == ld and _ld(rho_in) == ld and _ld(rho_out) == ld
-        self._call("bk_leapfrog_kick_drift", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
-                   ptr(grad), grad.stride(0), grad.stride(1), ptr(metric), eps, int(use_pre), pre,
-                   int(use_kick), kick, C, D, self._s())
+        if n_dev is None:
+            self._call("bk_leapfrog_kick_drift", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
+                       ptr(grad), grad.stride(0), grad.stride(1), ptr(metric), eps, int(use_pre), pre,
+                       int(use_kick), kick, C, D, self._s())
+        else:
+            self._call("bk_leapfrog_kick_drift_n", ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld,
+                       ptr(grad), grad.stride(0), grad.stride(1), ptr(metric), eps, int(use_pre), pre,
+                       int(use_kick), kick, C, D, ptr(n_dev), self._s())
 
-    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre):
+    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre,
+                          n_dev=None):
         D, n = theta_out.shape
         ld_in = _ld(theta_in)
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in and _ld(rho_out) == _ld(theta_out)
-        self._call("bk_leapfrog_first_step_gather", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in,
+        self._call("bk_leapfrog_first_step_gather_n", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in,
                    ptr(src_index), ptr(theta_out), ptr(rho_out), _ld(theta_out), ptr(metric), eps, pre,
-                   n, D, self._s())
+                   n, D, ptr(n_dev), self._s())
 
-    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out):
+    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out, n_dev=None, level=None,
+                        lanes_out=None, lanes_total=None):
+        """level: optional (logp, H, h, live) -- the dr_level_begin of the lanes the trajectory produced, done by
+        the same launch; lanes_out / lanes_total: the launch's lane count (written / added)."""
         D, C = rho_in.shape
         if rho_out is not None:
             assert _ld(rho_out) == _ld(rho_in)
         gs = (0, 0) if grad is None else grad.stride()
-        self._call("bk_leapfrog_finish", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), gs[0], gs[1],
-                   ptr(metric), half, int(negate), ptr(kin_out), C, D, self._s())
+        if n_dev is None and level is None and lanes_out is None and lanes_total is None:
+            self._call("bk_leapfrog_finish", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), gs[0], gs[1],
+                       ptr(metric), half, int(negate), ptr(kin_out), C, D, self._s())
+            return
+        logp, H, h, live = level if level is not None else (None,) * 4
+        self._call("bk_leapfrog_finish_level", ptr(rho_in), ptr(rho_out), _ld(rho_in), ptr(grad), gs[0], gs[1],
+                   ptr(metric), half, int(negate), ptr(kin_out), C, D, ptr(n_dev), ptr(logp), ptr(H), ptr(h),
+                   ptr(live), ptr(lanes_out), ptr(lanes_total), self._s())
 
     def mh_accept(self, mode, lp_cur, a_cur, lp_prop, a_prop, log_u, mask, ret, count):
         self._call("bk_mh_accept", mode, ptr(lp_cur), ptr(a_cur), ptr(lp_prop), ptr(a_prop), ptr(log_u),
@@ -429,12 +452,24 @@ class Ops:
                    ptr(count), C, D, self._s())
 
     # -- built-in targets -----------------------------------------------------------------------
-    def target_grad(self, kind, params, theta, grad, logp):
+    def target_grad(self, kind, params, theta, grad, logp, n_dev=None):
         D, C = theta.shape
         ld = _ld(theta)
         if grad is not None:
             assert _ld(grad) == ld
-        if kind == "iso_gaussian":
+        if n_dev is not None:
+            if kind == "iso_gaussian":
+                self._call("bk_target_iso_gaussian_grad_n", ptr(theta), ptr(grad), ptr(logp), ld, C, D, ptr(n_dev),
+                           self._s())
+            elif kind == "diag_gaussian":
+                self._call("bk_target_diag_gaussian_grad_n", ptr(theta), ptr(grad), ptr(logp), ld, ptr(params),
+                           C, D, ptr(n_dev), self._s())
+            elif kind == "funnel":
+                self._call("bk_target_funnel_grad_n", ptr(theta), ptr(grad), ptr(logp), ld, C, D, ptr(n_dev),
+                           self._s())
+            else:
+                raise BkHipError(f"built-in target {kind!r} has no counted gradient")
+        elif kind == "iso_gaussian":
             self._call("bk_target_iso_gaussian_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
         elif kind == "diag_gaussian":
             self._call("bk_target_diag_gaussian_grad", ptr(theta), ptr(grad), ptr(logp), ld, ptr(params),

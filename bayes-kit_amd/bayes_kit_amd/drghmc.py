@@ -105,22 +105,36 @@ class DrGhmcDiag(ManyChainSampler):
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
         # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
-        # Lane counts on the device (targets whose whole proposal is one library launch): the sizes of
-        # the lane sets -- which depend on the draw's own accept / retry decisions -- stay in device
-        # memory; every launch is sized for its parent set and surplus workgroups exit at once.  No
-        # host read inside sample(), so the draw is a FIXED launch sequence and replays as one
-        # hipGraph.  Other models keep compacted launches sized by three host reads per draw.
-        can_dev = self._fused and getattr(model, "bk_dr_proposal_supported", lambda: False)()
+        # Lane counts on the device: the sizes of the lane sets -- which depend on the draw's own accept / retry
+        # decisions -- stay in device memory; every launch is sized for its parent set and surplus workgroups
+        # exit at once.  No host read inside sample(), so the draw is a FIXED launch sequence and replays as one
+        # hipGraph.  Two kinds of model can run that way:
+        #   * one whose whole proposal is one library launch (bk.Funnel with the gradient inlined): _one_launch;
+        #   * ANY model whose gradient op takes its chain count from device memory (`bk_counted`: the built-in
+        #     targets' bk_target_*_grad_n, a CTarget with a counted_symbol of type bk_target_fn_n) -- the
+        #     trajectory is then the reference's own sequence of model calls (drghmc.py:280-283), one counted
+        #     gradient launch + one counted kick+drift launch per leapfrog step.
+        # Other models (PyTorch autograd: the call needs a host-side shape) keep compacted launches sized by
+        # three host reads per draw.
+        one_launch = self._fused and getattr(model, "bk_dr_proposal_supported", lambda: False)()
+        counted = self._batched and hasattr(model, "bk_eval") and getattr(model, "bk_counted", False) is True
+        can_dev = one_launch or counted
         if device_counts and not can_dev:
-            raise ValueError("device_counts=True needs a built-in target with a one-launch proposal (bk.Funnel, D <= 129)")
-        self._dev_counts = can_dev if device_counts is None else bool(device_counts)
+            raise ValueError("device_counts=True needs a model whose gradient op takes its chain count from device "
+                             "memory (a built-in target, or a CTarget with counted_symbol=)")
+        if device_counts is None:
+            # a counted step-by-step draw is ~2 launches per leapfrog step over every lane set: it wins where the
+            # draw is launch-bound; HBM-bound shapes keep the compacted 16-byte-per-lane kernels of the host-sized path
+            device_counts = one_launch or (counted and dev.type == "cuda" and D * C <= self.GRAPH_AUTO_MAX_ELEMS)
+        self._dev_counts = bool(device_counts)
+        self._one_launch = self._dev_counts and one_launch
         if graph is None:
             graph = self._dev_counts and dev.type == "cuda"
         if graph and not self._dev_counts:
             raise ValueError("graph=True needs device_counts (the host-sized path reads lane counts back every draw)")
-        # (device-count path) a proposal's launch also runs the first ghost of the lanes it produces; False keeps
+        # (one-launch path) a proposal's launch also runs the first ghost of the lanes it produces; False keeps
         # that ghost a launch of its own -- same results, for A/B timing and the tests
-        self._fuse_first_ghost = bool(fuse_first_ghost)
+        self._fuse_first_ghost = bool(fuse_first_ghost) and self._one_launch
         self._init_graph(graph)
         self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
             max(0, k - 1) for k in range(int(max_proposals)))
@@ -128,7 +142,7 @@ class DrGhmcDiag(ManyChainSampler):
         # row pitch that is a multiple of 4 KiB -- 32,768 chains: 256 KiB -- every row of a chain sits on the same
         # memory channel, and the gather / store phase of the first stage (all chains, 160 MB) queues up there:
         # 48 -> 34 us with the rows 576 bytes further apart (tools/funnel_traj_bench.py, PAD=72).
-        pad = 72 if (self._dev_counts and C >= 4096 and (C * 8) % 4096 == 0) else 0
+        pad = 72 if (self._one_launch and C >= 4096 and (C * 8) % 4096 == 0) else 0
         if pad:
             def padded(t):
                 p = torch.empty((D, C + pad), **f64)[:, :C]
@@ -144,7 +158,7 @@ class DrGhmcDiag(ManyChainSampler):
         if self._dev_counts:
             self._steps_total_base = 0.0
             self._make_schedule()
-            if int(max_proposals) > 1:
+            if int(max_proposals) > 1 and self._one_launch:
                 self._level0_alt = _Level(D, C, dev, pad)
 
     def _make_schedule(self):
@@ -462,6 +476,8 @@ class DrGhmcDiag(ManyChainSampler):
         dst = self._levels[lvl]
         slot = self._slot
         self._slot += 1
+        if not self._one_launch:
+            return self._proposal_steps_dev(src, idx, n_dev, h, steps, dst, slot, ghost)
         g0, fused, following = None, False, None
         if own_ghosts >= 1 and self._fuse_first_ghost:
             fused = True
@@ -475,6 +491,9 @@ class DrGhmcDiag(ManyChainSampler):
                                   lanes_total=self._slot_lanes_total[gslot:gslot + 1])
         # the launch also counts its lanes (per draw and in total) and sets up its level for accept()
         kw = {} if g0 is None else {"ghost0": g0}
+        if ghost is not None:
+            par, pr, nxt_list = ghost
+            ghost = self._ops.ghost_link(par.H, par.h, par.live, par.a, dst.a, pr, *(nxt_list or (None, None)))
         ok = self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, dst.theta, dst.rho, dst.grad, dst.logp,
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
                                         lanes_out=self._slot_lanes[slot:slot + 1],
@@ -482,6 +501,32 @@ class DrGhmcDiag(ManyChainSampler):
                                         level=(dst.H, dst.h, dst.live), job=job, ghost=ghost, **kw)
         assert ok
         return fused, following
+
+    def _proposal_steps_dev(self, src, idx, n_dev, h, steps, dst, slot, ghost):
+        """The same proposal as the reference's own sequence of model calls (drghmc.py:273-288), every launch
+        taking the lane count from the device: gathering first step, (steps - 1) x {counted gradient op,
+        kick + drift}, last gradient + log density, final half-kick + flip + kinetic energy -- whose launch also
+        sets the level up for accept() and counts the lanes -- and, for a ghost without ghosts of its own, its
+        acceptance probability + parent update.  2 * steps + 1 (+ 1) launches, no host read."""
+        ops, m, model, C = self._ops, self._metric_dev, self._model, self._C
+        th, rho, g = dst.theta, dst.rho, dst.grad
+        self._grad_calls += steps
+        ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h, n_dev=n_dev)   # :276-278
+        for _ in range(steps - 1):                                                                      # :280-283
+            model.bk_eval(th, g, None, n_dev)
+            ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h, n_dev=n_dev)
+        model.bk_eval(th, g, dst.logp, n_dev)                                                           # :285
+        ops.leapfrog_finish(rho, rho, g, m, 0.5 * h, True, dst.kin, n_dev=n_dev,                        # :286, :345
+                            level=(dst.logp, dst.H, dst.h, dst.live), lanes_out=self._slot_lanes[slot:slot + 1],
+                            lanes_total=self._slot_lanes_total[slot:slot + 1])
+        if ghost is not None:
+            par, pr, nxt_list = ghost
+            args = (dst.H, par.H, dst.h, par.h, idx, pr, dst.live, dst.a, C, par.live, par.a)          # :426-446
+            if nxt_list is None:
+                ops.dr_accept_prob_ghost(*args, n_dev=n_dev)
+            else:
+                ops.dr_accept_prob_ghost_next(*args, nxt_list[0], nxt_list[1], n_dev=n_dev)
+        return False, None
 
     def _new_list(self):
         """The next unused lane counter of this draw (zeroed by bk_dr_begin_retry)."""
@@ -518,8 +563,7 @@ class DrGhmcDiag(ManyChainSampler):
                 # its launch runs it: the ghost's acceptance probability and the update of this level (:426-446)
                 # are done by the ghost's launch
                 pr = 1.0 if self._prob_retry else 0.0
-                link = ops.ghost_link(P.H, P.h, P.live, P.a, nxt.a, pr, *(following or (None, None)))
-                self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=link, own_ghosts=i)
+                self._proposal_dev(P, gsub, m_dev, i, lvl + 1, ghost=(P, pr, following), own_ghosts=i)
             else:
                 done = self._proposal_dev(P, gsub, m_dev, i, lvl + 1, own_ghosts=i)
                 self._accept_dev(lvl + 1, m_dev, i, parent=P, sub=gsub, parent_next=following, first=done)
@@ -552,7 +596,8 @@ class DrGhmcDiag(ManyChainSampler):
         # proposals into the chains' current point can run INSIDE stage k+1's proposal launch (surplus
         # workgroups beside a sparse, latency-bound lane set): it reads stage k's buffers and writes columns
         # of accepted chains, the proposal reads columns of rejected chains and writes the other set.
-        level0 = [self._levels[0], self._level0_alt]
+        # (a step-by-step proposal carries no job: one buffer set, the scatter is a launch of its own)
+        level0 = [self._levels[0], self._level0_alt if self._one_launch else self._levels[0]]
         job = None
         for k in range(K):
             P0 = self._levels[0] = level0[k % 2]
@@ -570,11 +615,12 @@ class DrGhmcDiag(ManyChainSampler):
                                         self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, n_dev=n_dev)
             scatter = (P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad], [P0.theta, P0.rho, P0.grad],
                        self._lp, P0.logp)                                                          # :379-381
-            if k + 1 < K:
+            if k + 1 < K and self._one_launch:
                 job = ops.scatter_job(*scatter, n_dev=n_dev)   # rides on the next stage's proposal launch
-                idx, n_dev = nidx, ncount
             else:
                 ops.scatter_columns(*scatter, n_dev=n_dev)
+            if k + 1 < K:
+                idx, n_dev = nidx, ncount
         self._levels[0] = level0[0]
         self._feed_attached(self._theta_dc, self._cur_H, True)
 

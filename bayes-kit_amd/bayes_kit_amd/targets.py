@@ -40,9 +40,16 @@ class _BuiltinTarget:
     def dims(self) -> int:
         return self._D
 
-    # engine fast path: raw [D, n] buffers in, results written in place
-    def bk_eval(self, theta_dc, grad_out, logp_out):
-        self._get_ops().target_grad(self._kind, self._params, theta_dc, grad_out, logp_out)
+    # engine fast path: raw [D, n] buffers in, results written in place.  n_dev (optional): the number of chains
+    # to evaluate, in device memory (an int32 tensor [1]); the arrays' chain extent is then only a bound --
+    # what lets DrGhmcDiag run its data-dependent lane sets without reading their sizes back (bk_counted).
+    bk_counted = True
+
+    def bk_eval(self, theta_dc, grad_out, logp_out, n_dev=None):
+        if n_dev is None:
+            self._get_ops().target_grad(self._kind, self._params, theta_dc, grad_out, logp_out)
+        else:
+            self._get_ops().target_grad(self._kind, self._params, theta_dc, grad_out, logp_out, n_dev=n_dev)
 
     # public batched protocol
     def log_density(self, Theta):
@@ -90,9 +97,9 @@ class DiagGaussian(_BuiltinTarget):
             self._params = self._lam_host.to(device).contiguous()
         return self._params
 
-    def bk_eval(self, theta_dc, grad_out, logp_out):
+    def bk_eval(self, theta_dc, grad_out, logp_out, n_dev=None):
         self._lam(theta_dc.device)
-        super().bk_eval(theta_dc, grad_out, logp_out)
+        super().bk_eval(theta_dc, grad_out, logp_out, n_dev)
 
     def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
         """Whole leapfrog trajectory with the gradient inlined (register-resident)."""
@@ -138,6 +145,7 @@ class LogisticRegression(_BuiltinTarget):
     a likelihood temperature for smc.py's annealing."""
 
     _kind = "logistic"
+    bk_counted = False  # (two GEMMs over all chains: no counted form)
     SEGMENTS = 256  # blocks of observations whose log-likelihood partial sums are combined in order
 
     def __init__(self, X, y, prior_scale: float = 1.0, ops=None):
@@ -207,22 +215,35 @@ class CTarget(_BuiltinTarget):
     (its data pointer; device or host), a ``ctypes`` structure / array (host memory, kept alive
     here) or None.  The gradient call goes straight from the sampler to the user's launch: no
     PyTorch ops, no Python callback per chain.
+
+    ``counted_symbol``: optional second export of type ``bk_target_fn_n`` -- the same function taking the
+    number of chains from device memory.  With it ``DrGhmcDiag`` keeps the sizes of its lane sets on the
+    device and replays a whole delayed-rejection draw as one hipGraph (no host read inside a draw);
+    without it the sampler sizes every launch on the host (three reads per draw at K = 3).
     """
 
-    def __init__(self, library: str, symbol: str, dims: int, params=None, ops=None):
+    def __init__(self, library: str, symbol: str, dims: int, params=None, ops=None, counted_symbol=None):
         import ctypes
 
         super().__init__(dims, ops)
         self._cdll = ctypes.CDLL(library)
-        try:
-            fn = getattr(self._cdll, symbol)
-        except AttributeError as e:
-            raise _lib.BkHipError(f"{library} does not export {symbol}") from e
         I = ctypes.c_int64
         P = ctypes.c_void_p
-        fn.argtypes = [P, P, P, I, P, I, I, P]
-        fn.restype = ctypes.c_int
+
+        def export(name, argtypes):
+            try:
+                f = getattr(self._cdll, name)
+            except AttributeError as e:
+                raise _lib.BkHipError(f"{library} does not export {name}") from e
+            f.argtypes = argtypes
+            f.restype = ctypes.c_int
+            return f
+
+        fn = export(symbol, [P, P, P, I, P, I, I, P])
         self._fn, self._symbol = fn, symbol
+        self._fn_n = export(counted_symbol, [P, P, P, I, P, I, I, P, P]) if counted_symbol else None
+        self._counted_symbol = counted_symbol
+        self.bk_counted = self._fn_n is not None
         self._keep = params
         if params is None:
             self._pp = None
@@ -232,7 +253,7 @@ class CTarget(_BuiltinTarget):
             self._pp = ctypes.cast(ctypes.pointer(params), P) if not isinstance(params, ctypes.Array) \
                 else ctypes.cast(params, P)
 
-    def bk_eval(self, theta_dc, grad_out, logp_out):
+    def bk_eval(self, theta_dc, grad_out, logp_out, n_dev=None):
         D, C = theta_dc.shape
         ld = theta_dc.stride(0) if D > 1 else max(C, theta_dc.stride(0))
         if C > 1 and theta_dc.stride(1) != 1:
@@ -240,10 +261,16 @@ class CTarget(_BuiltinTarget):
         if grad_out is not None and (grad_out.stride(0) if D > 1 else ld) != ld:
             raise ValueError("theta and grad must share their leading dimension")
         stream = torch.cuda.current_stream(theta_dc.device).cuda_stream if theta_dc.is_cuda else None
-        rc = self._fn(theta_dc.data_ptr(), None if grad_out is None else grad_out.data_ptr(),
-                      None if logp_out is None else logp_out.data_ptr(), ld, self._pp, C, D, stream)
+        args = (theta_dc.data_ptr(), None if grad_out is None else grad_out.data_ptr(),
+                None if logp_out is None else logp_out.data_ptr(), ld, self._pp, C, D)
+        if n_dev is None:
+            rc, name = self._fn(*args, stream), self._symbol
+        else:
+            if self._fn_n is None:
+                raise _lib.BkHipError("this CTarget was loaded without a counted_symbol (bk_target_fn_n)")
+            rc, name = self._fn_n(*args, n_dev.data_ptr(), stream), self._counted_symbol
         if rc != 0:
-            raise _lib.BkHipError(f"{self._symbol} returned {rc}")
+            raise _lib.BkHipError(f"{name} returned {rc}")
 
 
 class TorchModel:

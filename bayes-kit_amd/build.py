@@ -63,21 +63,26 @@ def build(force=False, verbose=True):
     return LIB
 
 
-PLUGIN_SRC = os.path.join(HERE, "..", "examples", "plugin_target", "ar1_target.hip")
-PLUGIN_LIB = os.path.join(HERE, "..", "examples", "plugin_target", "libar1_target.so")
+PLUGIN_DIR = os.path.join(HERE, "..", "examples", "plugin_target")
+PLUGINS = ["ar1_target", "funnel_target"]  # <name>.hip -> lib<name>.so
+PLUGIN_LIB = os.path.join(PLUGIN_DIR, "libar1_target.so")
 
 
 def build_example_plugin(force=False, verbose=True):
-    """The example USER target (plugin ABI bk_target_fn): its own shared library, not part of
-    libbkhip.so; built here so that the tests can load it on the GPU box."""
-    src, lib = os.path.abspath(PLUGIN_SRC), os.path.abspath(PLUGIN_LIB)
-    if force or _stale(lib, [src]):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               src, "-o", lib]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-    return lib
+    """The example USER targets (plugin ABI bk_target_fn / bk_target_fn_n): shared libraries of their own, not
+    part of libbkhip.so; built here so that the tests can load them on the GPU box."""
+    libs = []
+    for name in PLUGINS:
+        src = os.path.abspath(os.path.join(PLUGIN_DIR, name + ".hip"))
+        lib = os.path.abspath(os.path.join(PLUGIN_DIR, "lib" + name + ".so"))
+        if force or _stale(lib, [src]):
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                   src, "-o", lib]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        libs.append(lib)
+    return libs[0]
 
 
 C_HOST_SRC = os.path.join(HERE, "..", "examples", "c_host", "hmc_main.c")

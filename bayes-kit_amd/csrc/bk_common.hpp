@@ -30,6 +30,17 @@ static inline bool bk_streams_past_llc(i64 elems) { return elems * 8 > ((i64)192
 // address derived from it is per-lane vector work (selects, 64-bit VGPR address math).
 __device__ __forceinline__ int bk_wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x / 64)); }
 
+// Lane count of a launch: `n` is what the host knows (an upper bound used to size the grid);
+// with n_dev the number of lanes actually in the set is read from device memory -- written by an
+// earlier kernel on the same stream (bk_compact_indices, the appending accept tests) -- so the host
+// never has to read it back and a whole delayed-rejection draw can be captured as one hipGraph.
+// Surplus threads exit.
+__device__ __forceinline__ i64 bk_lanes(i64 n, const uint32_t* n_dev) {
+  if (!n_dev) return n;
+  const i64 m = (i64)*n_dev;
+  return m < n ? m : n;
+}
+
 // ---- accepted columns -> the chains' current point (bk_scatter_columns) -----------------------------------
 // One unit = 64 lanes (lane = chain of the compacted set) x BK_SCT_ROWS dimensions: the copy of an accepted
 // column is spread over D / BK_SCT_ROWS units (one lane walking all D rows with dependent load -> store pairs

@@ -8,16 +8,6 @@ namespace {
 
 constexpr int SC_BLOCK = 256;
 
-// Lane count of a launch: `n` is what the host knows (an upper bound used to size the grid);
-// with n_dev the number of lanes actually in the set is read from device memory -- written by an
-// earlier kernel on the same stream (bk_compact_indices) -- so the host never has to read it back
-// and a whole delayed-rejection draw can be captured as one hipGraph.  Surplus threads exit.
-__device__ __forceinline__ i64 bk_lanes(i64 n, const uint32_t* n_dev) {
-  if (!n_dev) return n;
-  const i64 m = (i64)*n_dev;
-  return m < n ? m : n;
-}
-
 // ---- stable compaction: one workgroup, 16 wavefronts, 8 flags per thread per pass ---------
 constexpr int CP_BLOCK = 1024;
 constexpr int CP_ITEMS = 8;

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_kick_drift_tr(
 
 // ---- first step of a delayed-rejection stage with gather of the active chains ---------
 constexpr int PC_BLOCK = 64;  // per-chain kernels: one wavefront per workgroup
+constexpr int RED_BLOCK_N = 4 * BK_WAVE;
 constexpr int PC_UNROLL = 8;
 
 __global__ __launch_bounds__(PC_BLOCK) void k_first_step_gather(
@@ -182,6 +183,50 @@ __global__ __launch_bounds__(PC_BLOCK) void k_first_step_gather(
   }
 }
 
+// ---- kick + drift over a lane set whose size may live on the device ---------------------
+// The step of a delayed-rejection trajectory whose lane count only the device knows (and, with `idx`,
+// the gathering first step): a workgroup serves 64 lanes (lane = chain of the compacted set), its four
+// wavefronts and the gridDim.y row groups split the dimensions so that a wavefront has at most KN_U rows
+// -- all of a step's loads in flight at once: these sets are a few per cent of the chains, the launch is
+// one memory round trip deep.  The grid is sized for the host-side bound; workgroups past *n_dev exit.
+constexpr int KN_U = 8;
+__global__ __launch_bounds__(RED_BLOCK_N) void k_kick_drift_n(
+    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, i64 ldg, const int32_t* idx,
+    double* th_out, double* rho_out, i64 ld_out, const double* metric, double eps, int use_pre, double pre,
+    int use_kick, double kick, i64 n_host, i64 D, const uint32_t* n_dev) {
+  const i64 n = bk_lanes(n_host, n_dev);
+  const i64 j0 = (i64)blockIdx.x * BK_WAVE;
+  if (j0 >= n) return;
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 j = j0 + lane;
+  if (j >= n) return;
+  const i64 src = idx ? (i64)idx[j] : j;
+  const i64 stride = (i64)4 * gridDim.y;
+  for (i64 d0 = (i64)blockIdx.y * 4 + w; d0 < D; d0 += stride * KN_U) {
+    double t[KN_U], r[KN_U], g[KN_U], m[KN_U];
+#pragma unroll
+    for (int u = 0; u < KN_U; ++u) {
+      const i64 d = d0 + u * stride;
+      if (d < D) {
+        t[u] = th_in[d * ld_in + src];
+        r[u] = rho_in[d * ld_in + src];
+        g[u] = g_in[d * ldg + src];
+        m[u] = metric ? metric[d] : 1.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KN_U; ++u) {
+      const i64 d = d0 + u * stride;
+      if (d < D) {
+        double rn;
+        double tn = kd_elem(t[u], r[u], g[u], m[u], metric != nullptr, eps, use_pre, pre, use_kick, kick, rn);
+        rho_out[d * ld_out + j] = rn;
+        th_out[d * ld_out + j] = tn;
+      }
+    }
+  }
+}
+
 // ---- final half-kick + kinetic energy ---------------------------------------------------
 // Per-chain reductions: a workgroup of RED_WAVES wavefronts serves 64 chains (lane = chain);
 // wavefront w owns the contiguous quarter of the dimensions [w*Dq, (w+1)*Dq) and sums it
@@ -200,13 +245,32 @@ __device__ __forceinline__ double red_combine(double (&part)[RED_WAVES][BK_WAVE]
   return s;
 }
 
+// n_dev / level: the trajectory of a delayed-rejection level whose lane count lives on the device -- the
+// launch is sized for C (a bound), works on min(C, *n_dev) lanes, and sets the level up for accept()
+// (bk_dr_level_begin: H = joint(logp, kin), h = 0, live = 1) and counts its lanes in the same pass.
+struct FinishLevel {
+  const double* logp;
+  double* H;
+  double* h;
+  uint8_t* live;
+  uint32_t* lanes_out;
+  unsigned long long* lanes_total;
+};
+
 __global__ __launch_bounds__(RED_BLOCK) void k_finish(const double* rho_in, double* rho_out, i64 ld,
                                                       const double* grad, i64 ldg_d, i64 ldg_c,
                                                       const double* metric, double half, int negate,
-                                                      double* kin_out, i64 C, i64 D) {
+                                                      double* kin_out, i64 C_host, i64 D, const uint32_t* n_dev,
+                                                      FinishLevel lv) {
   __shared__ double part[RED_WAVES][BK_WAVE];
   constexpr int PC_UNROLL = FIN_UNROLL;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 C = bk_lanes(C_host, n_dev);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lv.lanes_out) *lv.lanes_out = (uint32_t)C;
+    if (lv.lanes_total) *lv.lanes_total += (unsigned long long)C;  // one writer per launch, launches are stream-ordered
+  }
+  if ((i64)blockIdx.x * BK_WAVE >= C) return;  // (whole workgroup past the set: uniform)
   const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
   const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
   const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
@@ -235,7 +299,15 @@ __global__ __launch_bounds__(RED_BLOCK) void k_finish(const double* rho_in, doub
   }
   if (!kin_out) return;  // uniform: no barrier needed without the reduction
   double s = red_combine(part, w, lane, kin);
-  if (w == 0 && c < C) kin_out[c] = 0.5 * s;
+  if (w == 0 && c < C) {
+    const double k = 0.5 * s;
+    kin_out[c] = k;
+    if (lv.H) {
+      lv.H[c] = dr_joint(lv.logp[c], k);
+      lv.h[c] = 0.0;
+      lv.live[c] = 1;
+    }
+  }
 }
 
 // The same with two chains (16 B) per lane: 128 chains per workgroup, 1 KiB per wavefront and row instead
@@ -564,36 +636,86 @@ int bk_leapfrog_kick_drift(const double* theta_in, double* theta_out, const doub
   BK_RETURN_LAUNCH_STATUS();
 }
 
+static unsigned kn_row_groups(i64 D) {
+  // at most KN_U rows per wavefront (4 wavefronts per workgroup, gridDim.y row groups)
+  i64 g = bk_cdiv(D, 4 * KN_U);
+  return (unsigned)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
+}
+
+int bk_leapfrog_kick_drift_n(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out,
+                             int64_t ld, const double* grad, int64_t ldg_d, int64_t ldg_c, const double* metric,
+                             double eps, int use_pre, double pre, int use_kick, double kick, int64_t C, int64_t D,
+                             const uint32_t* n_dev, void* stream) {
+  if (!n_dev)
+    return bk_leapfrog_kick_drift(theta_in, theta_out, rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, eps, use_pre,
+                                  pre, use_kick, kick, C, D, stream);
+  if (!theta_in || !theta_out || !rho_in || !rho_out || !grad || C < 0 || D < 0) return BK_E_ARG;
+  if (ldg_c != 1 && C > 1) return BK_E_ARG;  // (a counted lane set lives in the library's own chain-contiguous buffers)
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(C, BK_WAVE), kn_row_groups(D));
+  k_kick_drift_n<<<grid, dim3(RED_BLOCK_N), 0, bk_stream(stream)>>>(theta_in, rho_in, grad, ld, ldg_d, nullptr, theta_out,
+                                                                    rho_out, ld, metric, eps, use_pre, pre, use_kick,
+                                                                    kick, C, D, n_dev);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_leapfrog_first_step_gather_n(const double* theta_in, const double* rho_in, const double* grad_in,
+                                    int64_t ld_in, const int32_t* src_index, double* theta_out, double* rho_out,
+                                    int64_t ld_out, const double* metric, double eps, double pre, int64_t n,
+                                    int64_t D, const uint32_t* n_dev, void* stream) {
+  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || n < 0 || D < 0) return BK_E_ARG;
+  if (ld_out < n) return BK_E_ALIGN;
+  if (n == 0 || D == 0) return BK_OK;
+  dim3 grid((unsigned)bk_cdiv(n, BK_WAVE), kn_row_groups(D));
+  k_kick_drift_n<<<grid, dim3(RED_BLOCK_N), 0, bk_stream(stream)>>>(theta_in, rho_in, grad_in, ld_in, ld_in, src_index,
+                                                                    theta_out, rho_out, ld_out, metric, eps, 1, pre, 0,
+                                                                    0.0, n, D, n_dev);
+  BK_RETURN_LAUNCH_STATUS();
+}
+
 int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, const double* grad_in,
                                   int64_t ld_in, const int32_t* src_index, double* theta_out,
                                   double* rho_out, int64_t ld_out, const double* metric, double eps,
                                   double pre, int64_t n, int64_t D, void* stream) {
-  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || n < 0 || D < 0) return BK_E_ARG;
-  if (ld_out < n) return BK_E_ALIGN;
-  if (n == 0 || D == 0) return BK_OK;
-  k_first_step_gather<<<dim3((unsigned)bk_cdiv(n, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(
-      theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, ld_out, metric, eps, pre, n, D);
+  return bk_leapfrog_first_step_gather_n(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, ld_out,
+                                         metric, eps, pre, n, D, nullptr, stream);
+}
+
+int bk_leapfrog_finish_level(const double* rho_in, double* rho_out, int64_t ld, const double* grad, int64_t ldg_d,
+                             int64_t ldg_c, const double* metric, double half, int negate, double* kin_out,
+                             int64_t C, int64_t D, const uint32_t* n_dev, const double* logp, double* H_out,
+                             double* h_out, uint8_t* live_out, uint32_t* lanes_out, uint64_t* lanes_total,
+                             void* stream) {
+  if (!rho_in || C < 0 || D < 0) return BK_E_ARG;
+  if (H_out && (!logp || !h_out || !live_out || !kin_out)) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  hipStream_t s = bk_stream(stream);
+  if (C == 0) {
+    if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), s);
+    return BK_OK;
+  }
+  FinishLevel lv = {logp, H_out, h_out, live_out, lanes_out, reinterpret_cast<unsigned long long*>(lanes_total)};
+  const bool plain = !n_dev && !H_out && !lanes_out && !lanes_total;
+  // (two chains per lane halves the number of workgroups: only for arrays that do not live in L2 -- at
+  // 32,768 x 101 the one-chain form is faster, 7.4 vs 9.1 us)
+  const bool vec = plain && C % 2 == 0 && ld % 2 == 0 && C * D >= ((i64)1 << 22) && bk_aligned16(rho_in) &&
+                   (!rho_out || bk_aligned16(rho_out)) && (!kin_out || bk_aligned16(kin_out)) &&
+                   (!grad || (ldg_c == 1 && ldg_d % 2 == 0 && bk_aligned16(grad)));
+  if (vec)
+    k_finish_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(
+        rho_in, rho_out, ld, grad, ldg_d, metric, half, negate, kin_out, C / 2, D);
+  else
+    k_finish<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(
+        rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D, n_dev, lv);
   BK_RETURN_LAUNCH_STATUS();
 }
 
 int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld, const double* grad,
                        int64_t ldg_d, int64_t ldg_c, const double* metric, double half, int negate,
                        double* kin_out, int64_t C, int64_t D, void* stream) {
-  if (!rho_in || C < 0 || D < 0) return BK_E_ARG;
-  if (ld < C) return BK_E_ALIGN;
-  if (C == 0) return BK_OK;
-  // (two chains per lane halves the number of workgroups: only for arrays that do not live in L2 -- at
-  // 32,768 x 101 the one-chain form is faster, 7.4 vs 9.1 us)
-  const bool vec = C % 2 == 0 && ld % 2 == 0 && C * D >= ((i64)1 << 22) && bk_aligned16(rho_in) &&
-                   (!rho_out || bk_aligned16(rho_out)) && (!kin_out || bk_aligned16(kin_out)) &&
-                   (!grad || (ldg_c == 1 && ldg_d % 2 == 0 && bk_aligned16(grad)));
-  if (vec)
-    k_finish_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
-        rho_in, rho_out, ld, grad, ldg_d, metric, half, negate, kin_out, C / 2, D);
-  else
-    k_finish<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, bk_stream(stream)>>>(
-        rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D);
-  BK_RETURN_LAUNCH_STATUS();
+  return bk_leapfrog_finish_level(rho_in, rho_out, ld, grad, ldg_d, ldg_c, metric, half, negate, kin_out, C, D,
+                                  nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int bk_mh_accept(int mode, double* lp_cur, const double* a_cur, const double* lp_prop,

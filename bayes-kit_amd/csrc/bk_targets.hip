@@ -48,7 +48,9 @@ __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_v2(const double* th, do
 }
 
 __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_s(const double* th, double* g, i64 ld,
-                                                           const double* lam, i64 C, i64 D) {
+                                                           const double* lam, i64 C_host, i64 D,
+                                                           const uint32_t* n_dev) {
+  const i64 C = bk_lanes(C_host, n_dev);
   i64 c = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
   i64 d0 = (i64)blockIdx.y * TG_ROWS;
   if (c >= C) return;
@@ -65,10 +67,13 @@ __global__ __launch_bounds__(TG_BLOCK) void k_gauss_grad_s(const double* th, dou
 constexpr int RED_WAVES = 4;
 constexpr int RED_BLOCK = RED_WAVES * BK_WAVE;
 __global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp(const double* th, double* g, double* logp, i64 ld,
-                                                          const double* lam, i64 C, i64 D) {
+                                                          const double* lam, i64 C_host, i64 D,
+                                                          const uint32_t* n_dev) {
   __shared__ double part[RED_WAVES][BK_WAVE];
   constexpr int PC_UNROLL = 8;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 C = bk_lanes(C_host, n_dev);
+  if ((i64)blockIdx.x * BK_WAVE >= C) return;  // (whole workgroup past the set: uniform)
   const i64 c = (i64)blockIdx.x * BK_WAVE + lane;
   const i64 Dq = (D + RED_WAVES - 1) / RED_WAVES;
   const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
@@ -146,7 +151,8 @@ __global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp_v2(const double* th, d
 
 // Neal's funnel, any D: one lane per chain, sequential in d
 __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g, double* logp, i64 ld,
-                                                     i64 C, i64 D) {
+                                                     i64 C_host, i64 D, const uint32_t* n_dev) {
+  const i64 C = bk_lanes(C_host, n_dev);
   i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
   if (c >= C) return;
   double v = th[c];
@@ -244,10 +250,12 @@ __device__ __forceinline__ double funnel_reduce_lds(FunnelLds& lds, int w, int l
 // gradient / log density for n chains (chain j in column j)
 template <int SL>
 __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
-                                                          i64 n, i64 D) {
+                                                          i64 n_host, i64 D, const uint32_t* n_dev) {
   using G = FunnelGeo<SL>;
   __shared__ FunnelLds lds;
   const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 n = bk_lanes(n_host, n_dev);
+  if ((i64)blockIdx.x * BK_WAVE >= n) return;  // (whole workgroup past the set: uniform)
   const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
   double x[G::NU];
@@ -885,18 +893,27 @@ __global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double
 }
 
 int gauss(const double* theta, double* grad, double* logp, i64 ld, const double* lam, i64 C, i64 D,
-          void* stream) {
+          const uint32_t* n_dev, void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
+  if (n_dev) {  // lane count on the device: one chain per lane, launch sized for the bound C
+    if (logp)
+      k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D, n_dev);
+    else if (D > 0)
+      k_gauss_grad_s<<<dim3((unsigned)bk_cdiv(C, TG_BLOCK), (unsigned)bk_cdiv(D, TG_ROWS)), dim3(TG_BLOCK), 0, s>>>(
+          theta, grad, ld, lam, C, D, n_dev);
+    BK_RETURN_LAUNCH_STATUS();
+  }
   if (logp) {
     if (C % 2 == 0 && ld % 2 == 0 && C * D >= ((i64)1 << 22) && bk_aligned16(theta) && bk_aligned16(logp) &&
         (!grad || bk_aligned16(grad)))
       k_gauss_logp_v2<<<dim3((unsigned)bk_cdiv(C / 2, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam,
                                                                                           C / 2, D);
     else
-      k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D);
+      k_gauss_logp<<<dim3((unsigned)bk_cdiv(C, BK_WAVE)), dim3(RED_BLOCK), 0, s>>>(theta, grad, logp, ld, lam, C, D,
+                                                                                   nullptr);
     BK_RETURN_LAUNCH_STATUS();
   }
   if (D == 0) return BK_OK;
@@ -926,7 +943,7 @@ int gauss(const double* theta, double* grad, double* logp, i64 ld, const double*
     }
   } else {
     dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), (unsigned)bk_cdiv(D, TG_ROWS));
-    k_gauss_grad_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C, D);
+    k_gauss_grad_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta, grad, ld, lam, C, D, nullptr);
   }
   BK_RETURN_LAUNCH_STATUS();
 }
@@ -937,13 +954,24 @@ extern "C" {
 
 int bk_target_iso_gaussian_grad(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
                                 int64_t D, void* stream) {
-  return gauss(theta, grad, logp, ld, nullptr, C, D, stream);
+  return gauss(theta, grad, logp, ld, nullptr, C, D, nullptr, stream);
 }
 
 int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp, int64_t ld,
                                  const double* lam, int64_t C, int64_t D, void* stream) {
   if (!lam) return BK_E_ARG;
-  return gauss(theta, grad, logp, ld, lam, C, D, stream);
+  return gauss(theta, grad, logp, ld, lam, C, D, nullptr, stream);
+}
+
+int bk_target_iso_gaussian_grad_n(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
+                                  int64_t D, const uint32_t* n_dev, void* stream) {
+  return gauss(theta, grad, logp, ld, nullptr, C, D, n_dev, stream);
+}
+
+int bk_target_diag_gaussian_grad_n(const double* theta, double* grad, double* logp, int64_t ld,
+                                   const double* lam, int64_t C, int64_t D, const uint32_t* n_dev, void* stream) {
+  if (!lam) return BK_E_ARG;
+  return gauss(theta, grad, logp, ld, lam, C, D, n_dev, stream);
 }
 
 int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const double* rho_in,
@@ -1007,8 +1035,8 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
-                          int64_t D, void* stream) {
+int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
+                            int64_t D, const uint32_t* n_dev, void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 1) return BK_E_ARG;
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
@@ -1016,15 +1044,20 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
     const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
     dim3 grid((unsigned)bk_cdiv(C, BK_WAVE)), block(FN_BLOCK);
     hipStream_t s = bk_stream(stream);
-    if (need <= 2) k_funnel_coop<2><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
-    else if (need <= 4) k_funnel_coop<4><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
-    else if (need <= 7) k_funnel_coop<7><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
-    else k_funnel_coop<8><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D);
+    if (need <= 2) k_funnel_coop<2><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+    else if (need <= 4) k_funnel_coop<4><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+    else if (need <= 7) k_funnel_coop<7><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+    else k_funnel_coop<8><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
   }
   else
     k_funnel<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
-                                                                                           ld, C, D);
+                                                                                           ld, C, D, n_dev);
   BK_RETURN_LAUNCH_STATUS();
+}
+
+int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
+                          int64_t D, void* stream) {
+  return bk_target_funnel_grad_n(theta, grad, logp, ld, C, D, nullptr, stream);
 }
 
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,

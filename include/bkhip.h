@@ -141,6 +141,33 @@ int bk_leapfrog_finish(const double* rho_in, double* rho_out, int64_t ld,
                        const double* metric, double half, int negate,
                        double* kin_out, int64_t C, int64_t D, void* stream);
 
+/* ---- the same three steps over a lane set whose SIZE LIVES ON THE DEVICE -----------------------
+ * (drghmc.py:276-278, :280-283, :285-286 for the chains that reach a delayed-rejection proposal or one
+ * of its ghosts.)  n_dev: device pointer to the number of lanes in the set, written by an earlier launch
+ * on the same stream (bk_compact_indices, the appending accept tests); the launch is sized for the bound
+ * C / n and works on min(bound, *n_dev) lanes -- see "Lane counts on the device" below.  With these and a
+ * counted gradient (bk_target_*_grad_n, bk_target_fn_n) a delayed-rejection draw over ANY model that the
+ * library can call without the host is a fixed launch sequence: no lane count is read back, the draw
+ * replays as one hipGraph.  n_dev NULL = the host-sized entry points above.  Same arithmetic. */
+int bk_leapfrog_kick_drift_n(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out,
+                             int64_t ld, const double* grad, int64_t ldg_d, int64_t ldg_c,
+                             const double* metric, double eps, int use_pre, double pre, int use_kick,
+                             double kick, int64_t C, int64_t D, const uint32_t* n_dev, void* stream);
+int bk_leapfrog_first_step_gather_n(const double* theta_in, const double* rho_in, const double* grad_in,
+                                    int64_t ld_in, const int32_t* src_index, double* theta_out,
+                                    double* rho_out, int64_t ld_out, const double* metric, double eps,
+                                    double pre, int64_t n, int64_t D, const uint32_t* n_dev, void* stream);
+/* bk_leapfrog_finish for such a set, plus what the end of a delayed-rejection trajectory owes its level:
+ * H_out / h_out / live_out (all or none; needs logp = the log density at the end point and kin_out):
+ * bk_dr_level_begin for the produced lanes (H = -((-logp) + kin), h = 0, live = 1; drghmc.py:421 -> :249-251);
+ * lanes_out (may be NULL) receives the number of lanes worked on, lanes_total (may be NULL) is incremented
+ * by it (statistics: gradient evaluations = steps * lanes). */
+int bk_leapfrog_finish_level(const double* rho_in, double* rho_out, int64_t ld, const double* grad,
+                             int64_t ldg_d, int64_t ldg_c, const double* metric, double half, int negate,
+                             double* kin_out, int64_t C, int64_t D, const uint32_t* n_dev,
+                             const double* logp, double* H_out, double* h_out, uint8_t* live_out,
+                             uint32_t* lanes_out, uint64_t* lanes_total, void* stream);
+
 /* ---- Metropolis / Metropolis-Hastings accept ------------------------------------------
  * mode BK_ACCEPT_HMC  (hmc.py:57-63):  h0 = lp_cur - a_cur ; h1 = lp_prop - a_prop ;
  *        accept = log_u < h1 - h0 ;  ret[c] = accept ? h1 : h0   (joint log density)
@@ -371,6 +398,16 @@ int bk_target_diag_gaussian_grad(const double* theta, double* grad, double* logp
 int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld,
                           int64_t C, int64_t D, void* stream);
 
+/* The same gradients for a lane set whose size lives on the device (n_dev, see bk_leapfrog_kick_drift_n):
+ * chains [0, min(C, *n_dev)) of the arrays are evaluated, the launch is sized for C. */
+int bk_target_iso_gaussian_grad_n(const double* theta, double* grad, double* logp, int64_t ld,
+                                  int64_t C, int64_t D, const uint32_t* n_dev, void* stream);
+int bk_target_diag_gaussian_grad_n(const double* theta, double* grad, double* logp, int64_t ld,
+                                   const double* lam, int64_t C, int64_t D, const uint32_t* n_dev,
+                                   void* stream);
+int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld,
+                            int64_t C, int64_t D, const uint32_t* n_dev, void* stream);
+
 /* ---- user targets (plugin ABI) ------------------------------------------------------------
  * A model the USER compiles into their own shared library plugs in below the samplers through
  * one exported function of this type: GradModel.log_density_gradient (typing.py:25-27) for all
@@ -382,6 +419,17 @@ int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64
  * gradient call).  examples/plugin_target/ar1_target.hip is a complete one. */
 typedef int (*bk_target_fn)(const double* theta, double* grad, double* logp, int64_t ld,
                             const void* params, int64_t C, int64_t D, void* stream);
+
+/* The counted form of the plugin ABI (optional second export of a user target): as bk_target_fn, with the
+ * number of chains to evaluate read ON THE DEVICE -- chains [0, min(C, *n_dev)), n_dev never NULL, the launch
+ * sized for the bound C, surplus workgroups exit (one scalar load + compare per workgroup).  A target that
+ * exports it (bayes_kit_amd.CTarget(..., counted_symbol=...)) runs DrGhmcDiag without any host
+ * synchronisation inside a draw: the gradient calls of drghmc.py:280-283 for the data-dependent lane sets of
+ * a delayed-rejection stage become part of one captured hipGraph.  examples/plugin_target/funnel_target.hip
+ * exports both forms. */
+typedef int (*bk_target_fn_n)(const double* theta, double* grad, double* logp, int64_t ld,
+                              const void* params, int64_t C, int64_t D, const uint32_t* n_dev,
+                              void* stream);
 
 /* Whole HMC trajectory (hmc.py:40-53) for the separable Gaussian targets with the gradient
  * callback inlined: back half-step, `steps` x (kick, drift, grad = -(lam*theta)), forward

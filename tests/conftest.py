@@ -18,8 +18,9 @@ def pytest_sessionstart(session):
     # (hipcc cross-compiles without a GPU).  A failed build surfaces in the tests that load it.
     lib = os.path.join(ROOT, "bayes-kit_amd", "bayes_kit_amd", "lib", "libbkhip.so")
     plugin = os.path.join(ROOT, "examples", "plugin_target", "libar1_target.so")
+    plugin2 = os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so")
     c_host = os.path.join(ROOT, "examples", "c_host", "hmc_main")
-    if not (os.path.exists(lib) and os.path.exists(plugin) and os.path.exists(c_host)):
+    if not all(os.path.exists(f) for f in (lib, plugin, plugin2, c_host)):
         try:
             import __graft_entry__ as ge
 

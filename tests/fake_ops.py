@@ -91,8 +91,11 @@ class FakeOps:
         return g if metric is None else metric.numpy()[:, None] * g
 
     def kick_drift(self, theta_in, theta_out, rho_in, rho_out, grad, metric, eps, use_pre, pre,
-                   use_kick, kick):
+                   use_kick, kick, n_dev=None):
         self._count("kick_drift")
+        if n_dev is not None:  # device-side lane count: only the first n lanes exist
+            n = self._lanes(theta_out.shape[1], n_dev)
+            theta_in, theta_out, rho_in, rho_out, grad = (t[:, :n] for t in (theta_in, theta_out, rho_in, rho_out, grad))
         t = self._mt(metric, grad.numpy())
         r = rho_in.numpy().copy()
         if use_pre:
@@ -103,17 +106,32 @@ class FakeOps:
         rho_out.numpy()[...] = r
         theta_out.numpy()[...] = th
 
-    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre):
+    def first_step_gather(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, eps, pre,
+                          n_dev=None):
         self._count("first_step_gather")
-        n = theta_out.shape[1]
+        n = self._lanes(theta_out.shape[1], n_dev)
+        theta_out, rho_out = theta_out[:, :n], rho_out[:, :n]
         idx = np.arange(n) if src_index is None else src_index.numpy()[:n]
         t = self._mt(metric, grad_in.numpy()[:, idx])
         r = rho_in.numpy()[:, idx] + pre * t
         rho_out.numpy()[...] = r
         theta_out.numpy()[...] = theta_in.numpy()[:, idx] + eps * r
 
-    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out):
+    def leapfrog_finish(self, rho_in, rho_out, grad, metric, half, negate, kin_out, n_dev=None, level=None,
+                        lanes_out=None, lanes_total=None):
         self._count("leapfrog_finish")
+        if n_dev is not None or level is not None or lanes_out is not None or lanes_total is not None:
+            n = self._lanes(rho_in.shape[1], n_dev)
+            if lanes_out is not None:
+                lanes_out[0] = n
+            if lanes_total is not None:
+                lanes_total[0] += n
+            cut = lambda t: None if t is None else (t[:, :n] if t.dim() == 2 else t[:n])
+            self.leapfrog_finish(cut(rho_in), cut(rho_out), cut(grad), metric, half, negate, cut(kin_out))
+            if level is not None:
+                logp, H, h, live = level
+                self.dr_level_begin(logp, kin_out, H, h, live, n)
+            return
         if grad is None:
             v = rho_in.numpy().copy()
         else:
@@ -234,8 +252,13 @@ class FakeOps:
             theta_prop.numpy()[...] = (new_th + eps * new_g) + sqrt2eps * zt_next.numpy()[:, :D].T
 
     # -- targets ----------------------------------------------------------------------------------
-    def target_grad(self, kind, params, theta, grad, logp):
+    def target_grad(self, kind, params, theta, grad, logp, n_dev=None):
         self._count("target_grad")
+        if n_dev is not None:
+            n = self._lanes(theta.shape[1], n_dev)
+            theta = theta[:, :n]
+            grad = None if grad is None else grad[:, :n]
+            logp = None if logp is None else logp[:n]
         th = theta.numpy()
         D, C = th.shape
         if kind in ("iso_gaussian", "diag_gaussian"):

@@ -78,6 +78,15 @@ def test_example_plugin_target_loads_and_exports_its_entry_point():
     lib.ar1_target.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                                        ctypes.c_int64, ctypes.c_void_p]
     assert lib.ar1_target(None, None, None, 0, None, 1, 1, None) == -1
+    # a target with the counted form as well (bk_target_fn_n: chain count from device memory)
+    assert "typedef int (*bk_target_fn_n)(" in open(os.path.join(root, "include", "bkhip.h")).read()
+    lib2 = ctypes.CDLL(os.path.join(root, "examples", "plugin_target", "libfunnel_target.so"))
+    for name, extra in (("funnel_target", []), ("funnel_target_n", [ctypes.c_void_p])):
+        fn = getattr(lib2, name)
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + extra + [
+            ctypes.c_void_p]
+        assert fn(*([None, None, None, 0, None, 1, 1] + [None] * len(extra) + [None])) == -1
 
 
 def test_error_behaviour_of_the_c_abi_without_a_gpu():

@@ -1,4 +1,6 @@
 """Parity of the HIP samplers with the reference's golden vectors and with the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +9,7 @@ import bayes_kit_amd as bk
 from tests.sampler_parity import check_checkpoint_resume, check_many_chain, check_single_chain_host_model, funnel_tol
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag16_metric", "hmc_diag1024_cfg3",
         "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_diag48", "mala_init",
@@ -23,6 +26,14 @@ def ops():
 @pytest.mark.parametrize("name", MANY)
 def test_many_chain_vs_reference_golden(name, ops):
     check_many_chain(name, ops)
+
+
+@pytest.mark.parametrize("name", [n for n in MANY if n.startswith("drghmc")])
+def test_drghmc_model_opaque_device_counts_vs_reference_golden(name, ops):
+    """The reference's DRGHMC fixtures through the model-opaque path with lane counts on the device: one counted
+    gradient op + one counted kick+drift launch per leapfrog step (drghmc.py:280-283), no host read, one hipGraph."""
+    s = check_many_chain(name, ops, fuse_builtin=False, device_counts=True)
+    assert s._dev_counts and not s._one_launch and s._use_graph and s.host_syncs_per_draw == 0
 
 
 @pytest.mark.parametrize("name", [n for n in MANY if n.startswith("hmc")])
@@ -918,6 +929,67 @@ def test_drghmc_device_side_lane_counts_equal_host_sized_launches(ops, D, K):
         assert g._graph is not None and len(seen) >= 3
         total = float(g.lane_steps_total.item())
         assert total > 0 and total == float(b.lane_steps_total.item())
+
+
+def funnel_plugin(D):
+    """examples/plugin_target/libfunnel_target.so: a user target exporting bk_target_fn AND bk_target_fn_n."""
+    return bk.CTarget(os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so"), "funnel_target", D,
+                      counted_symbol="funnel_target_n")
+
+
+@pytest.mark.parametrize("D,K", [(11, 3), (101, 3), (21, 2), (40, 4), (150, 2)])
+def test_drghmc_model_opaque_device_counts_equal_host_sized_and_one_launch(ops, D, K):
+    """the gradient as a SEPARATE op per leapfrog step (drghmc.py:280-283) -- the library's
+    counted funnel op, and a user plugin behind bk_target_fn_n -- with every lane count on the device: no host
+    read in a draw, one hipGraph; same draws, joint log densities, momenta, stream positions and trajectories as
+    the host-sized compacted path and as the one-launch proposal kernel."""
+    sizes, counts = [0.3, 0.1, 0.03, 0.01][:K], [3, 6, 12, 24][:K]
+    for C in (700, 64):
+        mk = lambda model, **kw: bk.DrGhmcDiag(model, K, sizes, counts, 0.3, chains=C, seed=5, **kw)  # noqa: E731
+        a = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False)   # host-sized, step by step
+        f = mk(bk.Funnel(D)) if D <= 129 else None                       # one launch per proposal (+ graph)
+        e = mk(bk.Funnel(D), fuse_builtin=False, graph=False)           # counted steps, eager
+        g = mk(bk.Funnel(D), fuse_builtin=False)                        # counted steps, one hipGraph (the default)
+        p = mk(funnel_plugin(D))                                        # the user's plugin, counted, one hipGraph
+        h = mk(funnel_plugin(D), device_counts=False)                   # the plugin, host-sized
+        for s_ in (e, g, p):
+            assert s_._dev_counts and not s_._one_launch and s_.host_syncs_per_draw == 0
+        assert g._use_graph and p._use_graph and not e._use_graph and not a._dev_counts and not h._dev_counts
+        assert f is None or f._one_launch
+        for n in range(12):
+            ta, la = a.sample()
+            for name, s_ in (("one launch", f), ("eager", e), ("graph", g), ("plugin", p), ("plugin host-sized", h)):
+                if s_ is None:
+                    continue
+                t_, l_ = s_.sample()
+                assert torch.equal(ta, t_) and torch.equal(la, l_), (D, K, C, n, name)
+                assert a.last_stage_lanes == s_.last_stage_lanes, (D, K, C, n, name)
+            assert a.last_lane_steps == g.last_lane_steps == p.last_lane_steps
+            assert a.last_grad_evals == g.last_grad_evals
+        for s_ in (f, e, g, p, h):
+            if s_ is not None:
+                assert torch.equal(a._rho, s_._rho)
+                np.testing.assert_array_equal(a.rng_state(), s_.rng_state())
+        assert g._graph is not None and p._graph is not None
+        assert float(g.lane_steps_total.item()) == float(e.lane_steps_total.item()) > 0
+
+
+def test_drghmc_counted_steps_on_gaussians_with_metric(ops):
+    """The counted step-by-step draw on the targets without a one-launch proposal (iso / diag Gaussian, with a
+    diagonal metric, without probabilistic retry) against the host-sized path; odd and even chain counts."""
+    for C, D in ((257, 16), (1024, 33)):
+        lam, met = np.linspace(0.5, 3.0, D), np.linspace(0.8, 1.3, D)
+        for model, kw in ((lambda: bk.DiagGaussian(lam), dict(metric_diag=met)), (lambda: bk.IsoGaussian(D), dict(prob_retry=False))):
+            mk = lambda **k2: bk.DrGhmcDiag(model(), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, chains=C, seed=3, **kw, **k2)  # noqa: E731
+            a, g = mk(device_counts=False), mk()
+            assert g._dev_counts and g._use_graph and not g._one_launch and not a._dev_counts
+            for n in range(10):
+                ta, la = a.sample()
+                tg, lg = g.sample()
+                assert torch.equal(ta, tg) and torch.equal(la, lg), (C, D, n)
+                assert a.last_stage_lanes == g.last_stage_lanes
+            assert torch.equal(a._rho, g._rho)
+            np.testing.assert_array_equal(a.rng_state(), g.rng_state())
 
 
 def test_checkpoint_of_sampler_moments_recorder_and_draw_store(ops, tmp_path):

@@ -441,19 +441,49 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
     ops_u = FakeOps()
     u = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_u), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,
                       fuse_first_ghost=False, ops=ops_u)   # every ghost a launch of its own
-    assert b._dev_counts and not a._dev_counts
+    # model-opaque: the gradient a separate, COUNTED op per leapfrog step (drghmc.py:280-283), lane counts on the device
+    ops_o = FakeOps()
+    o = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_o), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,
+                      fuse_builtin=False, ops=ops_o)
+    assert b._dev_counts and not a._dev_counts and b._one_launch
+    assert o._dev_counts and not o._one_launch and not o._fused and o.host_syncs_per_draw == 0
     seen = set()
     for n in range(10):
         ta, la = a.sample()
         tb, lb = b.sample()
         tu, lu = u.sample()
+        to, lo = o.sample()
         assert np.array_equal(ta.numpy(), tb.numpy()) and np.array_equal(la.numpy(), lb.numpy()), (K, n)
         assert np.array_equal(ta.numpy(), tu.numpy()) and np.array_equal(la.numpy(), lu.numpy()), (K, n)
-        assert a.last_stage_lanes == b.last_stage_lanes == u.last_stage_lanes and a.last_lane_steps == b.last_lane_steps
+        assert np.array_equal(ta.numpy(), to.numpy()) and np.array_equal(la.numpy(), lo.numpy()), (K, n)
+        assert a.last_stage_lanes == b.last_stage_lanes == u.last_stage_lanes == o.last_stage_lanes
+        assert a.last_lane_steps == b.last_lane_steps == o.last_lane_steps and a.last_grad_evals == o.last_grad_evals
         seen.update(t for t, _ in a.last_stage_lanes)
-    assert np.array_equal(a._rho.numpy(), b._rho.numpy())
+    assert np.array_equal(a._rho.numpy(), b._rho.numpy()) and np.array_equal(a._rho.numpy(), o._rho.numpy())
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    np.testing.assert_array_equal(a.rng_state(), o.rng_state())
     assert len(seen) >= min(4, 2 ** (K - 1))
+    # the counted draw makes exactly the reference's model calls: one gradient op per leapfrog step of every trajectory
+    # in the schedule (empty lane sets included: the launch sequence is fixed), and never reads a count back
+    assert ops_o.calls["target_grad"] == 1 + 10 * sum(st for _, st in o._schedule)
+
+
+def test_drghmc_counted_steps_on_a_gaussian_with_metric_equal_host_sized_launches():
+    """The same for a target without a one-launch proposal (DiagGaussian), a diagonal metric and no
+    probabilistic retry: the counted step-by-step draw against the host-sized, stably compacted one."""
+    lam = np.linspace(0.5, 3.0, 9)
+    met = np.linspace(0.8, 1.3, 9)
+    mk = lambda ops, dc: bk.DrGhmcDiag(bk.DiagGaussian(lam, ops=ops), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, metric_diag=met,
+                                       chains=33, seed=3, prob_retry=False, device_counts=dc, ops=ops)
+    a, o = mk(FakeOps(), False), mk(FakeOps(), True)
+    assert o._dev_counts and not o._one_launch and not a._dev_counts
+    for n in range(12):
+        ta, la = a.sample()
+        to, lo = o.sample()
+        assert np.array_equal(ta.numpy(), to.numpy()) and np.array_equal(la.numpy(), lo.numpy()), n
+        assert a.last_stage_lanes == o.last_stage_lanes
+    assert np.array_equal(a._rho.numpy(), o._rho.numpy())
+    np.testing.assert_array_equal(a.rng_state(), o.rng_state())
 
 
 def test_drghmc_attached_diagnostics_equal_manual_updates():
