@@ -468,6 +468,10 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
     if full_rhat:
         out["rhat"] = [float(v) for v in rh]
     try:
+        out["model_opaque"] = bench_cfg4_model_opaque(ctx, C, D, warmup)
+    except Exception as e:  # context only
+        out["model_opaque"] = {"error": repr(e)}
+    try:
         # The same sampler further into its run: the timed draws above are draws 4..43 from N(0, I) starts, where the
         # chains are still finding the funnel and the delayed-rejection stages run over 2-3x the lanes of the
         # stationary regime (mean_grad_evals_per_draw above against the one below).
@@ -490,6 +494,54 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False):
                                   "diagnostics": "Welford moments inside the draw"}
     except Exception as e:  # context only
         out["after_100_draws"] = {"error": repr(e)}
+    return out
+
+
+def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
+    """Config 4 through the interface north_star names: the gradient a SEPARATE device op called once per leapfrog
+    step (drghmc.py:280-283) -- the library's own funnel op with fuse_builtin=False, and a user plugin behind the
+    counted plugin ABI (bk_target_fn_n) -- every lane count on the device, the draw one hipGraph.  Same warm-up as the
+    fused figure above (draws 4..), so the two are comparable; the fused sampler run beside it must end bit-identical."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
+    kw = dict(chains=C, chain_id0=ctx.rank * C, seed=20242)
+    plugin_lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "plugin_target", "libfunnel_target.so")
+
+    def run(model, n, **k2):
+        so = bk.DrGhmcDiag(model, *args, **kw, **k2)
+        for _ in range(warmup):
+            so.sample()
+        base = float(so.lane_steps_total.item()) if so._dev_counts else None
+        el = ctx.timed_loop(so.advance, n)
+        ls = (float(so.lane_steps_total.item()) - base) if so._dev_counts else float("nan")
+        return so, {"ms_per_draw": 1e3 * el / n, "draws": n, "grad_evals_per_sec": ls / el,
+                    "mean_grad_evals_per_draw": ls / (C * n), "host_syncs_per_draw": so.host_syncs_per_draw,
+                    "hipgraph": bool(so._use_graph), "device_counts": bool(so._dev_counts)}
+
+    ref, fused = run(bk.Funnel(D), draws)
+    out = {"workload": "configs[3] with the gradient as a separate op per leapfrog step (one counted gradient launch + one "
+                       "counted kick+drift launch per step, 2*sum(L)+O(1) = ~580 launches per draw, lane counts on the device)",
+           "bound": "launch latency (dependent chain of ~580 small launches per draw inside one hipGraph)",
+           "fused_one_launch_proposals_same_draws": fused}
+    so, r = run(bk.Funnel(D), draws, fuse_builtin=False)
+    r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
+                                   and torch.equal(so._rng_state, ref._rng_state))
+    out["builtin_gradient_op"] = r
+    del so
+    if os.path.exists(plugin_lib):
+        so, r = run(bk.CTarget(plugin_lib, "funnel_target", D, counted_symbol="funnel_target_n"), draws)
+        r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
+                                       and torch.equal(so._rng_state, ref._rng_state))
+        out["plugin_ctarget"] = r
+        del so
+    # the same draws with launches sized by host reads (three lane counts read back per draw; the path every model
+    # had before the counted entry points, and the one PyTorch-autograd models still take)
+    so, r = run(bk.Funnel(D), 5, fuse_builtin=False, device_counts=False)
+    out["host_sized_launches"] = r
+    out["ms_per_draw"] = out["builtin_gradient_op"]["ms_per_draw"]
     return out
 
 

@@ -28,6 +28,10 @@ namespace {
 
 constexpr int WAVES = 4;
 
+// SLOTS > 0: rows per class held in registers (D - 1 <= 16 * SLOTS): one batch of loads, no second pass over
+// theta -- on a small lane set a launch is a chain of memory round trips, so that is what its time is made of.
+// SLOTS = 0: any D, two passes.
+template <int SLOTS>
 __global__ __launch_bounds__(64 * WAVES) void k_funnel_plugin(const double* theta, double* grad, double* logp,
                                                               int64_t ld, int64_t C, int64_t D,
                                                               const uint32_t* n_dev) {
@@ -44,21 +48,40 @@ __global__ __launch_bounds__(64 * WAVES) void k_funnel_plugin(const double* thet
   const int64_t c = c0 + lane;
   const bool on = c < n;
   // group w: classes w, w+4, w+8, w+12; class k holds rows 1 + k, 1 + k + 16, ... in order
+  double x[SLOTS > 0 ? 4 * SLOTS : 1];
   double cs[4];
+  if (SLOTS > 0) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double acc = 0.0;
-    for (int64_t d = 1 + w + 4 * k; d < D; d += 16) {
-      const double x = on ? theta[d * ld + c] : 0.0;
-      acc = acc + x * x;
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int64_t d = 1 + w + 4 * k + 16 * i;
+        x[k * SLOTS + i] = (on && d < D) ? theta[d * ld + c] : 0.0;
+      }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i)
+        if (1 + w + 4 * k + 16 * i < D) acc = acc + x[k * SLOTS + i] * x[k * SLOTS + i];
+      cs[k] = acc;
     }
-    cs[k] = acc;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double acc = 0.0;
+      for (int64_t d = 1 + w + 4 * k; d < D; d += 16) {
+        const double t = on ? theta[d * ld + c] : 0.0;
+        acc = acc + t * t;
+      }
+      cs[k] = acc;
+    }
   }
+  const double v = on ? theta[c] : 0.0;
   q[w][lane] = ((cs[0] + cs[1]) + cs[2]) + cs[3];
   __syncthreads();
   if (!on) return;
   const double s = ((q[0][lane] + q[1][lane]) + q[2][lane]) + q[3][lane];
-  const double v = theta[c];
   const double ev = exp(-v);
   const double hn = 0.5 * (double)(D - 1);
   const double he = 0.5 * ev;
@@ -66,16 +89,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_funnel_plugin(const double* thet
     if (logp) logp[c] = ((-(v * v) / 18.0) - hn * v) - he * s;
     if (grad) grad[c] = ((-v / 9.0) - hn) + he * s;
   }
-  if (grad)
+  if (!grad) return;
+  if (SLOTS > 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < SLOTS; ++i) {
+        const int64_t d = 1 + w + 4 * k + 16 * i;
+        if (d < D) grad[d * ld + c] = -(ev * x[k * SLOTS + i]);
+      }
+  } else {
     for (int64_t d = 1 + w; d < D; d += 4) grad[d * ld + c] = -(ev * theta[d * ld + c]);
+  }
 }
 
 int launch(const double* theta, double* grad, double* logp, int64_t ld, int64_t C, int64_t D, const uint32_t* n_dev,
            void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 1 || ld < C) return -1;
   if (C == 0) return 0;
-  k_funnel_plugin<<<dim3((unsigned)((C + 63) / 64)), dim3(64 * WAVES), 0, static_cast<hipStream_t>(stream)>>>(
-      theta, grad, logp, ld, C, D, n_dev);
+  const dim3 grid((unsigned)((C + 63) / 64)), block(64 * WAVES);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (D - 1 <= 32) k_funnel_plugin<2><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+  else if (D - 1 <= 64) k_funnel_plugin<4><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+  else if (D - 1 <= 128) k_funnel_plugin<8><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
+  else k_funnel_plugin<0><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
   return (int)hipGetLastError();
 }
 

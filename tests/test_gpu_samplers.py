@@ -956,20 +956,38 @@ def test_drghmc_model_opaque_device_counts_equal_host_sized_and_one_launch(ops, 
             assert s_._dev_counts and not s_._one_launch and s_.host_syncs_per_draw == 0
         assert g._use_graph and p._use_graph and not e._use_graph and not a._dev_counts and not h._dev_counts
         assert f is None or f._one_launch
+        # (past 128 coordinates the library's funnel sums sequentially and the plugin keeps its class order: two valid
+        # targets that differ in the last bit -- the plugin is then compared with itself, counted against host-sized)
+        same_order = D - 1 <= 128
         for n in range(12):
             ta, la = a.sample()
+            th_, lh_ = h.sample()
             for name, s_ in (("one launch", f), ("eager", e), ("graph", g), ("plugin", p), ("plugin host-sized", h)):
                 if s_ is None:
                     continue
-                t_, l_ = s_.sample()
-                assert torch.equal(ta, t_) and torch.equal(la, l_), (D, K, C, n, name)
+                if s_ is h:
+                    t_, l_ = th_, lh_
+                else:
+                    t_, l_ = s_.sample()
+                if not same_order and s_ in (p, h):
+                    assert torch.equal(th_, t_) and torch.equal(lh_, l_), (D, K, C, n, name)
+                    assert h.last_stage_lanes == s_.last_stage_lanes, (D, K, C, n, name)
+                    continue
+                assert torch.equal(ta, t_), (D, K, C, n, name)
+                if s_ is f:
+                    # (the proposal kernel sums a trajectory's kinetic energy in its own lanes' order, bk_leapfrog_finish
+                    # in four quarters: the joint log densities agree to rounding, the draws bit for bit)
+                    torch.testing.assert_close(la, l_, rtol=1e-13, atol=1e-13)
+                else:
+                    assert torch.equal(la, l_), (D, K, C, n, name)
                 assert a.last_stage_lanes == s_.last_stage_lanes, (D, K, C, n, name)
-            assert a.last_lane_steps == g.last_lane_steps == p.last_lane_steps
+            assert a.last_lane_steps == g.last_lane_steps and h.last_lane_steps == p.last_lane_steps
             assert a.last_grad_evals == g.last_grad_evals
         for s_ in (f, e, g, p, h):
             if s_ is not None:
-                assert torch.equal(a._rho, s_._rho)
-                np.testing.assert_array_equal(a.rng_state(), s_.rng_state())
+                ref_ = a if (same_order or s_ not in (p, h)) else h
+                assert torch.equal(ref_._rho, s_._rho)
+                np.testing.assert_array_equal(ref_.rng_state(), s_.rng_state())
         assert g._graph is not None and p._graph is not None
         assert float(g.lane_steps_total.item()) == float(e.lane_steps_total.item()) > 0
 

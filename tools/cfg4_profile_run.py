@@ -5,10 +5,19 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk
 C, D, N = int(os.environ.get("C", 32768)), 101, int(os.environ.get("N", 200))
-s = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
+# OPAQUE=1: the gradient as a separate (counted) op per leapfrog step; OPAQUE=plugin: the same through the user plugin
+opaque = os.environ.get("OPAQUE", "0")
+model = bk.Funnel(D)
+kw = {}
+if opaque == "plugin":
+    model = bk.CTarget(os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so"), "funnel_target", D,
+                       counted_symbol="funnel_target_n")
+elif opaque != "0":
+    kw["fuse_builtin"] = False
+s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
                   device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
-                  fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1")
-for _ in range(100):
+                  fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)
+for _ in range(int(os.environ.get("WARM", 100))):
     s.sample()
 torch.cuda.synchronize()
 import time
@@ -17,5 +26,5 @@ for _ in range(N):
     s.sample()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
-print({"ms_per_draw": 1e3 * el / N, "fuse_first_ghost": s._fuse_first_ghost, "device_counts": s._dev_counts, "graph": s._use_graph, "lane_steps_last": s.last_lane_steps,
+print({"ms_per_draw": 1e3 * el / N, "opaque": opaque, "one_launch": s._one_launch, "fuse_first_ghost": s._fuse_first_ghost, "device_counts": s._dev_counts, "graph": s._use_graph, "lane_steps_last": s.last_lane_steps,
        "stages_last": s.last_stage_lanes})
