@@ -83,6 +83,7 @@ SIGNATURES = {
     "bk_gather_columns": [P, P, I, P, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
     "bk_welford_update": [P, P, P, I, I, I, I, P],
+    "bk_welford_update_ld": [P, P, I, P, I, I, I, I, P],
     "bk_record_series": [P, I, P, I, P, P, I, I, I, P],
     "bk_record_series_dev": [P, I, P, I, P, P, I, P, I, I, P],
     "bk_welford_update_dev": [P, P, I, P, I, P, I, I, I, P],
@@ -601,10 +602,10 @@ class Ops:
 
     # -- diagnostics --------------------------------------------------------------------------------
     def welford_update(self, mean, m2, theta, n):
+        """theta may have a row pitch of its own (padded sampler state); mean and m2 share theirs."""
         D, C = theta.shape
-        ld = _ld(theta)
-        assert _ld(mean) == ld and _ld(m2) == ld
-        self._call("bk_welford_update", ptr(mean), ptr(m2), ptr(theta), ld, n, C, D, self._s())
+        assert _ld(m2) == _ld(mean)
+        self._call("bk_welford_update_ld", ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), n, C, D, self._s())
 
     def record_series(self, theta, dims, logp, series, row):
         """series[k, row, :] = theta[dims[k], :] (k < K), series[K, row, :] = logp: one launch."""
@@ -665,6 +666,9 @@ class Ops:
     def autocorr(self, x, out):
         N, C = x.shape
         self._call("bk_autocorr", ptr(x), _ld(x), N, ptr(out), _ld(out), C, self._s())
+
+    def autocorr_fft_work_bytes(self, N, C):
+        return int(self.lib.bk_autocorr_fft_work_bytes(N, C))
 
     def autocorr_fft(self, x, out):
         """autocorr(x, out) by FFT (long chains): the library's own Stockham passes, scratch allocated here."""

@@ -114,8 +114,8 @@ class RunningMoments:
         """theta: the sampler's draw, either the engine's [D, C] buffer or the (C, D) view
         returned by ``sample()`` (told apart by shape, for C == D by strides: see _as_dc)."""
         t = _as_dc(theta, self.mean.shape[0], self.mean.shape[1], layout)
-        if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) != self.mean.stride(0)):
-            t = t.contiguous()  # (the kernel walks theta, mean and M2 with one row pitch)
+        if (t.shape[1] > 1 and t.stride(1) != 1) or t.dtype != torch.float64:
+            t = t.to(torch.float64).contiguous()  # (chains must be contiguous; theta's row pitch may differ from the moments')
         self.n += 1
         self._ops.welford_update(self.mean, self.m2, t, self.n)
 
@@ -156,21 +156,42 @@ class DrawRecorder:
         self._dims_dev = torch.tensor(self.dims, dtype=torch.int32, device=self._ops.device)
         self.n = 0
 
-    def record(self, theta, logp=None) -> None:
-        """theta: the (C, D) draw returned by ``sample()`` (or the [D, C] buffer behind it); logp: its (C,) log
-        density.  One launch (bk_record_series) for all tracked series."""
+    def _check_dims(self, D: int) -> None:
+        """Tracked coordinates against the draw's D: negative indices count from the end (as ``theta[:, d]`` did),
+        anything outside [-D, D) raises IndexError -- the kernel reads theta[dims[k] * ld + c] unchecked."""
+        if getattr(self, "_dims_D", None) == D:
+            return
+        norm = []
+        for d in self.dims:
+            if not -D <= d < D:
+                raise IndexError(f"tracked coordinate {d} is out of range for draws with {D} dimensions")
+            norm.append(d + D if d < 0 else d)
+        self._dims_dev = torch.tensor(norm, dtype=torch.int32, device=self._ops.device)
+        self._dims_norm, self._dims_D = norm, D
+
+    def record(self, theta, logp=None, layout=None) -> None:
+        """theta: the (C, D) draw returned by ``sample()`` or the [D, C] buffer behind it (told apart by shape, a
+        square draw by its strides or by ``layout`` = "cd" / "dc": diagnostics._as_dc); logp: its (C,) log density.
+        One launch (bk_record_series) for all tracked series."""
         if self.n >= self.series.shape[1]:
             raise IndexError("DrawRecorder is full")
         C = self.series.shape[2]
-        t = theta.t() if (theta.dim() == 2 and theta.shape[0] == C and (theta.shape[1] != C or theta.stride(0) == 1)) else theta
+        if theta.dim() != 2:
+            raise ValueError(f"expected a 2-D draw, got shape {tuple(theta.shape)}")
+        if layout == "dc" or (layout is None and theta.shape[1] == C and theta.shape[0] != C):
+            D = theta.shape[0]
+        else:
+            D = theta.shape[1]
+        t = _as_dc(theta, D, C, layout)
+        self._check_dims(D)
         lp = None
         if self.with_logp:
             lp = logp if (logp.dtype == torch.float64 and logp.is_contiguous()) else logp.to(torch.float64).contiguous()
-        if t.dim() == 2 and t.shape[1] == C and (C == 1 or t.stride(1) == 1) and t.dtype == torch.float64:
+        if (C == 1 or t.stride(1) == 1) and t.dtype == torch.float64:
             self._ops.record_series(t, self._dims_dev, lp, self.series, self.n)
-        else:  # a draw in some other layout: one strided copy per series
-            for k, d in enumerate(self.dims):
-                self.series[k, self.n].copy_(theta[:, d])
+        else:  # a draw in some other layout / dtype: one strided copy per series
+            for k, d in enumerate(self._dims_norm):
+                self.series[k, self.n].copy_(t[d])
             if self.with_logp:
                 self.series[-1, self.n].copy_(logp)
         self.n += 1
@@ -178,6 +199,7 @@ class DrawRecorder:
     def _record_dev(self, theta_dc, logp, row_dev, row_offset) -> None:
         """record() as a part of a sampler's draw (DrGhmcDiag.attach): row = row_dev[0] - row_offset, read on the
         device; the caller keeps self.n in step."""
+        self._check_dims(theta_dc.shape[0])
         self._ops.record_series_dev(theta_dc, self._dims_dev, logp if self.with_logp else None, self.series, row_dev,
                                     row_offset)
 
@@ -672,6 +694,9 @@ def _autocorr_fft(x: torch.Tensor, ops) -> torch.Tensor:
     N, C = x.shape
     size = 1 << int(np.ceil(np.log2(2 * N - 1)))
     block = max(128, (_FFT_SCRATCH_BYTES // (size * 16)) // 128 * 128)  # (2 buffers x size x block/2 x 16 B)
+    need = getattr(ops, "autocorr_fft_work_bytes", None)
+    while need is not None and block > 128 and need(N, min(block, C)) > 2 * _FFT_SCRATCH_BYTES:
+        block = max(128, block // 2 // 128 * 128)  # (the plan pads its rows: size the batch by what it will really take)
     out = torch.empty_like(x)
     for c0 in range(0, C, block):
         ops.autocorr_fft(x[:, c0:c0 + block], out[:, c0:c0 + block])

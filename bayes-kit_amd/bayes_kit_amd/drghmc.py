@@ -381,9 +381,15 @@ class DrGhmcDiag(ManyChainSampler):
                 obj.record(theta_dc, logp)
 
     def _count_attached(self):
-        for kind, obj, off in self._attached:
+        for i, (kind, obj, off) in enumerate(self._attached):
             if kind == "recorder" and obj.n >= obj.series.shape[1]:
                 raise IndexError("DrawRecorder is full")
+            # the device-side update count / row index is (sampler's draw counter - off): keep it equal to the object's
+            # own count whatever was restored since (load_state_dict of the sampler, of the object, in either order)
+            now = self._draws - obj.n
+            if now != off:
+                self._attached[i] = (kind, obj, now)
+                self._drop_graphs()  # (the offset is a scalar argument of the captured launches)
 
     def advance(self):
         """One draw of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed

@@ -537,6 +537,11 @@ int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld,
   return welford_launch(mean, m2, ld, theta, ld, n, nullptr, 0, C, D, stream);
 }
 
+int bk_welford_update_ld(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta, int64_t n,
+                         int64_t C, int64_t D, void* stream) {
+  return welford_launch(mean, m2, ld, theta, ld_theta, n, nullptr, 0, C, D, stream);
+}
+
 int bk_welford_update_dev(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
                           const int64_t* n_dev, int64_t n_offset, int64_t C, int64_t D, void* stream) {
   if (!n_dev) return BK_E_ARG;

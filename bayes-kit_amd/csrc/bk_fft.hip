@@ -208,7 +208,9 @@ FftPlan fft_plan(i64 N, i64 C) {
   while (p.S < 2 * N - 1) p.S <<= 1;
   p.Cp = (C + 1) / 2;
   const i64 mod = p.Cp >= 1024 ? 256 : 64;  // (narrow batches: 576 B off a 1-KiB multiple, less scratch wasted)
-  p.ldc = p.Cp + ((36 - p.Cp % mod) + mod) % mod;
+  // (fewer than 64 pairs of chains -- the reference's own call shape is ONE chain -- get no padding: a row is at most
+  // 1 KiB, there is nothing to spread, and a pad to 36 columns made one chain of 4M draws a 10 GB plan)
+  p.ldc = p.Cp < 64 ? p.Cp : p.Cp + ((36 - p.Cp % mod) + mod) % mod;
   p.blocks = (int)(N / 64 < 1 ? 1 : (N / 64 > FFT_MOMENT_BLOCKS ? FFT_MOMENT_BLOCKS : N / 64));
   const size_t buf = (size_t)p.S * (size_t)p.ldc * sizeof(dvec2);
   p.off_b = buf;

@@ -227,17 +227,28 @@ def _cgroup_cpu_limit():
         return None
 
 
-def cpu_baseline():
-    """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler object per
-    chain, chains spread over P worker processes, config-3 shape, a bounded sample.  P = os.cpu_count()
-    (every hardware thread the host exposes), and -- because on a many-thread host the
-    per-chain NumPy loop does not scale to every SMT thread -- a second point at P = 32; `value` is the
-    better of the two and `cores` the P it was measured with (both points are kept in `points`)."""
+def cpu_cores_that_can_run():
+    """Threads this process can actually run at once: its CPU affinity, capped by the cgroup CPU quota."""
+    import math
+
     total = os.cpu_count() or 1
     try:
         usable = len(os.sched_getaffinity(0))  # (a container may be pinned to fewer)
     except (AttributeError, OSError):
         usable = total
+    quota = _cgroup_cpu_limit()
+    can_run = max(1, usable if quota is None else min(usable, int(math.ceil(quota))))
+    return total, usable, quota, can_run
+
+
+def cpu_baseline():
+    """Oracle (NumPy restatement of the reference samplers) on the host cores: one sampler object per
+    chain -- the reference's execution model -- chains spread over P worker processes, config-3 shape, a
+    bounded sample (~1.5 s per process).  P = the threads that can run at once: min(CPU affinity,
+    ceil(cgroup CPU quota)); `cores` is that P.  One point (round 3 also spawned one process per hardware
+    thread of the host: 16x oversubscribed under the container's quota, noise)."""
+    total, usable, quota, P = cpu_cores_that_can_run()
+    P = min(P, 64)
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
 
     def fan_out(P, argv_of):
@@ -255,38 +266,31 @@ def cpu_baseline():
         busy = max(r[1] for r in res)  # slowest worker's compute time (excludes process start-up)
         return sum(r[0] for r in res) / busy, wall
 
-    points = []
-    for P in sorted({max(1, usable), min(32, max(1, usable))}, reverse=True):
-        # ~1.5 s of work per process at P <= 32; fewer chains / draws per process on a many-thread host so
-        # that the whole leg stays a bounded sample (8 x 400 x 64 = 205k leapfrog steps per process at most)
-        chains_per_proc, draws = (8, 400) if P <= 64 else (4, 200)
-        rate, wall = fan_out(P, lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
-        points.append({"cores": P, "value": rate,
-                       "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
-                                 f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s"})
-    best = max(points, key=lambda p: p["value"])
+    chains_per_proc, draws = 8, 400  # 8 x 400 x 64 = 205k leapfrog steps per process
+    rate, wall = fan_out(P, lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
     out = {
-        "value": best["value"],
+        "value": rate,
         "unit": "leapfrog steps/sec",
-        "cores": best["cores"],
+        "cores": P,
         "host_cores_total": total,
         "host_cores_usable": usable,
-        "cgroup_cpu_limit": _cgroup_cpu_limit(),
+        "cgroup_cpu_limit": quota,
         "cpu_model": _cpu_model(),
         "kind": "port",
-        "sample": best["sample"],
-        "points": points,
+        "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
+                  f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s",
+        "leg_seconds": wall,
     }
-    try:
-        # context only: the same arithmetic hand-vectorised over [D, C] arrays (not how the reference runs)
-        Pb = min(32, max(1, usable))
-        bc, bd = 512, 6
-        brate, bwall = fan_out(Pb, lambda p: ["batched", bc, bd, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3 + 1 + p])
-        out["batched_numpy"] = {"value": brate, "unit": "leapfrog steps/sec", "cores": Pb,
-                                "sample": f"{Pb} procs x {bc} chains x {bd} draws, [D, C] arrays, in-place ufuncs; "
-                                          f"wall incl. spawn {bwall:.1f}s"}
-    except Exception as e:  # the context figure must not cost the baseline
-        out["batched_numpy"] = {"error": repr(e)}
+    if os.environ.get("BK_BENCH_BATCHED_NUMPY"):
+        # context only (opt-in): the same arithmetic hand-vectorised over [D, C] arrays (not how the reference runs)
+        try:
+            bc, bd = 512, 6
+            brate, bwall = fan_out(P, lambda p: ["batched", bc, bd, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3 + 1 + p])
+            out["batched_numpy"] = {"value": brate, "unit": "leapfrog steps/sec", "cores": P,
+                                    "sample": f"{P} procs x {bc} chains x {bd} draws, [D, C] arrays, in-place ufuncs; "
+                                              f"wall incl. spawn {bwall:.1f}s"}
+        except Exception as e:  # the context figure must not cost the baseline
+            out["batched_numpy"] = {"error": repr(e)}
     return out
 
 
@@ -823,8 +827,15 @@ def run_rank(args):
             ess = torch.where(ess > 0, ess, torch.full_like(ess, float(N))).clamp(max=float(N))
             ess_min = ess.min(dim=0).values
             tot = bk.dist.sum_over_ranks(float(ess_min.sum().item()), device)
+            tot2 = bk.dist.sum_over_ranks(float((ess_min * ess_min).sum().item()), device)
+            n_ch = C * world
+            var_ch = max(0.0, (tot2 - tot * tot / n_ch) / max(1, n_ch - 1))  # between-chain variance of the per-chain ESS
             out["ess"] = {"draws": N, "tracked": ["theta[0]", "theta[D/2]", "theta[D-1]", "logp"],
-                          "ess_per_sec": tot / eel, "mean_min_ess_per_chain": tot / (C * world),
+                          "ess_per_sec": tot / eel, "mean_min_ess_per_chain": tot / n_ch,
+                          # Monte-Carlo standard error of the figure: the sum over n_ch independent chains of a
+                          # per-chain estimate with between-chain variance var_ch, over a wall time measured once
+                          "ess_per_sec_mcse": (var_ch * n_ch) ** 0.5 / eel,
+                          "sd_min_ess_per_chain": var_ch ** 0.5,
                           "mean_ess_per_tracked": [float(e.mean().item()) for e in ess],
                           "note": "whole job; per-chain minimum over the tracked series (each clipped to "
                                   "(0, N]: IAT <= 0 counts as N), summed over chains"}
@@ -936,7 +947,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-fused-extra", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' records (N=1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N>1 only)")
-    ap.add_argument("--ess-draws", type=int, default=50, help="extra draws for the ESS/sec figure (0 = skip)")
+    ap.add_argument("--ess-draws", type=int, default=200, help="extra draws for the ESS/sec figure (0 = skip)")
     args = ap.parse_args(argv)
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in (sys.argv[1:] if argv is None else argv))
     return args

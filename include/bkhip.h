@@ -613,6 +613,10 @@ int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld,
 /* bk_welford_update with the update count in device memory: n = *n_dev - n_offset (e.g. a sampler's draw counter), and
  * with theta's own row pitch.  A launch like this can be part of a captured draw (hipGraph): nothing of it changes
  * from one replay to the next on the host side. */
+/* bk_welford_update with a row pitch of its own for theta (a sampler's state rows may be padded off a
+ * power-of-two pitch while the moments are dense): no staging copy of the draw. */
+int bk_welford_update_ld(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
+                         int64_t n, int64_t C, int64_t D, void* stream);
 int bk_welford_update_dev(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
                           const int64_t* n_dev, int64_t n_offset, int64_t C, int64_t D, void* stream);
 

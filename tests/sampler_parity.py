@@ -318,3 +318,79 @@ def check_attached_diagnostics(ops, C=40, D=7, draws=12, **kw):
     with pytest.raises(IndexError):
         b.advance()  # the recorder is full
     return b
+
+
+def check_recorder_and_moments_edges(ops, C=12, D=5):
+    """tracked coordinates are validated against D (negative = from the end, out of range raises, nothing is
+    read unchecked); a square draw is told apart by strides or by layout=; a draw with padded rows feeds the Welford
+    update without a staging copy; attachments survive load_state_dict() of the sampler in either order."""
+    import pytest
+    import torch
+
+    dev = ops.device
+    g = torch.Generator().manual_seed(5)
+    dc = torch.randn((D, C), generator=g, dtype=torch.float64).to(dev)
+    lp = torch.randn(C, generator=g, dtype=torch.float64).to(dev)
+    # negative and out-of-range tracked coordinates
+    r = bk.DrawRecorder([0, -1, -D], 4, C, ops=ops)
+    r.record(dc.t(), lp)          # sample()'s (C, D) view
+    r.record(dc, lp)              # the [D, C] buffer
+    r.record(dc.t().contiguous(), lp)  # a row-major (C, D) copy: the strided fallback
+    for row in range(3):
+        assert torch.equal(r.series[0, row], dc[0]) and torch.equal(r.series[1, row], dc[D - 1])
+        assert torch.equal(r.series[2, row], dc[0]) and torch.equal(r.series[3, row], lp)
+    for bad in ([D], [-D - 1], [0, 10 ** 6]):
+        with pytest.raises(IndexError):
+            bk.DrawRecorder(bad, 2, C, ops=ops).record(dc.t(), lp)
+    # a square draw: strides decide, an ambiguous one needs layout=
+    sq = torch.randn((C, C), generator=g, dtype=torch.float64).to(dev)   # [D = C, C] buffer
+    rs = bk.DrawRecorder([1], 3, C, ops=ops)
+    rs.record(sq.t(), lp)                        # the (C, D) view of the buffer: stride(0) == 1
+    rs.record(sq, lp)                            # the buffer itself
+    rs.record(sq.t().contiguous(), lp, layout="cd")  # a contiguous (C, D) copy says what it is
+    for row in range(3):
+        assert torch.equal(rs.series[0, row], sq[1]), row
+    if C > 1:
+        one = torch.ones((1, 1), dtype=torch.float64, device=dev).expand(C, C)  # strides (0, 0): neither layout
+        with pytest.raises(ValueError):
+            bk.DrawRecorder([1], 1, C, ops=ops).record(one, lp)
+    # Welford update straight from a draw whose rows are padded (no .contiguous() staging copy)
+    padded = torch.zeros((D, C + 6), dtype=torch.float64, device=dev)[:, :C]
+    ma, mb = bk.RunningMoments(D, C, ops=ops), bk.RunningMoments(D, C, ops=ops)
+    for k in range(3):
+        x = torch.randn((D, C), generator=g, dtype=torch.float64).to(dev)
+        padded.copy_(x)
+        ma.update(x)
+        mb.update(padded.t() if k % 2 else padded)
+    assert torch.equal(ma.mean, mb.mean) and torch.equal(ma.m2, mb.m2)
+    # attach() offsets after restoring the sampler (the diagnostics keep counting from where THEY are)
+    args = (2, [0.5, 0.2], [2, 3], 0.4)
+    mk = lambda: bk.DrGhmcDiag(bk.Funnel(D, ops=ops), *args, chains=C, seed=3, ops=ops)  # noqa: E731
+    a, b = mk(), mk()
+    m_a, m_b = bk.RunningMoments(D, C, ops=ops), bk.RunningMoments(D, C, ops=ops)
+    r_b = bk.DrawRecorder([0], 8, C, ops=ops)
+    for _ in range(2):
+        a.sample()
+        b.sample()
+    sd = b.state_dict()           # the sampler at draw 2
+    b.attach(moments=m_b, recorder=r_b)
+    for _ in range(3):
+        b.advance()               # draws 3..5 seen by the diagnostics (n = 3)
+    b.load_state_dict(sd)         # back to draw 2; the diagnostics are NOT rewound: they go on at n = 3, 4, ...
+    for _ in range(2):
+        b.advance()
+    assert m_b.n == 5 and r_b.n == 5
+    ref = mk()
+    for _ in range(2):
+        ref.sample()
+    seen = []
+    for _ in range(3):
+        seen.append(ref.sample()[0].t().clone())
+    ref.load_state_dict(sd)
+    for _ in range(2):
+        seen.append(ref.sample()[0].t().clone())
+    for x in seen:
+        m_a.update(x)
+    assert torch.equal(m_a.mean, m_b.mean) and torch.equal(m_a.m2, m_b.m2)
+    for row, x in enumerate(seen):
+        assert torch.equal(r_b.series[0, row], x[0]), row

@@ -146,3 +146,18 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_mala_logq(p, p, p, p, 3, 0.1, p, p, 4, 8, None) == E_ALIGN
     assert lib.bk_mala_propose_from_normals(p, p, p, 5, 3, p, 4, 0.1, 0.2, 4, 8, None) == E_ALIGN  # z strides
     assert lib.bk_refresh_work_elems(5, 33) == 5 * 40
+
+
+def test_fft_plan_of_the_reference_call_shape_is_not_padded_to_a_wide_batch():
+    """ess(chain) / autocorr(chain) on ONE chain (the reference's call shape, ess.py:52-69): the plan's scratch is
+    two complex arrays of the transform size, not 36 columns of them (10 GB for 4M draws)."""
+    from bayes_kit_amd import _lib
+
+    lib = _lib.load()
+    for N, C in ((1_000_000, 1), (4_000_000, 2), (100_000, 7)):
+        size = 1 << (2 * N - 2).bit_length()
+        assert size >= 2 * N - 1
+        cp = (C + 1) // 2
+        assert lib.bk_autocorr_fft_work_bytes(N, C) <= 2 * size * cp * 16 + size * 16 + (1 << 20), (N, C)
+    # wide batches keep their rows off the power-of-two pitch
+    assert lib.bk_autocorr_fft_work_bytes(16384, 4096) > 2 * 32768 * 2048 * 16

@@ -1182,3 +1182,10 @@ def test_drghmc_attached_diagnostics_equal_manual_updates(ops):
     check_attached_diagnostics(ops, C=700, D=21, draws=8, graph=False)
     check_attached_diagnostics(ops, C=130, D=11, draws=8, device_counts=False)
     check_attached_diagnostics(ops, C=4096, D=21, draws=6)  # padded rows: theta's row pitch differs from the moments'
+
+
+def test_recorder_dims_square_draws_padded_moments_and_attach_after_restore(ops):
+    from tests.sampler_parity import check_recorder_and_moments_edges
+
+    check_recorder_and_moments_edges(ops)
+    check_recorder_and_moments_edges(ops, C=130, D=9)

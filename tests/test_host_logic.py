@@ -491,3 +491,9 @@ def test_drghmc_attached_diagnostics_equal_manual_updates():
 
     check_attached_diagnostics(FakeOps())                         # device-side lists (eager on the CPU stand-in)
     check_attached_diagnostics(FakeOps(), device_counts=False)    # host-sized path: fed after the draw
+
+
+def test_recorder_dims_square_draws_padded_moments_and_attach_after_restore():
+    from tests.sampler_parity import check_recorder_and_moments_edges
+
+    check_recorder_and_moments_edges(FakeOps())
