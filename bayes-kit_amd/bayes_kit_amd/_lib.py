@@ -76,6 +76,7 @@ SIGNATURES = {
     "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
+    "bk_gemm_chains_work_elems": [I, I, I],
     "bk_logistic_residual": [P, I, P, P, I, I, I, P],
     "bk_logistic_finish": [P, P, I, P, I, F, F, P, P, P, I, I, P],
     "bk_dot_columns": [P, P, I, F, P, I, I, P],
@@ -105,7 +106,7 @@ SIGNATURES = {
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
 }
-_RESTYPE = {"bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64,
+_RESTYPE = {"bk_gemm_chains_work_elems": c_int64, "bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64,
              "bk_autocorr_fft_work_bytes": c_int64}
 
 
@@ -552,6 +553,11 @@ class Ops:
         D, C = X.shape
         assert _ld(Y) == _ld(X) and M.stride(1) == 1
         self._call("bk_dense_metric_apply", ptr(M), M.stride(0), ptr(X), ptr(Y), _ld(X), C, D, self._s())
+
+    def gemm_chains_work(self, R, K, C):
+        """Split-K scratch for gemm_chains (a tensor of bk_gemm_chains_work_elems doubles, or None: no split)."""
+        n = int(self.lib.bk_gemm_chains_work_elems(R, K, C))
+        return torch.empty(n, dtype=torch.float64, device=self.device) if n > 0 else None
 
     def gemm_chains(self, A, X, Y, work=None):
         """Y[R, C] = A[R, K] @ X[K, C] on the fp64 matrix cores (work: optional split-K scratch)."""

@@ -71,15 +71,7 @@ class HMCDiag(ManyChainSampler):
                 raise ValueError("give metric_diag or metric_dense, not both")
             if not self._batched:
                 raise ValueError("metric_dense needs a batched device model")
-            Mt = torch.as_tensor(metric_dense, dtype=torch.float64)
-            if tuple(Mt.shape) != (self._dim, self._dim):
-                raise ValueError(f"metric_dense must be ({self._dim}, {self._dim})")
-            Mt = 0.5 * (Mt + Mt.t())
-            dev_ = self._ops.device
-            self._M = Mt.to(dev_).contiguous()
-            self._M_chol = torch.linalg.cholesky(Mt).to(dev_).contiguous()   # host-side set-up
-            self._M_inv = torch.linalg.inv(Mt)
-            self._M_inv = (0.5 * (self._M_inv + self._M_inv.t())).to(dev_).contiguous()
+            self._install_metric_dense(metric_dense)
             fuse_builtin = False
         self._init_graph(graph, prefetch_rng)
         # built-in separable targets can run the whole trajectory in registers
@@ -153,6 +145,34 @@ class HMCDiag(ManyChainSampler):
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._fused and self._M is None:
             self._tune_placement()
+
+    def _install_metric_dense(self, metric_dense):
+        Mt = torch.as_tensor(metric_dense, dtype=torch.float64).cpu()
+        if tuple(Mt.shape) != (self._dim, self._dim):
+            raise ValueError(f"metric_dense must be ({self._dim}, {self._dim})")
+        Mt = 0.5 * (Mt + Mt.t())
+        dev_ = self._ops.device
+        chol = torch.linalg.cholesky(Mt)   # host-side set-up
+        inv = torch.linalg.inv(Mt)
+        inv = 0.5 * (inv + inv.t())
+        if self._M is None:
+            self._M, self._M_chol, self._M_inv = (x.to(dev_).contiguous() for x in (Mt, chol, inv))
+        else:  # in place: launches already queued (or captured) keep pointing at these buffers
+            self._M.copy_(Mt)
+            self._M_chol.copy_(chol)
+            self._M_inv.copy_(inv)
+
+    def set_metric_dense(self, metric_dense):
+        """Replace the dense metric of a sampler that was built with one (an adaptation between draws: e.g. the
+        tempered SMC re-estimates it from its particles at every temperature).  Momenta generated ahead with the old
+        metric (prefetch_rng) are discarded: build such samplers with prefetch_rng=False to keep the stream order."""
+        if self._M is None:
+            raise ValueError("this sampler was built without metric_dense")
+        self._install_metric_dense(metric_dense)
+        if self._prefetch and self._pf_ready:
+            if self._pf_event is not None:
+                torch.cuda.current_stream().wait_event(self._pf_event)
+            self._pf_ready, self._pf_event = False, None
 
     def _tune_placement(self):
         """Roles (theta', grad', rho of each slot, grad): see ManyChainSampler._tune_roles."""

@@ -78,12 +78,18 @@ class _MALAKernel:
 
 
 class _TemperedTarget:
-    """The tempered density log_likelihood * t + log_prior as a batched GradModel."""
+    """The tempered density log_likelihood * t + log_prior as a batched GradModel.  For models with the engine's
+    fast path and a temperature argument (``bk_eval(theta, grad, logp, t, loglik_out)``: bk.LogisticRegression) the
+    sampler's calls go straight to it -- a leapfrog step then forms no log density at all -- and every call that does
+    form one also leaves the particles' untempered log likelihood in ``ll_last`` (what the next reweighting needs)."""
 
     batched = True
 
     def __init__(self, model):
         self._model, self.t = model, 1.0
+        self.ll_last = None
+        if hasattr(model, "bk_eval") and hasattr(model, "log_density_gradient_tempered") and hasattr(model, "log_likelihood"):
+            self.bk_eval = self._bk_eval
 
     def dims(self):
         return self._model.dims()
@@ -94,16 +100,48 @@ class _TemperedTarget:
     def log_density_gradient(self, Theta):
         return self._model.log_density_gradient_tempered(Theta, self.t)
 
+    def _bk_eval(self, theta_dc, grad_out, logp_out):
+        ll = None
+        if logp_out is not None:
+            ll = torch.empty(theta_dc.shape[1], dtype=torch.float64, device=theta_dc.device)
+        self._model.bk_eval(theta_dc, grad_out, logp_out, self.t, ll)
+        if ll is not None:
+            self.ll_last = ll
+
 
 class _HMCKernel:
     """`draws` HMC transitions (bayes_kit/hmc.py:55-63 arithmetic, through HMCDiag) on the tempered
-    density; optionally with a diagonal or a dense metric (dense = fp64 MFMA GEMMs)."""
+    density; optionally with a diagonal or a dense metric (dense = fp64 MFMA GEMMs).
 
-    def __init__(self, stepsize, steps, draws=1, metric_diag=None, metric_dense=None):
+    adapt_metric (extension): before the moves of every temperature the dense metric is set to the particles' own
+    per-coordinate variance (over all ranks) -- the scale of the tempered posterior shrinks by orders of magnitude
+    along the ladder (config 5: prior width 1 -> posterior width 0.05), and a fixed metric either barely moves the
+    early particles or rejects every late proposal."""
+
+    def __init__(self, stepsize, steps, draws=1, metric_diag=None, metric_dense=None, adapt_metric=False):
         self.stepsize, self.steps, self.draws = float(stepsize), int(steps), int(draws)
         self.metric_diag, self.metric_dense = metric_diag, metric_dense
+        self.adapt_metric = bool(adapt_metric)
         self._hmc = None
         self._target = None
+        self._ll = None
+        self.accept_rates = []
+
+    def _particle_variance(self, smc):
+        th = smc._theta_dc
+        n = torch.tensor([float(th.shape[1])], dtype=torch.float64, device=th.device)
+        stats = torch.cat([th.sum(dim=1), (th * th).sum(dim=1), n])
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(smc._group) > 1:
+            from . import dist as _bkdist
+
+            stats = sum(_bkdist.all_gather(stats, smc._group))
+        D = th.shape[0]
+        cnt = stats[-1]
+        mean = stats[:D] / cnt
+        var = (stats[D:2 * D] / cnt - mean * mean).clamp(min=1e-300) * (cnt / (cnt - 1.0).clamp(min=1.0))
+        return var
 
     def move(self, smc, t: float) -> None:
         from .hmc import HMCDiag
@@ -111,21 +149,42 @@ class _HMCKernel:
         if self._hmc is None:
             self._target = _TemperedTarget(smc._model)
             base = int(smc._rng_state[0, 0].item()) & ((1 << 63) - 1)  # the SMC's Philox key word
+            md = self.metric_dense
+            if self.adapt_metric and md is None and self.metric_diag is None:
+                md = torch.eye(smc.D, dtype=torch.float64)
             self._hmc = HMCDiag(self._target, self.stepsize, self.steps, metric_diag=self.metric_diag,
                                 init=smc.thetas, seed=base ^ 0x5DEECE66D, chains=smc.M, chain_id0=smc._slot0,
-                                metric_dense=self.metric_dense, graph=False, ops=smc._ops)
+                                metric_dense=md, graph=False, ops=smc._ops,
+                                prefetch_rng=False if self.adapt_metric else None)
         h = self._hmc
+        if self.adapt_metric and h._M is not None:
+            h.set_metric_dense(torch.diag(self._particle_variance(smc)).cpu())
         self._target.t = float(t)
         h._theta_dc.copy_(smc._theta_dc)
-        h._have_cache = False  # new temperature, new positions: (logp, grad) must be re-evaluated
+        track = hasattr(self._target, "bk_eval")
+        # new temperature, new positions: (logp, grad) of the current points are evaluated afresh
+        h._materialize(h._eval_grad(h._theta_dc, h._grad, h._lp), h._grad)
+        h._have_cache = True
+        ll = self._target.ll_last if track else None
+        acc0 = int(h._accepted.item()) if hasattr(h, "_accepted") else 0
         for _ in range(self.draws):
             h._run_draw(h._draw)
             h._draws += 1
+            if track and self.steps > 0:
+                ll = torch.where(h._mask.bool(), self._target.ll_last, ll)   # accepted particles: the end point's
+        self.accept_rates.append((int(h._accepted.item()) - acc0) / max(1, self.draws * smc.M))
+        self._ll = ll
         smc._theta_dc.copy_(h._theta_dc)
 
+    def loglik(self, smc):
+        """Untempered log likelihood of the particles as the move left them (None: not tracked)."""
+        ll, self._ll = self._ll, None
+        return ll
 
-def hmc_kernel(stepsize: float, steps: int, draws: int = 1, metric_diag=None, metric_dense=None) -> _HMCKernel:
-    return _HMCKernel(stepsize, steps, draws, metric_diag, metric_dense)
+
+def hmc_kernel(stepsize: float, steps: int, draws: int = 1, metric_diag=None, metric_dense=None,
+               adapt_metric: bool = False) -> _HMCKernel:
+    return _HMCKernel(stepsize, steps, draws, metric_diag, metric_dense, adapt_metric)
 
 
 def metropolis_kernel(scale: float) -> _RWMKernel:
@@ -138,12 +197,27 @@ def mala_kernel(epsilon: float, steps: int = 1) -> _MALAKernel:
 
 class TemperedLikelihoodSMC:
     def __init__(self, model, M: int, N: int, sample_initial, kernel, *, seed=None, slot_id0: int = 0,
-                 group=None, ops=None):
+                 group=None, ops=None, adaptive=None, max_steps: int = 100000):
         """M = particles held by THIS rank.  Across ranks (one process per GPU) pass the rank's
         first global slot as slot_id0; resampling is then global: weights and particles are
         all-gathered (RCCL over xGMI), every rank builds the same cumulative weights and draws
-        its own slots' indices into the global population."""
+        its own slots' indices into the global population.
+
+        adaptive (EXTENSION, not in the reference): a fraction in (0, 1).  The reference's ladder is t_n = n / N
+        (smc.py:42-43); on a large data set (config 5: 10^6 observations, log likelihoods differing by 10^3-10^4
+        between prior draws) any affordable N lets the first reweighting collapse the particle system onto one or two
+        particles.  With adaptive = a the next temperature is instead the largest t <= 1 at which the effective
+        sample size of the incremental weights exp((t - t_prev) * loglik) is still a * (number of particles, all
+        ranks): a geometric-looking ladder of as many steps as the problem needs; N is then ignored, run() ends
+        when t reaches 1, and `temperatures` / `ess_history` record the ladder."""
         self.M, self.N = int(M), int(N)
+        if adaptive is not None and not (0.0 < float(adaptive) < 1.0):
+            raise ValueError("adaptive must be a fraction in (0, 1): the effective sample size kept by every reweighting")
+        self.adaptive = None if adaptive is None else float(adaptive)
+        self.max_steps = int(max_steps)
+        self.t = 0.0                 # temperature reached so far
+        self.temperatures = []       # after every transition
+        self.ess_history = []        # effective sample size of every reweighting (all ranks' particles)
         self._group = group
         self._slot0 = int(slot_id0)
         self._model = model
@@ -199,9 +273,20 @@ class TemperedLikelihoodSMC:
         return self._per_particle(self._model.log_likelihood, Theta)
 
     def time(self, n: int) -> float:
+        if self.adaptive is not None:
+            # the ladder as far as it has been built (n = 0: the prior)
+            return 0.0 if n <= 0 else self.temperatures[min(n, len(self.temperatures)) - 1]
         return n / self.N
 
     def run(self) -> None:
+        if self.adaptive is not None:
+            n = len(self.temperatures)
+            while self.t < 1.0:
+                n += 1
+                if n > self.max_steps:
+                    raise RuntimeError(f"adaptive ladder did not reach t = 1 in {self.max_steps} steps (t = {self.t})")
+                self.transition(n)
+            return
         for n in range(1, self.N + 1):
             self.transition(n)
 
@@ -215,19 +300,76 @@ class TemperedLikelihoodSMC:
         Th = theta_dc.t()
         return (self.log_likelihood(Th) * t + self.log_prior(Th)).contiguous()
 
-    def transition(self, n: int) -> None:
-        ops = self._ops
-        self.kernel.move(self, self.time(n - 1))                      # smc.py:53-57
-        th = self._theta_dc
-        lpm1 = self._tempered(th, self.time(n - 1))
-        lp = self._tempered(th, self.time(n))
+    def _multi(self):
         import torch.distributed as dist
 
-        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1
+
+    def _next_temperature(self, ll):
+        """Largest step d <= 1 - t with ESS(exp(d * ll)) >= adaptive * (particles of all ranks): 64-point searches
+        on the device (the ESS falls monotonically in d), every rank on the same gathered vector."""
+        if self._multi():
+            from . import dist as _bkdist
+            from .diagnostics import _all_gather_counts
+
+            counts = _all_gather_counts(ll.shape[0], ll.device, self._group)
+            mmax = max(counts)
+            pad = ll if ll.shape[0] == mmax else torch.cat([ll, ll.new_full((mmax - ll.shape[0],), float("-inf"))])
+            ll = torch.cat([p[:c] for p, c in zip(_bkdist.all_gather(pad.contiguous(), self._group), counts)])
+        x = ll - ll.max()
+        want = self.adaptive * x.shape[0]
+
+        def ess(d):  # d: [k] candidates -> [k]
+            w = torch.exp(d[:, None] * x[None, :])
+            return w.sum(dim=1) ** 2 / (w * w).sum(dim=1)
+
+        room = 1.0 - self.t
+        full = torch.tensor([room], dtype=torch.float64, device=x.device)
+        if float(ess(full)[0].item()) >= want:
+            return room
+        # a geometric bracket first (the first step of a large data set is 1e-4 .. 1e-6 of the way), then two linear
+        # refinements: the step is found to 1 / 4096 of itself, three device round trips in all
+        halves = room * torch.pow(torch.tensor(0.5, dtype=torch.float64, device=x.device),
+                                  torch.arange(1, 65, dtype=torch.float64, device=x.device))
+        ok = ess(halves) >= want
+        k = int(ok.to(torch.int64).argmax().item()) if bool(ok.any().item()) else 63
+        lo, hi = float(halves[k].item()), float(halves[k].item()) * 2.0  # (nothing passes: the smallest candidate; the ESS record shows it)
+        for _ in range(2):
+            cand = lo + (hi - lo) * torch.arange(1, 65, dtype=torch.float64, device=x.device) / 64.0
+            passed = int((ess(cand) >= want).to(torch.int64).sum().item())  # (monotone: the first `passed` candidates pass)
+            lo, hi = (lo + (hi - lo) * passed / 64.0), (lo + (hi - lo) * min(64, passed + 1) / 64.0)
+            if passed == 64:
+                break
+        return lo
+
+    def transition(self, n: int) -> None:
+        ops = self._ops
+        t_prev = self.t if self.adaptive is not None else self.time(n - 1)
+        self.kernel.move(self, t_prev)                                # smc.py:53-57
+        th = self._theta_dc
+        Th = th.t()
+        # one evaluation of the two parts serves both densities of smc.py:47-51 (the reference evaluates each twice);
+        # a move kernel that tracked the particles' log likelihood hands it over
+        ll = self.kernel.loglik(self) if hasattr(self.kernel, "loglik") else None
+        if ll is None:
+            ll = self.log_likelihood(Th)
+        if self.adaptive is not None:
+            t_next = min(1.0, self.t + self._next_temperature(ll))
+            if 1.0 - t_next < 1e-12:
+                t_next = 1.0
+            logw = ll * (t_next - t_prev)
+        else:
+            t_next = self.time(n)
+            lprior = self.log_prior(Th)
+            lpm1 = (ll * t_prev + lprior).contiguous()
+            lp = (ll * t_next + lprior).contiguous()
+            logw = lp - lpm1
+        import torch.distributed as dist
+
+        multi = self._multi()
         # weights exp(lp - lpminus1) [smc.py:67-70], scaled by exp(-max) so that a large data set
         # (log-likelihood steps of 1e4 and more) cannot underflow every weight to zero; the
         # reference normalises by the sum (smc.py:73), so the common factor changes nothing
-        logw = lp - lpm1
         top = logw.max()
         if multi:
             dist.all_reduce(top, op=dist.ReduceOp.MAX, group=self._group)
@@ -240,6 +382,9 @@ class TemperedLikelihoodSMC:
             ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73
             ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
         self._theta_dc, self._prop_dc = self._prop_dc, self._theta_dc
+        self.t = t_next
+        self.temperatures.append(t_next)
+        self.ess_history.append(self.last_ess)
 
     def _resample_across_ranks(self, w, th):
         """Multinomial resampling over the particles of ALL ranks (smc.py:64-75 with the particle

@@ -156,24 +156,29 @@ class LogisticRegression(_BuiltinTarget):
         self._inv_s2 = 1.0 / float(prior_scale) ** 2
         self._dev = None
 
-    def _buffers(self, device, C):
+    def _buffers(self, device, C, ld):
+        """Scratch for C chains whose state rows are `ld` apart (G shares the state's pitch: the finish kernel walks
+        theta, G and grad together)."""
+        ops = self._get_ops()
         if self._dev is None or self._dev["X"].device != device:
             X = self._X_host.to(device).contiguous()
-            self._dev = {"X": X, "Xt": X.t().contiguous(), "y": self._y_host.to(device).contiguous(), "C": 0}
+            self._dev = {"X": X, "Xt": X.t().contiguous(), "y": self._y_host.to(device).contiguous(), "C": 0, "ld": 0}
         b = self._dev
+        f64 = dict(dtype=torch.float64, device=device)
         if b["C"] < C:
-            f64 = dict(dtype=torch.float64, device=device)
             b["Z"] = torch.empty((self._N, C), **f64)
             b["part"] = torch.empty((min(self.SEGMENTS, max(1, self._N)), C), **f64)
-            b["G"] = torch.empty((self._D, C), **f64)
-            b["work"] = torch.empty(min(64, max(1, self._N // 512)) * self._D * C, **f64)  # split-K slabs
+            b["work"] = ops.gemm_chains_work(self._D, self._N, C)  # split-K slabs of X^T r (a function of D, N only)
             b["C"] = C
+        if b["ld"] != ld:
+            b["G"] = torch.empty((self._D, ld), **f64)
+            b["ld"] = ld
         return b
 
     def bk_eval(self, theta_dc, grad_out, logp_out, t: float = 1.0, loglik_out=None):
         ops = self._get_ops()
         D, C = theta_dc.shape
-        b = self._buffers(theta_dc.device, C)
+        b = self._buffers(theta_dc.device, C, _lib._ld(theta_dc))
         Z = b["Z"][:, :C]
         # (a leapfrog step wants the gradient alone: the residual pass then skips the log likelihood)
         part = b["part"][:, :C] if (logp_out is not None or loglik_out is not None) else None

@@ -215,42 +215,26 @@ __global__ __launch_bounds__(64) void k_dot_columns(const double* x, const doubl
   out[c] = scale * s;
 }
 
-// deterministic reduction of split-K slabs: Y = sum_s P[s] in increasing s
-__global__ __launch_bounds__(256) void k_sum_slabs(const double* P, i64 slab, int S, double* Y, i64 n) {
-  i64 i = (i64)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+// deterministic reduction of split-K slabs: Y = sum_s P[s] in increasing s (slab rows of pitch ldw, Y rows of pitch ldy)
+__global__ __launch_bounds__(256) void k_sum_slabs(const double* P, i64 slab, int S, i64 ldw, double* Y, i64 ldy, i64 R,
+                                                   i64 C) {
+  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= C || r >= R) return;
+  const i64 i = r * ldw + c;
   double a = P[i];
   for (int s = 1; s < S; ++s) a = a + P[(i64)s * slab + i];
-  Y[i] = a;
+  Y[r * ldy + c] = a;
 }
 
 }  // namespace
 namespace {
 
-static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, i64 ldx, double* Y, i64 ldy, i64 C,
-                       double* work, i64 work_elems, void* stream, const double* y_rows = nullptr) {
-  if (!A || !X || !Y || C < 0 || R < 0 || K < 0 || lda < K) return BK_E_ARG;
-  if (ldx < C || ldy < C) return BK_E_ALIGN;
-  if (C == 0 || R == 0) return BK_OK;
+// one GEMM launch (+ one for a last partial block of rows): `out` rows of pitch ldy, split-K slab q at out + q * slab_elems
+static int gemm_block(const double* A, i64 lda, i64 R, i64 K, const double* X, i64 ldx, double* out, i64 ldy, i64 C,
+                      i64 S, i64 k_chunk, i64 slab_elems, void* stream, const double* y_rows) {
   i64 rb = bk_cdiv(R, BM), cb = bk_cdiv(C, BN);
   i64 per = (cb + 7) / 8;
   if (per * 8 * rb > 0x7fffffff) return BK_E_ARG;
-  // split the inner dimension when the output has too few tiles to fill 256 CUs x 2 workgroups
-  i64 S = 1;
-  if (work && !y_rows && rb * cb < 1024 && K >= 64 * BK) {
-    S = bk_cdiv(2048, rb * cb);
-    i64 maxS = K / (32 * BK);  // keep >= 32 K-panels per split
-    if (S > maxS) S = maxS;
-    if (S * R * ldy > work_elems) S = work_elems / (R * ldy);
-    if (S > 65535) S = 65535;
-    if (S < 2) S = 1;
-  }
-  i64 k_chunk = K;
-  if (S > 1) {
-    k_chunk = bk_cdiv(bk_cdiv(K, S), BK) * BK;
-    S = bk_cdiv(K, k_chunk);
-  }
-  double* out = S > 1 ? work : Y;
   const bool full_but_rows = (K % BK == 0) && (C % BN == 0) && (lda % 2 == 0) && (ldx % 2 == 0) && bk_aligned16(A) &&
                              bk_aligned16(X);
   hipStream_t st = bk_stream(stream);
@@ -262,10 +246,10 @@ static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, 
     const dim3 grid((unsigned)(per * 8 * rbf), (unsigned)S);
     if (y_rows)
       k_dense_apply<true, 1><<<grid, dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R_full, K, (int)rbf, (int)cb,
-                                                         k_chunk, R * ldy, y_rows);
+                                                         k_chunk, slab_elems, y_rows);
     else
       k_dense_apply<true, 0><<<grid, dim3(256), 0, st>>>(A, lda, X, out, ldx, ldy, C, R_full, K, (int)rbf, (int)cb,
-                                                         k_chunk, R * ldy, nullptr);
+                                                         k_chunk, slab_elems, nullptr);
   }
   if (R_full < R) {
     // rows [R_full, R): its split-K slabs sit at the same row offset inside each slab of R rows
@@ -273,16 +257,61 @@ static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, 
     const dim3 grid((unsigned)(per * 8 * rbr), (unsigned)S);
     if (y_rows)
       k_dense_apply<false, 1><<<grid, dim3(256), 0, st>>>(A + R_full * lda, lda, X, out + R_full * ldy, ldx, ldy, C, rr, K,
-                                                          (int)rbr, (int)cb, k_chunk, R * ldy, y_rows + R_full);
+                                                          (int)rbr, (int)cb, k_chunk, slab_elems, y_rows + R_full);
     else
       k_dense_apply<false, 0><<<grid, dim3(256), 0, st>>>(A + R_full * lda, lda, X, out + R_full * ldy, ldx, ldy, C, rr, K,
-                                                          (int)rbr, (int)cb, k_chunk, R * ldy, nullptr);
-  }
-  if (S > 1) {
-    i64 n = R * ldy;
-    k_sum_slabs<<<dim3((unsigned)bk_cdiv(n, 256)), dim3(256), 0, st>>>(work, n, (int)S, Y, n);
+                                                          (int)rbr, (int)cb, k_chunk, slab_elems, nullptr);
   }
   BK_RETURN_LAUNCH_STATUS();
+}
+
+// Split of a long inner dimension: how many slabs, and how many k per slab.  A function of (R, K) ONLY -- never of
+// the number of chains in the call -- so that a chain's result does not depend on how many chains share its launch
+// (a shard of 256 chains must reproduce its slice of a 2,048-chain run bit for bit).  The factor is
+// what fills 256 CUs x 2 workgroups at the reference width of GEMM_COLS chains; wider calls are cut into column
+// blocks of that width (which also bounds the slab scratch), narrower ones run with fewer tiles.
+constexpr i64 GEMM_COLS = 2048;
+static i64 gemm_slabs(i64 R, i64 K, i64* k_chunk_out) {
+  const i64 rb = bk_cdiv(R, BM), cb_ref = GEMM_COLS / BN;
+  i64 S = 1;
+  if (rb * cb_ref < 1024 && K >= 64 * BK) {
+    S = bk_cdiv(2048, rb * cb_ref);
+    const i64 maxS = K / (32 * BK);  // keep >= 32 K-panels per split
+    if (S > maxS) S = maxS;
+    if (S > 65535) S = 65535;
+    if (S < 2) S = 1;
+  }
+  i64 k_chunk = K;
+  if (S > 1) {
+    k_chunk = bk_cdiv(bk_cdiv(K, S), BK) * BK;
+    S = bk_cdiv(K, k_chunk);
+  }
+  if (k_chunk_out) *k_chunk_out = k_chunk;
+  return S;
+}
+
+static int gemm_launch(const double* A, i64 lda, i64 R, i64 K, const double* X, i64 ldx, double* Y, i64 ldy, i64 C,
+                       double* work, i64 work_elems, void* stream, const double* y_rows = nullptr) {
+  if (!A || !X || !Y || C < 0 || R < 0 || K < 0 || lda < K) return BK_E_ARG;
+  if (ldx < C || ldy < C) return BK_E_ALIGN;
+  if (C == 0 || R == 0) return BK_OK;
+  i64 k_chunk = K, S = 1;
+  if (work && !y_rows) S = gemm_slabs(R, K, &k_chunk);
+  if (S > 1) {
+    // column blocks of GEMM_COLS chains, each through the same S slabs of pitch ldw (the scratch is reused: the
+    // launches are stream-ordered)
+    const i64 ldw = C < GEMM_COLS ? C + (C & 1) : GEMM_COLS;
+    if (work_elems < S * R * ldw) return BK_E_ARG;  // (a smaller S would change the bits: refuse instead)
+    for (i64 c0 = 0; c0 < C; c0 += GEMM_COLS) {
+      const i64 cw = C - c0 < GEMM_COLS ? C - c0 : GEMM_COLS;
+      int rc = gemm_block(A, lda, R, K, X + c0, ldx, work, ldw, cw, S, k_chunk, R * ldw, stream, nullptr);
+      if (rc != BK_OK) return rc;
+      k_sum_slabs<<<dim3((unsigned)bk_cdiv(cw, 256), (unsigned)R), dim3(256), 0, bk_stream(stream)>>>(
+          work, R * ldw, (int)S, ldw, Y + c0, ldy, R, cw);
+    }
+    BK_RETURN_LAUNCH_STATUS();
+  }
+  return gemm_block(A, lda, R, K, X, ldx, Y, ldy, C, 1, K, 0, stream, y_rows);
 }
 
 }  // namespace
@@ -292,6 +321,14 @@ extern "C" {
 int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double* Y, int64_t ld, int64_t C,
                           int64_t D, void* stream) {
   return gemm_launch(M, ldm, D, D, X, ld, Y, ld, C, nullptr, 0, stream);
+}
+
+int64_t bk_gemm_chains_work_elems(int64_t R, int64_t K, int64_t C) {
+  if (R < 1 || K < 1 || C < 1) return 0;
+  const i64 S = gemm_slabs(R, K, nullptr);
+  if (S < 2) return 0;
+  const i64 ldw = C < GEMM_COLS ? C + (C & 1) : GEMM_COLS;
+  return S * R * ldw;
 }
 
 int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx, double* Y,

@@ -557,8 +557,13 @@ int bk_dense_metric_apply(const double* M, int64_t ldm, const double* X, double*
 /* The same MFMA GEMM with a rectangular left factor: Y[R x C] = A[R x K] @ X[K x C], all three
  * with the chain index contiguous on the right (design matrices: X_data @ Theta with R = number
  * of observations, X_data^T @ residuals with R = dims).  `work` (may be NULL; work_elems
- * doubles, caller-owned) lets the library split a long inner dimension over several workgroups
- * when the output has too few tiles to fill the chip; the slabs are summed in a fixed order. */
+ * doubles, caller-owned, at least bk_gemm_chains_work_elems(R, K, C) of them) lets the library split a
+ * long inner dimension over several workgroups when the output has too few tiles to fill the chip; the
+ * slabs are summed in a fixed order.  The split is a function of (R, K) only and calls wider than 2,048
+ * chains are cut into column blocks: a chain's result does not depend on how many chains share its call
+ * (chains sharded over GPUs reproduce the unsharded run bit for bit).  A `work` that is too small is
+ * refused (BK_E_ARG), never answered with another split. */
+int64_t bk_gemm_chains_work_elems(int64_t R, int64_t K, int64_t C);
 int bk_gemm_chains(const double* A, int64_t lda, int64_t R, int64_t K, const double* X, int64_t ldx,
                    double* Y, int64_t ldy, int64_t C, double* work, int64_t work_elems, void* stream);
 

@@ -98,6 +98,25 @@ def main():
                                       bk.metropolis_kernel(0.4), seed=22, group=solo_group, ops=ops)
     solo_o.run()
     assert np.array_equal(np.concatenate(parts_o, axis=0), solo_o.thetas.numpy())
+    # 6b) the ADAPTIVE ladder across ranks: the next temperature is found on the log likelihoods of ALL ranks'
+    #     particles (gathered), the HMC move's metric from the particles of all ranks -- same ladder, same particles
+    ll_big = lambda Th: -400.0 * ((Th - 0.3) ** 2).sum(dim=1)
+    mk = lambda m, init_, **kw: bk.TemperedLikelihoodSMC(bk.TorchPriorLikelihoodModel(lp_fn, ll_big, Dp), m, 3, init_,  # noqa: E731
+                                                         bk.hmc_kernel(0.6, 2, adapt_metric=True), seed=23, ops=ops,
+                                                         adaptive=0.6, **kw)
+    M_ad = 41
+    init_a = np.random.default_rng(6).normal(size=(M_ad, Dp))
+    f8, n8 = bk.dist.shard(M_ad)
+    smc_a = mk(n8, init_a[f8:f8 + n8], slot_id0=f8)
+    smc_a.run()
+    parts_a = [None, None]
+    dist.all_gather_object(parts_a, (smc_a.thetas.numpy().copy(), list(smc_a.temperatures), list(smc_a.ess_history)))
+    solo_a = mk(M_ad, init_a, group=solo_group)
+    solo_a.run()
+    assert parts_a[0][1] == parts_a[1][1] and len(solo_a.temperatures) > 3   # (the ranks agree exactly; one process sums
+    np.testing.assert_allclose(parts_a[0][1], solo_a.temperatures, rtol=1e-9)  #  the particle moments in another order)
+    np.testing.assert_allclose(parts_a[0][2], solo_a.ess_history, rtol=1e-9)
+    np.testing.assert_allclose(np.concatenate([parts_a[0][0], parts_a[1][0]], axis=0), solo_a.thetas.numpy(), rtol=1e-9, atol=1e-12)
     # 7) the sample sort behind the cross-rank rank normalisation: global ranks of a sharded series ==
     #    ranks of the pooled series in one process, including ties (resolved by pooled order) and a
     #    heavily skewed split of the value range between the ranks

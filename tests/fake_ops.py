@@ -395,6 +395,9 @@ class FakeOps:
     def dense_metric_apply(self, M, X, Y):
         Y.numpy()[...] = M.numpy() @ X.numpy()
 
+    def gemm_chains_work(self, R, K, C):
+        return None
+
     def gemm_chains(self, A, X, Y, work=None):
         Y.numpy()[...] = A.numpy() @ X.numpy()
 

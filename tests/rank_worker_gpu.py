@@ -63,6 +63,21 @@ def main():
         np.testing.assert_allclose(ess_sum, want_ess, rtol=1e-12)
         np.testing.assert_allclose(rn, bk.rank_normalized_rhat(rrec.series[0, :N], group=solo), rtol=1e-12)
         assert torch.equal(rrec.series[0, :N, first:first + n], rec.series[0, :N])  # my shard, bit for bit
+    # logistic regression (two MFMA GEMMs per gradient, X^T r split over the observations) under HMC with a dense
+    # metric: the split is a function of (D, N) only, so a shard's chains are the one-process run's, bit for bit
+    gen = torch.Generator().manual_seed(5)
+    Nl, Dl, Cl = 20_000, 32, 301
+    X = (torch.randn((Nl, Dl), dtype=torch.float64, generator=gen) / Dl ** 0.5).to(dev)
+    y = (torch.rand(Nl, dtype=torch.float64, generator=gen) < 0.5).to(torch.float64).to(dev)
+    Md = torch.eye(Dl, dtype=torch.float64) * 0.02 + 0.001
+    f2, n2 = bk.dist.shard(Cl)
+    sl = bk.HMCDiag(bk.LogisticRegression(X, y), 0.1, 3, chains=n2, chain_id0=f2, seed=seed, metric_dense=Md)
+    mine = [sl.sample() for _ in range(3)]
+    if rank == 0:
+        rl = bk.HMCDiag(bk.LogisticRegression(X, y), 0.1, 3, chains=Cl, seed=seed, metric_dense=Md)
+        for n_, (t_, l_) in enumerate(mine):
+            tr, lr = rl.sample()
+            assert torch.equal(tr[f2:f2 + n2], t_) and torch.equal(lr[f2:f2 + n2], l_), ("logistic shard", n_)
     dist.barrier()
     dist.destroy_process_group()
     import json

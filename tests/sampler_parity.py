@@ -394,3 +394,42 @@ def check_recorder_and_moments_edges(ops, C=12, D=5):
     assert torch.equal(m_a.mean, m_b.mean) and torch.equal(m_a.m2, m_b.m2)
     for row, x in enumerate(seen):
         assert torch.equal(r_b.series[0, row], x[0]), row
+
+
+def check_adaptive_smc_ladder(ops, M=600, D=3, n_obs=4000, seed=5):
+    """The adaptive ladder (extension of bayes_kit/smc.py:42-43: next temperature = the largest step that keeps the ESS
+    of the incremental weights at a fraction of the particles) on a conjugate Gaussian model with MANY observations --
+    where the reference's t = n / N collapses at its first reweighting: every reweighting keeps its ESS, the ladder
+    ends at exactly 1, and the particles carry the exact posterior (known in closed form)."""
+    import torch
+
+    rng = np.random.default_rng(seed)
+    mu_true = rng.normal(size=D)
+    ybar = torch.tensor(mu_true + rng.normal(size=D) / np.sqrt(n_obs), dtype=torch.float64)
+    dev = ops.device
+    ybar_d = ybar.to(dev)
+    log_prior = lambda Th: -0.5 * (Th * Th).sum(dim=1)                           # N(0, I)
+    log_lik = lambda Th: -0.5 * n_obs * ((Th - ybar_d[None, :]) ** 2).sum(dim=1)   # n_obs observations of N(theta, 1)
+    model = bk.TorchPriorLikelihoodModel(log_prior, log_lik, D)
+    init = rng.normal(size=(M, D))
+    # (the reference's ladder with an affordable N: the first reweighting keeps a handful of particles)
+    fixed = bk.TemperedLikelihoodSMC(model, M, 8, init, bk.metropolis_kernel(0.05), seed=seed, ops=ops)
+    fixed.transition(1)
+    assert fixed.last_ess < 0.05 * M
+    smc = bk.TemperedLikelihoodSMC(model, M, 8, init, bk.hmc_kernel(0.7, 3, adapt_metric=True), seed=seed, ops=ops,
+                                   adaptive=0.5)
+    smc.run()
+    T = np.array(smc.temperatures)
+    assert T[-1] == 1.0 and smc.t == 1.0 and np.all(np.diff(T) > 0) and 5 < len(T) < 400
+    ess = np.array(smc.ess_history)
+    assert np.all(ess[:-1] >= 0.5 * M * (1 - 1e-3)) and ess[-1] >= 0.5 * M * (1 - 1e-3)  # (the last step may be shorter)
+    assert np.all(ess[:-1] <= 0.5 * M * 1.05)   # ... and each step is as long as the target allows
+    assert smc.time(0) == 0.0 and smc.time(1) == T[0] and smc.time(len(T)) == 1.0
+    th = np.asarray(smc.thetas.cpu())
+    post_var = 1.0 / (1.0 + n_obs)
+    post_mean = ybar.numpy() * n_obs * post_var
+    z = (th.mean(axis=0) - post_mean) / np.sqrt(post_var / (M / 4))
+    assert np.abs(z).max() < 4.0, z
+    np.testing.assert_allclose(th.var(axis=0, ddof=1), post_var, rtol=0.25)
+    assert min(smc.kernel.accept_rates) > 0.3   # the adapted metric keeps the moves alive along the whole ladder
+    return smc

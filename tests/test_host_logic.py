@@ -497,3 +497,9 @@ def test_recorder_dims_square_draws_padded_moments_and_attach_after_restore():
     from tests.sampler_parity import check_recorder_and_moments_edges
 
     check_recorder_and_moments_edges(FakeOps())
+
+
+def test_adaptive_smc_ladder_keeps_its_ess_and_finds_the_posterior():
+    from tests.sampler_parity import check_adaptive_smc_ladder
+
+    check_adaptive_smc_ladder(FakeOps())
