@@ -153,6 +153,80 @@ def _visible_gpus():
 
 
 # ---------------------------------------------------------------------------------------------
+# CPU placement of a rank
+# ---------------------------------------------------------------------------------------------
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_numa_node(index):
+    """NUMA node of the index-th render node (no HIP: sysfs), or None."""
+    try:
+        import glob
+
+        cards = sorted(glob.glob("/sys/class/drm/renderD*/device/numa_node"),
+                       key=lambda p: int(p.split("renderD")[1].split("/")[0]))
+        node = int(open(cards[index]).read())
+        return node if node >= 0 else None
+    except (OSError, ValueError, IndexError):
+        return None
+
+
+def rank_cpu_set(local_rank, world, affinity=None, numa_of_gpu=_gpu_numa_node, node_cpus=None):
+    """The CPUs rank `local_rank` of `world` ranks on this node should run on: those of its GPU's NUMA node that this
+    process may use, shared evenly between the ranks whose GPUs sit on the same node (launch-bound workloads -- config 2
+    at 8 us per step, config 4's twelve launches per draw -- are the ones a host thread migrating across sockets hurts);
+    when the topology is not readable, an even contiguous slice of the allowed CPUs.  Pure: inputs can be injected."""
+    if affinity is None:
+        try:
+            affinity = os.sched_getaffinity(0)
+        except (AttributeError, OSError):
+            affinity = set(range(os.cpu_count() or 1))
+    allowed = sorted(affinity)
+    if world <= 1 or len(allowed) <= 1:
+        return set(allowed)
+
+    def cpus_of(node):
+        if node_cpus is not None:
+            return set(node_cpus.get(node, ()))
+        try:
+            return _parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+        except OSError:
+            return set()
+
+    nodes = [numa_of_gpu(r) for r in range(world)]
+    mine = nodes[local_rank]
+    if mine is not None:
+        pool = sorted(cpus_of(mine) & set(allowed))
+        peers = [r for r in range(world) if nodes[r] == mine]
+        if len(pool) >= len(peers):
+            k, per = peers.index(local_rank), len(pool) // len(peers)
+            return set(pool[k * per:(k + 1) * per])
+    per = max(1, len(allowed) // world)
+    k = local_rank % max(1, len(allowed) // per)
+    return set(allowed[k * per:(k + 1) * per])
+
+
+def pin_rank(local_rank, world):
+    """Apply rank_cpu_set() to this process (BEFORE torch / HIP start their threads: they inherit it).  Returns a
+    record for the JSON line; BK_BENCH_NO_PIN=1 leaves the affinity alone."""
+    if world <= 1 or os.environ.get("BK_BENCH_NO_PIN"):
+        return None
+    try:
+        cpus = rank_cpu_set(local_rank, world)
+        os.sched_setaffinity(0, cpus)
+        return {"cpus": len(cpus), "first_cpu": min(cpus), "numa_node_of_gpu": _gpu_numa_node(local_rank)}
+    except (AttributeError, OSError, ValueError) as e:
+        return {"error": repr(e)}
+
+
+# ---------------------------------------------------------------------------------------------
 # workload builders
 # ---------------------------------------------------------------------------------------------
 def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG3, chain_tile=None, fused=False,
@@ -714,6 +788,7 @@ def run_rank(args):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.only is None:
         cpu = cpu_baseline()  # before the GPU is initialised (worker processes never touch it)
+    pinned = pin_rank(local_rank, world)  # before torch / HIP create their threads
 
     import torch
 
@@ -944,6 +1019,8 @@ def run_rank(args):
         out["secondary"] = run_secondary(ctx, ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"])
     if cpu is not None:
         out["cpu_baseline"] = cpu
+    if pinned is not None:
+        out["rank0_cpu_affinity"] = pinned
     if rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

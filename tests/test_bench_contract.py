@@ -100,3 +100,42 @@ def test_launcher_counts_gpus_without_loading_hip(tmp_path, monkeypatch):
     for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         monkeypatch.delenv(var, raising=False)
     assert bench._visible_gpus() == 2
+
+
+def test_eight_ranks_on_the_cpu_stand_in_reduce_rhat_over_all_chains_and_get_their_own_cpus():
+    """8-GPU readiness without an 8-GPU box: the launcher starts 8 ranks; each pins itself to its
+    share of the allowed CPUs before anything else, runs config 4's algorithm on C chains with global chain ids
+    rank*C.., and the R-hat over all 8 C chains through the process group equals one process holding every chain."""
+    sys.path.insert(0, ROOT)
+    import io
+
+    import bench
+
+    stub = [sys.executable, os.path.join(ROOT, "tests", "bench_rank_stub.py")]
+    buf = io.StringIO()
+    rc = bench.launch_ranks(8, stub + ["cfg4"], {"OMP_NUM_THREADS": "1"}, timeout=600, out=buf)
+    assert rc == 0
+    r = json.loads(buf.getvalue().strip().splitlines()[-1])
+    assert r["n_gpus"] == 8 and r["rhat_over_chains"] == 8 * 6 and r["chain_id0"] == [6 * k for k in range(8)]
+    assert r["rhat_equals_one_process"]
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert r["affinity_disjoint"] and min(r["affinity_sizes"]) >= 1
+
+
+def test_rank_cpu_sets_follow_the_numa_node_of_the_gpu():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    # two sockets of 8 CPUs, GPUs 0-3 on node 0 and 4-7 on node 1, the container allowed 12 of the 16 CPUs
+    node_cpus = {0: range(0, 8), 1: range(8, 16)}
+    allowed = set(range(2, 14))
+    sets = [bench.rank_cpu_set(r, 8, affinity=allowed, numa_of_gpu=lambda i: i // 4, node_cpus=node_cpus) for r in range(8)]
+    assert all(s and s <= allowed for s in sets)
+    assert all(s <= set(node_cpus[r // 4]) for r, s in enumerate(sets))          # on the GPU's own node
+    assert all(not (sets[i] & sets[j]) for i in range(8) for j in range(i))      # nobody shares a CPU
+    # no topology: even slices of what is allowed; one rank: everything
+    flat = [bench.rank_cpu_set(r, 4, affinity=set(range(8)), numa_of_gpu=lambda i: None) for r in range(4)]
+    assert flat == [{0, 1}, {2, 3}, {4, 5}, {6, 7}]
+    assert bench.rank_cpu_set(0, 1, affinity={3, 4}) == {3, 4}
+    # more ranks than CPUs: ranks share, nobody gets an empty set
+    assert all(bench.rank_cpu_set(r, 8, affinity={0, 1}, numa_of_gpu=lambda i: None) for r in range(8))
