@@ -482,8 +482,11 @@ class ManyChainSampler:
 
         pool = list(arrays)
         try:
-            pool += [self._new_state() for _ in range(self.TUNE_PLACEMENT_SPARES)]
-        except torch.cuda.OutOfMemoryError:
+            # spare candidates come straight from the driver (hipMalloc), not from PyTorch's caching allocator: the ones
+            # that are not chosen go back to the driver when they are dropped, with no torch.cuda.empty_cache() -- a
+            # sampler's constructor must not flush the user's allocator
+            pool += [self._new_state(raw=True) for _ in range(self.TUNE_PLACEMENT_SPARES)]
+        except (torch.cuda.OutOfMemoryError, _lib.BkHipError):
             pool = list(arrays)  # no room for spare candidates: permute what there is
         for a in pool:
             a.zero_()  # timing on defined values
@@ -501,8 +504,8 @@ class ManyChainSampler:
             if ms < best_ms:
                 best, best_ms = perm, ms
         chosen = [pool[i] for i in best[:len(arrays)]]
-        del pool
-        torch.cuda.empty_cache()  # hand the spare arrays back to the driver
+        torch.cuda.synchronize()  # (the timing launches are done before any spare is handed back)
+        del pool  # unchosen spares: hipFree; displaced originals: back into PyTorch's cache, like any dropped tensor
         return chosen, {"ms_as_allocated": first_ms, "ms_chosen": best_ms, "assignments_tried": len(candidates)}
 
     @staticmethod
@@ -532,9 +535,14 @@ class ManyChainSampler:
             return max(0, int(env))
         return self.STATE_PAD_COLUMNS if (self._batched and C >= 4096 and (C * 8) % 4096 == 0) else 0
 
-    def _new_state(self):
-        """A [D, C] state array (rows `_state_pad` columns further apart than C)."""
-        t = torch.empty((self._dim, self._C + self._state_pad), dtype=torch.float64, device=self._ops.device)
+    def _new_state(self, raw=False):
+        """A [D, C] state array (rows `_state_pad` columns further apart than C).  raw: memory of its own from the
+        driver instead of PyTorch's caching allocator (_lib.RawDeviceArray)."""
+        shape = (self._dim, self._C + self._state_pad)
+        if raw and self._ops.device.type == "cuda":
+            t = _lib.RawDeviceArray(shape).tensor()
+        else:
+            t = torch.empty(shape, dtype=torch.float64, device=self._ops.device)
         return t[:, :self._C] if self._state_pad else t
 
     def _select(self, mask, th, thp, g=None, gp=None):

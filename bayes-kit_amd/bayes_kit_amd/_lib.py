@@ -169,6 +169,46 @@ def require_gpu() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class RawDeviceArray:
+    """A float64 array in device memory of its own (hipMalloc / hipFree through the HIP runtime PyTorch loaded), outside
+    PyTorch's caching allocator: for scratch whose release must not touch the user's allocator state (no
+    torch.cuda.empty_cache()).  ``tensor()`` is a PyTorch view of it (via __cuda_array_interface__) that keeps this
+    object alive; the memory is freed when the last reference goes."""
+
+    _hip = None
+    live = 0  # arrays currently allocated (tests)
+
+    def __init__(self, shape):
+        if RawDeviceArray._hip is None:
+            RawDeviceArray._hip = ctypes.CDLL("libamdhip64.so")
+        self.shape = tuple(int(x) for x in shape)
+        n = 8
+        for x in self.shape:
+            n *= x
+        p = c_void_p()
+        rc = RawDeviceArray._hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(max(n, 8)))
+        if rc != 0 or not p.value:
+            raise BkHipError(f"hipMalloc of {n} bytes failed: hipError_t {rc}")
+        self._ptr = p.value
+        RawDeviceArray.live += 1
+        self.__cuda_array_interface__ = {"shape": self.shape, "typestr": "<f8", "data": (self._ptr, False), "version": 2,
+                                         "strides": None}
+
+    def tensor(self):
+        t = torch.as_tensor(self, device=torch.device("cuda", torch.cuda.current_device()))
+        t._bk_raw = self  # (belt and braces: the view holds its owner)
+        return t
+
+    def __del__(self):
+        p, self._ptr = getattr(self, "_ptr", None), None
+        if p and RawDeviceArray._hip is not None:
+            RawDeviceArray.live -= 1
+            try:
+                RawDeviceArray._hip.hipFree(c_void_p(p))  # (hipFree waits for work in flight on the device)
+            except Exception:  # interpreter shutdown
+                pass
+
+
 def check(status: int, what: str) -> None:
     if status != 0:
         kind = "argument/layout error" if status < 0 else "hipError_t"

@@ -690,6 +690,35 @@ def test_placement_tuning_is_only_a_choice_of_buffers(ops):
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
 
 
+def test_placement_tuning_leaves_the_users_allocator_alone(ops):
+    """the spare candidates of the placement tuning come from the driver (hipMalloc) and go back
+    to it; PyTorch's caching allocator is not flushed (a block the USER freed stays cached), nothing of the sampler's
+    own scratch is leaked, and the chosen arrays survive the spares."""
+    import gc
+
+    lam = np.logspace(0, 1, 64)
+    mk = lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 3, chains=4096, seed=2, fuse_builtin=False, graph=False,  # noqa: E731
+                            tune_placement=True)
+    mk().sample()   # (first use: code objects, the runtime's own pools)
+    gc.collect()
+    torch.cuda.synchronize()
+    user = torch.empty(64 << 20, dtype=torch.uint8, device=ops.device)   # a user's block ...
+    del user                                                             # ... freed: now cached by PyTorch
+    reserved = torch.cuda.memory_reserved()
+    raw = bk._lib.RawDeviceArray
+    assert raw.live == 0
+    s = mk()
+    assert s.placement["assignments_tried"] == bk.HMCDiag.TUNE_PLACEMENT_TRIALS
+    assert torch.cuda.memory_reserved() >= reserved     # (empty_cache() would have returned the user's block)
+    assert 0 <= raw.live <= bk.HMCDiag.TUNE_PLACEMENT_SPARES  # only the spares that were CHOSEN are still allocated
+    t0, _ = s.sample()
+    t1, _ = s.sample()
+    assert torch.isfinite(t0).all() and torch.isfinite(t1).all()
+    del s, t0, t1
+    gc.collect()
+    assert raw.live == 0    # ... and they go back to the driver with the sampler
+
+
 def test_mala_placement_tuning_is_only_a_choice_of_buffers(ops):
     lam = np.logspace(0, 1, 48)
     a = bk.MALA(bk.DiagGaussian(lam), 0.02, chains=600, seed=5, graph=False, tune_placement=False, two_pass=False)
