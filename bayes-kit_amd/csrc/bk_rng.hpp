@@ -7,8 +7,8 @@
 //     caller-owned SoA table  state[BK_RNG_WORDS][ld]  of u64 (one chain per column);
 //   * double in [0,1): (u64 >> 11) * 2^-53;
 //   * standard normal: NumPy's 256-layer ziggurat with NumPy's own tables
-//     (ziggurat_tables.inc), including the tail branch, which needs glibc's log1p
-//     reproduced exactly (bk_log1p below) for the draws to be bit-identical.
+//     (ziggurat_tables.inc), including the tail branch, which needs the host libm's log1p
+//     reproduced exactly (bk_log1p below: fdlibm's) for the draws to be bit-identical.
 //
 // Everything here is __host__ __device__ so the exact source the GPU runs can also be
 // exercised on the host by the library's bk_host_* self-test hooks (tests only).
@@ -228,9 +228,15 @@ struct Pcg64 {
   }
 };
 
-// ---- glibc 2.35 log1p (sysdeps/ieee754/dbl-64/s_log1p.c) for finite x > -1 -----------
-// fdlibm argument reduction with glibc's split polynomial; every operation individually
-// rounded (the library is built with -ffp-contract=off).  Ported algorithm and constants:
+// ---- log1p for finite x > -1: Sun fdlibm 5.3 `s_log1p.c` ---------------------------------
+// The algorithm, its thresholds and its constants are fdlibm's (the text FreeBSD msun and every libm since descend
+// from): argument reduction 1 + x = 2^k (1 + f) with the correction term c, then log(1 + f) = f - f^2/2 + s (f^2/2 + R(z)),
+// s = f / (2 + f), z = s^2, R a degree-7 polynomial in z with fdlibm's coefficients Lp1..Lp7.  Every operation is
+// individually rounded (the library is built with -ffp-contract=off).  The ONE choice fdlibm leaves open that shows
+// in the last bit is the order in which R's terms are summed: the reference's NumPy evaluates the ziggurat tail with
+// the HOST libm's log1p, and the libm of this image sums R in pairs -- (Lp2 + z Lp3), (Lp4 + z Lp5), (Lp6 + z Lp7),
+// weighted by z^2, z^4, z^6 -- rather than by Horner's rule; that order is used here so that the device returns the
+// host's double, and tests/test_abi.py checks the equality on 20,000 arguments instead of assuming it.
 //   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
 //   Developed at SunPro, a Sun Microsystems, Inc. business.
 //   Permission to use, copy, modify, and distribute this software is freely granted,

@@ -11,9 +11,10 @@ the image's numpy 2.2.6.  Its published algorithms, restated here on Python ints
 * ``normal()``: the 256-layer ziggurat of numpy ``random/src/distributions/distributions.c``
   (``random_standard_normal``), tables extracted from numpy by
   ``tests/golden/make_ziggurat_tables.py``;
-* the ziggurat tail uses libm ``log1p``; ``log1p_glibc`` restates glibc 2.35's
-  ``sysdeps/ieee754/dbl-64/s_log1p.c`` (fdlibm argument reduction, glibc's split
-  polynomial) so the device can reproduce tail draws bit-for-bit without libm.
+* the ziggurat tail uses the host libm's ``log1p``; ``log1p_fdlibm`` restates Sun fdlibm 5.3 ``s_log1p.c`` (argument
+  reduction, thresholds, constants; notice in THIRD_PARTY.md) with the degree-7 polynomial summed in pairs -- the
+  order this image's libm uses, which is what decides the last bit -- so the device can reproduce tail draws
+  bit-for-bit without libm; ``tests/test_oracle_rng.py`` checks it against ``math.log1p``.
 
 ``tests/test_oracle_rng.py`` checks each piece against numpy itself (raw words, doubles,
 normals, final ``bit_generator.state``), so this file is pinned by the dependency's own
@@ -96,8 +97,9 @@ _LP = (
 )
 
 
-def log1p_glibc(x: float) -> float:
-    """glibc 2.35 ``__log1p`` for finite x > -1 (the only inputs the ziggurat produces)."""
+def log1p_fdlibm(x: float) -> float:
+    """fdlibm ``log1p`` (polynomial summed in pairs, as the host libm does) for finite x > -1: the only inputs the
+    ziggurat produces.  Equal to ``math.log1p`` on this image bit for bit (tested)."""
     hx = _hi_word(x)
     ax = hx & 0x7FFFFFFF
     k = 1
