@@ -278,6 +278,226 @@ class CTarget(_BuiltinTarget):
             raise _lib.BkHipError(f"{name} returned {rc}")
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# CTarget.from_source: a density written as a few lines of HIP C++, compiled at construction
+# ---------------------------------------------------------------------------------------------------------------
+_SRC_PRELUDE = r"""
+// Generated by bayes_kit_amd.CTarget.from_source (plugin ABI bk_target_fn / bk_target_fn_n, include/bkhip.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+typedef int64_t i64;
+typedef double bk_dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i64 bk_count(i64 n, const uint32_t* n_dev) {
+  if (!n_dev) return n;
+  const i64 m = (i64)*n_dev;
+  return m < n ? m : n;
+}
+"""
+
+_SRC_ELEMENTWISE = r"""
+// ---- user code: the density is a SUM OVER COORDINATES of bk_term ------------------------------------------------
+//   __device__ void bk_term(double th, i64 d, const double* params, double& term, double& grad)
+//   term = this coordinate's contribution to the log density, grad = d term / d th
+%(user)s
+// -------------------------------------------------------------------------------------------------------------------
+namespace {
+// gradient only (what a leapfrog step asks for): a streaming elementwise kernel, two chains (16 B) per lane
+template <int ROWS, bool NT>
+__global__ __launch_bounds__(256) void k_src_grad_v2(const double* th, double* g, i64 ld, const double* params, i64 C2, i64 D) {
+  const i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x, d0 = (i64)blockIdx.y * ROWS;
+  if (c2 >= C2) return;
+  bk_dvec2 t[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+    if (d0 + i < D) {
+      const bk_dvec2* p = reinterpret_cast<const bk_dvec2*>(th + (d0 + i) * ld + 2 * c2);
+      t[i] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+    if (d0 + i < D) {
+      double term, gx, gy;
+      bk_term(t[i].x, d0 + i, params, term, gx);
+      bk_term(t[i].y, d0 + i, params, term, gy);
+      const bk_dvec2 o = {gx, gy};
+      bk_dvec2* q = reinterpret_cast<bk_dvec2*>(g + (d0 + i) * ld + 2 * c2);
+      if (NT) __builtin_nontemporal_store(o, q);
+      else *q = o;
+    }
+}
+// one chain per lane: odd shapes, unaligned views, and every launch whose chain count lives on the device
+__global__ __launch_bounds__(256) void k_src_grad_s(const double* th, double* g, i64 ld, const double* params, i64 C_host, i64 D,
+                                                    const uint32_t* n_dev) {
+  const i64 C = bk_count(C_host, n_dev);
+  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x, d0 = (i64)blockIdx.y * 4;
+  if (c >= C) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (d0 + i < D) {
+      double term, gr;
+      bk_term(th[(d0 + i) * ld + c], d0 + i, params, term, gr);
+      g[(d0 + i) * ld + c] = gr;
+    }
+}
+// log density (+ gradient): 4 wavefronts per 64 chains, wavefront w sums its contiguous quarter of the coordinates
+// sequentially, the quarters are combined ((p0 + p1) + p2) + p3 -- the library's own order for per-chain sums
+__global__ __launch_bounds__(256) void k_src_logp(const double* th, double* g, double* logp, i64 ld, const double* params,
+                                                  i64 C_host, i64 D, const uint32_t* n_dev) {
+  __shared__ double part[4][64];
+  const i64 C = bk_count(C_host, n_dev);
+  if ((i64)blockIdx.x * 64 >= C) return;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const i64 c = (i64)blockIdx.x * 64 + lane;
+  const i64 Dq = (D + 3) / 4, dlo = w * Dq, dhi = dlo + Dq < D ? dlo + Dq : D;
+  double s = 0.0;
+  if (c < C)
+    for (i64 d0 = dlo; d0 < dhi; d0 += 8) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (d0 + u < dhi) t[u] = th[(d0 + u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (d0 + u < dhi) {
+          double term, gr;
+          bk_term(t[u], d0 + u, params, term, gr);
+          s = s + term;
+          if (g) g[(d0 + u) * ld + c] = gr;
+        }
+    }
+  part[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < C) logp[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
+           void* stream) {
+  if (!th || (!g && !logp) || C < 0 || D < 0 || ld < C) return -1;
+  if (C == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double* p = static_cast<const double*>(params);
+  if (logp) {
+    k_src_logp<<<dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s>>>(th, g, logp, ld, p, C, D, n_dev);
+  } else if (D > 0) {
+    const bool vec = !n_dev && C %% 2 == 0 && ld %% 2 == 0 && (((uintptr_t)th | (uintptr_t)g) & 15u) == 0;
+    if (vec && 2 * C * D * 8 > ((i64)192 << 20) && D <= 65535)  // streams well past the Infinity Cache: one row per thread, non-temporal
+      k_src_grad_v2<1, true><<<dim3((unsigned)((C / 2 + 255) / 256), (unsigned)D), dim3(256), 0, s>>>(th, g, ld, p, C / 2, D);
+    else if (vec)
+      k_src_grad_v2<2, false><<<dim3((unsigned)((C / 2 + 255) / 256), (unsigned)((D + 1) / 2)), dim3(256), 0, s>>>(th, g, ld, p, C / 2, D);
+    else
+      k_src_grad_s<<<dim3((unsigned)((C + 255) / 256), (unsigned)((D + 3) / 4)), dim3(256), 0, s>>>(th, g, ld, p, C, D, n_dev);
+  }
+  return (int)hipGetLastError();
+}
+}  // namespace
+"""
+
+_SRC_CHAIN = r"""
+// Accessors handed to the user's function: th[d] reads coordinate d of this lane's chain, g.set(d, v) writes its gradient
+struct BkTheta {
+  const double* p; i64 ld;
+  __device__ __forceinline__ double operator[](i64 d) const { return p[d * ld]; }
+};
+struct BkGrad {
+  double* p; i64 ld;
+  __device__ __forceinline__ void set(i64 d, double v) const { if (p) p[d * ld] = v; }
+  __device__ __forceinline__ bool wanted() const { return p != nullptr; }
+};
+// ---- user code: ONE CHAIN per call ----------------------------------------------------------------------------------
+//   __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)
+//   returns the log density; writes the gradient with g.set(d, value) (a no-op when none is wanted)
+%(user)s
+// -------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, double* logp, i64 ld, const double* params,
+                                                  i64 C_host, i64 D, const uint32_t* n_dev) {
+  const i64 C = bk_count(C_host, n_dev);
+  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const BkTheta t = {th + c, ld};
+  const BkGrad gr = {g ? g + c : nullptr, ld};
+  const double lp = bk_chain(t, gr, D, params);
+  if (logp) logp[c] = lp;
+}
+int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
+           void* stream) {
+  if (!th || (!g && !logp) || C < 0 || D < 0 || ld < C) return -1;
+  if (C == 0) return 0;
+  k_src_chain<<<dim3((unsigned)((C + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+      th, g, logp, ld, static_cast<const double*>(params), C, D, n_dev);
+  return (int)hipGetLastError();
+}
+}  // namespace
+"""
+
+_SRC_EXPORTS = r"""
+extern "C" int bk_src_target(const double* theta, double* grad, double* logp, int64_t ld, const void* params, int64_t C,
+                             int64_t D, void* stream) {
+  return launch(theta, grad, logp, ld, params, C, D, nullptr, stream);
+}
+extern "C" int bk_src_target_n(const double* theta, double* grad, double* logp, int64_t ld, const void* params, int64_t C,
+                               int64_t D, const uint32_t* n_dev, void* stream) {
+  if (!n_dev) return -1;
+  return launch(theta, grad, logp, ld, params, C, D, n_dev, stream);
+}
+"""
+
+
+def _compile_source_target(user_source: str, form: str, contract: bool) -> str:
+    """hipcc the generated translation unit into a shared library (cached by content); returns its path."""
+    import hashlib
+    import os
+    import subprocess
+    import tempfile
+
+    if form not in ("elementwise", "chain"):
+        raise ValueError("form must be 'elementwise' (bk_term: one coordinate's term and derivative) or 'chain' "
+                         "(bk_chain: one chain's log density and gradient)")
+    body = (_SRC_ELEMENTWISE if form == "elementwise" else _SRC_CHAIN) % {"user": user_source}
+    text = _SRC_PRELUDE + body + _SRC_EXPORTS
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
+             "-ffp-contract=" + ("fast" if contract else "off")]
+    tag = hashlib.sha256((text + " ".join(flags)).encode()).hexdigest()[:20]
+    root = os.environ.get("BK_SOURCE_TARGET_DIR") or os.path.join(tempfile.gettempdir(), f"bayes_kit_amd_src_{os.getuid()}")
+    os.makedirs(root, exist_ok=True)
+    src, lib = os.path.join(root, f"t_{tag}.hip"), os.path.join(root, f"libt_{tag}.so")
+    if not os.path.exists(lib):
+        with open(src, "w") as f:
+            f.write(text)
+        hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), "hipcc")
+        tmp = lib + f".{os.getpid()}.tmp"
+        r = subprocess.run([hipcc] + flags + [src, "-o", tmp], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise _lib.BkHipError("CTarget.from_source: hipcc failed\n" + r.stderr[-4000:])
+        os.replace(tmp, lib)  # (atomic: several ranks may compile the same source at once)
+    return lib
+
+
+def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "elementwise", contract: bool = False,
+                         ops=None):
+    """A device model from a few lines of HIP C++, compiled with hipcc when the object is built (cached by content
+    under the temporary directory; BK_SOURCE_TARGET_DIR overrides) into the plugin ABI -- both forms, so every
+    sampler, DrGhmcDiag's device-side lane counts and hipGraph replay included, treats it like a built-in target:
+    the gradient call goes from the sampler straight to the compiled launch, no PyTorch ops, no build to write.
+
+    form="elementwise": the log density is a sum over coordinates; ``source`` defines
+        ``__device__ void bk_term(double th, i64 d, const double* params, double& term, double& grad)``
+    and the library supplies the kernels (a streaming 16-byte-per-lane gradient kernel, per-chain sums in the
+    library's own order).  form="chain": any density; ``source`` defines
+        ``__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)``
+    called by one lane per chain (``th[d]``, ``g.set(d, v)``).  ``params``: a float64 device tensor (or None).
+    contract=False compiles with -ffp-contract=off (every product and sum rounded, as NumPy does)."""
+    lib = _compile_source_target(source, form, contract)
+    if params is not None and not (isinstance(params, torch.Tensor) and params.dtype == torch.float64):
+        raise TypeError("params must be a float64 torch tensor (device memory the compiled function reads) or None")
+    t = cls(lib, "bk_src_target", dims, params=params, ops=ops, counted_symbol="bk_src_target_n")
+    t.source_library = lib
+    return t
+
+
+CTarget.from_source = classmethod(_ctarget_from_source)
+
+
 class TorchModel:
     """Any differentiable PyTorch log density, batched over chains.
 

@@ -678,6 +678,29 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
                             "steps_per_sec": C * ctx.world * L / per_dc,
                             "path_hbm_frac_56D_model": C * L / per_dc * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
                             "accept_rate": s.accept_rate()}
+    del s
+    # the same density as six lines of HIP C++ handed to CTarget.from_source: compiled with hipcc at construction into
+    # the plugin ABI (bk_target_fn / bk_target_fn_n) -- what a Python user reaches without writing a build
+    try:
+        src = ("__device__ __forceinline__ void bk_term(double th, i64 d, const double* lam, double& term, double& grad) {\n"
+               "  const double t = lam[d] * th;\n  term = -0.5 * (th * t);\n  grad = -t;\n}\n")
+        t0 = time.perf_counter()
+        model = bk.CTarget.from_source(src, D, params=lam)
+        build_s = time.perf_counter() - t0
+        s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
+                       metric_diag=torch.ones(D, dtype=torch.float64))
+        s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
+        for _ in range(warmup + 1):
+            s.sample()
+        n = max(draws, 5)
+        per_src = ctx.timed_loop(s.sample, n) / n
+        out["compiled_source"] = {"what": "CTarget.from_source(<6 lines of HIP C++>, form='elementwise'): hipcc at construction, "
+                                          "plugin ABI, streaming 16-byte-per-lane gradient kernel",
+                                  "ms_per_draw": 1e3 * per_src, "steps_per_sec": C * ctx.world * L / per_src,
+                                  "path_hbm_frac_56D_model": C * L / per_src * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
+                                  "accept_rate": s.accept_rate(), "construction_s_incl_hipcc_or_cache": build_s}
+    except Exception as e:  # context only
+        out["compiled_source"] = {"error": repr(e)}
     return out
 
 

@@ -161,3 +161,32 @@ def test_fft_plan_of_the_reference_call_shape_is_not_padded_to_a_wide_batch():
         assert lib.bk_autocorr_fft_work_bytes(N, C) <= 2 * size * cp * 16 + size * 16 + (1 << 20), (N, C)
     # wide batches keep their rows off the power-of-two pitch
     assert lib.bk_autocorr_fft_work_bytes(16384, 4096) > 2 * 32768 * 2048 * 16
+
+
+def test_source_targets_compile_without_a_gpu_and_export_both_plugin_forms(tmp_path, monkeypatch):
+    """CTarget.from_source: the generated translation unit cross-compiles with hipcc (no GPU needed) and exports the
+    host-sized and the counted plugin entry points; argument validation happens before any launch."""
+    import ctypes
+
+    from bayes_kit_amd import targets
+
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(tmp_path))
+    elem = "__device__ void bk_term(double th, i64 d, const double* p, double& term, double& grad) { term = -0.5 * th * th; grad = -th; }"
+    chain = ("__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* p) {"
+             " double s = 0.0; for (i64 d = 0; d < D; ++d) { s = s + th[d] * th[d]; g.set(d, -th[d]); } return -0.5 * s; }")
+    for form, src in (("elementwise", elem), ("chain", chain)):
+        path = targets._compile_source_target(src, form, False)
+        assert path.startswith(str(tmp_path)) and targets._compile_source_target(src, form, False) == path  # cached by content
+        lib = ctypes.CDLL(path)
+        for name, extra in (("bk_src_target", 0), ("bk_src_target_n", 1)):
+            fn = getattr(lib, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + [
+                ctypes.c_void_p] * (1 + extra)
+            assert fn(*([None, None, None, 0, None, 1, 1] + [None] * (1 + extra))) == -1
+    import pytest
+
+    with pytest.raises(ValueError):
+        targets._compile_source_target(elem, "rowwise", False)
+    with pytest.raises(targets._lib.BkHipError):
+        targets._compile_source_target("not C++", "elementwise", False)
