@@ -62,6 +62,7 @@ SIGNATURES = {
     "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P, P],
     "bk_normals_chain_major_bg": [c_int, P, I, P, I, I, I, P, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
+    "bk_mala_single_draw": [c_int, P, I, P, P, P, P, P, P, P, I, P, P, F, F, I, c_int, F, P],
     "bk_mala_step_supported": [I, I, I],
     "bk_mala_step": [P, P, P, P, P, I, P, P, P, P, I, F, F, P, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],

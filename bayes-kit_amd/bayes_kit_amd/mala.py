@@ -37,10 +37,12 @@ class MALA(ManyChainSampler):
     # 1.39 -> 1.27 ms per draw with the rows 1,152 bytes further apart (1.57 -> 1.38 on a box whose allocations sit
     # worse; pads 48..400 columns within 2 % of each other, 0 / 8 / 32 / 528 are the bad ones).
     STATE_PAD_COLUMNS = 144
+    SINGLE_LAUNCH_MAX_DIMS = 4096  # (one lane walks the coordinates: the single-chain mode is for small models)
 
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
                  chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None,
-                 tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None, ops=None):
+                 tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None,
+                 single_launch: Optional[bool] = None, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph, prefetch_rng)
@@ -100,6 +102,24 @@ class MALA(ManyChainSampler):
         self._cur_slot = 0         # slot whose unit the last draw consumed
         if self._two_pass:
             self._snap = [torch.empty_like(self._rng_state) for _ in range(nbuf)]
+        # ONE chain driven by a reference-style host model (the README example, config 1): after the model call a draw is
+        # ONE launch (bk_mala_single_draw: proposal densities, accept test, select AND the next draw's proposal), the
+        # model's outputs go in and the draw comes out through pinned host memory the device addresses directly, and
+        # the host waits on a sequence word instead of synchronising the stream: 1 launch + 1 model call per draw
+        # (the step-by-step path: 6 launches, 2 device-to-host and 1 host-to-device copies, 121 us per draw).
+        can_single = (not self._batched) and dev.type == "cuda" and D <= self.SINGLE_LAUNCH_MAX_DIMS
+        if single_launch and not can_single:
+            raise ValueError("single_launch=True needs a single-chain host model on a GPU and at most "
+                             f"{self.SINGLE_LAUNCH_MAX_DIMS} dimensions")
+        self._single = can_single if single_launch is None else bool(single_launch)
+        if self._single:
+            self.path = "single chain, one launch per draw (bk_mala_single_draw)"
+            self._h_in = torch.zeros(D + 1, dtype=torch.float64).pin_memory()
+            self._h_out = torch.zeros(2 * D + 3, dtype=torch.float64).pin_memory()
+            self._h_in_np, self._h_out_np = self._h_in.numpy(), self._h_out.numpy()
+            self._snap1 = self._rng_state.clone()  # (a generator's store() leaves the key words alone)
+            self._seq = 0.0
+            self._single_fn = self._ops.lib.bk_mala_single_draw
         self.placement = None
         if self._wants_placement_tuning(tune_placement) and not self._two_pass:
             self._tune_placement()
@@ -114,7 +134,7 @@ class MALA(ManyChainSampler):
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
     def _invalidate_pipe(self, restore_stream):
-        if self._two_pass and self._pipe_valid and restore_stream:
+        if (self._two_pass or getattr(self, "_single", False)) and self._pipe_valid and restore_stream:
             self._rng_state.copy_(self._logical_rng())  # un-consume what was generated ahead
         self._pipe_valid, self._unit_ready, self._pf_event = False, False, None
         self._drop_graphs()
@@ -146,6 +166,11 @@ class MALA(ManyChainSampler):
         return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
 
     def _logical_rng(self):
+        if getattr(self, "_single", False):
+            if not self._pipe_valid:
+                return self._rng_state
+            torch.cuda.synchronize()
+            return self._snap1  # (the next draw's normals are already consumed: the position after this draw's uniform)
         if self._two_pass:
             if not self._pipe_valid:
                 return self._rng_state
@@ -272,7 +297,42 @@ class MALA(ManyChainSampler):
     def _graph_key(self):
         return float(self._epsilon)
 
+    # -- one chain, one launch per draw ---------------------------------------------------------------------------
+    def _launch_single(self, have_prop):
+        self._seq += 1.0
+        eps = float(self._epsilon)
+        rc = self._single_fn(self._rng_kind, self._rng_state.data_ptr(), self._rng_state.stride(0),
+                             self._theta_dc.data_ptr(), self._grad.data_ptr(), self._lp.data_ptr(), self._theta_p.data_ptr(),
+                             self._h_in.data_ptr(), self._h_out.data_ptr(), self._snap1.data_ptr(), self._snap1.stride(0),
+                             self._mask.data_ptr(), self._accepted.data_ptr(), eps, math.sqrt(2 * eps), self._dim,
+                             int(have_prop), self._seq, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "bk_mala_single_draw")
+        # wait for the launch's last store (the sequence word, released at system scope behind everything else)
+        flag, i, want = self._h_out_np, 2 * self._dim + 2, self._seq
+        for _ in range(200000):
+            if flag[i] == want:
+                return
+        torch.cuda.current_stream().synchronize()  # (a slow box, or an error that the synchronisation reports)
+        if flag[i] != want:
+            raise _lib.BkHipError("bk_mala_single_draw did not complete")
+
+    def _sample_single(self):
+        D = self._dim
+        if not self._pipe_valid:
+            self._launch_single(0)  # this draw's proposal from the stream's next D normals (mala.py:41-45)
+            self._pipe_valid = True
+        hin, hout = self._h_in_np, self._h_out_np
+        self._grad_calls += 1
+        lp, g = self._model.log_density_gradient(np.array(hout[D + 2:2 * D + 2]))             # mala.py:46-48
+        hin[1:] = np.broadcast_to(np.asarray(g, dtype=np.float64), (D,))  # array-likes allowed (mala.py:32)
+        hin[0] = float(lp)
+        self._launch_single(1)                                                                 # mala.py:50-66, then :41-45
+        self._draws += 1
+        return np.array(hout[:D]), np.float64(hout[D])
+
     def sample(self):
+        if self._single:
+            return self._sample_single()
         self._run_draw(self._draw2 if self._two_pass else self._draw)
         self._join_side_stream()
         self._draws += 1

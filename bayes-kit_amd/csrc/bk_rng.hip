@@ -583,11 +583,100 @@ __global__ __launch_bounds__(256) void k_mala_propose_zt(const double* th, const
   }
 }
 
+// ---- ONE chain, ONE launch per MALA draw (the reference's own call shape: README.md:13-32) -----------------------
+// A single chain driven by a host model cannot hide anything: its draw is a chain of small launches and copies
+// (proposal, D2H, model call, H2D, proposal densities, accept test, select, D2H: 121 us).  Here the part of a draw
+// that follows the model call -- proposal densities (mala.py:50-53, :68-79), accept test (metropolis.py:70-76), select
+// (mala.py:62-64) -- and the NEXT draw's proposal (mala.py:41-45) are one launch of one lane; the model's outputs
+// arrive in, and the draw and the next proposal leave through, host memory the device can address (pinned, mapped),
+// and `seq` is written last so that the host can wait on it: 1 launch + 1 model call per draw.
+// Stream order: this draw's uniform, then the next draw's D normals -- the reference's order; the table as it
+// stands after the uniform (where the reference's generator stands between two sample() calls) goes to `snapshot`.
+// Per-chain sums in the order of bk_mala_logq (four contiguous quarters, ((p0+p1)+p2)+p3).
+template <typename G>
+__global__ __launch_bounds__(64) void k_mala_single(uint64_t* st, i64 ldr, double* theta, double* grad, double* lp,
+                                                    double* theta_prop, const double* host_in, double* host_out,
+                                                    uint64_t* snapshot, i64 lds, uint8_t* mask, uint32_t* count,
+                                                    double eps, double s2, i64 D, int have_prop, double seq) {
+  __shared__ ZigLds tab;
+  load_tables(tab);
+  if (threadIdx.x != 0) return;
+  G g;
+  g.load(st, ldr, (i64)0);
+  if (have_prop) {
+    const double lp_p = host_in[0];
+    const double* grad_p = host_in + 1;
+    const i64 Dq = (D + 3) / 4;
+    double pf[4] = {0.0, 0.0, 0.0, 0.0}, pr[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < 4; ++q) {
+      const i64 dlo = q * Dq, dhi = dlo + Dq < D ? dlo + Dq : D;
+      double sf = 0.0, sr = 0.0;
+      for (i64 d = dlo; d < dhi; ++d) {
+        const double a = theta[d], b = grad[d], p = theta_prop[d], qg = grad_p[d];
+        const double xf = (p - a) - eps * b;  // mala.py:78
+        const double xr = (a - p) - eps * qg;
+        sf = sf + xf * xf;
+        sr = sr + xr * xr;
+      }
+      pf[q] = sf;
+      pr[q] = sr;
+    }
+    const double k = -0.25 / eps;  // mala.py:79
+    const double fwd = k * (((pf[0] + pf[1]) + pf[2]) + pf[3]), rev = k * (((pr[0] + pr[1]) + pr[2]) + pr[3]);
+    const double lu = log(bk::next_double(g));                     // metropolis.py:74
+    const double l0 = lp[0];
+    const bool acc = lu < (lp_p - l0) + (rev - fwd);               // metropolis.py:70-76 (strict <)
+    if (acc) {
+      for (i64 d = 0; d < D; ++d) {                                // mala.py:62-64
+        theta[d] = theta_prop[d];
+        grad[d] = grad_p[d];
+      }
+      lp[0] = lp_p;
+      if (count) atomicAdd(count, 1u);
+    }
+    if (mask) mask[0] = acc ? 1 : 0;
+    host_out[D] = acc ? lp_p : l0;                                 // mala.py:66
+    host_out[D + 1] = acc ? 1.0 : 0.0;
+    for (i64 d = 0; d < D; ++d) host_out[d] = theta[d];
+  }
+  if (snapshot) g.store(snapshot, lds, (i64)0);   // the logical stream position between two sample() calls
+  for (i64 d = 0; d < D; ++d) {                                    // the next draw's proposal, mala.py:41-45
+    const double z = bk::next_normal(g, tab.ki, tab.wi, tab.fi);
+    const double p = (theta[d] + eps * grad[d]) + s2 * z;
+    theta_prop[d] = p;
+    host_out[D + 2 + d] = p;
+  }
+  g.store(st, ldr, (i64)0);
+  __threadfence_system();
+  *reinterpret_cast<volatile double*>(host_out + 2 * D + 2) = seq;  // last: the host waits for this
+}
+
 }  // namespace
 
 extern "C" {
 
 int bk_version(void) { return 100; }
+
+int bk_mala_single_draw(int rng_kind, uint64_t* state, int64_t ldr, double* theta, double* grad, double* lp,
+                        double* theta_prop, const double* host_in, double* host_out, uint64_t* snapshot,
+                        int64_t lds, uint8_t* accept_mask, uint32_t* accept_count, double eps, double sqrt2eps,
+                        int64_t D, int have_prop, double seq, void* stream) {
+  if (!state || !theta || !grad || !lp || !theta_prop || !host_out || (have_prop && !host_in) || D < 0 || ldr < 1 ||
+      (snapshot && lds < 1))
+    return BK_E_ARG;
+  hipStream_t s = bk_stream(stream);
+  if (rng_kind == BK_RNG_PHILOX)
+    k_mala_single<bk::Philox><<<dim3(1), dim3(64), 0, s>>>(state, ldr, theta, grad, lp, theta_prop, host_in, host_out,
+                                                          snapshot, lds, accept_mask, accept_count, eps, sqrt2eps, D,
+                                                          have_prop, seq);
+  else if (rng_kind == BK_RNG_PCG64)
+    k_mala_single<bk::Pcg64><<<dim3(1), dim3(64), 0, s>>>(state, ldr, theta, grad, lp, theta_prop, host_in, host_out,
+                                                         snapshot, lds, accept_mask, accept_count, eps, sqrt2eps, D,
+                                                         have_prop, seq);
+  else
+    return BK_E_ARG;
+  BK_RETURN_LAUNCH_STATUS();
+}
 
 int bk_rng_init_philox(uint64_t* state, int64_t ldr, uint64_t key0, uint64_t chain_id0, int64_t C,
                        void* stream) {

@@ -347,6 +347,23 @@ int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* z
 int bk_normals_chain_major_bg(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
                               int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream);
 
+/* ONE chain driven by a host model (the reference's own call shape, README.md:13-32; mala.py:40-66): everything of a
+ * draw that follows the model call, and the next draw's proposal, in ONE launch of one lane.
+ *   have_prop != 0: host_in[0] = log density at theta_prop, host_in[1 .. D] = its gradient (written by the caller
+ *     into host memory the device can address: pinned + mapped); proposal densities as bk_mala_logq, accept test
+ *     as bk_mh_accept(BK_ACCEPT_MALA) with the next uniform of the chain's stream, select into theta / grad / lp
+ *     (device, [D], [D], [1]); host_out[0 .. D) = theta after the draw, host_out[D] = the returned log density
+ *     (mala.py:66), host_out[D + 1] = 1.0 / 0.0 accepted.
+ *   always: snapshot (may be NULL; a table like state) = the stream table at this point -- where the reference's
+ *     generator stands between two sample() calls --; then theta_prop = (theta + eps*grad) + sqrt2eps*z from the next
+ *     D normals (mala.py:41-45), also to host_out[D + 2 .. 2D + 2); finally host_out[2D + 2] = seq, written last
+ *     (system-scope release) so that the host may wait on it instead of synchronising the stream.
+ * state: the table of ONE chain (column 0 of a table with row pitch ldr). */
+int bk_mala_single_draw(int rng_kind, uint64_t* state, int64_t ldr, double* theta, double* grad, double* lp,
+                        double* theta_prop, const double* host_in, double* host_out, uint64_t* snapshot,
+                        int64_t lds, uint8_t* accept_mask, uint32_t* accept_count, double eps, double sqrt2eps,
+                        int64_t D, int have_prop, double seq, void* stream);
+
 /* lp_forward[c] = (-0.25/eps) * |(theta_prop - theta) - eps*grad|^2       mala.py:50-52
  * lp_reverse[c] = (-0.25/eps) * |(theta - theta_prop) - eps*grad_prop|^2   mala.py:53,68-79 */
 int bk_mala_logq(const double* theta, const double* grad, const double* theta_prop,

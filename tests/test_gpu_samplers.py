@@ -1298,3 +1298,69 @@ def test_annealed_smc_on_the_logistic_target_against_a_long_hmc_run(ops):
     z = (m_smc - m_hmc) / (mcse_hmc ** 2 + mcse_smc ** 2) ** 0.5
     assert float(z.abs().max().item()) < 4.0, z
     assert float((v_smc.sqrt() / v_hmc.sqrt() - 1.0).abs().max().item()) < 0.15
+
+
+def test_single_chain_one_launch_per_draw_equals_the_step_by_step_path(ops):
+    """the single-chain drop-in (a reference-style NumPy model, the README example) with ONE launch
+    per MALA draw (bk_mala_single_draw: proposal densities, accept test, select and the next proposal; model outputs
+    and draws through pinned, device-addressable host memory) against the step-by-step launches: same draws, same
+    returned log densities, same accept flags, same stream position after every draw -- PCG64 (an int seed: the
+    reference's own stream) and Philox, D = 1 and D = 37; one model call per draw + one at construction."""
+    class StdNormal:  # README.md:17-23
+        def dims(self):
+            return 1
+
+        def log_density(self, theta):
+            return -0.5 * theta[0] * theta[0]
+
+        def log_density_gradient(self, theta):
+            return -0.5 * theta[0] * theta[0], -theta
+
+    class Gauss:
+        def __init__(self, lam):
+            self.lam, self.calls = np.asarray(lam, dtype=np.float64), 0
+
+        def dims(self):
+            return self.lam.shape[0]
+
+        def log_density(self, th):
+            return float(-0.5 * np.dot(th, self.lam * th))
+
+        def log_density_gradient(self, th):
+            self.calls += 1
+            return float(-0.5 * np.dot(th, self.lam * th)), -(self.lam * th)
+
+    for make, eps, seed in ((lambda: StdNormal(), 0.2, 12345), (lambda: Gauss(np.linspace(0.5, 4.0, 37)), 0.05, np.random.Philox(key=[7, 3])),
+                            (lambda: Gauss([2.0]), 0.3, 99)):
+        mk_seed = (lambda: np.random.Philox(key=[7, 3])) if not isinstance(seed, int) else (lambda: seed)
+        ma, mb = make(), make()
+        a = bk.MALA(ma, eps, seed=mk_seed(), single_launch=False)
+        b = bk.MALA(mb, eps, seed=mk_seed())
+        assert b._single and not a._single and "one launch" in b.path
+        for n in range(60):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert np.array_equal(ta, tb) and la == lb and type(lb) is np.float64, n
+            assert a.last_accept == b.last_accept
+            if n % 17 == 0:
+                np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+                assert np.array_equal(a._theta, b._theta) and a._log_p_theta == b._log_p_theta
+        np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+        assert abs(a.accept_rate() - b.accept_rate()) < 1e-12
+        if hasattr(mb, "calls"):
+            assert mb.calls == 60 + 1   # mala.py:31 once, :46 once per draw
+        # checkpoint in the middle of the pipeline (a proposal is pending), restore into a fresh sampler, go on
+        sd = b.state_dict()
+        c = bk.MALA(make(), eps, seed=mk_seed())
+        c.load_state_dict(sd)
+        for n in range(10):
+            tb, lb = b.sample()
+            tc, lc = c.sample()
+            assert np.array_equal(tb, tc) and lb == lc, n
+        # refresh_cache() discards the pending proposal and draws its normals again: the stream does not move
+        before = b.rng_state().copy()
+        b.refresh_cache()
+        np.testing.assert_array_equal(b.rng_state(), before)
+        tb, _ = b.sample()
+        tc, _ = c.sample()
+        assert np.array_equal(tb, tc)
