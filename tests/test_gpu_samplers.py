@@ -706,17 +706,18 @@ def test_placement_tuning_leaves_the_users_allocator_alone(ops):
     del user                                                             # ... freed: now cached by PyTorch
     reserved = torch.cuda.memory_reserved()
     raw = bk._lib.RawDeviceArray
-    assert raw.live == 0
+    gc.collect()
+    base = raw.live          # (samplers of earlier tests that are still referenced somewhere keep theirs)
     s = mk()
     assert s.placement["assignments_tried"] == bk.HMCDiag.TUNE_PLACEMENT_TRIALS
     assert torch.cuda.memory_reserved() >= reserved     # (empty_cache() would have returned the user's block)
-    assert 0 <= raw.live <= bk.HMCDiag.TUNE_PLACEMENT_SPARES  # only the spares that were CHOSEN are still allocated
+    assert 0 <= raw.live - base <= bk.HMCDiag.TUNE_PLACEMENT_SPARES  # only the spares that were CHOSEN are still allocated
     t0, _ = s.sample()
     t1, _ = s.sample()
     assert torch.isfinite(t0).all() and torch.isfinite(t1).all()
     del s, t0, t1
     gc.collect()
-    assert raw.live == 0    # ... and they go back to the driver with the sampler
+    assert raw.live == base    # ... and they go back to the driver with the sampler
 
 
 def test_mala_placement_tuning_is_only_a_choice_of_buffers(ops):
