@@ -147,6 +147,16 @@ class HMCDiag(ManyChainSampler):
             self._tune_placement()
 
     def _install_metric_dense(self, metric_dense):
+        if isinstance(metric_dense, torch.Tensor) and metric_dense.dim() == 1 and self._M is not None:
+            # a DIAGONAL metric given by its entries (the SMC's per-temperature adaptation): factor and inverse are
+            # elementwise, formed on the device -- no host round trip, no Cholesky of a D x D matrix
+            v = metric_dense.to(device=self._ops.device, dtype=torch.float64)
+            if v.shape[0] != self._dim:
+                raise ValueError(f"a diagonal metric needs {self._dim} entries")
+            self._M.copy_(torch.diag(v))
+            self._M_chol.copy_(torch.diag(torch.sqrt(v)))
+            self._M_inv.copy_(torch.diag(1.0 / v))
+            return
         Mt = torch.as_tensor(metric_dense, dtype=torch.float64).cpu()
         if tuple(Mt.shape) != (self._dim, self._dim):
             raise ValueError(f"metric_dense must be ({self._dim}, {self._dim})")
@@ -164,7 +174,7 @@ class HMCDiag(ManyChainSampler):
 
     def set_metric_dense(self, metric_dense):
         """Replace the dense metric of a sampler that was built with one (an adaptation between draws: e.g. the
-        tempered SMC re-estimates it from its particles at every temperature).  Momenta generated ahead with the old
+        tempered SMC re-estimates it from its particles at every temperature); a 1-D tensor = the entries of a diagonal one.  Momenta generated ahead with the old
         metric (prefetch_rng) are discarded: build such samplers with prefetch_rng=False to keep the stream order."""
         if self._M is None:
             raise ValueError("this sampler was built without metric_dense")

@@ -88,6 +88,8 @@ class _TemperedTarget:
     def __init__(self, model):
         self._model, self.t = model, 1.0
         self.ll_last = None
+        self.gll_last = None   # the likelihood's gradient at the points of the last evaluation that formed a log density
+        self.track_gradient = hasattr(model, "bk_retemper")
         if hasattr(model, "bk_eval") and hasattr(model, "log_density_gradient_tempered") and hasattr(model, "log_likelihood"):
             self.bk_eval = self._bk_eval
 
@@ -101,10 +103,18 @@ class _TemperedTarget:
         return self._model.log_density_gradient_tempered(Theta, self.t)
 
     def _bk_eval(self, theta_dc, grad_out, logp_out):
-        ll = None
+        ll = gll = None
         if logp_out is not None:
             ll = torch.empty(theta_dc.shape[1], dtype=torch.float64, device=theta_dc.device)
-        self._model.bk_eval(theta_dc, grad_out, logp_out, self.t, ll)
+            if self.track_gradient and grad_out is not None:
+                if self.gll_last is None or self.gll_last.shape != theta_dc.shape or self.gll_last.stride() != theta_dc.stride():
+                    self.gll_last = torch.empty_strided(theta_dc.shape, theta_dc.stride(), dtype=torch.float64,
+                                                        device=theta_dc.device)
+                gll = self.gll_last
+        if gll is not None:
+            self._model.bk_eval(theta_dc, grad_out, logp_out, self.t, ll, gll)
+        else:
+            self._model.bk_eval(theta_dc, grad_out, logp_out, self.t, ll)
         if ll is not None:
             self.ll_last = ll
 
@@ -125,6 +135,7 @@ class _HMCKernel:
         self._hmc = None
         self._target = None
         self._ll = None
+        self._ll_cur, self._gll, self._parts_ok = None, None, False   # untempered (loglik, its gradient) of the particles
         self.accept_rates = []
 
     def _particle_variance(self, smc):
@@ -158,23 +169,45 @@ class _HMCKernel:
                                 prefetch_rng=False if self.adapt_metric else None)
         h = self._hmc
         if self.adapt_metric and h._M is not None:
-            h.set_metric_dense(torch.diag(self._particle_variance(smc)).cpu())
+            h.set_metric_dense(self._particle_variance(smc))   # (1-D: a diagonal metric, installed on the device)
         self._target.t = float(t)
         h._theta_dc.copy_(smc._theta_dc)
         track = hasattr(self._target, "bk_eval")
-        # new temperature, new positions: (logp, grad) of the current points are evaluated afresh
-        h._materialize(h._eval_grad(h._theta_dc, h._grad, h._lp), h._grad)
+        tg = track and self._target.track_gradient
+        if tg and self._parts_ok:
+            # new temperature, same points (resampled: the tracked parts were gathered with them): the tempered log
+            # density and gradient follow from the UNTEMPERED parts kept from the last evaluation -- no pass over the data
+            smc._model.bk_retemper(h._theta_dc, self._gll, self._ll_cur, t, h._grad, h._lp)
+            ll = self._ll_cur
+        else:
+            # (logp, grad) of the current points evaluated afresh
+            h._materialize(h._eval_grad(h._theta_dc, h._grad, h._lp), h._grad)
+            ll = self._target.ll_last if track else None
+            if tg:
+                self._gll = self._target.gll_last.clone()
         h._have_cache = True
-        ll = self._target.ll_last if track else None
         acc0 = int(h._accepted.item()) if hasattr(h, "_accepted") else 0
         for _ in range(self.draws):
             h._run_draw(h._draw)
             h._draws += 1
             if track and self.steps > 0:
                 ll = torch.where(h._mask.bool(), self._target.ll_last, ll)   # accepted particles: the end point's
+                if tg:
+                    smc._ops.select_columns(h._mask, self._gll, self._target.gll_last)
         self.accept_rates.append((int(h._accepted.item()) - acc0) / max(1, self.draws * smc.M))
         self._ll = ll
+        self._ll_cur, self._parts_ok = ll, False   # (valid again once the resampling has been applied to them)
         smc._theta_dc.copy_(h._theta_dc)
+
+    def resampled(self, smc, idx):
+        """The SMC has replaced particle m by particle idx[m] (single rank): the tracked parts follow."""
+        if self._gll is None or self._ll_cur is None:
+            return
+        new = torch.empty_like(self._gll)
+        smc._ops.gather_columns(idx, self._gll, new)
+        self._gll = new
+        self._ll_cur = self._ll_cur[idx.to(torch.int64)].contiguous()
+        self._parts_ok = True
 
     def loglik(self, smc):
         """Untempered log likelihood of the particles as the move left them (None: not tracked)."""
@@ -381,6 +414,8 @@ class TemperedLikelihoodSMC:
             self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
             ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73
             ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
+            if hasattr(self.kernel, "resampled"):
+                self.kernel.resampled(self, self._idx)
         self._theta_dc, self._prop_dc = self._prop_dc, self._theta_dc
         self.t = t_next
         self.temperatures.append(t_next)

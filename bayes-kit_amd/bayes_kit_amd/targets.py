@@ -175,7 +175,10 @@ class LogisticRegression(_BuiltinTarget):
             b["ld"] = ld
         return b
 
-    def bk_eval(self, theta_dc, grad_out, logp_out, t: float = 1.0, loglik_out=None):
+    def bk_eval(self, theta_dc, grad_out, logp_out, t: float = 1.0, loglik_out=None, gll_out=None):
+        """t: likelihood temperature (log density = t * loglik + logprior).  loglik_out ([C]) / gll_out ([D, C], the
+        state's pitch): the UNTEMPERED log likelihood and its gradient X^T (y - sigmoid(X theta)) of the evaluated
+        points -- what bk_retemper() turns into (logp, grad) at another temperature without touching the data."""
         ops = self._get_ops()
         D, C = theta_dc.shape
         b = self._buffers(theta_dc.device, C, _lib._ld(theta_dc))
@@ -192,6 +195,16 @@ class LogisticRegression(_BuiltinTarget):
             G = b["G"][:, :C]
             ops.gemm_chains(b["Xt"], Z, G, b["work"])     # X^T r                (MFMA, split over N)
         ops.logistic_finish(G, theta_dc, part, self._inv_s2, float(t), grad_out, logp_out, loglik_out)
+        if gll_out is not None:
+            if G is None:
+                raise ValueError("gll_out needs grad_out (the likelihood gradient is formed for it)")
+            gll_out.copy_(G)
+
+    def bk_retemper(self, theta_dc, gll, loglik, t: float, grad_out, logp_out):
+        """(logp, grad) at temperature t from the untempered parts of an earlier evaluation AT THE SAME POINTS:
+        grad = t * gll - theta / s^2, logp = t * loglik - |theta|^2 / (2 s^2).  No pass over the data."""
+        self._get_ops().logistic_finish(gll, theta_dc, loglik.reshape(1, -1), self._inv_s2, float(t), grad_out, logp_out,
+                                        None)
 
     # batched LogPriorLikelihoodModel
     def log_likelihood(self, Theta):

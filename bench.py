@@ -768,7 +768,9 @@ def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
     el = time.perf_counter() - t0
     T = smc.temperatures
     post = smc.thetas.mean(dim=0)
-    evals = len(T) * (L_smc + 1)  # evaluations of all particles: one at the new temperature + L per move
+    # evaluations of all particles: L per move (+ one at the very first temperature; afterwards the log density and gradient
+    # at a new temperature come from the untempered parts kept with each particle: bk_retemper, no pass over the data)
+    evals = len(T) * L_smc + 1
     out["annealed_smc"] = {"particles": C, "ladder": f"adaptive, ESS target {ess_target} x particles (extension; the reference "
                                                      "has t = n/N)", "temperatures": len(T),
                            "first_temperatures": T[:3], "min_ess_over_ladder": min(smc.ess_history),

@@ -433,3 +433,25 @@ def check_adaptive_smc_ladder(ops, M=600, D=3, n_obs=4000, seed=5):
     np.testing.assert_allclose(th.var(axis=0, ddof=1), post_var, rtol=0.25)
     assert min(smc.kernel.accept_rates) > 0.3   # the adapted metric keeps the moves alive along the whole ladder
     return smc
+
+
+def check_logistic_retemper(ops, N=3000, D=12, C=50):
+    """bk.LogisticRegression.bk_retemper: (logp, grad) at another temperature from the untempered parts of an earlier
+    evaluation equal a fresh evaluation at that temperature (same arithmetic in the finishing kernel: bit for bit)."""
+    import torch
+
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn((N, D), dtype=torch.float64, generator=g) / D ** 0.5
+    y = (torch.rand(N, dtype=torch.float64, generator=g) < 0.4).to(torch.float64)
+    m = bk.LogisticRegression(X.to(ops.device), y.to(ops.device), prior_scale=0.7, ops=ops)
+    th = (torch.randn((D, C), dtype=torch.float64, generator=g) * 0.3).to(ops.device)
+    f64 = dict(dtype=torch.float64, device=ops.device)
+    g1, lp1, ll, gll = torch.empty_like(th), torch.empty(C, **f64), torch.empty(C, **f64), torch.empty_like(th)
+    m.bk_eval(th, g1, lp1, 0.25, ll, gll)
+    for t in (0.0, 0.25, 0.6, 1.0):
+        gf, lf = torch.empty_like(th), torch.empty(C, **f64)
+        m.bk_eval(th, gf, lf, t)
+        gr, lr = torch.empty_like(th), torch.empty(C, **f64)
+        m.bk_retemper(th, gll, ll, t, gr, lr)
+        assert torch.equal(gr, gf), t
+        torch.testing.assert_close(lr, lf, rtol=1e-13, atol=1e-13)  # (the fresh call sums 256 segment partials, this one has their sum)

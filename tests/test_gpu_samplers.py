@@ -1365,3 +1365,10 @@ def test_single_chain_one_launch_per_draw_equals_the_step_by_step_path(ops):
         tb, _ = b.sample()
         tc, _ = c.sample()
         assert np.array_equal(tb, tc)
+
+
+def test_logistic_retemper_equals_a_fresh_evaluation(ops):
+    from tests.sampler_parity import check_logistic_retemper
+
+    check_logistic_retemper(ops)
+    check_logistic_retemper(ops, N=40_000, D=64, C=300)

@@ -503,3 +503,9 @@ def test_adaptive_smc_ladder_keeps_its_ess_and_finds_the_posterior():
     from tests.sampler_parity import check_adaptive_smc_ladder
 
     check_adaptive_smc_ladder(FakeOps())
+
+
+def test_logistic_retemper_equals_a_fresh_evaluation():
+    from tests.sampler_parity import check_logistic_retemper
+
+    check_logistic_retemper(FakeOps())

@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 el = time.perf_counter() - t0
 post = smc.thetas.mean(dim=0)
 T = smc.temperatures
-evals = len(T) * (L + 1)  # model evaluations of all particles: the cache refresh + L per move
+evals = len(T) * L + 1  # model evaluations of all particles: L per move (+ the first temperature's; then bk_retemper)
 print(json.dumps({"N": N, "D": D, "particles": C, "ess_target": target, "eps": eps, "L": L, "temperatures": len(T),
                   "first_temperatures": T[:4], "min_ess": min(smc.ess_history), "seconds": el,
                   "tflops_fp64": evals * 4.0 * N * D * C / el / 1e12,
