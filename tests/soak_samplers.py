@@ -80,14 +80,38 @@ def funnel_paths(rng):
                                     prob_retry=pr, **kw)
     a = mk(device_counts=False)
     b = mk(device_counts=True, graph=graph, fuse_first_ghost=fuse)
+    # round 4: the gradient as a separate COUNTED op per leapfrog step (built-in op, or the user plugin), lane counts on
+    # the device -- against the same host-sized path (step by step, so that the joint log densities agree bit for bit too)
+    opaque = str(rng.choice(["none", "builtin", "plugin"]))
+    desc["opaque"] = opaque
+    o = a2 = None
+    if opaque != "none":
+        a2 = mk(device_counts=False, fuse_builtin=False)
+        if opaque == "plugin":
+            import os as _os
+
+            lib = _os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so")
+            o = bk.DrGhmcDiag(bk.CTarget(lib, "funnel_target", D, counted_symbol="funnel_target_n"), K, sizes, counts, damp,
+                              metric_diag=metric, chains=C, seed=seed, prob_retry=pr, device_counts=True, graph=graph)
+        else:
+            o = mk(device_counts=True, graph=graph, fuse_builtin=False)
     for n in range(N):
         ta, la = a.sample()
         tb, lb = b.sample()
         same = torch.equal(ta, tb) or (torch.isnan(ta) == torch.isnan(tb)).all() and torch.equal(ta.nan_to_num(), tb.nan_to_num())
         assert same and torch.equal(la.nan_to_num(), lb.nan_to_num()), ("theta", desc, n)
         assert a.last_stage_lanes == b.last_stage_lanes and a.last_lane_steps == b.last_lane_steps, ("lanes", desc, n)
+        if o is not None:
+            t2, l2 = a2.sample()
+            to, lo = o.sample()
+            assert torch.equal(ta.nan_to_num(), to.nan_to_num()) and torch.equal(t2.nan_to_num(), to.nan_to_num()), ("opaque theta", desc, n)
+            assert torch.equal(l2.nan_to_num(), lo.nan_to_num()), ("opaque logp", desc, n)
+            assert a.last_stage_lanes == o.last_stage_lanes, ("opaque lanes", desc, n)
     assert torch.equal(a._rho.nan_to_num(), b._rho.nan_to_num()), ("rho", desc)
     assert np.array_equal(a.rng_state(), b.rng_state()), ("stream", desc)
+    if o is not None:
+        assert torch.equal(a._rho.nan_to_num(), o._rho.nan_to_num()), ("opaque rho", desc)
+        assert np.array_equal(a.rng_state(), o.rng_state()), ("opaque stream", desc)
     return "drfunnel"
 
 
