@@ -251,12 +251,21 @@ class Ops:
         self.lib = load()
         self.device = require_gpu()
         # optional per-launch HIP-event timing: {entry point: [(start, end), ...]} on the
-        # stream the kernels are enqueued on (bench.py's roofline measurement)
+        # stream the kernels are enqueued on (bench.py's roofline measurement).  timed_stride = n: only every n-th
+        # launch of a timed entry point is bracketed by events -- an event record is a packet of its own on the
+        # queue (about 6 us each: 256 of them cost a config-3 draw 1.6 ms = 4 % when every launch was bracketed)
         self.timed = None
+        self.timed_stride = 1
+        self._timed_seen = {}
 
     # -- helpers ---------------------------------------------------------------------
     def _call(self, name, *args):
         rec = self.timed.get(name) if self.timed is not None else None
+        if rec is not None and self.timed_stride > 1:
+            k = self._timed_seen.get(name, 0)
+            self._timed_seen[name] = k + 1
+            if k % self.timed_stride:
+                rec = None
         if rec is None:
             check(getattr(self.lib, name)(*args), name)
             return

@@ -846,8 +846,12 @@ def run_rank(args):
         s.sample()
     if not args.no_kernel_events:
         ops.timed = {"bk_leapfrog_kick_drift": [], "bk_target_diag_gaussian_grad": []}
+        # every 8th launch of each is bracketed by HIP events (a sample spread evenly over the timed region): an event
+        # record is a packet of its own on the queue, and 256 of them per draw cost the draw itself 4 %
+        ops.timed_stride = int(os.environ.get("BK_BENCH_EVENT_STRIDE", "8"))
     elapsed = ctx.timed_loop(s.sample, args.steps)
     timed, ops.timed = ops.timed, None
+    event_stride, ops.timed_stride = ops.timed_stride, 1
     accept = s.accept_rate()
 
     total_steps = float(C) * world * L * args.steps
@@ -902,6 +906,8 @@ def run_rank(args):
             "traffic": _pmc_traffic(C, D),
             "avg_launch_ms": kd_ms,
             "launches": len(kd),
+            "launches_in_timed_region": len(kd) * event_stride,
+            "event_stride": event_stride,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         }
         if gr:
