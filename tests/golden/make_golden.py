@@ -255,6 +255,25 @@ SAMPLER_CASES = [
          model=dict(kind="diag_gaussian", D=16, log10_lo=0, log10_hi=1), max_proposals=3,
          leapfrog_step_sizes=[0.5, 0.25, 0.1], leapfrog_step_counts=[3, 6, 12], damping=0.3,
          metric=dict(kind="linspace", lo=0.5, hi=1.5), chains=8, draws=80, seed=305),
+    # --- round 4: the edges of the paths added in that round ---
+    # D = 129: the last shape of the one-launch funnel proposal (128 coordinate rows); D = 130: the first one past it
+    # (the library's funnel then sums sequentially; DRGHMC runs counted steps or host-sized launches)
+    dict(name="drghmc_funnel129_k3", alg="drghmc", model=dict(kind="funnel", D=129), max_proposals=3,
+         leapfrog_step_sizes=[0.15, 0.05, 0.015], leapfrog_step_counts=[4, 8, 16], damping=0.2, chains=4, draws=20, seed=309),
+    dict(name="drghmc_funnel130_k2", alg="drghmc", model=dict(kind="funnel", D=130), max_proposals=2,
+         leapfrog_step_sizes=[0.15, 0.05], leapfrog_step_counts=[4, 12], damping=0.2, chains=4, draws=20, seed=310),
+    # a full momentum refresh every draw (damping = 1) with three stages, D >= 32
+    dict(name="drghmc_iso64_k3_damp1", alg="drghmc", model=dict(kind="iso_gaussian", D=64), max_proposals=3,
+         leapfrog_step_sizes=[0.9, 0.3, 0.1], leapfrog_step_counts=[2, 6, 18], damping=1.0, chains=4, draws=40, seed=311),
+    # MALA at the largest D of its one-pass step kernel
+    dict(name="mala_diag1024", alg="mala", model=dict(kind="diag_gaussian", D=1024, log10_lo=0, log10_hi=2),
+         epsilon=2e-4, chains=4, draws=8, seed=206),
+    # a single-chain PCG64 stream with D > 1 (the one-launch-per-draw path of the drop-in mode)
+    dict(name="mala_pcg_d5", alg="mala", model=dict(kind="iso_gaussian", D=5), epsilon=0.15, chains=2, draws=60,
+         pcg_seed=4321),
+    # HMC: one leapfrog step with a non-trivial metric
+    dict(name="hmc_diag40_metric_steps1", alg="hmc", model=dict(kind="diag_gaussian", D=40, log10_lo=0, log10_hi=1),
+         stepsize=0.1, steps=1, chains=4, draws=40, seed=105, metric=dict(kind="linspace", lo=0.6, hi=1.3)),
 ]
 
 

@@ -18,6 +18,8 @@ SAMPLER_CASES = [
     "drghmc_funnel33_k2_metric_noretry",
     "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
     "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed",
+    "drghmc_funnel129_k3", "drghmc_funnel130_k2", "drghmc_iso64_k3_damp1", "mala_diag1024", "mala_pcg_d5",
+    "hmc_diag40_metric_steps1",
 ]
 
 

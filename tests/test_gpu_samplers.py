@@ -15,7 +15,10 @@ MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_iso128_cfg2", "hmc_diag1
         "mala_stdnormal", "mala_iso8", "mala_diag16", "mala_diag48", "mala_init",
         "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1", "drghmc_funnel11_k3",
         "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40", "drghmc_funnel17_k4",
-        "drghmc_funnel33_k2_metric_noretry", "metropolis_rw_iso3", "mh_ar_iso2"]
+        "drghmc_funnel33_k2_metric_noretry", "metropolis_rw_iso3", "mh_ar_iso2",
+        # round 4: the edges of the new paths (one-launch proposal at its last D and one past it, full refresh, MALA's
+        # step kernel at its largest D, one leapfrog step with a metric)
+        "drghmc_funnel129_k3", "drghmc_funnel130_k2", "drghmc_iso64_k3_damp1", "mala_diag1024", "hmc_diag40_metric_steps1"]
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +51,7 @@ def test_hmc_step_by_step_path_vs_reference_golden(name, ops):
                                   "drghmc_stdnormal_k3", "drghmc_k1",
                                   # the reference's own scipy-based test model with its finite-difference gradient
                                   "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
-                                  "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed"])
+                                  "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed", "mala_pcg_d5", "mala_diag16"])
 def test_single_chain_drop_in_vs_reference_golden(name, ops):
     check_single_chain_host_model(name, ops, chains=[0, 1])
 

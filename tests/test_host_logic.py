@@ -16,10 +16,11 @@ from tests.sampler_parity import check_many_chain, check_single_chain_host_model
 MANY = ["hmc_stdnormal", "hmc_steps0", "hmc_iso4", "hmc_diag16_metric", "mala_stdnormal", "mala_iso8",
         "mala_diag16", "mala_diag48", "mala_init", "drghmc_stdnormal_k3", "drghmc_iso4_k2_noretry", "drghmc_k1",
         "drghmc_funnel11_k3", "drghmc_funnel101_cfg4", "drghmc_diag16_metric", "drghmc_diag40",
-        "drghmc_funnel17_k4", "drghmc_funnel33_k2_metric_noretry", "metropolis_rw_iso3", "mh_ar_iso2"]
+        "drghmc_funnel17_k4", "drghmc_funnel33_k2_metric_noretry", "metropolis_rw_iso3", "mh_ar_iso2",
+        "drghmc_funnel130_k2", "drghmc_iso64_k3_damp1", "hmc_diag40_metric_steps1"]
 SINGLE = ["hmc_pcg_seed", "hmc_iso4", "mala_stdnormal", "mala_init", "drghmc_stdnormal_k3", "drghmc_k1",
           "hmc_ref_binomial", "mala_ref_binomial", "drghmc_ref_binomial",
-          "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed"]
+          "metropolis_rw_iso3", "mh_ar_iso2", "metropolis_pcg_seed", "mala_pcg_d5"]
 
 
 @pytest.mark.parametrize("name", MANY)
