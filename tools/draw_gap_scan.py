@@ -1,3 +1,6 @@
+"""One draw of a sampler in a rocprofv3 --kernel-trace CSV (the kernels between the last-but-two and last-but-one launch of a marker
+kernel): per-kernel time, busy time and gaps of the main queue, and what the side-stream kernels cost the ones they overlap.
+usage: draw_gap_scan.py <dir or kernel_trace.csv> [marker kernel name = k_mh_accept]"""
 import csv, glob, os, sys
 path = sys.argv[1]
 if os.path.isdir(path):
@@ -6,7 +9,8 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n): return n.replace("(anonymous namespace)::","").replace("void ","").split("(")[0][:40]
 # last draw: between the last two k_mh_accept
-acc=[i for i,r in enumerate(rows) if "k_mh_accept" in r["Kernel_Name"]]
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_mh_accept"
+acc=[i for i,r in enumerate(rows) if marker in r["Kernel_Name"]]
 a,b=acc[-3],acc[-2]
 seg=rows[a+1:b+1]
 t0=int(seg[0]["Start_Timestamp"])
