@@ -248,6 +248,19 @@ def test_full_size_cfg4_properties(ops):
     assert torch.isfinite(tb).all() and torch.isfinite(lb).all()
     assert torch.equal(big._rho[20000:20096], small._rho)
     np.testing.assert_array_equal(big.rng_state()[:, 20000:20096], small.rng_state())
+    # the same draws with the gradient as a SEPARATE counted op per leapfrog step -- the library's own and the user plugin's
+    # (bk_target_fn_n) -- 581 launches per draw inside one hipGraph, no host read: theta, rho and stream positions of all
+    # 32,768 chains equal the one-launch path bit for bit (round 4)
+    for model, kw in ((bk.Funnel(101), dict(fuse_builtin=False)), (funnel_plugin(101), {})):
+        o = bk.DrGhmcDiag(model, *args, chains=32768, seed=20242, **kw)
+        assert o._dev_counts and not o._one_launch and o._use_graph and o.host_syncs_per_draw == 0
+        for _ in range(3):
+            to, lo = o.sample()
+        assert torch.equal(to, tb) and torch.equal(o._rho, big._rho)
+        torch.testing.assert_close(lo, lb, rtol=1e-13, atol=1e-13)   # (kinetic energy summed in another order)
+        np.testing.assert_array_equal(o.rng_state(), big.rng_state())
+        assert o.last_stage_lanes == big.last_stage_lanes
+        del o
 
 
 @pytest.mark.parametrize("prefetch", [False, True])
@@ -1375,3 +1388,47 @@ def test_logistic_retemper_equals_a_fresh_evaluation(ops):
 
     check_logistic_retemper(ops)
     check_logistic_retemper(ops, N=40_000, D=64, C=300)
+
+
+def test_single_chain_one_launch_mala_against_the_oracle_over_random_shapes(ops):
+    """The single-chain drop-in (one launch per draw) against the oracle's MALA -- the reference's arithmetic on the
+    reference's NumPy streams -- over random dimensions, step sizes and seeds of both stream kinds: draws bit for bit,
+    the returned log density to summation order, the generator's position exact."""
+    from oracle import samplers as osamp
+
+    class Gauss:
+        def __init__(self, lam):
+            self.lam = np.asarray(lam, dtype=np.float64)
+
+        def dims(self):
+            return self.lam.shape[0]
+
+        def log_density(self, th):
+            return -0.5 * float(np.sum(th * (self.lam * th)))
+
+        def log_density_gradient(self, th):
+            return -0.5 * float(np.sum(th * (self.lam * th))), -(self.lam * th)
+
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        D = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 70, 200]))
+        lam = rng.uniform(0.5, 4.0, size=D)
+        eps = float(rng.uniform(0.02, 0.4)) / max(1.0, D ** 0.33)
+        if trial % 2:
+            mk_seed = lambda k=int(rng.integers(1, 2 ** 31)): k                       # noqa: E731  int -> PCG64, the reference's default_rng
+        else:
+            key = [int(rng.integers(1, 2 ** 40)), int(rng.integers(0, 1000))]
+            mk_seed = lambda key=key: np.random.Philox(key=key)                       # noqa: E731
+        s = bk.MALA(Gauss(lam), eps, seed=mk_seed())
+        o = osamp.MALA(Gauss(lam), eps, seed=mk_seed())
+        assert s._single
+        np.testing.assert_array_equal(s._theta, o._theta)
+        for n in range(25):
+            th, lp = s.sample()
+            oth, olp = o.sample()
+            assert np.array_equal(th, oth), (trial, D, n)
+            assert abs(lp - olp) <= 1e-12 * max(1.0, abs(olp)), (trial, D, n)
+        from tests.helpers import rng_state_words
+
+        w = rng_state_words(o._rng)   # (11 words for Philox, 4 for PCG64)
+        np.testing.assert_array_equal(s.rng_state()[:len(w), 0], w)
