@@ -22,9 +22,13 @@ One JSON line is printed by rank 0.  `value` is the weak-scaling figure (65,536 
 GPU); `value_strong` is the same metric with 65,536 chains per NODE (65,536 / N per GPU).
 `roofline` is for the dominant kernel (the fused kick+drift, 40*D algorithmic bytes per chain
 per launch), its duration measured live with HIP events on the launch stream over the timed
-region.  `cpu_baseline` times the oracle (NumPy restatement of the reference) on the host
-cores, rank 0 at N=1 only.  `secondary` (N=1) carries the other BASELINE.json configs, each
-with its own bound and bytes / flop model.
+region -- around every 8th launch, spread evenly (`roofline.event_stride`): an event record is a
+packet of its own on the queue and bracketing all 128 launches of a draw cost the draw 4 %.
+`cpu_baseline` times the oracle (NumPy restatement of the reference) on the host cores that can
+run at once (affinity capped by the cgroup quota), rank 0 at N=1 only.  `secondary` (N=1) carries the
+other BASELINE.json configs, each with its own bound and bytes / flop model; at N > 1 config 4 runs at
+every world size with R-hat / ESS over the process group, and every rank pins itself to its GPU's NUMA
+share of the CPUs before torch starts.
 """
 import argparse
 import hashlib
