@@ -417,7 +417,10 @@ class ManyChainSampler:
             m.bk_eval(theta_dc, grad_out, logp_out)
             return grad_out
         if self._batched:
-            lp, g = m.log_density_gradient(theta_dc.t())
+            if logp_out is None and hasattr(m, "gradient"):
+                lp, g = None, m.gradient(theta_dc.t())   # (a model that can give the gradient without the log density)
+            else:
+                lp, g = m.log_density_gradient(theta_dc.t())
             if g.dtype != torch.float64 or g.device != theta_dc.device:
                 g = g.to(device=theta_dc.device, dtype=torch.float64)  # the kernels read raw fp64 pointers
             if tuple(g.shape) != (theta_dc.shape[1], theta_dc.shape[0]):

@@ -523,16 +523,23 @@ class TorchModel:
     contiguous, vectorised elementwise kernels instead of the generic strided ones the transposed (C, D) view of
     the same memory gets, and autograd returns the gradient in the layout the streamed kick + drift kernel reads
     (no turn through LDS): config-3 shape 2.6 -> 1.8 ms per leapfrog step.  Same values either way.
+
+    grad_fn (optional): the gradient written out in PyTorch ops, same argument and the argument's shape back.  The
+    samplers then never build an autograd graph, and a leapfrog step -- which discards the log density (hmc.py:45,50)
+    -- calls ``grad_fn`` alone: for an elementwise density that is one torch kernel instead of autograd's eight passes.
     """
 
     batched = True
 
-    def __init__(self, fn, dims: int, layout: str = "cd"):
+    def __init__(self, fn, dims: int, layout: str = "cd", grad_fn=None):
         if layout not in ("cd", "dc"):
             raise ValueError("layout must be 'cd' (fn takes (C, D), the reference's shape) or 'dc' (fn takes (D, C))")
         self._fn = fn
+        self._grad_fn = grad_fn
         self._D = int(dims)
         self._dc = layout == "dc"
+        if grad_fn is not None:
+            self.gradient = self._gradient  # (the engine's gradient-only call; absent for autograd, which needs the forward pass anyway)
 
     def dims(self) -> int:
         return self._D
@@ -546,8 +553,19 @@ class TorchModel:
             return self._fn(self._arg(Theta))
 
     def log_density_gradient(self, Theta):
+        if self._grad_fn is not None:
+            with torch.no_grad():
+                x = self._arg(Theta)
+                g = self._grad_fn(x)
+                return self._fn(x), (g.t() if self._dc else g)
         x = self._arg(Theta).detach().requires_grad_(True)
         with torch.enable_grad():
             lp = self._fn(x)
             (g,) = torch.autograd.grad(lp.sum(), x)
         return lp.detach(), (g.t() if self._dc else g)
+
+    def _gradient(self, Theta):
+        """The gradient alone, (C, D) like log_density_gradient's second output (only with grad_fn)."""
+        with torch.no_grad():
+            g = self._grad_fn(self._arg(Theta))
+        return g.t() if self._dc else g

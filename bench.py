@@ -683,6 +683,24 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
                             "path_hbm_frac_56D_model": C * L / per_dc * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
                             "accept_rate": s.accept_rate()}
     del s
+    # ... and with the gradient written out in torch ops as well (TorchModel(grad_fn=...)): no autograd graph, a leapfrog
+    # step is one torch kernel beside the engine's kick+drift
+    try:
+        model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), D, layout="dc",
+                              grad_fn=lambda Th: -(lam[:, None] * Th))
+        s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
+                       metric_diag=torch.ones(D, dtype=torch.float64), tune_placement=False)
+        s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
+        for _ in range(warmup):
+            s.sample()
+        per_g = ctx.timed_loop(s.sample, draws) / draws
+        out["written_out_gradient"] = {"what": "TorchModel(fn, D, layout='dc', grad_fn=...): the gradient as torch ops, no autograd",
+                                       "ms_per_draw": 1e3 * per_g, "steps_per_sec": C * ctx.world * L / per_g,
+                                       "path_hbm_frac_56D_model": C * L / per_g * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
+                                       "accept_rate": s.accept_rate()}
+        del s
+    except Exception as e:  # context only
+        out["written_out_gradient"] = {"error": repr(e)}
     # the same density as six lines of HIP C++ handed to CTarget.from_source: compiled with hipcc at construction into
     # the plugin ABI (bk_target_fn / bk_target_fn_n) -- what a Python user reaches without writing a build
     try:

@@ -510,3 +510,40 @@ def test_logistic_retemper_equals_a_fresh_evaluation():
     from tests.sampler_parity import check_logistic_retemper
 
     check_logistic_retemper(FakeOps())
+
+
+def test_torch_model_with_a_written_out_gradient_equals_autograd():
+    """TorchModel(fn, D, grad_fn=...): no autograd graph, and a leapfrog step calls grad_fn alone (the engine's
+    gradient-only hook); for the diagonal Gaussian the written-out gradient -(lam * theta) is autograd's bit for bit."""
+    import torch
+
+    lam = torch.logspace(0, 1, 9, dtype=torch.float64)
+    calls = {"fn": 0, "grad": 0}
+
+    def fn(Th):
+        calls["fn"] += 1
+        return -0.5 * (Th * Th * lam).sum(dim=1)
+
+    def grad_fn(Th):
+        calls["grad"] += 1
+        return -(lam * Th)
+
+    for mk in (lambda m: bk.HMCDiag(m, 0.2, 5, chains=17, seed=3, ops=FakeOps()),
+               lambda m: bk.MALA(m, 0.05, chains=17, seed=3, ops=FakeOps()),
+               lambda m: bk.DrGhmcDiag(m, 2, [0.4, 0.15], [2, 4], 0.5, chains=17, seed=3, ops=FakeOps())):
+        a = mk(bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), 9))
+        b = mk(bk.TorchModel(fn, 9, grad_fn=grad_fn))
+        for n in range(6):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (type(a).__name__, n)
+    assert calls["grad"] > calls["fn"] > 0   # trajectories ask for the gradient alone
+    # layout="dc": both functions take the (D, C) array
+    a = bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), 9, layout="dc"), 0.2, 5, chains=8, seed=4,
+                   ops=FakeOps())
+    b = bk.HMCDiag(bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), 9, layout="dc",
+                                 grad_fn=lambda Th: -(lam[:, None] * Th)), 0.2, 5, chains=8, seed=4, ops=FakeOps())
+    for n in range(4):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb), n
