@@ -12,6 +12,19 @@ kw = {}
 if opaque == "plugin":
     model = bk.CTarget(os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so"), "funnel_target", D,
                        counted_symbol="funnel_target_n")
+elif opaque == "source":   # the funnel as a per-chain function handed to CTarget.from_source (one lane per chain)
+    model = bk.CTarget.from_source("""
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double*) {
+  const double v = th[0];
+  double cs[16];
+  for (int c = 0; c < 16; ++c) { double a = 0.0; for (i64 d = 1 + c; d < D; d += 16) { const double x = th[d]; a = a + x * x; } cs[c] = a; }
+  double q[4];
+  for (int k = 0; k < 4; ++k) q[k] = ((cs[k] + cs[k + 4]) + cs[k + 8]) + cs[k + 12];
+  const double s = ((q[0] + q[1]) + q[2]) + q[3];
+  const double ev = exp(-v), hn = 0.5 * (double)(D - 1), he = 0.5 * ev;
+  if (g.wanted()) { g.set(0, ((-v / 9.0) - hn) + he * s); for (i64 d = 1; d < D; ++d) g.set(d, -(ev * th[d])); }
+  return ((-(v * v) / 18.0) - hn * v) - he * s;
+}""", D, form="chain")
 elif opaque != "0":
     kw["fuse_builtin"] = False
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
