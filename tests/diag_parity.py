@@ -100,6 +100,18 @@ def check_diagnostics(ops, ess_rtol):
     np.testing.assert_allclose([bk.ess(c, ops=ops) for c in short], z["short_ess"], rtol=ess_rtol)
     np.testing.assert_allclose(np.concatenate([bk.autocorr(c, ops=ops) for c in short]), z["short_autocorr_flat"],
                                rtol=0, atol=1e-12)
+    # long chains (20,000 draws >= FFT_MIN_DRAWS: the library's own FFT), 1-D as the reference is called and as one [N, C] array
+    from tests.helpers import long_ar_chains
+
+    lc = long_ar_chains(z["long_seed"], z["long_n"], z["long_phi"])
+    xl = torch.from_numpy(np.ascontiguousarray(np.stack(lc).T)).to(ops.device)
+    np.testing.assert_allclose(bk.ess(xl, ops=ops).cpu().numpy(), z["long_ess"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.ess_ipse(xl, ops=ops).cpu().numpy(), z["long_ess_ipse"], rtol=ess_rtol)
+    np.testing.assert_allclose(bk.iat(xl, ops=ops).cpu().numpy(), z["long_iat"], rtol=ess_rtol)
+    acl = bk.autocorr(xl, ops=ops).cpu().numpy()
+    np.testing.assert_allclose(acl[:64].T, z["long_autocorr_head"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(acl[-8:].T, z["long_autocorr_tail"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(bk.ess(lc[2], ops=ops), z["long_ess"][2], rtol=ess_rtol)
     # known answer held by the reference's test (test/test_autocorr.py:10-14)
     np.testing.assert_allclose(bk.autocorr([1, 0, 0, 0], ops=ops), [1.0, -0.083, -0.167, -0.25], atol=0.001)
     # error behaviour (rhat.py:159-162, ess.py:67-68, iat.py, autocorr.py:23-24)

@@ -322,6 +322,18 @@ def run_diagnostics():
     out["short_flat"] = np.concatenate(short)
     out["short_ess"] = np.asarray([ref.ess(c) for c in short])
     out["short_autocorr_flat"] = np.concatenate([ref.autocorr(c) for c in short])
+    # round 4: LONG chains (20,000 draws: the library's own FFT path, from 16,384 draws on).  The series are regenerated
+    # from (long_seed, long_phi) by tests/helpers.long_ar_chains -- only the reference's OUTPUTS are stored
+    from tests.helpers import long_ar_chains
+
+    out["long_seed"], out["long_n"] = np.int64(4242), np.int64(20000)
+    out["long_phi"] = np.asarray([-0.5, 0.3, 0.9, 0.99])
+    lc = long_ar_chains(int(out["long_seed"]), int(out["long_n"]), out["long_phi"])
+    out["long_ess"] = np.asarray([ref.ess(c) for c in lc])
+    out["long_ess_ipse"] = np.asarray([ref.ess_ipse(c) for c in lc])
+    out["long_iat"] = np.asarray([ref.iat(c) for c in lc])
+    out["long_autocorr_head"] = np.stack([ref.autocorr(c)[:64] for c in lc])
+    out["long_autocorr_tail"] = np.stack([ref.autocorr(c)[-8:] for c in lc])
     return out
 
 

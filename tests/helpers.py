@@ -113,3 +113,18 @@ def rng_state_words(gen):
     s = st["state"]
     m = 2**64 - 1
     return np.asarray([s["state"] >> 64, s["state"] & m, s["inc"] >> 64, s["inc"] & m], dtype=np.uint64)
+
+
+def long_ar_chains(seed, n, phis):
+    """AR(1) series x[i] = phi x[i-1] + e[i] from a seeded PCG64 stream (deterministic everywhere): the inputs of the
+    long-chain diagnostics fixture, regenerated instead of stored (4 x 20,000 doubles)."""
+    rng = np.random.default_rng(int(seed))
+    out = []
+    for phi in phis:
+        e = rng.normal(size=int(n))
+        x = np.empty(int(n))
+        x[0] = e[0]
+        for i in range(1, int(n)):
+            x[i] = phi * x[i - 1] + e[i]
+        out.append(x)
+    return out

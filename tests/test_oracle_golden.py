@@ -116,6 +116,14 @@ def test_diagnostics_match_reference():
     short = np.split(z["short_flat"], np.cumsum(z["short_lens"])[:-1])
     np.testing.assert_array_equal(np.asarray([od.ess(c) for c in short]), z["short_ess"])
     np.testing.assert_array_equal(np.concatenate([od.autocorr(c) for c in short]), z["short_autocorr_flat"])
+    # long chains (20,000 draws), regenerated from their seed
+    from tests.helpers import long_ar_chains
+
+    for i, ch in enumerate(long_ar_chains(z["long_seed"], z["long_n"], z["long_phi"])):
+        assert od.ess(ch) == z["long_ess"][i] and od.ess_ipse(ch) == z["long_ess_ipse"][i] and od.iat(ch) == z["long_iat"][i]
+        ac = od.autocorr(ch)
+        np.testing.assert_array_equal(ac[:64], z["long_autocorr_head"][i])
+        np.testing.assert_array_equal(ac[-8:], z["long_autocorr_tail"][i])
 
 
 def test_diagnostics_known_answers_from_reference_tests():
