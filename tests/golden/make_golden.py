@@ -334,6 +334,13 @@ def run_diagnostics():
     out["long_iat"] = np.asarray([ref.iat(c) for c in lc])
     out["long_autocorr_head"] = np.stack([ref.autocorr(c)[:64] for c in lc])
     out["long_autocorr_tail"] = np.stack([ref.autocorr(c)[-8:] for c in lc])
+    # pooled ranks with MANY TIES (draws of small integers): how the reference ranks equal values (rhat.py:27-69)
+    tg = np.random.default_rng(99)
+    ties = [tg.integers(0, 7, size=80).astype(np.float64) for _ in range(6)]
+    out["ties_chains"] = np.stack(ties)
+    out["ties_ranks"] = np.asarray(ref.rhat.__globals__["rank_chains"](ties))
+    out["ties_rank_normalized"] = np.asarray(ref.rhat.__globals__["rank_normalize_chains"](ties))
+    out["ties_rank_normalized_rhat"] = np.float64(ref.rhat.__globals__["rank_normalized_rhat"](ties))
     return out
 
 

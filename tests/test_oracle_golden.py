@@ -116,6 +116,10 @@ def test_diagnostics_match_reference():
     short = np.split(z["short_flat"], np.cumsum(z["short_lens"])[:-1])
     np.testing.assert_array_equal(np.asarray([od.ess(c) for c in short]), z["short_ess"])
     np.testing.assert_array_equal(np.concatenate([od.autocorr(c) for c in short]), z["short_autocorr_flat"])
+    tc = list(z["ties_chains"])   # many ties: small integers
+    np.testing.assert_array_equal(np.asarray(od.rank_chains(tc)), z["ties_ranks"])
+    np.testing.assert_array_equal(np.asarray(od.rank_normalize_chains(tc)), z["ties_rank_normalized"])
+    assert od.rank_normalized_rhat(tc) == z["ties_rank_normalized_rhat"]
     # long chains (20,000 draws), regenerated from their seed
     from tests.helpers import long_ar_chains
 
