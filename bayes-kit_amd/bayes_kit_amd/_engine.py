@@ -417,8 +417,8 @@ class ManyChainSampler:
             m.bk_eval(theta_dc, grad_out, logp_out)
             return grad_out
         if self._batched:
-            if logp_out is None and hasattr(m, "gradient"):
-                lp, g = None, m.gradient(theta_dc.t())   # (a model that can give the gradient without the log density)
+            if logp_out is None and hasattr(m, "bk_gradient"):
+                lp, g = None, m.bk_gradient(theta_dc.t())   # (a model that can give the gradient without the log density)
             else:
                 lp, g = m.log_density_gradient(theta_dc.t())
             if g.dtype != torch.float64 or g.device != theta_dc.device:

@@ -299,13 +299,9 @@ _SRC_PRELUDE = r"""
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
-typedef int64_t i64;
+#include "bk_common.hpp"
 typedef double bk_dvec2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ i64 bk_count(i64 n, const uint32_t* n_dev) {
-  if (!n_dev) return n;
-  const i64 m = (i64)*n_dev;
-  return m < n ? m : n;
-}
+__device__ __forceinline__ i64 bk_count(i64 n, const uint32_t* n_dev) { return bk_lanes(n, n_dev); }
 """
 
 _SRC_ELEMENTWISE = r"""
@@ -314,7 +310,15 @@ _SRC_ELEMENTWISE = r"""
 //   term = this coordinate's contribution to the log density, grad = d term / d th
 %(user)s
 // -------------------------------------------------------------------------------------------------------------------
+#include "bk_elementwise.hpp"
 namespace {
+// the library's whole-trajectory / whole-draw HMC kernels (bk_elementwise.hpp) see the density through this
+struct BkSrcTerm {
+  __device__ __forceinline__ static void eval(double th, i64 d, const double* params, double& term, double& grad) {
+    bk_term(th, d, params, term, grad);
+  }
+  __device__ __forceinline__ static double finish(double s) { return s; }
+};
 // gradient only (what a leapfrog step asks for): a streaming elementwise kernel, two chains (16 B) per lane
 template <int ROWS, bool NT>
 __global__ __launch_bounds__(256) void k_src_grad_v2(const double* th, double* g, i64 ld, const double* params, i64 C2, i64 D) {
@@ -403,6 +407,22 @@ int launch(const double* th, double* g, double* logp, i64 ld, const void* params
   return (int)hipGetLastError();
 }
 }  // namespace
+// whole HMC trajectory / whole HMC draw with bk_term inlined: the argument lists of bk_hmc_trajectory_gaussian /
+// bk_hmc_draw_gaussian (include/bkhip.h) with `params` where those take `lam`
+extern "C" int bk_src_hmc_trajectory(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out,
+                                     int64_t ld, const void* params, const double* metric, double eps, int64_t steps,
+                                     int64_t C, int64_t D, void* stream) {
+  return bke::hmc_trajectory_launch<BkSrcTerm>(theta_in, theta_out, rho_in, rho_out, ld, static_cast<const double*>(params),
+                                               metric, eps, steps, C, D, stream);
+}
+extern "C" int bk_src_hmc_draw(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in, const double* zt,
+                               int64_t ldz, const void* params, const double* metric, double eps, int64_t steps, double* part,
+                               double* kin0, double* kin1, double* lp_out, double* lp_cur, const double* log_u,
+                               uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C, int64_t D, void* stream) {
+  return bke::hmc_draw_launch<BkSrcTerm>(theta_in, theta_out, ld, rho_in, zt, ldz, static_cast<const double*>(params), metric,
+                                         eps, steps, part, kin0, kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count,
+                                         C, D, stream);
+}
 """
 
 _SRC_CHAIN = r"""
@@ -443,6 +463,43 @@ int launch(const double* th, double* g, double* logp, i64 ld, const void* params
 }  // namespace
 """
 
+_SRC_LANES = r"""
+#include "bk_lanes.hpp"
+// ---- user code: ONE CHAIN, its coordinates spread over 4 / 8 / 16 lanes of a wavefront (bk_lanes.hpp) ---------------
+//   template <class L> __device__ double bk_lanes_density(L& c, const double* params)
+//   c.dims(), c.head(i), c.sum(f), c.grad_head(i, g), c.grad(f) with f(double theta_d, i64 d); returns the log density
+%(user)s
+// -------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BkSrcDensity {
+  static constexpr int HEAD = %(head)d;
+  template <class L>
+  __device__ __forceinline__ static double eval(L& c, const double* params) { return bk_lanes_density(c, params); }
+};
+constexpr int BK_SRC_SL = %(sl)d;  // slots per class for this D (0: D - HEAD > 128, the gradient op walks the rows in memory)
+int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
+           void* stream) {
+  return bkl::target_launch<BkSrcDensity, BK_SRC_SL>(th, g, logp, ld, static_cast<const double*>(params), C, D, n_dev, stream);
+}
+}  // namespace
+#if %(sl)d > 0
+// one whole delayed-rejection proposal per launch with bk_lanes_density inlined: the argument list of
+// bk_dr_proposal_funnel_job (include/bkhip.h) + params
+extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                                      const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                                      double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                                      int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                                      uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
+                                      const bk_scatter_job* job, const bk_ghost_link* ghost, const bk_ghost0* ghost0,
+                                      const void* params, void* stream) {
+  return bkl::dr_proposal_launch<BkSrcDensity, BK_SRC_SL>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out,
+                                                          grad_out, logp_out, kin_out, ld_out, metric, h, steps, n, D, n_dev,
+                                                          lanes_out, lanes_total, H_out, h_out, live_out, job, ghost, ghost0,
+                                                          static_cast<const double*>(params), stream);
+}
+#endif
+"""
+
 _SRC_EXPORTS = r"""
 extern "C" int bk_src_target(const double* theta, double* grad, double* logp, int64_t ld, const void* params, int64_t C,
                              int64_t D, void* stream) {
@@ -455,56 +512,271 @@ extern "C" int bk_src_target_n(const double* theta, double* grad, double* logp, 
 }
 """
 
+_LANES_MAX_ROWS = 128  # bk_lanes.hpp MAX_ROWS: spread rows a trajectory kernel keeps in registers
+_LANES_MAX_HEAD = 8
 
-def _compile_source_target(user_source: str, form: str, contract: bool) -> str:
-    """hipcc the generated translation unit into a shared library (cached by content); returns its path."""
+
+def _csrc_dir():
+    """The library's kernel headers (bk_lanes.hpp, bk_elementwise.hpp, bk_common.hpp): generated sources include them."""
+    import os
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for d in (os.path.join(here, "csrc"), os.path.join(here, "..", "csrc")):
+        if os.path.exists(os.path.join(d, "bk_common.hpp")):
+            return os.path.abspath(d)
+    raise _lib.BkHipError("CTarget.from_source: the library's kernel headers (csrc/bk_common.hpp) were not found")
+
+
+def _check_private(path, what, want_dir):
+    """Refuse a cache directory / cached library somebody else could have written: it must be a real directory / regular
+    file (no symlink), owned by this user, without group or world write permission."""
+    import os
+    import stat
+
+    st = os.lstat(path)
+    ok_type = stat.S_ISDIR(st.st_mode) if want_dir else stat.S_ISREG(st.st_mode)
+    if not ok_type:
+        raise _lib.BkHipError(f"CTarget.from_source: {what} {path} is not a plain {'directory' if want_dir else 'file'} "
+                              "(a symlink or special file is refused)")
+    if st.st_uid != os.getuid():
+        raise _lib.BkHipError(f"CTarget.from_source: {what} {path} is owned by uid {st.st_uid}, not by this user "
+                              f"({os.getuid()}): refusing to load code from it")
+    if st.st_mode & 0o022:
+        raise _lib.BkHipError(f"CTarget.from_source: {what} {path} is group- or world-writable "
+                              f"(mode {stat.S_IMODE(st.st_mode):o}): refusing to load code from it")
+
+
+def _source_cache_dir():
+    """Where compiled sources are cached: BK_SOURCE_TARGET_DIR, else $XDG_CACHE_HOME/bayes_kit_amd, else
+    ~/.cache/bayes_kit_amd -- created 0700 and REFUSED unless it is a real directory owned by this user that nobody else can
+    write.  Without a usable home (read-only, unset) a fresh private directory from mkdtemp serves this process."""
+    import os
+    import tempfile
+
+    explicit = os.environ.get("BK_SOURCE_TARGET_DIR")
+    if explicit:
+        root = explicit
+    else:
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        root = os.path.join(base, "bayes_kit_amd")
+    try:
+        os.makedirs(root, mode=0o700, exist_ok=True)
+    except OSError:
+        if explicit:
+            raise
+        global _PROCESS_CACHE_DIR
+        if _PROCESS_CACHE_DIR is None:
+            _PROCESS_CACHE_DIR = tempfile.mkdtemp(prefix="bayes_kit_amd_src_")  # (0700, unique: nobody can have planted it)
+        return _PROCESS_CACHE_DIR
+    _check_private(root, "the cache directory", True)
+    return root
+
+
+_PROCESS_CACHE_DIR = None
+
+
+def _find_hipcc():
+    import os
+    import shutil
+
+    for c in (os.environ.get("HIPCC"), os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")):
+        if c and os.path.exists(c):
+            return c
+    c = shutil.which("hipcc")
+    if c:
+        return c
+    raise _lib.BkHipError("CTarget.from_source compiles its source with hipcc when the object is built, and no hipcc was "
+                          "found (HIPCC, $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc, PATH).  Build the target on a box with "
+                          "ROCm and load the cached library there, or use CTarget(library, symbol, ...) with a library you "
+                          "compiled yourself.")
+
+
+def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
+    if form not in ("elementwise", "chain", "lanes"):
+        raise ValueError("form must be 'elementwise' (bk_term: one coordinate's term and derivative), 'chain' "
+                         "(bk_chain: one chain's log density and gradient, one lane per chain) or 'lanes' "
+                         "(bk_lanes_density: one chain spread over the lanes of a wavefront)")
+    if form == "lanes":
+        if not 0 <= int(head) <= _LANES_MAX_HEAD:
+            raise ValueError(f"head must be 0..{_LANES_MAX_HEAD} (the coordinates every lane of a chain holds)")
+        if dims < max(1, head):
+            raise ValueError("dims must be at least max(1, head)")
+        rows = dims - head
+        sl = 0 if rows > _LANES_MAX_ROWS else max(1, -(-rows // 16))
+        body = _SRC_LANES % {"user": user_source, "head": int(head), "sl": sl}
+    elif form == "elementwise":
+        body = _SRC_ELEMENTWISE % {"user": user_source}
+    else:
+        body = _SRC_CHAIN % {"user": user_source}
+    return _SRC_PRELUDE + body + _SRC_EXPORTS
+
+
+_SRC_REQUIRED_EXPORTS = ("bk_src_target", "bk_src_target_n")
+
+
+def _compile_source_target(user_source: str, form: str, contract: bool, dims: int = 1, head: int = 0) -> str:
+    """hipcc the generated translation unit into a shared library (cached by content: the generated text, the flags and the
+    library headers it includes); returns its path."""
+    import ctypes
     import hashlib
     import os
     import subprocess
-    import tempfile
 
-    if form not in ("elementwise", "chain"):
-        raise ValueError("form must be 'elementwise' (bk_term: one coordinate's term and derivative) or 'chain' "
-                         "(bk_chain: one chain's log density and gradient)")
-    body = (_SRC_ELEMENTWISE if form == "elementwise" else _SRC_CHAIN) % {"user": user_source}
-    text = _SRC_PRELUDE + body + _SRC_EXPORTS
+    text = _source_text(user_source, form, int(dims), int(head))
+    csrc = _csrc_dir()
+    inc = os.path.abspath(os.path.join(csrc, "..", "..", "include"))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
              "-ffp-contract=" + ("fast" if contract else "off")]
-    tag = hashlib.sha256((text + " ".join(flags)).encode()).hexdigest()[:20]
-    root = os.environ.get("BK_SOURCE_TARGET_DIR") or os.path.join(tempfile.gettempdir(), f"bayes_kit_amd_src_{os.getuid()}")
-    os.makedirs(root, exist_ok=True)
-    src, lib = os.path.join(root, f"t_{tag}.hip"), os.path.join(root, f"libt_{tag}.so")
-    if not os.path.exists(lib):
-        with open(src, "w") as f:
+    h = hashlib.sha256((text + " ".join(flags)).encode())
+    for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", os.path.join(inc, "bkhip.h")):
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    tag = h.hexdigest()[:20]
+    root = _source_cache_dir()
+    lib = os.path.join(root, f"libt_{tag}.so")
+    if os.path.lexists(lib):
+        _check_private(lib, "the cached library", False)
+        return lib
+    hipcc = _find_hipcc()
+    # (several ranks may compile the same source at once: everything is written under per-process names, the finished
+    # library is checked for its exports and only then published with an atomic rename)
+    src = os.path.join(root, f"t_{tag}.{os.getpid()}.hip")
+    tmp = lib + f".{os.getpid()}.tmp"
+    try:
+        fd = os.open(src, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        with os.fdopen(fd, "w") as f:
             f.write(text)
-        hipcc = next((c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc") if c and os.path.exists(c)), "hipcc")
-        tmp = lib + f".{os.getpid()}.tmp"
-        r = subprocess.run([hipcc] + flags + [src, "-o", tmp], capture_output=True, text=True)
+        r = subprocess.run([hipcc] + flags + ["-I" + csrc, "-I" + inc, src, "-o", tmp], capture_output=True, text=True)
         if r.returncode != 0:
-            raise _lib.BkHipError("CTarget.from_source: hipcc failed\n" + r.stderr[-4000:])
-        os.replace(tmp, lib)  # (atomic: several ranks may compile the same source at once)
+            raise _lib.BkHipError("CTarget.from_source: hipcc failed\n" + r.stderr[-6000:])
+        os.chmod(tmp, 0o700)
+        probe = ctypes.CDLL(tmp)
+        for name in _SRC_REQUIRED_EXPORTS:
+            if not hasattr(probe, name):
+                raise _lib.BkHipError(f"CTarget.from_source: the compiled library does not export {name}")
+        os.replace(tmp, lib)
+    finally:
+        for f_ in (src, tmp):
+            try:
+                os.unlink(f_)
+            except OSError:
+                pass
     return lib
 
 
+def _bind_source_fast_paths(t):
+    """Attach the whole-proposal / whole-draw hooks the samplers look for (bk_dr_proposal, bk_hmc_draw,
+    bk_hmc_trajectory) when the generated library exports them: the same hooks the built-in targets have."""
+    import ctypes
+    import types
+
+    I, P, F = ctypes.c_int64, ctypes.c_void_p, ctypes.c_double
+    ptr = _lib.ptr
+
+    def export(name, argtypes):
+        try:
+            f = getattr(t._cdll, name)
+        except AttributeError:
+            return None
+        f.argtypes, f.restype = argtypes, ctypes.c_int
+        return f
+
+    def check(rc, name):
+        if rc != 0:
+            raise _lib.BkHipError(f"{name} returned {rc}")
+
+    def stream(x):
+        return torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else None
+
+    f_traj = export("bk_src_hmc_trajectory", [P, P, P, P, I, P, P, F, I, I, I, P])
+    f_draw = export("bk_src_hmc_draw", [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P])
+    f_prop = export("bk_src_dr_proposal_job", [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P])
+
+    if f_traj is not None:
+        def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
+            """Whole leapfrog trajectory with the compiled term inlined (register-resident; bk_elementwise.hpp)."""
+            D, C = theta_in.shape
+            ld = _lib._ld(theta_in)
+            assert _lib._ld(theta_out) == ld and _lib._ld(rho_in) == ld and _lib._ld(rho_out) == ld
+            check(f_traj(ptr(theta_in), ptr(theta_out), ptr(rho_in), ptr(rho_out), ld, self._pp, ptr(metric), eps, steps,
+                         C, D, stream(theta_in)), "bk_src_hmc_trajectory")
+
+        t.bk_hmc_trajectory = types.MethodType(bk_hmc_trajectory, t)
+    if f_draw is not None:
+        def bk_hmc_draw(self, theta_in, theta_out, rho_in, zt, metric, eps, steps, part, kin0, kin1, lp_out, accept=None):
+            """Trajectory + energies (+ accept test) of one HMC draw in one pass, the compiled term inlined."""
+            D, C = theta_in.shape
+            ld = _lib._ld(theta_in)
+            assert _lib._ld(theta_out) == ld and (rho_in is None or _lib._ld(rho_in) == ld) and part.numel() >= 12 * C
+            ldz = 0
+            if zt is not None:
+                assert zt.shape[0] == C and zt.stride(1) == 1 and zt.shape[1] >= D
+                ldz = zt.stride(0)
+            lp_cur, log_u, mask, ret, count = accept if accept is not None else (None,) * 5
+            check(f_draw(ptr(theta_in), ptr(theta_out), ld, ptr(rho_in), ptr(zt), ldz, self._pp, ptr(metric), eps, steps,
+                         ptr(part), ptr(kin0), ptr(kin1), ptr(lp_out), ptr(lp_cur), ptr(log_u), ptr(mask), ptr(ret),
+                         ptr(count), C, D, stream(theta_in)), "bk_src_hmc_draw")
+
+        t.bk_hmc_draw = types.MethodType(bk_hmc_draw, t)
+    if f_prop is not None:
+        def bk_dr_proposal(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out,
+                           metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None, ghost=None,
+                           ghost0=None):
+            """Whole delayed-rejection proposal in one launch with the compiled density inlined (bk_lanes.hpp;
+            arguments as Funnel.bk_dr_proposal); False if the shape is unsupported."""
+            D, n = theta_out.shape
+            ld_in, ld_out = _lib._ld(theta_in), _lib._ld(theta_out)
+            if max(ld_in, ld_out) * (16 + self._head) * 8 >= 2 ** 32:
+                return False
+            assert _lib._ld(rho_in) == ld_in and _lib._ld(grad_in) == ld_in
+            assert _lib._ld(rho_out) == ld_out and _lib._ld(grad_out) == ld_out
+            H, hh, live = level if level is not None else (None, None, None)
+            check(f_prop(ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index), ptr(theta_out), ptr(rho_out),
+                         ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric), h, steps, n, D, ptr(n_dev),
+                         ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live),
+                         None if job is None else ctypes.cast(ctypes.pointer(job), P),
+                         None if ghost is None else ctypes.cast(ctypes.pointer(ghost), P),
+                         None if ghost0 is None else ctypes.cast(ctypes.pointer(ghost0), P), self._pp,
+                         stream(theta_in)), "bk_src_dr_proposal_job")
+            return True
+
+        t.bk_dr_proposal = types.MethodType(bk_dr_proposal, t)
+        t.bk_dr_proposal_supported = lambda: True
+
+
 def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "elementwise", contract: bool = False,
-                         ops=None):
+                         ops=None, head: int = 0):
     """A device model from a few lines of HIP C++, compiled with hipcc when the object is built (cached by content
-    under the temporary directory; BK_SOURCE_TARGET_DIR overrides) into the plugin ABI -- both forms, so every
-    sampler, DrGhmcDiag's device-side lane counts and hipGraph replay included, treats it like a built-in target:
-    the gradient call goes from the sampler straight to the compiled launch, no PyTorch ops, no build to write.
+    in a private per-user directory: $XDG_CACHE_HOME/bayes_kit_amd or ~/.cache/bayes_kit_amd, BK_SOURCE_TARGET_DIR
+    overrides; a directory or cached library that another user could have written is refused) into the plugin ABI --
+    both forms, so every sampler, DrGhmcDiag's device-side lane counts and hipGraph replay included, treats it like a
+    built-in target: the gradient call goes from the sampler straight to the compiled launch, no PyTorch ops, no build to
+    write.  The integrator text stays the library's (csrc/bk_elementwise.hpp, csrc/bk_lanes.hpp): the compiled function
+    is the only inlined callee.
 
     form="elementwise": the log density is a sum over coordinates; ``source`` defines
         ``__device__ void bk_term(double th, i64 d, const double* params, double& term, double& grad)``
-    and the library supplies the kernels (a streaming 16-byte-per-lane gradient kernel, per-chain sums in the
-    library's own order).  form="chain": any density; ``source`` defines
+    and the library supplies the kernels: a streaming 16-byte-per-lane gradient kernel, per-chain sums in the library's
+    own order, and the register-resident whole-trajectory / whole-draw HMC kernels the built-in Gaussians have
+    (``HMCDiag`` then runs a draw as generator + ONE pass over the state, bit-identical to the step-by-step path).
+    form="lanes": a density of head coordinates and sums over the other ("spread") rows -- hierarchical models;
+    ``head`` = number of leading coordinates every lane holds; ``source`` defines
+        ``template <class L> __device__ double bk_lanes_density(L& c, const double* params)``
+    with ``c.dims()``, ``c.head(i)``, ``c.sum(f)``, ``c.grad_head(i, g)``, ``c.grad(f)`` (``f(double theta_d, i64 d)``).  A
+    chain is served by 4 / 8 / 16 lanes of a wavefront, sums reduced by DPP in a fixed order; with dims - head <= 128
+    ``DrGhmcDiag`` runs every delayed-rejection proposal as ONE launch (the path ``bk.Funnel`` has), else the counted
+    step-by-step path.  form="chain": any density; ``source`` defines
         ``__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)``
     called by one lane per chain (``th[d]``, ``g.set(d, v)``).  ``params``: a float64 device tensor (or None).
     contract=False compiles with -ffp-contract=off (every product and sum rounded, as NumPy does)."""
-    lib = _compile_source_target(source, form, contract)
+    lib = _compile_source_target(source, form, contract, dims, head)
     if params is not None and not (isinstance(params, torch.Tensor) and params.dtype == torch.float64):
         raise TypeError("params must be a float64 torch tensor (device memory the compiled function reads) or None")
     t = cls(lib, "bk_src_target", dims, params=params, ops=ops, counted_symbol="bk_src_target_n")
     t.source_library = lib
+    t.source_form = form
+    t._head = int(head)
+    _bind_source_fast_paths(t)
     return t
 
 
@@ -527,19 +799,82 @@ class TorchModel:
     grad_fn (optional): the gradient written out in PyTorch ops, same argument and the argument's shape back.  The
     samplers then never build an autograd graph, and a leapfrog step -- which discards the log density (hmc.py:45,50)
     -- calls ``grad_fn`` alone: for an elementwise density that is one torch kernel instead of autograd's eight passes.
+
+    compile=True: an autograd-free fast lane.  ``fn`` is read once with ``torch.fx``; if it is elementwise plus a sum over
+    the coordinates (+ - * / neg exp log log1p expm1 pow sigmoid logsigmoid softplus tanh sqrt square abs sin cos, constants
+    broadcast along the coordinate axis) its per-coordinate term and the hand-differentiated derivative are emitted as HIP
+    source and compiled by ``CTarget.from_source`` (``.traced_source``, ``.compiled``): the model is then a compiled target
+    like a built-in one.  Anything else warns (naming the node, ``.compile_note``) and keeps autograd.
     """
 
     batched = True
 
-    def __init__(self, fn, dims: int, layout: str = "cd", grad_fn=None):
+    def __init__(self, fn, dims: int, layout: str = "cd", grad_fn=None, compile: bool = False, contract: bool = False):
         if layout not in ("cd", "dc"):
             raise ValueError("layout must be 'cd' (fn takes (C, D), the reference's shape) or 'dc' (fn takes (D, C))")
         self._fn = fn
         self._grad_fn = grad_fn
         self._D = int(dims)
         self._dc = layout == "dc"
+        self.compiled = None        # the CTarget the traced source was compiled into (compile=True and traceable)
+        self.traced_source = None   # ... and its bk_term source
+        self.compile_note = None    # why compile=True kept autograd, if it did
         if grad_fn is not None:
-            self.gradient = self._gradient  # (the engine's gradient-only call; absent for autograd, which needs the forward pass anyway)
+            # (the engine's gradient-only call; absent for autograd, which needs the forward pass anyway.  A namespaced
+            # opt-in: a user model's own `gradient` member is never called)
+            self.bk_gradient = self._gradient
+        if compile:
+            self._compile(contract)
+
+    def _compile(self, contract):
+        """compile=True: read ``fn`` once with torch.fx; if it is elementwise-plus-sum-over-the-coordinates, emit its
+        ``bk_term`` (value and hand-differentiated derivative, trace.py) and run through CTarget.from_source -- the
+        model then IS a compiled target for every sampler (streaming gradient kernel, counted launches, the
+        whole-draw HMC kernel).  Otherwise: a warning naming the unsupported node, and autograd as before."""
+        import warnings
+
+        from . import trace
+
+        try:
+            src, params, info = trace.term_source(self._fn, self._D, "dc" if self._dc else "cd")
+        except trace.Unsupported as e:
+            self.compile_note = str(e)
+            warnings.warn(f"TorchModel(compile=True): not traceable ({e}); keeping autograd", stacklevel=3)
+            return
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        p = None if params is None else params.to(dev)
+        target = CTarget.from_source(src, self._D, params=p, form="elementwise", contract=contract)
+        if dev.type == "cuda":
+            note = self._check_compiled(target, dev)
+            if note is not None:
+                self.compile_note = note
+                warnings.warn(f"TorchModel(compile=True): {note}; keeping autograd", stacklevel=3)
+                return
+        self.compiled, self.traced_source, self.trace_info = target, src, info
+        # the hooks the samplers look for, straight to the compiled target
+        self.bk_eval, self.bk_counted = target.bk_eval, target.bk_counted
+        for name in ("bk_hmc_draw", "bk_hmc_trajectory"):
+            if hasattr(target, name):
+                setattr(self, name, getattr(target, name))
+        self.__dict__.pop("bk_gradient", None)
+
+    def _check_compiled(self, target, dev):
+        """The compiled source against the function itself on a few random points (a tracer records ONE path through
+        Python code: a data-dependent branch would be frozen silently).  None if they agree."""
+        try:
+            g = torch.Generator(device="cpu").manual_seed(20250)
+            Theta = (0.5 * torch.randn((16, self._D), generator=g, dtype=torch.float64)).to(dev)
+            x = self._arg(Theta).detach().requires_grad_(True)
+            with torch.enable_grad():
+                lp = self._fn(x)
+                (gr,) = torch.autograd.grad(lp.sum(), x)
+            gr = gr.t() if self._dc else gr
+        except Exception:  # the function cannot be evaluated here (e.g. its constants live elsewhere): nothing to compare
+            return None
+        lp_c, g_c = target.log_density_gradient(Theta)
+        ok = (torch.allclose(lp_c, lp.detach(), rtol=1e-9, atol=1e-9, equal_nan=True)
+              and torch.allclose(g_c, gr, rtol=1e-9, atol=1e-9, equal_nan=True))
+        return None if ok else "the compiled source disagrees with the function on random points"
 
     def dims(self) -> int:
         return self._D
@@ -549,10 +884,14 @@ class TorchModel:
         return Theta.t() if self._dc else Theta
 
     def log_density(self, Theta):
+        if self.compiled is not None:
+            return self.compiled.log_density(Theta)
         with torch.no_grad():
             return self._fn(self._arg(Theta))
 
     def log_density_gradient(self, Theta):
+        if self.compiled is not None:
+            return self.compiled.log_density_gradient(Theta)
         if self._grad_fn is not None:
             with torch.no_grad():
                 x = self._arg(Theta)

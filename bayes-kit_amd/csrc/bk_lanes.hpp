@@ -1,0 +1,751 @@
+// Lane-spread densities: the library's trajectory and gradient kernels for ANY log density of the shape
+//
+//     log p(theta) = F( head coordinates, sums over the remaining ("spread") coordinates of per-row terms )
+//
+// (hierarchical models: a few shared hyper-parameters + many exchangeable rows; Neal's funnel is HEAD = 1).
+// The density is the ONLY model-specific code: a struct with
+//
+//     static constexpr int HEAD;                       // leading coordinates every lane of a chain holds
+//     template <class L> static double eval(L& c, const double* params);   // returns log p
+//
+// written against a lane context `c`:
+//
+//     c.dims()                  D
+//     c.head(i)                 theta_i, i < HEAD (i a constant)
+//     c.sum(f)                  sum over the spread rows d >= HEAD of f(theta_d, d), in the library's canonical
+//                               order (below); the same value in every lane of the chain
+//     c.grad_head(i, g)         d log p / d theta_i
+//     c.grad(f)                 d log p / d theta_d = f(theta_d, d) for every spread row; call it ONCE and LAST
+//                               (a trajectory context advances the row as its gradient is delivered; a sum() after
+//                               grad() traps)
+//
+// The integrator text is the library's: bayes_kit/drghmc.py:253-289 (leapfrog), :319-346 (proposal map),
+// :391-446 (accept recursion, first ghost) are kernels of THIS header, instantiated once for the built-in funnel
+// (bk_targets.hip) and once per CTarget.from_source(form="lanes") density (the generated translation unit includes
+// this file; the user's function is the only inlined callee).
+//
+// Canonical summation order (results do not depend on how many chains are in flight, on the grid, or on which
+// geometry runs).  Spread row d belongs to class c = (d - HEAD) mod 16, slot i = (d - HEAD) div 16:
+//     cs[c] = sum over i, in order, of f(theta[HEAD + c + 16 i])       (16 class sums)
+//     q[g]  = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12],  g = 0..3      (4 group sums)
+//     s     = ((q[0] + q[1]) + q[2]) + q[3]
+// LPC adjacent lanes of ONE wavefront serve a chain and s is reduced with DPP moves inside the wavefront -- no
+// LDS, no workgroup barrier in the leapfrog loop:
+//     LPC = 4  (throughput: every chain): 16 chains per wavefront; lane p of a chain's quad holds the classes of
+//              group p (p, p+4, p+8, p+12: up to 32 rows), forms q[p] itself, s over the quad.
+//     LPC = 8  : lane p holds classes p and p + 8.
+//     LPC = 16 (latency: sparse, long later stages): 4 chains per wavefront, one 16-lane DPP row each; lane p holds
+//              class p (up to 8 rows).
+// Every lane integrates the head coordinates redundantly; one lane per chain writes them.
+#pragma once
+#include "bk_common.hpp"
+#include <math.h>
+#include <stdlib.h>
+
+namespace bkl {
+
+constexpr int WAVES = 4;
+constexpr int CLASSES = 16;
+constexpr int MAX_SLOTS = 8;  // slots per class held in registers: D - HEAD <= 128
+constexpr int MAX_ROWS = CLASSES * MAX_SLOTS;
+constexpr int BLOCK = WAVES * BK_WAVE;
+constexpr int MAX_HEAD = 8;
+
+// ---- DPP moves of a double (two 32-bit halves) ------------------------------------------------------------------
+// Lanes the control does not reach (row / bank masks, a shift whose source lies outside the 16-lane row) keep `old`.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, BANK_MASK, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHL = 0x100;  // + n: lane i reads lane i + n of its row
+constexpr int DPP_ROW_SHR = 0x110;  // + n: lane i reads lane i - n of its row
+// the same for controls under which every lane that matters has a source lane: no `old` operand, so no copy
+// of the source in front of the move (lanes without a source read 0)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_all(double src) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ double quad_bcast(double x) {  // lane K of every quad, to the whole quad
+  return dpp_f64_all<K * 0x55>(x);
+}
+
+//   LPC = 4 : p = lane % 4 is the class GROUP; register slot u = k*SL + i holds class p + 4k, slot i.
+//   LPC = 8 : p = lane % 8;                    register slot u = k*SL + i holds class p + 8k, slot i (k = 0, 1).
+//   LPC = 16: p = lane % 16 is the CLASS;      register slot u = i     holds class p,      slot i.
+// A lane's rows are HEAD + p + off(u) with a lane-independent off(u): row addresses are a per-lane 32-bit
+// offset (row HEAD + p of the lane's chain) on top of a wavefront-uniform row base, and only the LAST slot
+// of a class can run past D (SL is exactly ceil((D-HEAD)/16)): every other row needs no guard.
+template <int LPC, int SL>
+struct Geo {
+  static_assert(LPC == 4 || LPC == 8 || LPC == 16, "a chain is served by a quad, half a DPP row or a DPP row");
+  static constexpr int KC = CLASSES / LPC;      // classes per lane
+  static constexpr int NU = KC * SL;            // register slots per lane
+  static constexpr int CHAINS = BK_WAVE / LPC;  // chains per wavefront
+  __host__ __device__ static constexpr int off(int u) {  // row of slot u, relative to the lane's first row
+    return LPC * (u / SL) + CLASSES * (u % SL);  // (LPC = 16: one class per lane, u / SL = 0)
+  }
+  __host__ __device__ static constexpr bool last_slot(int u) { return u % SL == SL - 1; }
+};
+
+// s (canonical order) of the chain this lane serves, from the lane's class sums; valid in EVERY lane
+// of the chain.  All 64 lanes must be active.
+template <int LPC>
+__device__ __forceinline__ double reduce_lanes(const double* cs) {
+  double q;
+  if (LPC == 4) {
+    q = ((cs[0] + cs[1]) + cs[2]) + cs[3];  // this lane holds classes p, p+4, p+8, p+12
+  } else if (LPC == 8) {
+    // lane p of the 8-lane group holds cs[p] and cs[p+8]; lanes 0..3 fetch cs[p+4], cs[p+12] from lane p + 4
+    const double b = dpp_f64_all<DPP_ROW_SHL + 4>(cs[0]);
+    const double d = dpp_f64_all<DPP_ROW_SHL + 4>(cs[1]);
+    q = ((cs[0] + b) + cs[1]) + d;
+  } else {
+    // lane p of the row holds cs[p]; in lanes 0..3: q[p] = ((cs[p] + cs[p+4]) + cs[p+8]) + cs[p+12]
+    // (the other twelve lanes compute something nobody reads)
+    const double b = dpp_f64_all<DPP_ROW_SHL + 4>(cs[0]);
+    const double c = dpp_f64_all<DPP_ROW_SHL + 8>(cs[0]);
+    const double d = dpp_f64_all<DPP_ROW_SHL + 12>(cs[0]);
+    q = ((cs[0] + b) + c) + d;
+  }
+  // lane p of the quad holds q[p]
+  double s = ((quad_bcast<0>(q) + quad_bcast<1>(q)) + quad_bcast<2>(q)) + quad_bcast<3>(q);
+  if (LPC == 16) {
+    // s is right in lanes 0..3 of the row: hand it to lanes 4..7, then lanes 0..7 hand it to 8..15
+    s = dpp_f64<DPP_ROW_SHR + 4, 0xF, 0x2>(s, s);
+    s = dpp_f64<DPP_ROW_SHR + 8, 0xF, 0xC>(s, s);
+  } else if (LPC == 8) {
+    // s is right in lanes 0..3 of each 8-lane group: hand it to lanes 4..7 (banks 1 and 3 of the row)
+    s = dpp_f64<DPP_ROW_SHR + 4, 0xF, 0xA>(s, s);
+  }
+  return s;
+}
+
+// class sums of term(u) over this lane's rows (tail_ok[k]: the last slot of class k exists), each class
+// sequential in its slots
+template <class G, int SL, class T>
+__device__ __forceinline__ void class_sums(double* cs, const bool* tail_ok, T&& term) {
+#pragma unroll
+  for (int k = 0; k < G::KC; ++k) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < SL; ++i) {
+      const int u = k * SL + i;
+      if (!G::last_slot(u) || tail_ok[k]) acc = acc + term(u);
+    }
+    cs[k] = acc;
+  }
+}
+
+// ---- the lane context of a trajectory: rows in registers, the gradient delivered INTO the kick -----------------
+//   r  += hk * (metric * grad)            (drghmc.py:277 / :281 / :286)
+//   x  += hd * r     when DRIFT           (drghmc.py:278 / :282)
+//   g_out <- grad    when STORE           (the proposal's end point keeps its gradient, drghmc.py:285)
+// MTR: the 16-lane geometry keeps its rows' metric entries in registers (<= 8 rows), the others re-read them (L1).
+template <int LPC, int SL, bool HM, int HEAD, bool STORE, bool DRIFT>
+struct TrajCtx {
+  using G = Geo<LPC, SL>;
+  static constexpr int NU = G::NU, KC = G::KC;
+  static constexpr bool MTR = HM && LPC == 16;
+  double* x;             // [NU] this lane's rows
+  double* r;             // [NU] their momenta
+  const double* v;       // [HEAD] head coordinates
+  double* rv;            // [HEAD] their momenta
+  double* gv;            // [HEAD] out: the head gradient
+  const bool* tail_ok;   // [KC]
+  const double* mt;      // [NU] row metric entries (MTR)
+  const double* mvh;     // [HEAD] head metric entries
+  const double* metric;  // device array (or NULL)
+  double hk, hd;
+  int pos;
+  i64 D;
+  double* g_out;  // STORE
+  i64 ld_out;
+  uint32_t bo_out;
+  bool on;
+  bool rows_done;
+
+  __device__ __forceinline__ i64 dims() const { return D; }
+  __device__ __forceinline__ double head(int i) const { return v[i]; }
+  __device__ __forceinline__ i64 row(int u) const { return (i64)(HEAD + pos + G::off(u)); }
+  __device__ __forceinline__ bool ok(int u) const { return !G::last_slot(u) || tail_ok[u / SL]; }
+  __device__ __forceinline__ double metric_of(int u) const { return MTR ? mt[MTR ? u : 0] : metric[HEAD + pos + G::off(u)]; }
+
+  template <class F>
+  __device__ __forceinline__ double sum(F&& f) {
+    if (rows_done) __builtin_trap();  // (folds away: the flag is a compile-time constant after inlining)
+    double cs[KC];
+    class_sums<G, SL>(cs, tail_ok, [&](int u) { return f(x[u], row(u)); });
+    return reduce_lanes<LPC>(cs);
+  }
+  __device__ __forceinline__ void grad_head(int i, double g) {
+    gv[i] = g;
+    const double t = HM ? mvh[i] * g : g;
+    rv[i] = rv[i] + hk * t;
+  }
+  template <class F>
+  __device__ __forceinline__ void grad(F&& f) {
+    if (rows_done) __builtin_trap();
+    rows_done = true;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (ok(u)) {
+        const double gi = f(x[u], row(u));
+        const double t = HM ? metric_of(u) * gi : gi;
+        r[u] = r[u] + hk * t;
+        if (DRIFT) x[u] = x[u] + hd * r[u];
+        if (STORE && on)
+          *reinterpret_cast<double*>(reinterpret_cast<char*>(g_out + (i64)G::off(u) * ld_out) + bo_out) = gi;
+      }
+      // bound the live temporaries (registers -> occupancy)
+      if (DRIFT && LPC != 16 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// What a proposal launch carries besides the trajectory (include/bkhip.h: bk_dr_proposal_funnel_job).
+struct TrajArgs {
+  const double* th_in; const double* rho_in; const double* g_in; i64 ld_in; const int32_t* idx;
+  double* th_out; double* rho_out; double* g_out; double* logp_out; double* kin_out; i64 ld_out;
+  const double* metric; double h; int steps; i64 n_host; i64 D; const uint32_t* n_dev; uint32_t* lanes_out;
+  unsigned long long* lanes_total; double* H_out; double* hh_out; uint8_t* live_out; unsigned traj_blocks;
+  const double* params;
+};
+
+// One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE launch: gather chain
+// idx[j] of the source point, first half-kick with the source's cached gradient + drift, (steps-1) x {gradient,
+// kick, drift}, final gradient + log density, last half-kick, momentum flip, kinetic energy.  theta, rho never
+// leave registers, and the sums over a chain's coordinates never leave the wavefront.
+// LPC: lanes per chain; SL = slots per class = ceil((D-HEAD)/16) exactly; HM = a metric is given.  All
+// compile-time: with generic sizes and a run-time metric flag the kernel needed 330 registers.
+// A wavefront-step costs ~580 / ~700 / ~1100 cycles with 16 / 8 / 4 lanes per chain and serves 4 / 8 / 16
+// chains; up to one wavefront per SIMD (1024 of them) the fewest cycles win, beyond that the fewest cycles per
+// chain: 16 lanes per chain below AUTO_MID lanes, 8 below AUTO_WIDE, 4 from there on.
+constexpr i64 AUTO_MID = 4608, AUTO_WIDE = 12288;
+
+template <class DEN, int LPC, int SL, bool HM>
+__device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_ghost_link& ghost, const bk_ghost0& g0,
+                                          int lane, int wave) {
+  constexpr int HEAD = DEN::HEAD;
+  static_assert(HEAD >= 0 && HEAD <= MAX_HEAD, "0 <= HEAD <= 8");
+  using G = Geo<LPC, SL>;
+  constexpr int NU = G::NU, H1 = HEAD > 0 ? HEAD : 1;
+  constexpr bool hm = HM;
+  const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;  // first chain of this wavefront
+  if (j0 >= n) return;  // whole wavefront past the set (uniform; the wavefronts of a workgroup are independent)
+  const int pos = lane & (LPC - 1);
+  const i64 j = j0 + lane / LPC;
+  const bool on = j < n;
+  const bool writer = on && pos == 0;  // the lane that owns the head coordinates / the scalars
+  const i64 src = on ? (a.idx ? (i64)a.idx[j] : j) : 0;
+  const i64 ld_in = a.ld_in, ld_out = a.ld_out, D = a.D;
+  const double h = a.h, half = 0.5 * a.h;
+  const double* metric = a.metric;
+  // this lane's rows: d(u) = HEAD + pos + off(u).  Byte offsets of its first row (host checked: < 2^32)
+  const uint32_t bo_in = (uint32_t)(((i64)(HEAD + pos) * ld_in + src) * 8);
+  const uint32_t bo_out = (uint32_t)(((i64)(HEAD + pos) * ld_out + (on ? j : 0)) * 8);
+#define BKL_IN(p, u) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>((p) + (i64)G::off(u) * ld_in) + bo_in))
+#define BKL_OUT(p, u) (*reinterpret_cast<double*>(reinterpret_cast<char*>((p) + (i64)G::off(u) * ld_out) + bo_out))
+  bool tail_ok[G::KC];  // does the last slot of class k exist for this lane?
+#pragma unroll
+  for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * SL + SL - 1) < D;
+#define BKL_OK(u) (!G::last_slot(u) || tail_ok[(u) / SL])
+  double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
+  // gather + first half-kick + drift (drghmc.py:276-278)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    // (lanes past the set read chain 0 -- src = 0 -- and compute on it; they store nothing.  No branch
+    // around the loads of rows that exist for every lane.)
+    const bool ok = BKL_OK(u);
+    x[u] = ok ? BKL_IN(a.th_in, u) : 0.0;
+    r[u] = ok ? BKL_IN(a.rho_in, u) : 0.0;
+    double gin = ok ? BKL_IN(a.g_in, u) : 0.0;
+    const double mi = (hm && BKL_OK(u)) ? metric[HEAD + pos + G::off(u)] : 1.0;
+    if (HM && LPC == 16) mt[u] = mi;
+    double t = hm ? mi * gin : gin;
+    r[u] = r[u] + half * t;
+    x[u] = x[u] + h * r[u];
+    // the gather is issued in batches of 8 rows: all 3*NU loads in flight at once would set the
+    // kernel's register count (and so its occupancy for the whole trajectory)
+    if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+  }
+  double v[H1], rv[H1], mvh[H1], gv[H1];
+#pragma unroll
+  for (int i = 0; i < HEAD; ++i) {
+    v[i] = a.th_in[(i64)i * ld_in + src];
+    rv[i] = a.rho_in[(i64)i * ld_in + src];
+    mvh[i] = hm ? metric[i] : 1.0;
+    const double gin = a.g_in[(i64)i * ld_in + src];
+    const double t = hm ? mvh[i] * gin : gin;
+    rv[i] = rv[i] + half * t;
+    v[i] = v[i] + h * rv[i];
+  }
+  using StepCtx = TrajCtx<LPC, SL, HM, HEAD, false, true>;
+  using KickCtx = TrajCtx<LPC, SL, HM, HEAD, false, false>;
+  using EndCtx = TrajCtx<LPC, SL, HM, HEAD, true, false>;
+  // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283)
+  for (int step = 0; step + 1 < a.steps; ++step) {
+    StepCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, h, h, pos, D, nullptr, 0, 0u, false, false};
+    DEN::eval(c, a.params);
+#pragma unroll
+    for (int i = 0; i < HEAD; ++i) v[i] = v[i] + h * rv[i];
+  }
+  // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
+  double logp_j;
+  {
+    EndCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, half, 0.0, pos, D, a.g_out, ld_out, bo_out, on, false};
+    logp_j = DEN::eval(c, a.params);
+    if (writer) {
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) a.g_out[(i64)i * ld_out + j] = gv[i];
+      a.logp_out[j] = logp_j;
+    }
+  }
+  // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250; same canonical order), outputs
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    if (BKL_OK(u)) {
+      r[u] = -r[u];
+      if (on) {
+        BKL_OUT(a.rho_out, u) = r[u];
+        BKL_OUT(a.th_out, u) = x[u];
+      }
+    }
+  }
+  double cs[G::KC];
+  class_sums<G, SL>(cs, tail_ok, [&](int u) {
+    return r[u] * (hm ? ((HM && LPC == 16) ? mt[(HM && LPC == 16) ? u : 0] : metric[HEAD + pos + G::off(u)]) * r[u] : r[u]);
+  });
+  const double ksum = reduce_lanes<LPC>(cs);
+  double H_own = 0.0;
+#pragma unroll
+  for (int i = 0; i < HEAD; ++i) rv[i] = -rv[i];
+  if (writer) {
+    double hs = 0.0;
+#pragma unroll
+    for (int i = 0; i < HEAD; ++i) {
+      const double mr = hm ? mvh[i] * rv[i] : rv[i];
+      a.rho_out[(i64)i * ld_out + j] = rv[i];
+      a.th_out[(i64)i * ld_out + j] = v[i];
+      hs = i == 0 ? rv[i] * mr : hs + rv[i] * mr;
+    }
+    const double kin = 0.5 * (HEAD > 0 ? hs + ksum : ksum);
+    a.kin_out[j] = kin;
+    if (a.H_out) {
+      // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
+      // H = -((-logp) + kin) (drghmc.py:421 -> :249-251); h and live follow below
+      const double potential = -logp_j;
+      const double Hj = -(potential + kin);
+      H_own = Hj;
+      a.H_out[j] = Hj;
+    }
+  }
+  double h_own = 0.0;    // the produced level's h / live for this lane (h = 0, live = 1 unless its first ghost
+  bool live_own = true;  // is run here as well)
+
+  // ---- the proposal's FIRST GHOST, in the same wavefront (drghmc.py:424-436 with i = 0) ----------------------
+  // Every lane of a level gets ghost 0, lane for lane, and a ghost of the first proposal kind has no ghosts of its
+  // own: the wavefront that has just produced proposal P integrates P's ghost straight from its registers
+  // (theta_P and the flipped momentum; the gradient at theta_P is evaluated again, the same values) --
+  // no store + gather of the ghost's source, no ghost arrays at all (only its joint log density is ever used),
+  // one launch instead of two.  Same operation sequence as a launch of its own.
+  if (g0.steps > 0) {
+    const double h2 = g0.h, half2 = 0.5 * g0.h;
+    {  // first half-kick + drift from the proposal's end point (drghmc.py:276-278)
+      StepCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, half2, h2, pos, D, nullptr, 0, 0u, false, false};
+      DEN::eval(c, a.params);
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) v[i] = v[i] + h2 * rv[i];
+    }
+    for (int step = 0; step + 1 < g0.steps; ++step) {
+      StepCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, h2, h2, pos, D, nullptr, 0, 0u, false, false};
+      DEN::eval(c, a.params);
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) v[i] = v[i] + h2 * rv[i];
+    }
+    double logp_g;
+    {
+      KickCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, half2, 0.0, pos, D, nullptr, 0, 0u, false, false};
+      logp_g = DEN::eval(c, a.params);
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      if (BKL_OK(u)) r[u] = -r[u];
+    class_sums<G, SL>(cs, tail_ok, [&](int u) {
+      return r[u] * (hm ? ((HM && LPC == 16) ? mt[(HM && LPC == 16) ? u : 0] : metric[HEAD + pos + G::off(u)]) * r[u] : r[u]);
+    });
+    const double ksum_g = reduce_lanes<LPC>(cs);
+    bool goes_on = false;
+    if (writer) {
+      double hs = 0.0;
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) {
+        const double rr = -rv[i];
+        const double mr = hm ? mvh[i] * rr : rr;
+        hs = i == 0 ? rr * mr : hs + rr * mr;
+      }
+      const double kin_g = 0.5 * (HEAD > 0 ? hs + ksum_g : ksum_g);
+      const double H_g = -((-logp_g) + kin_g);
+      // the ghost against the proposal it came from (parent h = 0: this is the proposal's first ghost), then the
+      // proposal's level entry: bk_dr_level_begin + bk_dr_accept_prob_ghost in one
+      const double g = dr_accept_logprob(H_g, H_own, 0.0, 0.0, g0.prob_retry);
+      if (g == 0.0) {  // drghmc.py:430-432
+        live_own = false;
+        g0.parent_a[j] = -INFINITY;
+      } else {
+        h_own = 0.0 + log1p(-exp(g));  // drghmc.py:434-435
+        goes_on = true;
+      }
+    }
+    if (g0.next_index) bk_append(goes_on, (int32_t)j, g0.next_index, g0.next_count);
+  }
+  if (writer && a.H_out) {
+    a.hh_out[j] = h_own;
+    a.live_out[j] = live_own ? 1 : 0;
+  }
+
+  // ---- a GHOST level that is complete here (no ghosts of its own, or one and it ran above): its acceptance
+  // probability against the parent lane it came from and the parent's update (bk_dr_accept_prob_ghost;
+  // drghmc.py:426-446), instead of a launch of their own.  One ghost lane per parent lane: nobody else touches
+  // lane `src` of the parent level.
+  if (ghost.parent_H) {
+    bool parent_goes_on = false;
+    if (writer) {
+      double g = -INFINITY;  // (a dead lane: one of its own ghosts was accepted with probability one)
+      if (live_own) {
+        g = dr_accept_logprob(H_own, ghost.parent_H[src], h_own, ghost.parent_h[src], ghost.prob_retry);
+        ghost.a_out[j] = g;
+      }
+      if (g == 0.0) {  // drghmc.py:430-432
+        ghost.parent_a[src] = -INFINITY;
+        ghost.parent_live[src] = 0;
+      } else {
+        ghost.parent_h[src] = ghost.parent_h[src] + log1p(-exp(g));  // drghmc.py:434-435
+        parent_goes_on = true;
+      }
+    }
+    // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
+    if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
+  }
+#undef BKL_IN
+#undef BKL_OUT
+#undef BKL_OK
+}
+
+// LPC_ARG = 4, 8 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows.
+// The grid is sized for the 16-lane form of the bound n_host.
+template <class DEN, int LPC_ARG, int SL, bool HM>
+__global__ __launch_bounds__(BLOCK) void k_lane_traj(TrajArgs a, bk_scatter_job job, bk_ghost_link ghost, bk_ghost0 g0) {
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
+  if (blockIdx.x >= a.traj_blocks) {
+    // surplus workgroups: the previous stage's scatter (bk_scatter_job), one 64-lane unit per wavefront
+    i64 jn = job.n;
+    if (job.n_dev) {
+      const i64 m = (i64)*job.n_dev;
+      jn = m < jn ? m : jn;
+    }
+    const i64 ux_count = (job.n + 63) / 64;  // (units are laid out for the host-side bound)
+    const i64 unit = ((i64)blockIdx.x - a.traj_blocks) * WAVES + wave;
+    const i64 ux = unit % ux_count, uy = unit / ux_count;
+    if (uy * BK_SCT_ROWS < job.D)
+      bk_scatter_unit(ux, uy, lane, job.mask, job.index, jn, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
+                      job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc);
+    return;
+  }
+  // lanes actually in the set: read from device memory when the host only knows an upper bound
+  i64 n = a.n_host;
+  if (a.n_dev) {
+    const i64 m = (i64)*a.n_dev;
+    n = m < n ? m : n;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (a.lanes_out) *a.lanes_out = (uint32_t)n;
+    if (a.lanes_total) *a.lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
+    if (g0.steps > 0) {  // the fused first ghost runs over the same lanes
+      if (g0.lanes_out) *g0.lanes_out = (uint32_t)n;
+      if (g0.lanes_total) *reinterpret_cast<unsigned long long*>(g0.lanes_total) += (unsigned long long)n;
+    }
+  }
+  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) traj_body<DEN, 4, SL, HM>(a, n, ghost, g0, lane, wave);
+  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) traj_body<DEN, 8, SL, HM>(a, n, ghost, g0, lane, wave);
+  else traj_body<DEN, 16, SL, HM>(a, n, ghost, g0, lane, wave);
+}
+
+// Host side of bk_dr_proposal_funnel_job for any density (include/bkhip.h documents the arguments).
+// SL_ONLY > 0: only that slot count is instantiated (a generated translation unit knows its D).
+template <class DEN, int SL_ONLY = 0>
+static int dr_proposal_launch(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                              const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                              double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                              int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                              uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
+                              const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, const bk_ghost0* g0_in,
+                              const double* params, void* stream) {
+  constexpr int HEAD = DEN::HEAD;
+  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
+      steps < 1 || steps > 0x7fffffff || n < 0 || D < HEAD || D < 1)
+    return BK_E_ARG;
+  if (D - HEAD > MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
+  if (H_out && (!h_out || !live_out)) return BK_E_ARG;
+  if (ld_out < n) return BK_E_ALIGN;
+  bk_ghost_link ghost = {};
+  if (ghost_in) {
+    ghost = *ghost_in;
+    if (!H_out || !ghost.parent_H || !ghost.parent_h || !ghost.parent_live || !ghost.parent_a || !ghost.a_out ||
+        (ghost.next_index && (!ghost.next_count || ghost.next_index == src_index)))
+      return BK_E_ARG;
+  }
+  bk_ghost0 g0 = {};
+  if (g0_in) {
+    g0 = *g0_in;
+    // (a level that has further ghosts is not complete in this launch: no link)
+    if (g0.steps < 1 || g0.steps > 0x7fffffff || !H_out || !g0.parent_a ||
+        (g0.next_index && (!g0.next_count || g0.next_index == src_index || ghost_in)))
+      return BK_E_ARG;
+  }
+  bk_scatter_job job = {};
+  unsigned job_blocks = 0;
+  if (job_in) {
+    job = *job_in;
+    if (!job.mask || !job.dst0 || !job.src0 || (job.dst1 && !job.src1) || (job.dst2 && !job.src2) ||
+        (job.sdst && !job.ssrc) || job.n < 0 || job.D < 0)
+      return BK_E_ARG;
+    if (job.n > 0 && job.D > 0)
+      job_blocks = (unsigned)bk_cdiv(bk_cdiv(job.n, 64) * bk_cdiv(job.D, BK_SCT_ROWS), WAVES);
+  }
+  // the kernel addresses a lane's rows with 32-bit byte offsets from wavefront-uniform row bases
+  if ((ld_in > ld_out ? ld_in : ld_out) >= ((i64)1 << 32) / (8 * (CLASSES + HEAD))) return BK_E_ARG;
+  hipStream_t s = bk_stream(stream);
+  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
+  if (need < 1) need = 1;
+  if (SL_ONLY > 0 && need != SL_ONLY) return BK_E_ARG;
+  if (n == 0) {  // nothing to propose: a job still runs (every workgroup of the launch is a surplus one)
+    if (g0.steps > 0 && g0.lanes_out) {
+      int rc = (int)hipMemsetAsync(g0.lanes_out, 0, sizeof(uint32_t), s);
+      if (rc != 0) return rc;
+    }
+    if (lanes_out) {
+      int rc = (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), s);
+      if (rc != 0) return rc;
+    }
+    if (!job_blocks) return BK_OK;
+  }
+  // Geometry.  A set known to be small -> 16 lanes per chain, 16 chains per workgroup; known to be large -> 4
+  // lanes per chain, 64 chains per workgroup; a set whose size only the device knows (every set after the first
+  // stage) -> decided by the kernel from *n_dev when the bound allows a large one.  Same values either way.
+  // BK_FUNNEL_GEOMETRY=wide|mid|narrow overrides (wide = 4 lanes per chain).
+  static const int forced = []() {
+    const char* e = getenv("BK_FUNNEL_GEOMETRY");
+    return !e ? 0 : (e[0] == 'n' ? 2 : e[0] == 'm' ? 3 : 1);  // wide | mid (8 lanes per chain) | narrow
+  }();
+  // 16: 16 lanes per chain; 4: 4 lanes per chain; 0: the kernel decides from *n_dev
+  int geo;
+  if (forced) geo = forced == 2 ? 16 : (forced == 3 ? 8 : 4);
+  else if (n_dev) geo = n >= AUTO_MID ? 0 : 16;
+  else geo = n >= AUTO_WIDE ? 4 : (n >= AUTO_MID ? 8 : 16);
+  const unsigned traj_blocks =
+      n == 0 ? 0u : (unsigned)bk_cdiv(n, WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
+  const TrajArgs a = {theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out,
+                      ld_out, metric, h, (int)steps, n, D, n_dev, lanes_out,
+                      reinterpret_cast<unsigned long long*>(lanes_total), H_out, h_out, live_out, traj_blocks, params};
+  dim3 grid(traj_blocks + job_blocks);
+#define BKL_FT(LPC, R, M) k_lane_traj<DEN, LPC, R, M><<<grid, dim3(BLOCK), 0, s>>>(a, job, ghost, g0)
+#define BKL_FT_ROWS(R)                 \
+  do {                                 \
+    if (geo == 16) {                   \
+      if (metric) BKL_FT(16, R, true); \
+      else BKL_FT(16, R, false);       \
+    } else if (geo == 4) {             \
+      if (metric) BKL_FT(4, R, true);  \
+      else BKL_FT(4, R, false);        \
+    } else if (geo == 8) {             \
+      if (metric) BKL_FT(8, R, true);  \
+      else BKL_FT(8, R, false);        \
+    } else {                           \
+      if (metric) BKL_FT(0, R, true);  \
+      else BKL_FT(0, R, false);        \
+    }                                  \
+  } while (0)
+  if constexpr (SL_ONLY > 0) {
+    BKL_FT_ROWS(SL_ONLY);
+  } else {
+    switch (need) {  // slots per class, exactly: only a class's last slot can run past D
+      case 1: BKL_FT_ROWS(1); break;
+      case 2: BKL_FT_ROWS(2); break;
+      case 3: BKL_FT_ROWS(3); break;
+      case 4: BKL_FT_ROWS(4); break;
+      case 5: BKL_FT_ROWS(5); break;
+      case 6: BKL_FT_ROWS(6); break;
+      case 7: BKL_FT_ROWS(7); break;
+      default: BKL_FT_ROWS(8); break;
+    }
+  }
+#undef BKL_FT_ROWS
+#undef BKL_FT
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+// ---- the same density as a gradient OP (plugin ABI bk_target_fn / bk_target_fn_n) ------------------------------
+// The rows of a chain are spread over LPC lanes of one wavefront exactly as in the trajectory kernel; theta is
+// read from and the gradient written to [D][ld] arrays.  SL > 0: a lane's rows sit in registers (one batch of
+// loads, no second pass: on a small lane set a launch is a chain of memory round trips).  SL = 0: any D, the
+// rows are walked twice (sums, then gradient).
+template <int LPC, int SL, int HEAD>
+struct GradCtx {
+  using G = Geo<LPC, (SL > 0 ? SL : 1)>;
+  static constexpr int NU = SL > 0 ? G::NU : 1, KC = G::KC;
+  const double* x;      // [NU] rows (SL > 0)
+  const double* v;      // [HEAD]
+  double* gv;           // [HEAD]
+  const bool* tail_ok;  // [KC] (SL > 0)
+  const double* th;     // column of this lane's chain: th[d * ld]
+  double* g;            // the same of the gradient (NULL: none wanted)
+  i64 ld;
+  int pos;
+  i64 D;
+  bool on;
+  bool rows_done;
+
+  __device__ __forceinline__ i64 dims() const { return D; }
+  __device__ __forceinline__ double head(int i) const { return v[i]; }
+  __device__ __forceinline__ i64 row(int u) const { return (i64)(HEAD + pos + G::off(u)); }
+  __device__ __forceinline__ bool ok(int u) const { return !G::last_slot(u) || tail_ok[u / (SL > 0 ? SL : 1)]; }
+
+  template <class F>
+  __device__ __forceinline__ double sum(F&& f) {
+    if (rows_done) __builtin_trap();
+    double cs[KC];
+    if constexpr (SL > 0) {
+      class_sums<G, SL>(cs, tail_ok, [&](int u) { return f(x[u], row(u)); });
+    } else {
+#pragma unroll
+      for (int k = 0; k < KC; ++k) {
+        double acc = 0.0;
+#pragma unroll 4
+        for (i64 d = HEAD + pos + LPC * k; d < D; d += CLASSES) acc = acc + f(th[d * ld], d);
+        cs[k] = acc;
+      }
+    }
+    return reduce_lanes<LPC>(cs);
+  }
+  __device__ __forceinline__ void grad_head(int i, double gval) { gv[i] = gval; }
+  template <class F>
+  __device__ __forceinline__ void grad(F&& f) {
+    if (rows_done) __builtin_trap();
+    rows_done = true;
+    if (!g) return;
+    if constexpr (SL > 0) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        if (ok(u)) {
+          const double gi = f(x[u], row(u));
+          if (on) g[row(u) * ld] = gi;
+        }
+    } else {
+#pragma unroll 4
+      for (i64 d = HEAD + pos; d < D; d += LPC) {
+        const double gi = f(th[d * ld], d);
+        if (on) g[d * ld] = gi;
+      }
+    }
+  }
+};
+
+template <class DEN, int LPC, int SL>
+__device__ __forceinline__ void grad_body(const double* th, double* g, double* logp, i64 ld, const double* params,
+                                          i64 n, i64 D, int lane, int wave) {
+  constexpr int HEAD = DEN::HEAD;
+  using C = GradCtx<LPC, SL, HEAD>;
+  using G = typename C::G;
+  constexpr int H1 = HEAD > 0 ? HEAD : 1;
+  const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;
+  if (j0 >= n) return;  // (whole wavefront past the set)
+  const int pos = lane & (LPC - 1);
+  const i64 j = j0 + lane / LPC;
+  const bool on = j < n;
+  const i64 col = on ? j : 0;  // (lanes past the set compute on chain 0 and store nothing: the DPP reduction wants all 64)
+  bool tail_ok[G::KC];
+  double x[C::NU];
+  if constexpr (SL > 0) {
+#pragma unroll
+    for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * (SL > 0 ? SL : 1) + (SL > 0 ? SL : 1) - 1) < D;
+#pragma unroll
+    for (int u = 0; u < C::NU; ++u) {
+      const bool ok = !G::last_slot(u) || tail_ok[u / (SL > 0 ? SL : 1)];
+      x[u] = ok ? th[(i64)(HEAD + pos + G::off(u)) * ld + col] : 0.0;
+    }
+  }
+  double v[H1], gv[H1];
+#pragma unroll
+  for (int i = 0; i < HEAD; ++i) v[i] = th[(i64)i * ld + col];
+  C c{x, v, gv, tail_ok, th + col, g ? g + col : nullptr, ld, pos, D, on, false};
+  const double lp = DEN::eval(c, params);
+  if (on && pos == 0) {
+    if (logp) logp[j] = lp;
+    if (g) {
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) g[(i64)i * ld + j] = gv[i];
+    }
+  }
+}
+
+template <class DEN, int LPC_ARG, int SL>
+__global__ __launch_bounds__(BLOCK) void k_lane_grad(const double* th, double* g, double* logp, i64 ld, const double* params,
+                                                     i64 n_host, i64 D, const uint32_t* n_dev) {
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
+  const i64 n = bk_lanes(n_host, n_dev);
+  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) grad_body<DEN, 4, SL>(th, g, logp, ld, params, n, D, lane, wave);
+  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) grad_body<DEN, 8, SL>(th, g, logp, ld, params, n, D, lane, wave);
+  else grad_body<DEN, 16, SL>(th, g, logp, ld, params, n, D, lane, wave);
+}
+
+// Host side of the plugin ABI (bk_target_fn, and bk_target_fn_n with n_dev) for a lane-spread density.
+template <class DEN, int SL_ONLY = -1>
+static int target_launch(const double* theta, double* grad, double* logp, int64_t ld, const double* params, int64_t C,
+                         int64_t D, const uint32_t* n_dev, void* stream) {
+  constexpr int HEAD = DEN::HEAD;
+  if (!theta || (!grad && !logp) || C < 0 || D < HEAD || D < 1) return BK_E_ARG;
+  if (ld < C) return BK_E_ALIGN;
+  if (C == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
+  if (need < 1) need = 1;
+  if (need > MAX_SLOTS) need = 0;  // rows walked in memory
+  if (SL_ONLY >= 0 && need != SL_ONLY) return BK_E_ARG;
+  int geo;
+  if (n_dev) geo = C >= AUTO_MID ? 0 : 16;
+  else geo = C >= AUTO_WIDE ? 4 : (C >= AUTO_MID ? 8 : 16);
+  const unsigned blocks = (unsigned)bk_cdiv(C, WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
+#define BKL_G(LPC, R) k_lane_grad<DEN, LPC, R><<<dim3(blocks), dim3(BLOCK), 0, s>>>(theta, grad, logp, ld, params, C, D, n_dev)
+#define BKL_G_ROWS(R)               \
+  do {                              \
+    if (geo == 16) BKL_G(16, R);    \
+    else if (geo == 4) BKL_G(4, R); \
+    else if (geo == 8) BKL_G(8, R); \
+    else BKL_G(0, R);               \
+  } while (0)
+  if constexpr (SL_ONLY >= 0) {
+    BKL_G_ROWS(SL_ONLY);
+  } else {
+    switch (need) {
+      case 0: BKL_G_ROWS(0); break;
+      case 1: BKL_G_ROWS(1); break;
+      case 2: BKL_G_ROWS(2); break;
+      case 3: BKL_G_ROWS(3); break;
+      case 4: BKL_G_ROWS(4); break;
+      case 5: BKL_G_ROWS(5); break;
+      case 6: BKL_G_ROWS(6); break;
+      case 7: BKL_G_ROWS(7); break;
+      default: BKL_G_ROWS(8); break;
+    }
+  }
+#undef BKL_G_ROWS
+#undef BKL_G
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+}  // namespace bkl

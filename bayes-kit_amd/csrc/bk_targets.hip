@@ -8,6 +8,8 @@
 // (16 algorithmic bytes per element: read theta, write grad).  When logp is requested the
 // per-chain sum runs sequentially over d in one lane.
 #include "bk_common.hpp"
+#include "bk_elementwise.hpp"
+#include "bk_lanes.hpp"
 #include <stdlib.h>
 
 namespace {
@@ -196,18 +198,8 @@ __global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g
 // Geometries that produce exactly these values:
 //   * the gradient op (k_funnel_coop): a 4-wavefront workgroup, 64 chains, lane = chain; wavefront w owns
 //     the four classes of group w and contributes q[w] through LDS.
-//   * the trajectory kernel (k_funnel_traj): LPC adjacent lanes of ONE wavefront serve a chain, and s is
-//     reduced with DPP moves inside the wavefront -- no LDS, no workgroup barrier in the leapfrog loop
-//     (round 2 reduced through LDS with a 4-wavefront barrier per step: 0.59 us per step).
-//       LPC = 4  (throughput: the first stage, every chain): 16 chains per wavefront; lane p of a chain's
-//                quad holds the classes of group p (p, p+4, p+8, p+12: up to 32 rows), forms q[p] by itself,
-//                and s is ((q0 + q1) + q2) + q3 over the quad (four quad_perm broadcasts).
-//       LPC = 16 (latency: the sparse, long later stages -- a few per cent of the chains, 40 / 160 steps):
-//                4 chains per wavefront, one 16-lane DPP row each; lane p holds class p (up to 8 rows).
-//                Lanes 0..3 of the row fetch cs[p+4], cs[p+8], cs[p+12] with row_shl, form q[p], the quad
-//                sums it to s, and two masked row_shr moves hand s to the other twelve lanes.
-// Every lane integrates v = theta_0 redundantly (it needs exp(-v) for its own rows); one lane per
-// chain writes it.
+//   * the trajectory kernel (bk_lanes.hpp, k_lane_traj<FunnelDensity, ...>): 4 / 8 / 16 adjacent lanes of ONE wavefront
+//     serve a chain, and s is reduced with DPP moves inside the wavefront (geometries described there).
 constexpr int FN_WAVES = 4;
 constexpr int FN_CLASSES = 16;
 constexpr int FN_MAX_SLOTS = 8;  // slots per class held in registers: D - 1 <= 128
@@ -283,423 +275,6 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
       if (d < D) g[d * ld + j] = -(ev * x[u]);
     }
   }
-}
-
-// ---- lanes of one wavefront serving one chain: geometry and the DPP reduction ------------------------
-// DPP move of a double (two 32-bit halves).  Lanes the control does not reach (row / bank masks, a shift
-// whose source lies outside the 16-lane row) keep `old`.
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ double bk_dpp_f64(double old, double src) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, BANK_MASK, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, BANK_MASK, false);
-  return __hiloint2double(hi, lo);
-}
-constexpr int BK_DPP_ROW_SHL = 0x100;  // + n: lane i reads lane i + n of its row
-constexpr int BK_DPP_ROW_SHR = 0x110;  // + n: lane i reads lane i - n of its row
-// the same for controls under which every lane that matters has a source lane: no `old` operand, so no copy
-// of the source in front of the move (lanes without a source read 0)
-template <int CTRL>
-__device__ __forceinline__ double bk_dpp_f64_all(double src) {
-  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(src), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(src), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-template <int K>
-__device__ __forceinline__ double bk_quad_bcast(double x) {  // lane K of every quad, to the whole quad
-  return bk_dpp_f64_all<K * 0x55>(x);
-}
-
-//   LPC = 4 : p = lane % 4 is the class GROUP; register slot u = k*SL + i holds class p + 4k, slot i.
-//   LPC = 8 : p = lane % 8;                    register slot u = k*SL + i holds class p + 8k, slot i (k = 0, 1).
-//   LPC = 16: p = lane % 16 is the CLASS;      register slot u = i     holds class p,      slot i.
-// A lane's rows are 1 + p + off(u) with a lane-independent off(u): row addresses are a per-lane 32-bit
-// offset (row 1 + p of the lane's chain) on top of a wavefront-uniform row base, and only the LAST slot
-// of a class can run past D (SL is exactly ceil((D-1)/16)): every other row needs no guard.
-template <int LPC, int SL>
-struct FunnelLanes {
-  static_assert(LPC == 4 || LPC == 8 || LPC == 16, "a chain is served by a quad, half a DPP row or a DPP row");
-  static constexpr int KC = FN_CLASSES / LPC;     // classes per lane
-  static constexpr int NU = KC * SL;              // register slots per lane
-  static constexpr int CHAINS = BK_WAVE / LPC;    // chains per wavefront
-  __host__ __device__ static constexpr int off(int u) {  // row of slot u, relative to the lane's first row
-    return LPC * (u / SL) + FN_CLASSES * (u % SL);  // (LPC = 16: one class per lane, u / SL = 0)
-  }
-  __host__ __device__ static constexpr bool last_slot(int u) { return u % SL == SL - 1; }
-};
-
-// s (canonical order) of the chain this lane serves, from the lane's class sums; valid in EVERY lane
-// of the chain.  All 64 lanes must be active.
-template <int LPC>
-__device__ __forceinline__ double funnel_reduce_lanes(const double* cs) {
-  double q;
-  if (LPC == 4) {
-    q = ((cs[0] + cs[1]) + cs[2]) + cs[3];  // this lane holds classes p, p+4, p+8, p+12
-  } else if (LPC == 8) {
-    // lane p of the 8-lane group holds cs[p] and cs[p+8]; lanes 0..3 fetch cs[p+4], cs[p+12] from lane p + 4
-    const double b = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[0]);
-    const double d = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[1]);
-    q = ((cs[0] + b) + cs[1]) + d;
-  } else {
-    // lane p of the row holds cs[p]; in lanes 0..3: q[p] = ((cs[p] + cs[p+4]) + cs[p+8]) + cs[p+12]
-    // (the other twelve lanes compute something nobody reads)
-    const double b = bk_dpp_f64_all<BK_DPP_ROW_SHL + 4>(cs[0]);
-    const double c = bk_dpp_f64_all<BK_DPP_ROW_SHL + 8>(cs[0]);
-    const double d = bk_dpp_f64_all<BK_DPP_ROW_SHL + 12>(cs[0]);
-    q = ((cs[0] + b) + c) + d;
-  }
-  // lane p of the quad holds q[p]
-  double s = ((bk_quad_bcast<0>(q) + bk_quad_bcast<1>(q)) + bk_quad_bcast<2>(q)) + bk_quad_bcast<3>(q);
-  if (LPC == 16) {
-    // s is right in lanes 0..3 of the row: hand it to lanes 4..7, then lanes 0..7 hand it to 8..15
-    s = bk_dpp_f64<BK_DPP_ROW_SHR + 4, 0xF, 0x2>(s, s);
-    s = bk_dpp_f64<BK_DPP_ROW_SHR + 8, 0xF, 0xC>(s, s);
-  } else if (LPC == 8) {
-    // s is right in lanes 0..3 of each 8-lane group: hand it to lanes 4..7 (banks 1 and 3 of the row)
-    s = bk_dpp_f64<BK_DPP_ROW_SHR + 4, 0xF, 0xA>(s, s);
-  }
-  return s;
-}
-
-// class sums of `expr` over this lane's rows (tail_ok[k]: the last slot of class k exists), each class
-// sequential in its slots
-#define BK_FL_CLASS_SUMS(cs, expr)                                   \
-  _Pragma("unroll") for (int k = 0; k < G::KC; ++k) {                \
-    double acc_ = 0.0;                                               \
-    _Pragma("unroll") for (int i = 0; i < SL; ++i) {                 \
-      const int u = k * SL + i;                                      \
-      if (!G::last_slot(u) || tail_ok[k]) acc_ = acc_ + (expr);      \
-    }                                                                \
-    cs[k] = acc_;                                                    \
-  }
-
-// One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE
-// launch: gather chain idx[j] of the source point, first half-kick with the source's cached
-// gradient + drift, (steps-1) x {gradient, kick, drift}, final gradient + log density,
-// last half-kick, momentum flip, kinetic energy.  theta, rho never leave registers, and the sum over a
-// chain's coordinates never leaves the wavefront.
-// LPC: lanes per chain (above); SL = slots per class = ceil((D-1)/16) exactly; HM = a metric is given.
-// All compile-time: with generic sizes and a run-time metric flag the kernel needed 330 registers (one
-// wavefront per SIMD, AGPR spills).
-// LPC_ARG = 4, 8 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows.
-// A wavefront-step costs ~580 / ~700 / ~1100 cycles with 16 / 8 / 4 lanes per chain and serves 4 / 8 / 16
-// chains; up to one wavefront per SIMD (1024 of them) the fewest cycles win, beyond that the fewest cycles per
-// chain: 16 lanes per chain below FN_AUTO_MID lanes, 8 below FN_AUTO_WIDE, 4 from there on.  The grid is sized
-// for the 16-lane form of the bound n_host.
-constexpr i64 FN_AUTO_MID = 4608, FN_AUTO_WIDE = 12288;
-template <int LPC, int SL, bool HM>
-__device__ __forceinline__ void funnel_traj_body(
-    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
-    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
-    const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
-    const bk_ghost_link& ghost, const bk_ghost0& g0, int lane, int wave);
-
-template <int LPC_ARG, int SL, bool HM>
-__global__ __launch_bounds__(FN_BLOCK) void k_funnel_traj(
-    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
-    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
-    const double* metric, double h, int steps, i64 n_host, i64 D, const uint32_t* n_dev, uint32_t* lanes_out,
-    unsigned long long* lanes_total, double* H_out, double* hh_out, uint8_t* live_out, unsigned traj_blocks,
-    bk_scatter_job job, bk_ghost_link ghost, bk_ghost0 g0) {
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
-  if (blockIdx.x >= traj_blocks) {
-    // surplus workgroups: the previous stage's scatter (bk_scatter_job), one 64-lane unit per wavefront
-    i64 jn = job.n;
-    if (job.n_dev) {
-      const i64 m = (i64)*job.n_dev;
-      jn = m < jn ? m : jn;
-    }
-    const i64 ux_count = (job.n + 63) / 64;  // (units are laid out for the host-side bound)
-    const i64 unit = ((i64)blockIdx.x - traj_blocks) * FN_WAVES + wave;
-    const i64 ux = unit % ux_count, uy = unit / ux_count;
-    if (uy * BK_SCT_ROWS < job.D)
-      bk_scatter_unit(ux, uy, lane, job.mask, job.index, jn, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
-                      job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc);
-    return;
-  }
-  // lanes actually in the set: read from device memory when the host only knows an upper bound
-  i64 n = n_host;
-  if (n_dev) {
-    const i64 m = (i64)*n_dev;
-    n = m < n ? m : n;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    if (lanes_out) *lanes_out = (uint32_t)n;
-    if (lanes_total) *lanes_total += (unsigned long long)n;  // one writer per launch, launches are stream-ordered
-    if (g0.steps > 0) {  // the fused first ghost runs over the same lanes
-      if (g0.lanes_out) *g0.lanes_out = (uint32_t)n;
-      if (g0.lanes_total) *reinterpret_cast<unsigned long long*>(g0.lanes_total) += (unsigned long long)n;
-    }
-  }
-#define BK_FT_BODY(L)                                                                                              \
-  funnel_traj_body<L, SL, HM>(th_in, rho_in, g_in, ld_in, idx, th_out, rho_out, g_out, logp_out, kin_out, ld_out, \
-                              metric, h, steps, n, D, H_out, hh_out, live_out, ghost, g0, lane, wave)
-  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= FN_AUTO_WIDE)) BK_FT_BODY(4);
-  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= FN_AUTO_MID)) BK_FT_BODY(8);
-  else BK_FT_BODY(16);
-#undef BK_FT_BODY
-}
-
-template <int LPC, int SL, bool HM>
-__device__ __forceinline__ void funnel_traj_body(
-    const double* th_in, const double* rho_in, const double* g_in, i64 ld_in, const int32_t* idx,
-    double* th_out, double* rho_out, double* g_out, double* logp_out, double* kin_out, i64 ld_out,
-    const double* metric, double h, int steps, i64 n, i64 D, double* H_out, double* hh_out, uint8_t* live_out,
-    const bk_ghost_link& ghost, const bk_ghost0& g0, int lane, int wave) {
-  using G = FunnelLanes<LPC, SL>;
-  constexpr int NU = G::NU;
-  const i64 j0 = ((i64)blockIdx.x * FN_WAVES + wave) * G::CHAINS;  // first chain of this wavefront
-  if (j0 >= n) return;  // whole wavefront past the set (uniform; the wavefronts of a workgroup are independent)
-  const int pos = lane & (LPC - 1);
-  const i64 j = j0 + lane / LPC;
-  const bool on = j < n;
-  const bool writer = on && pos == 0;  // the lane that owns theta_0 / the scalars
-  const i64 src = on ? (idx ? (i64)idx[j] : j) : 0;
-  const double half = 0.5 * h;
-  const double hn = 0.5 * (double)(D - 1);
-  constexpr bool hm = HM;
-  // this lane's rows: d(u) = 1 + pos + off(u).  Byte offsets of its first row (host checked: < 2^32)
-  const uint32_t bo_in = (uint32_t)(((i64)(1 + pos) * ld_in + src) * 8);
-  const uint32_t bo_out = (uint32_t)(((i64)(1 + pos) * ld_out + (on ? j : 0)) * 8);
-#define BK_FL_IN(p, u) (*reinterpret_cast<const double*>(reinterpret_cast<const char*>((p) + (i64)G::off(u) * ld_in) + bo_in))
-#define BK_FL_OUT(p, u) (*reinterpret_cast<double*>(reinterpret_cast<char*>((p) + (i64)G::off(u) * ld_out) + bo_out))
-  bool tail_ok[G::KC];  // does the last slot of class k exist for this lane?
-#pragma unroll
-  for (int k = 0; k < G::KC; ++k) tail_ok[k] = 1 + pos + G::off(k * SL + SL - 1) < D;
-#define BK_FL_OK(u) (!G::last_slot(u) || tail_ok[(u) / SL])
-  double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
-  // gather + first half-kick + drift (drghmc.py:276-278)
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    // (lanes past the set read chain 0 -- src = 0 -- and compute on it; they store nothing.  No branch
-    // around the loads of rows that exist for every lane.)
-    const bool ok = BK_FL_OK(u);
-    x[u] = ok ? BK_FL_IN(th_in, u) : 0.0;
-    r[u] = ok ? BK_FL_IN(rho_in, u) : 0.0;
-    double g0 = ok ? BK_FL_IN(g_in, u) : 0.0;
-    const double mi = (hm && BK_FL_OK(u)) ? metric[1 + pos + G::off(u)] : 1.0;
-    if (HM && LPC == 16) mt[u] = mi;
-    double t = hm ? mi * g0 : g0;
-    r[u] = r[u] + half * t;
-    x[u] = x[u] + h * r[u];
-    // the gather is issued in batches of 8 rows: all 3*NU loads in flight at once would set the
-    // kernel's register count (and so its occupancy for the whole trajectory)
-    if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
-  }
-  double v = th_in[src], rv = rho_in[src];
-  const double mv = hm ? metric[0] : 1.0;
-  {
-    double g0 = g_in[src];
-    double t = hm ? mv * g0 : g0;
-    rv = rv + half * t;
-    v = v + h * rv;
-  }
-  // the metric entry of row u: held in registers by the 16-lane geometry (<= 8 rows), re-read (L1) by the quad one
-#define BK_FL_METRIC(u) ((HM && LPC == 16) ? mt[(HM && LPC == 16) ? (u) : 0] : metric[1 + pos + G::off(u)])
-  double cs[G::KC];
-  // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283)
-  for (int step = 0; step + 1 < steps; ++step) {
-    BK_FL_CLASS_SUMS(cs, x[u] * x[u])
-    const double s = funnel_reduce_lanes<LPC>(cs);
-    const double ev = exp(-v);
-    const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
-    {
-      double t = hm ? mv * gv : gv;
-      rv = rv + h * t;
-      v = v + h * rv;
-    }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (BK_FL_OK(u)) {
-        double gi = -(ev * x[u]);
-        double t = hm ? BK_FL_METRIC(u) * gi : gi;
-        r[u] = r[u] + h * t;
-        x[u] = x[u] + h * r[u];
-      }
-      if (LPC != 16 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // bound the live temporaries (registers -> occupancy)
-    }
-  }
-  // final gradient + log density (drghmc.py:285) and the last half-kick (:286)
-  double logp_j = 0.0, ev_end = 0.0, gv_end = 0.0;
-  {
-    BK_FL_CLASS_SUMS(cs, x[u] * x[u])
-    const double s = funnel_reduce_lanes<LPC>(cs);
-    const double ev = exp(-v);
-    const double he = 0.5 * ev;
-    const double gv = ((-v / 9.0) - hn) + he * s;
-    ev_end = ev;
-    gv_end = gv;
-    {
-      double t = hm ? mv * gv : gv;
-      rv = rv + half * t;
-    }
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (BK_FL_OK(u)) {
-        double gi = -(ev * x[u]);
-        double t = hm ? BK_FL_METRIC(u) * gi : gi;
-        r[u] = r[u] + half * t;
-        if (on) BK_FL_OUT(g_out, u) = gi;
-      }
-    }
-    logp_j = ((-(v * v) / 18.0) - hn * v) - he * s;
-    if (writer) {
-      g_out[j] = gv;
-      logp_out[j] = logp_j;
-    }
-  }
-  // momentum flip (drghmc.py:345), kinetic energy (drghmc.py:250; same canonical order), outputs
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    if (BK_FL_OK(u)) {
-      r[u] = -r[u];
-      if (on) {
-        BK_FL_OUT(rho_out, u) = r[u];
-        BK_FL_OUT(th_out, u) = x[u];
-      }
-    }
-  }
-  BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
-  double ksum = funnel_reduce_lanes<LPC>(cs);
-  double H_own = 0.0;
-  if (writer) {
-    double rr = -rv;
-    double mr = hm ? mv * rr : rr;
-    rho_out[j] = rr;
-    th_out[j] = v;
-    const double kin = 0.5 * (rr * mr + ksum);
-    kin_out[j] = kin;
-    if (H_out) {
-      // the level set-up of accept() (bk_dr_level_begin) for this lane, in the same launch:
-      // H = -((-logp) + kin) (drghmc.py:421 -> :249-251); h and live follow below
-      const double potential = -logp_j;
-      const double Hj = -(potential + kin);
-      H_own = Hj;
-      H_out[j] = Hj;
-    }
-  }
-  double h_own = 0.0;    // the produced level's h / live for this lane (h = 0, live = 1 unless its first ghost
-  bool live_own = true;  // is run here as well)
-
-  // ---- the proposal's FIRST GHOST, in the same wavefront (drghmc.py:424-436 with i = 0) ----------------------
-  // Every lane of a level gets ghost 0, lane for lane, and a ghost of the first proposal kind has no ghosts of its
-  // own: the wavefront that has just produced proposal P integrates P's ghost straight from its registers
-  // (theta_P, the flipped momentum, the gradient at theta_P = -(e^-v x) with the e^-v of the last evaluation) --
-  // no store + gather of the ghost's source, no ghost arrays at all (only its joint log density is ever used),
-  // one launch instead of two.  Same operation sequence as a launch of its own.
-  if (g0.steps > 0) {
-    const double h2 = g0.h, half2 = 0.5 * g0.h;
-    // first half-kick + drift from the proposal's end point (drghmc.py:276-278)
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (BK_FL_OK(u)) {
-        double gi = -(ev_end * x[u]);
-        double t = hm ? BK_FL_METRIC(u) * gi : gi;
-        r[u] = r[u] + half2 * t;
-        x[u] = x[u] + h2 * r[u];
-      }
-    }
-    double rv2 = -rv;
-    {
-      double t = hm ? mv * gv_end : gv_end;
-      rv2 = rv2 + half2 * t;
-      v = v + h2 * rv2;
-    }
-    for (int step = 0; step + 1 < g0.steps; ++step) {
-      BK_FL_CLASS_SUMS(cs, x[u] * x[u])
-      const double s = funnel_reduce_lanes<LPC>(cs);
-      const double ev = exp(-v);
-      const double gv = ((-v / 9.0) - hn) + (0.5 * ev) * s;
-      {
-        double t = hm ? mv * gv : gv;
-        rv2 = rv2 + h2 * t;
-        v = v + h2 * rv2;
-      }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        if (BK_FL_OK(u)) {
-          double gi = -(ev * x[u]);
-          double t = hm ? BK_FL_METRIC(u) * gi : gi;
-          r[u] = r[u] + h2 * t;
-          x[u] = x[u] + h2 * r[u];
-        }
-        if (LPC != 16 && (u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    double logp_g = 0.0;
-    {
-      BK_FL_CLASS_SUMS(cs, x[u] * x[u])
-      const double s = funnel_reduce_lanes<LPC>(cs);
-      const double ev = exp(-v);
-      const double he = 0.5 * ev;
-      const double gv = ((-v / 9.0) - hn) + he * s;
-      {
-        double t = hm ? mv * gv : gv;
-        rv2 = rv2 + half2 * t;
-      }
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        if (BK_FL_OK(u)) {
-          double gi = -(ev * x[u]);
-          double t = hm ? BK_FL_METRIC(u) * gi : gi;
-          r[u] = r[u] + half2 * t;
-          r[u] = -r[u];
-        }
-      }
-      logp_g = ((-(v * v) / 18.0) - hn * v) - he * s;
-    }
-    BK_FL_CLASS_SUMS(cs, r[u] * (hm ? BK_FL_METRIC(u) * r[u] : r[u]))
-    const double ksum_g = funnel_reduce_lanes<LPC>(cs);
-    bool goes_on = false;
-    if (writer) {
-      const double rr = -rv2;
-      const double mr = hm ? mv * rr : rr;
-      const double kin_g = 0.5 * (rr * mr + ksum_g);
-      const double H_g = -((-logp_g) + kin_g);
-      // the ghost against the proposal it came from (parent h = 0: this is the proposal's first ghost), then the
-      // proposal's level entry: bk_dr_level_begin + bk_dr_accept_prob_ghost in one
-      const double g = dr_accept_logprob(H_g, H_own, 0.0, 0.0, g0.prob_retry);
-      if (g == 0.0) {  // drghmc.py:430-432
-        live_own = false;
-        g0.parent_a[j] = -INFINITY;
-      } else {
-        h_own = 0.0 + log1p(-exp(g));  // drghmc.py:434-435
-        goes_on = true;
-      }
-    }
-    if (g0.next_index) bk_append(goes_on, (int32_t)j, g0.next_index, g0.next_count);
-  }
-  if (writer && H_out) {
-    hh_out[j] = h_own;
-    live_out[j] = live_own ? 1 : 0;
-  }
-
-  // ---- a GHOST level that is complete here (no ghosts of its own, or one and it ran above): its acceptance
-  // probability against the parent lane it came from and the parent's update (bk_dr_accept_prob_ghost;
-  // drghmc.py:426-446), instead of a launch of their own.  One ghost lane per parent lane: nobody else touches
-  // lane `src` of the parent level.
-  if (ghost.parent_H) {
-    bool parent_goes_on = false;
-    if (writer) {
-      double g = -INFINITY;  // (a dead lane: one of its own ghosts was accepted with probability one)
-      if (live_own) {
-        g = dr_accept_logprob(H_own, ghost.parent_H[src], h_own, ghost.parent_h[src], ghost.prob_retry);
-        ghost.a_out[j] = g;
-      }
-      if (g == 0.0) {  // drghmc.py:430-432
-        ghost.parent_a[src] = -INFINITY;
-        ghost.parent_live[src] = 0;
-      } else {
-        ghost.parent_h[src] = ghost.parent_h[src] + log1p(-exp(g));  // drghmc.py:434-435
-        parent_goes_on = true;
-      }
-    }
-    // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
-    if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
-  }
-#undef BK_FL_IN
-#undef BK_FL_OUT
-#undef BK_FL_OK
-#undef BK_FL_METRIC
 }
 
 // Whole HMC trajectory of the separable Gaussians in registers (hmc.py:40-53 with
@@ -892,6 +467,35 @@ __global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double
   }
 }
 
+// The separable Gaussians as a per-coordinate term (bk_elementwise.hpp): term = theta*(lam*theta) summed, log p = -1/2 sum.
+template <bool HL>
+struct GaussTerm {
+  __device__ __forceinline__ static void eval(double th, i64 d, const double* lam, double& term, double& grad) {
+    const double lt = HL ? lam[d] * th : th;
+    term = th * lt;
+    grad = -lt;
+  }
+  __device__ __forceinline__ static double finish(double s) { return -0.5 * s; }
+};
+
+// Neal's funnel as a lane-spread density (bk_lanes.hpp): v = theta_0 is the head coordinate, the rows d >= 1 are
+// exchangeable given v.  The library's trajectory kernel k_lane_traj<FunnelDensity, ...> is the built-in
+// one-launch proposal; a CTarget.from_source(form="lanes") density goes through the same template.
+struct FunnelDensity {
+  static constexpr int HEAD = 1;
+  template <class L>
+  __device__ __forceinline__ static double eval(L& c, const double*) {
+    const double v = c.head(0);
+    const double s = c.sum([](double x, i64) { return x * x; });
+    const double ev = exp(-v);
+    const double hn = 0.5 * (double)(c.dims() - 1);
+    const double he = 0.5 * ev;
+    c.grad_head(0, ((-v / 9.0) - hn) + he * s);
+    c.grad([ev](double x, i64) { return -(ev * x); });
+    return ((-(v * v) / 18.0) - hn * v) - he * s;
+  }
+};
+
 int gauss(const double* theta, double* grad, double* logp, i64 ld, const double* lam, i64 C, i64 D,
           const uint32_t* n_dev, void* stream) {
   if (!theta || (!grad && !logp) || C < 0 || D < 0) return BK_E_ARG;
@@ -1012,6 +616,14 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
     return BK_E_ARG;
   if (ld < C || (zt && ldz < D)) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
+  static const bool generic = getenv("BK_GAUSS_GENERIC") != nullptr;
+  if (generic) {
+    if (lam)
+      return bke::hmc_draw_launch<GaussTerm<true>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
+                                                   kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
+    return bke::hmc_draw_launch<GaussTerm<false>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
+                                                  kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
+  }
   hipStream_t s = bk_stream(stream);
   // one wavefront per workgroup while that still leaves CUs idle (4096 chains: 256 workgroups instead of 64)
   const int tq_block = C * 4 <= 256 * TG_BLOCK ? BK_WAVE : TG_BLOCK;
@@ -1067,104 +679,9 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                               uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
                               const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, const bk_ghost0* g0_in,
                               void* stream) {
-  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
-      steps < 1 || steps > 0x7fffffff || n < 0 || D < 1)
-    return BK_E_ARG;
-  if (D - 1 > FN_MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path
-  if (H_out && (!h_out || !live_out)) return BK_E_ARG;
-  if (ld_out < n) return BK_E_ALIGN;
-  bk_ghost_link ghost = {};
-  if (ghost_in) {
-    ghost = *ghost_in;
-    if (!H_out || !ghost.parent_H || !ghost.parent_h || !ghost.parent_live || !ghost.parent_a || !ghost.a_out ||
-        (ghost.next_index && (!ghost.next_count || ghost.next_index == src_index)))
-      return BK_E_ARG;
-  }
-  bk_ghost0 g0 = {};
-  if (g0_in) {
-    g0 = *g0_in;
-    // (a level that has further ghosts is not complete in this launch: no link)
-    if (g0.steps < 1 || g0.steps > 0x7fffffff || !H_out || !g0.parent_a ||
-        (g0.next_index && (!g0.next_count || g0.next_index == src_index || ghost_in)))
-      return BK_E_ARG;
-  }
-  bk_scatter_job job = {};
-  unsigned job_blocks = 0;
-  if (job_in) {
-    job = *job_in;
-    if (!job.mask || !job.dst0 || !job.src0 || (job.dst1 && !job.src1) || (job.dst2 && !job.src2) ||
-        (job.sdst && !job.ssrc) || job.n < 0 || job.D < 0)
-      return BK_E_ARG;
-    if (job.n > 0 && job.D > 0)
-      job_blocks = (unsigned)bk_cdiv(bk_cdiv(job.n, 64) * bk_cdiv(job.D, BK_SCT_ROWS), FN_WAVES);
-  }
-  // the kernel addresses a lane's rows with 32-bit byte offsets from wavefront-uniform row bases
-  if ((ld_in > ld_out ? ld_in : ld_out) >= ((i64)1 << 32) / (8 * (FN_CLASSES + 1))) return BK_E_ARG;
-  if (n == 0) {
-    if (job_blocks) {  // nothing to propose: the job still runs
-      int rc = bk_scatter_columns(job.mask, job.index, job.n, job.D, job.dst0, job.src0, job.dst1, job.src1, job.dst2,
-                                  job.src2, job.ld_dst, job.ld_src, job.sdst, job.ssrc, job.n_dev, stream);
-      if (rc != BK_OK) return rc;
-    }
-    if (g0.steps > 0 && g0.lanes_out) {
-      int rc = (int)hipMemsetAsync(g0.lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
-      if (rc != 0) return rc;
-    }
-    if (lanes_out) return (int)hipMemsetAsync(lanes_out, 0, sizeof(uint32_t), bk_stream(stream));
-    return BK_OK;
-  }
-  const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
-  hipStream_t s = bk_stream(stream);
-  // Geometry.  A set known to be small -> 16 lanes per chain, 16 chains per workgroup; known to be large -> 4
-  // lanes per chain, 64 chains per workgroup; a set whose size only the device knows (every set after the first
-  // stage) -> decided by the kernel from *n_dev when the bound allows a large one.  Same values either way.
-  // BK_FUNNEL_GEOMETRY=wide|narrow overrides (wide = 4 lanes per chain).
-  static const int forced = []() {
-    const char* e = getenv("BK_FUNNEL_GEOMETRY");
-    return !e ? 0 : (e[0] == 'n' ? 2 : e[0] == 'm' ? 3 : 1);  // wide | mid (8 lanes per chain) | narrow
-  }();
-  // 16: 16 lanes per chain; 4: 4 lanes per chain; 0: the kernel decides from *n_dev
-  int geo;
-  if (forced) geo = forced == 2 ? 16 : (forced == 3 ? 8 : 4);
-  else if (n_dev) geo = n >= FN_AUTO_MID ? 0 : 16;
-  else geo = n >= FN_AUTO_WIDE ? 4 : (n >= FN_AUTO_MID ? 8 : 16);
-  const unsigned traj_blocks = (unsigned)bk_cdiv(n, FN_WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
-  dim3 grid(traj_blocks + job_blocks);
-#define BK_FT(LPC, R, M)                                                                                          \
-  k_funnel_traj<LPC, R, M><<<grid, dim3(FN_BLOCK), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, \
-                                                           rho_out, grad_out, logp_out, kin_out, ld_out, metric, h, \
-                                                           (int)steps, n, D, n_dev, lanes_out,                     \
-                                                           reinterpret_cast<unsigned long long*>(lanes_total),    \
-                                                           H_out, h_out, live_out, traj_blocks, job, ghost, g0)
-#define BK_FT_ROWS(R)                   \
-  do {                                  \
-    if (geo == 16) {                    \
-      if (metric) BK_FT(16, R, true);   \
-      else BK_FT(16, R, false);         \
-    } else if (geo == 4) {              \
-      if (metric) BK_FT(4, R, true);    \
-      else BK_FT(4, R, false);          \
-    } else if (geo == 8) {              \
-      if (metric) BK_FT(8, R, true);    \
-      else BK_FT(8, R, false);          \
-    } else {                            \
-      if (metric) BK_FT(0, R, true);    \
-      else BK_FT(0, R, false);          \
-    }                                   \
-  } while (0)
-  switch (need < 1 ? 1 : need) {  // slots per class, exactly: only a class's last slot can run past D
-    case 1: BK_FT_ROWS(1); break;
-    case 2: BK_FT_ROWS(2); break;
-    case 3: BK_FT_ROWS(3); break;
-    case 4: BK_FT_ROWS(4); break;
-    case 5: BK_FT_ROWS(5); break;
-    case 6: BK_FT_ROWS(6); break;
-    case 7: BK_FT_ROWS(7); break;
-    default: BK_FT_ROWS(8); break;
-  }
-#undef BK_FT_ROWS
-#undef BK_FT
-  BK_RETURN_LAUNCH_STATUS();
+  return bkl::dr_proposal_launch<FunnelDensity>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out,
+                                                logp_out, kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out,
+                                                lanes_total, H_out, h_out, live_out, job_in, ghost_in, g0_in, nullptr, stream);
 }
 
 

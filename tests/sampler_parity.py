@@ -108,11 +108,12 @@ def device_proposal(spec, chains, chain_id0, ops):
     return proposal_fn, transition_lp_fn
 
 
-def check_many_chain(name, ops, **extra):
-    """All C chains of a golden case in ONE many-chain sampler on a built-in device target."""
+def check_many_chain(name, ops, model_factory=None, **extra):
+    """All C chains of a golden case in ONE many-chain sampler on a built-in device target (model_factory(spec, ops):
+    another provider of the same density, e.g. one compiled from source)."""
     case, z = load_case(name)
     N, C, D = z["draws"].shape
-    model = product_model(case["model"], ops)
+    model = (model_factory or product_model)(case["model"], ops)
     s = build_sampler(case, model, ops, case["seed"], chains=C, **extra)
     exact = case["model"]["kind"] != "funnel"
     th0 = s._theta.cpu().numpy()

@@ -1,0 +1,156 @@
+"""CTarget.from_source on the build box (no GPU): hipcc cross-compiles the generated translation units, the libraries
+export what the samplers bind, and the cache refuses anything another user could have written (VERDICT r4
+item 6).  No compute calls."""
+import ctypes
+import os
+import stat
+
+import pytest
+
+import bayes_kit_amd as bk
+from bayes_kit_amd import targets as T
+
+TERM = """
+__device__ void bk_term(double th, i64 d, const double* lam, double& term, double& grad) {
+  const double t = lam[d] * th; term = -0.5 * (th * t); grad = -t;
+}
+"""
+CHAIN = """
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double*) {
+  double s = 0.0;
+  for (i64 d = 0; d < D; ++d) { s = s + th[d] * th[d]; g.set(d, -th[d]); }
+  return -0.5 * s;
+}
+"""
+LANES = """
+template <class L> __device__ double bk_lanes_density(L& c, const double*) {
+  const double v = c.head(0);
+  const double s = c.sum([](double x, i64) { return x * x; });
+  const double ev = exp(-v);
+  c.grad_head(0, -v / 9.0 + 0.5 * ev * s);
+  c.grad([ev](double x, i64) { return -(ev * x); });
+  return -(v * v) / 18.0 - 0.5 * ev * s;
+}
+"""
+
+
+@pytest.fixture()
+def cache(tmp_path, monkeypatch):
+    d = tmp_path / "cache"
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(d))
+    return d
+
+
+def exports(lib):
+    h = ctypes.CDLL(lib)
+    return {n for n in ("bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory",
+                        "bk_src_dr_proposal_job") if hasattr(h, n)}
+
+
+def test_every_form_compiles_and_exports_its_entry_points(cache):
+    e = T._compile_source_target(TERM, "elementwise", False, 16, 0)
+    assert exports(e) == {"bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory"}
+    c = T._compile_source_target(CHAIN, "chain", False, 16, 0)
+    assert exports(c) == {"bk_src_target", "bk_src_target_n"}
+    l = T._compile_source_target(LANES, "lanes", False, 101, 1)
+    assert exports(l) == {"bk_src_target", "bk_src_target_n", "bk_src_dr_proposal_job"}
+    big = T._compile_source_target(LANES, "lanes", False, 300, 1)  # > 128 spread rows: gradient op only
+    assert exports(big) == {"bk_src_target", "bk_src_target_n"}
+    # the cache: 0700 directory, private files, a second request is served from it (same path, no temporaries left)
+    assert stat.S_IMODE(os.lstat(cache).st_mode) == 0o700
+    assert T._compile_source_target(TERM, "elementwise", False, 16, 0) == e
+    assert sorted(os.listdir(cache)) == sorted(os.path.basename(p) for p in (e, c, l, big))
+    for p in (e, c, l, big):
+        assert not os.lstat(p).st_mode & 0o022
+    # the objects: hooks the samplers look for exist exactly where the library exports them
+    te = bk.CTarget.from_source(TERM, 16)
+    tl = bk.CTarget.from_source(LANES, 101, form="lanes", head=1)
+    tb = bk.CTarget.from_source(LANES, 300, form="lanes", head=1)
+    tc = bk.CTarget.from_source(CHAIN, 16, form="chain")
+    assert hasattr(te, "bk_hmc_draw") and hasattr(te, "bk_hmc_trajectory") and not hasattr(te, "bk_dr_proposal")
+    assert hasattr(tl, "bk_dr_proposal") and tl.bk_dr_proposal_supported() and not hasattr(tl, "bk_hmc_draw")
+    assert not hasattr(tb, "bk_dr_proposal") and not hasattr(tc, "bk_dr_proposal") and not hasattr(tc, "bk_hmc_draw")
+    assert all(t.bk_counted for t in (te, tl, tb, tc))
+
+
+def test_bad_arguments(cache):
+    with pytest.raises(ValueError):
+        bk.CTarget.from_source(TERM, 4, form="rows")
+    with pytest.raises(ValueError):
+        bk.CTarget.from_source(LANES, 4, form="lanes", head=9)
+    with pytest.raises(ValueError):
+        bk.CTarget.from_source(LANES, 1, form="lanes", head=2)
+    with pytest.raises(bk._lib.BkHipError, match="hipcc failed"):
+        bk.CTarget.from_source("this is not C++", 3)
+    assert os.listdir(cache) == []  # nothing published, no temporaries left behind
+
+
+def test_cache_directory_others_can_write_is_refused(cache):
+    os.makedirs(cache, mode=0o700)
+    os.chmod(cache, 0o777)
+    with pytest.raises(bk._lib.BkHipError, match="writable"):
+        bk.CTarget.from_source(TERM, 4)
+    os.chmod(cache, 0o770)
+    with pytest.raises(bk._lib.BkHipError, match="writable"):
+        bk.CTarget.from_source(TERM, 4)
+
+
+def test_cache_directory_that_is_a_symlink_is_refused(cache, tmp_path):
+    real = tmp_path / "elsewhere"
+    real.mkdir(mode=0o700)
+    os.symlink(real, cache)
+    with pytest.raises(bk._lib.BkHipError, match="symlink"):
+        bk.CTarget.from_source(TERM, 4)
+
+
+def test_cached_library_others_can_write_or_own_is_refused(cache):
+    lib = T._compile_source_target(TERM, "elementwise", False, 4, 0)
+    os.chmod(lib, 0o666)
+    with pytest.raises(bk._lib.BkHipError, match="writable"):
+        bk.CTarget.from_source(TERM, 4)
+    os.chmod(lib, 0o700)
+    bk.CTarget.from_source(TERM, 4)
+    # a planted symlink in place of the library
+    os.rename(lib, lib + ".real")
+    os.symlink(lib + ".real", lib)
+    with pytest.raises(bk._lib.BkHipError, match="symlink"):
+        bk.CTarget.from_source(TERM, 4)
+    os.unlink(lib)
+    os.rename(lib + ".real", lib)
+    if os.getuid() == 0:  # only root can hand a file to another user
+        os.chown(lib, 12345, -1)
+        with pytest.raises(bk._lib.BkHipError, match="owned by uid 12345"):
+            bk.CTarget.from_source(TERM, 4)
+        os.chown(lib, 0, -1)
+        os.chown(cache, 12345, -1)
+        with pytest.raises(bk._lib.BkHipError, match="owned by uid 12345"):
+            bk.CTarget.from_source(TERM, 4)
+        os.chown(cache, 0, -1)
+
+
+def test_default_cache_is_private_and_per_user(tmp_path, monkeypatch):
+    monkeypatch.delenv("BK_SOURCE_TARGET_DIR", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "xdg"))
+    d = T._source_cache_dir()
+    assert d == str(tmp_path / "xdg" / "bayes_kit_amd") and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    monkeypatch.delenv("XDG_CACHE_HOME")
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
+    assert T._source_cache_dir() == str(tmp_path / "home" / ".cache" / "bayes_kit_amd")
+    # no usable home: a fresh mkdtemp directory (0700, unpredictable name), never a fixed path under /tmp
+    ro = tmp_path / "ro"
+    ro.mkdir()
+    (ro / "file").write_text("")
+    monkeypatch.setenv("XDG_CACHE_HOME", str(ro / "file"))  # makedirs under a FILE fails for every uid, root included
+    monkeypatch.setattr(T, "_PROCESS_CACHE_DIR", None)
+    d = T._source_cache_dir()
+    assert os.path.basename(d).startswith("bayes_kit_amd_src_") and stat.S_IMODE(os.lstat(d).st_mode) == 0o700
+    assert T._source_cache_dir() == d
+    os.rmdir(d)
+
+
+def test_missing_hipcc_says_so(cache, monkeypatch):
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    monkeypatch.setenv("ROCM_PATH", "/nonexistent")
+    monkeypatch.setenv("PATH", "")
+    with pytest.raises(bk._lib.BkHipError, match="no hipcc was found"):
+        bk.CTarget.from_source(TERM + "// never compiled before\n", 4)

@@ -131,3 +131,206 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     # a source that does not compile says so (hipcc's message), it does not fall back to anything
     with pytest.raises(bk._lib.BkHipError):
         bk.CTarget.from_source("this is not C++", 3)
+
+
+# ---- round 5: the library's one-launch kernels for ANY compiled-source density --------------------------------------
+FUNNEL_LANES_SRC = """
+// Neal's funnel for the lane-spread form (head = 1: v = theta_0 is held by every lane of the chain)
+template <class L>
+__device__ double bk_lanes_density(L& c, const double* /*params*/) {
+  const double v = c.head(0);
+  const double s = c.sum([](double x, i64) { return x * x; });
+  const double ev = exp(-v);
+  const double hn = 0.5 * (double)(c.dims() - 1);
+  const double he = 0.5 * ev;
+  c.grad_head(0, ((-v / 9.0) - hn) + he * s);
+  c.grad([ev](double x, i64) { return -(ev * x); });
+  return ((-(v * v) / 18.0) - hn * v) - he * s;
+}
+"""
+
+# a hierarchical model that is NOT the funnel: two head coordinates (mu, log tau), rows theta_d ~ N(mu, tau^2) observed
+# with unit noise at y_d = params[d]; exercises head = 2, the row index and params inside the row functions
+HIER_LANES_SRC = """
+template <class L>
+__device__ double bk_lanes_density(L& c, const double* y) {
+  const double mu = c.head(0), lt = c.head(1);
+  const double it2 = exp(-2.0 * lt);  // 1 / tau^2
+  const double n = (double)(c.dims() - 2);
+  const double sq = c.sum([mu](double x, i64) { const double r = x - mu; return r * r; });
+  const double sr = c.sum([mu](double x, i64) { return x - mu; });
+  const double sy = c.sum([y](double x, i64 d) { const double r = y[d] - x; return r * r; });
+  c.grad_head(0, it2 * sr - mu / 25.0);
+  c.grad_head(1, (it2 * sq - n) - lt);
+  c.grad([mu, it2, y](double x, i64 d) { return (y[d] - x) - it2 * (x - mu); });
+  return (((-0.5 * it2) * sq - n * lt) - 0.5 * sy) - (mu * mu / 50.0 + 0.5 * (lt * lt));
+}
+"""
+
+
+def funnel_lanes(D):
+    return bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1)
+
+
+def funnel_plugin(D):
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return bk.CTarget(os.path.join(root, "examples", "plugin_target", "libfunnel_target.so"), "funnel_target", D,
+                      counted_symbol="funnel_target_n")
+
+
+def _same_state(a, b):
+    return (torch.equal(a._theta_dc, b._theta_dc) and torch.equal(a._rho_dc, b._rho_dc)
+            and torch.equal(a._rng_state, b._rng_state) and torch.equal(a._lp, b._lp))
+
+
+def test_lanes_form_runs_the_one_launch_proposals_of_the_builtin_funnel(ops):
+    """the funnel written as from_source(form="lanes") source goes through the SAME one-launch
+    delayed-rejection proposal kernel template as bk.Funnel (csrc/bk_lanes.hpp) -- theta, rho, log density and RNG
+    state bit-identical, no host synchronisation, one hipGraph per draw; with and without a metric, K = 1..4, shapes
+    with 1..8 slots per class; through the reference goldens as well."""
+    from tests.sampler_parity import check_many_chain
+
+    cases = [(101, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, None, 3000),
+             (17, 4, [0.3, 0.15, 0.07, 0.03], [3, 6, 12, 24], 0.3, None, 700),
+             (33, 2, [0.25, 0.1], [4, 8], 0.5, "metric", 1500),
+             (129, 3, [0.2, 0.06, 0.02], [5, 15, 45], 0.2, None, 5000),
+             (2, 2, [0.4, 0.2], [3, 6], 0.4, None, 300),
+             (64, 1, [0.1], [7], 1.0, "metric", 20000)]
+    for D, K, sizes, counts, damping, metric, C in cases:
+        m = None if metric is None else np.linspace(0.5, 2.0, D)
+        a = bk.DrGhmcDiag(bk.Funnel(D), K, sizes, counts, damping, metric_diag=m, chains=C, seed=11)
+        b = bk.DrGhmcDiag(funnel_lanes(D), K, sizes, counts, damping, metric_diag=m, chains=C, seed=11)
+        assert b._one_launch and b._dev_counts and b._use_graph and b.host_syncs_per_draw == 0, D
+        for n in range(6):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), (D, n)
+        assert _same_state(a, b), D
+    for name in ("drghmc_funnel101_cfg4", "drghmc_funnel129_k3", "drghmc_funnel11_k3", "drghmc_funnel17_k4",
+                 "drghmc_funnel33_k2_metric_noretry"):
+        s = check_many_chain(name, ops, model_factory=lambda spec, ops_: funnel_lanes(spec["D"]))
+        assert s._one_launch, name
+
+
+def test_lanes_form_gradient_op_is_the_plugin_on_the_counted_path(ops):
+    """the same source as a gradient OP (a chain spread over 4 / 8 / 16 lanes, DPP sums in the library's
+    fixed order) on the counted step-by-step path: bit-identical to the hand-written plugin and to the one-launch path;
+    past 128 spread rows (no one-launch kernel) the op walks the rows in memory, the plugin's class order."""
+    from tests.sampler_parity import check_many_chain
+
+    args = (3, [0.2, 0.05, 0.0125], [5, 10, 20], 0.1)
+    for D, C in ((101, 2500), (40, 13000), (130, 800), (300, 500)):
+        one = D - 1 <= 128
+        a = bk.DrGhmcDiag(funnel_lanes(D), *args, chains=C, seed=21, fuse_builtin=False)
+        p = bk.DrGhmcDiag(funnel_plugin(D), *args, chains=C, seed=21)
+        f = bk.DrGhmcDiag(funnel_lanes(D), *args, chains=C, seed=21) if one else None
+        assert a._dev_counts and a._use_graph and not a._one_launch and (f is None or f._one_launch)
+        if not one:
+            assert not bk.DrGhmcDiag(funnel_lanes(D), *args, chains=64, seed=1)._one_launch
+        for n in range(5):
+            ta, la = a.sample()
+            tp, lpp = p.sample()
+            assert torch.equal(ta, tp) and torch.equal(la, lpp), (D, n)
+            if f is not None:
+                tf, _ = f.sample()
+                assert torch.equal(ta, tf), (D, n)
+        assert _same_state(a, p), D
+    # the op on its own: every geometry (lane count on the host / on the device, small / mid / large sets), logp-only calls
+    for D in (101, 7, 300):
+        for n in (1, 63, 4608, 12288 + 5):
+            th = torch.randn((D, n), dtype=torch.float64, device=ops.device)
+            out = []
+            for model in (funnel_plugin(D), funnel_lanes(D)):
+                g = torch.zeros_like(th)
+                lp, lp2 = (torch.zeros(n, dtype=torch.float64, device=ops.device) for _ in range(2))
+                model.bk_eval(th, g, lp)
+                model.bk_eval(th, None, lp2)
+                g_n = torch.zeros_like(th)
+                nd = torch.tensor([max(1, n - 3)], dtype=torch.int32, device=ops.device)
+                model.bk_eval(th, g_n, None, n_dev=nd)
+                out.append((g, lp, lp2, g_n))
+            for x, y in zip(*out):
+                assert torch.equal(x, y), (D, n)
+            assert torch.equal(out[1][3][:, n - 3:], torch.zeros_like(out[1][3][:, n - 3:])) or n <= 3
+    # a reference golden through the counted path of the compiled source
+    check_many_chain("drghmc_funnel130_k2", ops, model_factory=lambda spec, ops_: funnel_lanes(spec["D"]))
+
+
+def test_lanes_form_hierarchical_model_with_two_head_coordinates(ops):
+    """A density that is not the funnel (head = 2, three sums, params indexed by row): the one-launch path, the counted
+    step-by-step path and the host-sized path agree bit for bit, and the compiled gradient is the autograd gradient of the
+    same density written in PyTorch (rel 1e-12)."""
+    D, C = 2 + 50, 1800
+    y = torch.linspace(-2.0, 3.0, D, dtype=torch.float64, device=ops.device)
+    mk = lambda: bk.CTarget.from_source(HIER_LANES_SRC, D, params=y, form="lanes", head=2)  # noqa: E731
+
+    def torch_lp(Th):
+        mu, lt, x = Th[:, 0], Th[:, 1], Th[:, 2:]
+        it2 = torch.exp(-2.0 * lt)
+        sq = ((x - mu[:, None]) ** 2).sum(dim=1)
+        sy = ((y[2:] - x) ** 2).sum(dim=1)
+        return -0.5 * it2 * sq - (D - 2) * lt - 0.5 * sy - (mu * mu / 50.0 + 0.5 * lt * lt)
+
+    Th = torch.randn((C, D), dtype=torch.float64, device=ops.device) * 0.7
+    lp, g = mk().log_density_gradient(Th)
+    x = Th.clone().requires_grad_(True)
+    lp_t = torch_lp(x)
+    (g_t,) = torch.autograd.grad(lp_t.sum(), x)
+    np.testing.assert_allclose(lp.cpu().numpy(), lp_t.detach().cpu().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=1e-11, atol=1e-11)
+    args = (3, [0.15, 0.05, 0.02], [4, 8, 16], 0.2)
+    m = np.linspace(0.7, 1.4, D)
+    f = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31)
+    c = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False)
+    h = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False, device_counts=False)
+    assert f._one_launch and c._dev_counts and not c._one_launch and not h._dev_counts
+    for n in range(6):
+        tf, lf = f.sample()
+        tc, lc = c.sample()
+        th_, lh = h.sample()
+        assert torch.equal(tf, tc) and torch.equal(tf, th_), n
+        np.testing.assert_allclose(lf.cpu().numpy(), lc.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    assert torch.equal(f._rng_state, c._rng_state) and torch.equal(f._rng_state, h._rng_state)
+    assert torch.isfinite(f._theta_dc).all()
+
+
+def test_elementwise_form_runs_the_whole_draw_hmc_kernel(ops):
+    """a from_source(form="elementwise") density gets the register-resident whole-trajectory /
+    whole-draw HMC kernels the built-in Gaussians have (csrc/bk_elementwise.hpp): one pass over the state per draw,
+    bit-identical to its own step-by-step path and to the built-in target; reference goldens through it."""
+    from tests.sampler_parity import check_many_chain
+
+    for D, C, eps, L, metric in ((48, 1500, 0.02, 9, None), (1024, 256, 0.006, 16, "m"), (33, 4097, 0.05, 5, "m"), (5, 64, 0.1, 0, None)):
+        lam = np.logspace(0, 2, D)
+        lam_d = torch.from_numpy(lam).to(ops.device)
+        m = None if metric is None else np.linspace(0.5, 2.0, D)
+        src = lambda: bk.CTarget.from_source(DIAG_SRC, D, params=lam_d)  # noqa: E731
+        kw = dict(metric_diag=m, chains=C, seed=3)
+        f = bk.HMCDiag(src(), eps, L, **kw)
+        s = bk.HMCDiag(src(), eps, L, fuse_builtin=False, **kw)
+        b = bk.HMCDiag(bk.DiagGaussian(lam), eps, L, **kw)
+        g = bk.HMCDiag(src(), eps, L, graph=True, **kw)
+        assert f._fused_draw and not s._fused and b._fused_draw and g._fused_draw
+        for n in range(6):
+            tf, lf = f.sample()
+            for o in (s, b, g):
+                to, lo = o.sample()
+                assert torch.equal(tf, to) and torch.equal(lf, lo), (D, n)
+        np.testing.assert_array_equal(f.rng_state(), s.rng_state())
+        assert f.accept_rate() == s.accept_rate()
+    # PCG64 streams take the state-layout momentum (no chain-major generator): the same kernels' other input form
+    f = bk.HMCDiag(bk.CTarget.from_source(DIAG_SRC, 48, params=torch.from_numpy(np.logspace(0, 2, 48)).to(ops.device)), 0.02, 9,
+                   chains=40, seed=3)
+    assert f._fused_draw
+
+    def factory(spec, ops_):
+        if spec["kind"] in ("iso_gaussian", "std_normal"):
+            D_ = spec.get("D", 1)
+            return bk.CTarget.from_source(DIAG_SRC, D_, params=torch.ones(D_, dtype=torch.float64, device=ops.device))
+        lam_ = torch.from_numpy(np.logspace(spec["log10_lo"], spec["log10_hi"], spec["D"])).to(ops.device)
+        return bk.CTarget.from_source(DIAG_SRC, spec["D"], params=lam_)
+
+    for name in ("hmc_diag1024_cfg3", "hmc_iso128_cfg2", "hmc_diag40_metric_steps1", "hmc_steps0"):
+        check_many_chain(name, ops, model_factory=factory)
