@@ -649,7 +649,7 @@ def rank_normalized_rhat(chains, *, ops=None, group=None):
     sort over the process group (_ranks_pooled_across_ranks: each rank sends and receives its own
     share of the draws once, nothing is replicated); every rank then turns its own chains' ranks
     into normal scores and joins the usual cross-rank split R-hat."""
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _bkdist.collectives_active(group)
     if not multi:
         return split_rhat(rank_normalize_chains(chains, ops=ops), ops=ops, group=group)  # (a one-rank group stays local)
     if not _is_matrix(chains):

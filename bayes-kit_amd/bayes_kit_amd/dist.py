@@ -51,6 +51,20 @@ def init_from_env(backend: str = None):
 collective_calls = {"all_gather": 0, "all_reduce": 0, "all_to_all": 0}
 
 
+# A process group of ONE rank keeps its summaries local (nothing to exchange).  force_collectives (or the environment variable
+# BK_DIST_FORCE_COLLECTIVES=1) sends them through the group all the same: every collective the N > 1 path issues -- all_gather
+# with a tensor list, all_to_all_single with count lists, all_reduce -- then runs on RCCL with a single-rank group on ONE GPU,
+# which is how a one-GPU box exercises the backend the 8-GPU run will use (tests/test_gpu_multirank.py).
+force_collectives = bool(os.environ.get("BK_DIST_FORCE_COLLECTIVES"))
+
+
+def collectives_active(group=None) -> bool:
+    """Whether summaries go through the process group: more than one rank, or a group whose use is forced."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or force_collectives
+
+
 def host_staged(t: torch.Tensor, group=None) -> torch.Tensor:
     """`t` as the process group can move it.  RCCL moves device memory; gloo implements all_gather /
     all_to_all for host memory only, so a device tensor is staged through the host there (the CPU tests,
@@ -86,10 +100,7 @@ def all_to_all_single(recv: torch.Tensor, send: torch.Tensor, recv_counts=None, 
 def gather_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """Sum of `t` over the ranks of `group`, accumulated in rank order (deterministic: the result does
     not depend on the collective's reduction order).  ONE all_gather.  No-op without a process group."""
-    if not (dist.is_available() and dist.is_initialized()):
-        return t
-    world = dist.get_world_size(group)
-    if world == 1:
+    if not collectives_active(group):
         return t
     parts = all_gather(t, group)
     out = parts[0].clone()
@@ -100,7 +111,7 @@ def gather_sum(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def sum_over_ranks(value: float, device=None, group=None) -> float:
     """Scalar sum over ranks (e.g. total ESS, accepted counts)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not collectives_active(group):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, group=group)

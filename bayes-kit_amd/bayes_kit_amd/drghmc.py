@@ -71,6 +71,7 @@ class DrGhmcDiag(ManyChainSampler):
         device_counts: Optional[bool] = None,
         graph: Optional[bool] = None,
         fuse_first_ghost: bool = True,
+        fuse_steps: bool = True,
         ops=None,
     ):
         self._max_proposals = max_proposals
@@ -105,6 +106,9 @@ class DrGhmcDiag(ManyChainSampler):
         # built-in targets that can run a whole proposal (gather, L_k steps, flip, energies) in
         # one launch with the gradient inlined (bk_dr_proposal_funnel); same results
         self._fused = bool(fuse_builtin) and self._batched and hasattr(model, "bk_dr_proposal")
+        # ... and models whose leapfrog step {gradient, kick, drift} is one launch (bk_leapfrog_step: a lane-spread density
+        # compiled from source): the step-by-step paths then issue one launch per step instead of two; same results
+        self._step_hook = bool(fuse_steps) and self._batched and hasattr(model, "bk_leapfrog_step")
         # Lane counts on the device: the sizes of the lane sets -- which depend on the draw's own accept / retry
         # decisions -- stay in device memory; every launch is sized for its parent set and surplus workgroups
         # exit at once.  No host read inside sample(), so the draw is a FIXED launch sequence and replays as one
@@ -326,6 +330,10 @@ class DrGhmcDiag(ManyChainSampler):
             return
         ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h)
         for _ in range(steps - 1):
+            if self._step_hook:
+                self._grad_calls += 1
+                self._model.bk_leapfrog_step(th, rho, m, h)
+                continue
             g = self._eval_grad(th, gbuf, None)
             ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h)
         g = self._materialize(self._eval_grad(th, gbuf, dst.logp[:n]), gbuf)
@@ -519,6 +527,9 @@ class DrGhmcDiag(ManyChainSampler):
         self._grad_calls += steps
         ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h, n_dev=n_dev)   # :276-278
         for _ in range(steps - 1):                                                                      # :280-283
+            if self._step_hook:
+                model.bk_leapfrog_step(th, rho, m, h, n_dev)
+                continue
             model.bk_eval(th, g, None, n_dev)
             ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h, n_dev=n_dev)
         model.bk_eval(th, g, dst.logp, n_dev)                                                           # :285

@@ -482,6 +482,13 @@ int launch(const double* th, double* g, double* logp, i64 ld, const void* params
   return bkl::target_launch<BkSrcDensity, BK_SRC_SL>(th, g, logp, ld, static_cast<const double*>(params), C, D, n_dev, stream);
 }
 }  // namespace
+// one leapfrog step {gradient, kick, drift} per launch, theta and rho advanced in place (lane count optionally on the device):
+// what the step-by-step paths call instead of {bk_src_target_n, bk_leapfrog_kick_drift} -- half the launches
+extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
+                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
+  return bkl::step_launch<BkSrcDensity, BK_SRC_SL>(theta, rho, ld, metric, h, static_cast<const double*>(params), n, D, n_dev,
+                                                   stream);
+}
 #if %(sl)d > 0
 // one whole delayed-rejection proposal per launch with bk_lanes_density inlined: the argument list of
 // bk_dr_proposal_funnel_job (include/bkhip.h) + params
@@ -692,6 +699,18 @@ def _bind_source_fast_paths(t):
     f_draw = export("bk_src_hmc_draw", [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P])
     f_prop = export("bk_src_dr_proposal_job", [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P])
 
+    f_step = export("bk_src_leapfrog_step", [P, P, I, P, F, P, I, I, P, P])
+    if f_step is not None:
+        def bk_leapfrog_step(self, theta, rho, metric, h, n_dev=None):
+            """One leapfrog step {gradient, kick, drift} (drghmc.py:280-283) of the chains in theta / rho ([D, n], advanced in
+            place) as ONE launch with the compiled density inlined; n_dev: the lane count in device memory."""
+            D, n = theta.shape
+            ld = _lib._ld(theta)
+            assert _lib._ld(rho) == ld
+            check(f_step(ptr(theta), ptr(rho), ld, ptr(metric), h, self._pp, n, D, ptr(n_dev), stream(theta)),
+                  "bk_src_leapfrog_step")
+
+        t.bk_leapfrog_step = types.MethodType(bk_leapfrog_step, t)
     if f_traj is not None:
         def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
             """Whole leapfrog trajectory with the compiled term inlined (register-resident; bk_elementwise.hpp)."""

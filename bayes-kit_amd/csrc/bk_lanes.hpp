@@ -227,6 +227,19 @@ struct TrajArgs {
 // chain: 16 lanes per chain below AUTO_MID lanes, 8 below AUTO_WIDE, 4 from there on.
 constexpr i64 AUTO_MID = 4608, AUTO_WIDE = 12288;
 
+// Workgroups a launch needs for a set of at most n chains.  geo = 4 / 8 / 16: that many lanes per chain.  geo = 0 (the kernel
+// picks the geometry from the count on the device): the most any admissible count needs -- fewer than AUTO_MID chains at 16 per
+// workgroup, fewer than AUTO_WIDE at 32, n at 64 -- which is a quarter of sizing for 16 lanes per chain throughout (surplus
+// workgroups are not free: ~1.5 ns each on the dispatcher, 2.4 us per launch at a bound of 32,768 chains).
+static inline unsigned blocks_for(i64 n, int geo) {
+  if (geo != 0) return (unsigned)bk_cdiv(n, WAVES * (BK_WAVE / geo));
+  const i64 a = bk_cdiv(n < AUTO_MID ? n : AUTO_MID - 1, WAVES * (BK_WAVE / 16));
+  const i64 b = n < AUTO_MID ? 0 : bk_cdiv(n < AUTO_WIDE ? n : AUTO_WIDE - 1, WAVES * (BK_WAVE / 8));
+  const i64 c = n < AUTO_WIDE ? 0 : bk_cdiv(n, WAVES * (BK_WAVE / 4));
+  const i64 m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  return (unsigned)m;
+}
+
 template <class DEN, int LPC, int SL, bool HM>
 __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_ghost_link& ghost, const bk_ghost0& g0,
                                           int lane, int wave) {
@@ -437,7 +450,7 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
 }
 
 // LPC_ARG = 4, 8 or 16: that geometry; 0: chosen at run time from the lane count, which only the device knows.
-// The grid is sized for the 16-lane form of the bound n_host.
+// The grid is sized by blocks_for(): what the largest admissible count of each geometry needs.
 template <class DEN, int LPC_ARG, int SL, bool HM>
 __global__ __launch_bounds__(BLOCK) void k_lane_traj(TrajArgs a, bk_scatter_job job, bk_ghost_link ghost, bk_ghost0 g0) {
   const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
@@ -547,8 +560,7 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
   if (forced) geo = forced == 2 ? 16 : (forced == 3 ? 8 : 4);
   else if (n_dev) geo = n >= AUTO_MID ? 0 : 16;
   else geo = n >= AUTO_WIDE ? 4 : (n >= AUTO_MID ? 8 : 16);
-  const unsigned traj_blocks =
-      n == 0 ? 0u : (unsigned)bk_cdiv(n, WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
+  const unsigned traj_blocks = n == 0 ? 0u : blocks_for(n, geo);
   const TrajArgs a = {theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out,
                       ld_out, metric, h, (int)steps, n, D, n_dev, lanes_out,
                       reinterpret_cast<unsigned long long*>(lanes_total), H_out, h_out, live_out, traj_blocks, params};
@@ -719,7 +731,7 @@ static int target_launch(const double* theta, double* grad, double* logp, int64_
   int geo;
   if (n_dev) geo = C >= AUTO_MID ? 0 : 16;
   else geo = C >= AUTO_WIDE ? 4 : (C >= AUTO_MID ? 8 : 16);
-  const unsigned blocks = (unsigned)bk_cdiv(C, WAVES * (geo == 4 ? BK_WAVE / 4 : geo == 8 ? BK_WAVE / 8 : BK_WAVE / 16));
+  const unsigned blocks = blocks_for(C, geo);
 #define BKL_G(LPC, R) k_lane_grad<DEN, LPC, R><<<dim3(blocks), dim3(BLOCK), 0, s>>>(theta, grad, logp, ld, params, C, D, n_dev)
 #define BKL_G_ROWS(R)               \
   do {                              \
@@ -745,6 +757,189 @@ static int target_launch(const double* theta, double* grad, double* logp, int64_
   }
 #undef BKL_G_ROWS
 #undef BKL_G
+  BK_RETURN_LAUNCH_STATUS();
+}
+
+// ---- one leapfrog step {gradient, kick, drift} (drghmc.py:280-283) as ONE launch, state in memory ---------------------
+// For the step-by-step ("counted") path of a lane-spread density: theta and rho are advanced in place over min(n, *n_dev)
+// chains -- half the launches of {gradient op, bk_leapfrog_kick_drift}, and the gradient never travels through memory.  Same
+// arithmetic as those two launches (and as the trajectory kernel): bit-identical results.
+// SL > 0: a lane's rows in registers (TrajCtx).  SL = 0: any D; the rows are walked in memory, sums first, then
+// gradient + kick + drift row by row (every lane of a chain has finished its sums before the first row is rewritten: the lanes
+// of a chain share a wavefront, and sum() ends in a cross-lane reduction).
+template <int LPC, bool HM, int HEAD>
+struct MemStepCtx {
+  using G = Geo<LPC, 1>;
+  static constexpr int KC = G::KC;
+  const double* v;       // [HEAD]
+  double* rv;            // [HEAD]
+  double* gv;            // [HEAD]
+  const double* mvh;     // [HEAD]
+  const double* metric;  // device array (or NULL)
+  double* th;            // column of this lane's chain: th[d * ld]
+  double* rho;
+  i64 ld;
+  double hk, hd;
+  int pos;
+  i64 D;
+  bool on;
+  bool rows_done;
+
+  __device__ __forceinline__ i64 dims() const { return D; }
+  __device__ __forceinline__ double head(int i) const { return v[i]; }
+  template <class F>
+  __device__ __forceinline__ double sum(F&& f) {
+    if (rows_done) __builtin_trap();
+    double cs[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) {
+      double acc = 0.0;
+#pragma unroll 4
+      for (i64 d = HEAD + pos + LPC * k; d < D; d += CLASSES) acc = acc + f(th[d * ld], d);
+      cs[k] = acc;
+    }
+    return reduce_lanes<LPC>(cs);
+  }
+  __device__ __forceinline__ void grad_head(int i, double g) {
+    gv[i] = g;
+    const double t = HM ? mvh[i] * g : g;
+    rv[i] = rv[i] + hk * t;
+  }
+  template <class F>
+  __device__ __forceinline__ void grad(F&& f) {
+    if (rows_done) __builtin_trap();
+    rows_done = true;
+#pragma unroll 4
+    for (i64 d = HEAD + pos; d < D; d += LPC) {
+      const double x = th[d * ld];
+      const double gi = f(x, d);
+      const double t = HM ? metric[d] * gi : gi;
+      const double r = rho[d * ld] + hk * t;
+      if (on) {
+        rho[d * ld] = r;
+        th[d * ld] = x + hd * r;
+      }
+    }
+  }
+};
+
+template <class DEN, int LPC, int SL, bool HM>
+__device__ __forceinline__ void step_body(double* th, double* rho, i64 ld, const double* metric, double h, const double* params,
+                                          i64 n, i64 D, int lane, int wave) {
+  constexpr int HEAD = DEN::HEAD;
+  using G = Geo<LPC, (SL > 0 ? SL : 1)>;
+  constexpr int NU = SL > 0 ? G::NU : 1, H1 = HEAD > 0 ? HEAD : 1;
+  const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;
+  if (j0 >= n) return;  // (whole wavefront past the set)
+  const int pos = lane & (LPC - 1);
+  const i64 j = j0 + lane / LPC;
+  const bool on = j < n;
+  const i64 col = on ? j : 0;  // (lanes past the set compute on chain 0 and store nothing)
+  double v[H1], rv[H1], mvh[H1], gv[H1];
+#pragma unroll
+  for (int i = 0; i < HEAD; ++i) {
+    v[i] = th[(i64)i * ld + col];
+    rv[i] = rho[(i64)i * ld + col];
+    mvh[i] = HM ? metric[i] : 1.0;
+  }
+  if constexpr (SL > 0) {
+    bool tail_ok[G::KC];
+#pragma unroll
+    for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * SL + SL - 1) < D;
+    double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const bool ok = !G::last_slot(u) || tail_ok[u / SL];
+      const i64 o = (i64)(HEAD + pos + G::off(u)) * ld + col;
+      x[u] = ok ? th[o] : 0.0;
+      r[u] = ok ? rho[o] : 0.0;
+      if (HM && LPC == 16) mt[u] = ok ? metric[HEAD + pos + G::off(u)] : 1.0;
+    }
+    TrajCtx<LPC, SL, HM, HEAD, false, true> c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, h, h, pos, D, nullptr, 0, 0u, false, false};
+    DEN::eval(c, params);
+    if (on) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        if (!G::last_slot(u) || tail_ok[u / SL]) {
+          const i64 o = (i64)(HEAD + pos + G::off(u)) * ld + j;
+          rho[o] = r[u];
+          th[o] = x[u];
+        }
+    }
+  } else {
+    MemStepCtx<LPC, HM, HEAD> c{v, rv, gv, mvh, metric, th + col, rho + col, ld, h, h, pos, D, on, false};
+    DEN::eval(c, params);
+  }
+  if (on && pos == 0) {
+#pragma unroll
+    for (int i = 0; i < HEAD; ++i) {
+      rho[(i64)i * ld + j] = rv[i];
+      th[(i64)i * ld + j] = v[i] + h * rv[i];
+    }
+  }
+}
+
+template <class DEN, int LPC_ARG, int SL, bool HM>
+__global__ __launch_bounds__(BLOCK) void k_lane_step(double* th, double* rho, i64 ld, const double* metric, double h,
+                                                     const double* params, i64 n_host, i64 D, const uint32_t* n_dev) {
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
+  const i64 n = bk_lanes(n_host, n_dev);
+  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) step_body<DEN, 4, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
+  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) step_body<DEN, 8, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
+  else step_body<DEN, 16, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
+}
+
+// Host side: theta, rho [D][ld] advanced in place by one leapfrog step of size h over min(n, *n_dev) chains.
+template <class DEN, int SL_ONLY = -1>
+static int step_launch(double* theta, double* rho, int64_t ld, const double* metric, double h, const double* params, int64_t n,
+                       int64_t D, const uint32_t* n_dev, void* stream) {
+  constexpr int HEAD = DEN::HEAD;
+  if (!theta || !rho || n < 0 || D < HEAD || D < 1) return BK_E_ARG;
+  if (ld < n) return BK_E_ALIGN;
+  if (n == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
+  if (need < 1) need = 1;
+  if (need > MAX_SLOTS) need = 0;
+  if (SL_ONLY >= 0 && need != SL_ONLY) return BK_E_ARG;
+  int geo;
+  if (n_dev) geo = n >= AUTO_MID ? 0 : 16;
+  else geo = n >= AUTO_WIDE ? 4 : (n >= AUTO_MID ? 8 : 16);
+  const unsigned blocks = blocks_for(n, geo);
+#define BKL_S(LPC, R, M) k_lane_step<DEN, LPC, R, M><<<dim3(blocks), dim3(BLOCK), 0, s>>>(theta, rho, ld, metric, h, params, n, D, n_dev)
+#define BKL_S_ROWS(R)                    \
+  do {                                   \
+    if (geo == 16) {                     \
+      if (metric) BKL_S(16, R, true);    \
+      else BKL_S(16, R, false);          \
+    } else if (geo == 4) {               \
+      if (metric) BKL_S(4, R, true);     \
+      else BKL_S(4, R, false);           \
+    } else if (geo == 8) {               \
+      if (metric) BKL_S(8, R, true);     \
+      else BKL_S(8, R, false);           \
+    } else {                             \
+      if (metric) BKL_S(0, R, true);     \
+      else BKL_S(0, R, false);           \
+    }                                    \
+  } while (0)
+  if constexpr (SL_ONLY >= 0) {
+    BKL_S_ROWS(SL_ONLY);
+  } else {
+    switch (need) {
+      case 0: BKL_S_ROWS(0); break;
+      case 1: BKL_S_ROWS(1); break;
+      case 2: BKL_S_ROWS(2); break;
+      case 3: BKL_S_ROWS(3); break;
+      case 4: BKL_S_ROWS(4); break;
+      case 5: BKL_S_ROWS(5); break;
+      case 6: BKL_S_ROWS(6); break;
+      case 7: BKL_S_ROWS(7); break;
+      default: BKL_S_ROWS(8); break;
+    }
+  }
+#undef BKL_S_ROWS
+#undef BKL_S
   BK_RETURN_LAUNCH_STATUS();
 }
 

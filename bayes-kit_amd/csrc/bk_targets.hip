@@ -277,196 +277,6 @@ __global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, doub
   }
 }
 
-// Whole HMC trajectory of the separable Gaussians in registers (hmc.py:40-53 with
-// grad = -(lam*theta) inlined): every (d, c) element is independent of all others through
-// the L steps, so theta and rho are read once and written once (32 B per element per
-// TRAJECTORY instead of 56 B per element per STEP) and the kernel is bound by the fp64
-// vector units, not by HBM.  The per-element operation sequence is exactly the one the
-// step-by-step kernels execute, so the results are bit-identical.
-// HL / HM: lam / metric given (compile-time, so that the loop carries no selects); the ROWS rows of
-// a thread advance together, which gives 2*ROWS independent dependency chains per lane.
-template <int ROWS, bool HL, bool HM>
-__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss(const double* th_in, double* th_out,
-                                                         const double* rho_in, double* rho_out, i64 ld,
-                                                         const double* lam, const double* metric, double eps,
-                                                         int steps, i64 C2, i64 D) {
-  i64 c2 = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
-  i64 d0 = (i64)blockIdx.y * ROWS;
-  if (c2 >= C2) return;
-  const double half = 0.5 * eps;
-  dvec2 th[ROWS], r[ROWS], t[ROWS];
-  double l[ROWS], m[ROWS];
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const i64 d = (d0 + i < D) ? d0 + i : D - 1;  // rows past the end recompute the last one, not stored
-    th[i] = *reinterpret_cast<const dvec2*>(th_in + d * ld + 2 * c2);
-    r[i] = *reinterpret_cast<const dvec2*>(rho_in + d * ld + 2 * c2);
-    l[i] = HL ? lam[d] : 1.0;
-    m[i] = HM ? metric[d] : 1.0;
-  }
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    double gx = HL ? -(l[i] * th[i].x) : -th[i].x, gy = HL ? -(l[i] * th[i].y) : -th[i].y;
-    t[i].x = HM ? m[i] * gx : gx;
-    t[i].y = HM ? m[i] * gy : gy;
-    r[i].x = r[i].x + (-half) * t[i].x;  // hmc.py:46
-    r[i].y = r[i].y + (-half) * t[i].y;
-  }
-  for (int n = 0; n < steps; ++n) {
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      r[i].x = r[i].x + eps * t[i].x;  // hmc.py:48
-      r[i].y = r[i].y + eps * t[i].y;
-      th[i].x = th[i].x + eps * r[i].x;  // hmc.py:49
-      th[i].y = th[i].y + eps * r[i].y;
-      double gx = HL ? -(l[i] * th[i].x) : -th[i].x;  // hmc.py:50
-      double gy = HL ? -(l[i] * th[i].y) : -th[i].y;
-      t[i].x = HM ? m[i] * gx : gx;
-      t[i].y = HM ? m[i] * gy : gy;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    r[i].x = r[i].x + half * t[i].x;  // hmc.py:52
-    r[i].y = r[i].y + half * t[i].y;
-    if (d0 + i < D) {
-      *reinterpret_cast<dvec2*>(th_out + (d0 + i) * ld + 2 * c2) = th[i];
-      *reinterpret_cast<dvec2*>(rho_out + (d0 + i) * ld + 2 * c2) = r[i];
-    }
-  }
-}
-
-__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_s(const double* th_in, double* th_out,
-                                                           const double* rho_in, double* rho_out, i64 ld,
-                                                           const double* lam, const double* metric, double eps,
-                                                           int steps, i64 C, i64 D) {
-  i64 c = (i64)blockIdx.x * TG_BLOCK + threadIdx.x;
-  i64 d = blockIdx.y;
-  if (c >= C) return;
-  const double half = 0.5 * eps;
-  double th = th_in[d * ld + c], r = rho_in[d * ld + c];
-  const double l = lam ? lam[d] : 1.0, m = metric ? metric[d] : 1.0;
-  double g = lam ? -(l * th) : -th;
-  double t = metric ? m * g : g;
-  r = r + (-half) * t;
-  for (int n = 0; n < steps; ++n) {
-    r = r + eps * t;
-    th = th + eps * r;
-    g = lam ? -(l * th) : -th;
-    t = metric ? m * g : g;
-  }
-  r = r + half * t;
-  th_out[d * ld + c] = th;
-  rho_out[d * ld + c] = r;
-}
-
-// The same trajectory as the trajectory + energies of a whole HMC draw (hmc.py:55-59): one thread
-// per (chain, QUARTER of the dimensions) walks its quarter in chunks of TQ_ROWS rows -- each chunk
-// is a register-resident trajectory as above -- and accumulates, sequentially in d, the three
-// per-chain sums a draw needs:
-//     kin0 = 1/2 sum rho0*(m*rho0)   [hmc.py:57 -> :37]    (momentum as drawn)
-//     kin1 = 1/2 sum rho1*(m*rho1)   [hmc.py:59 -> :37]    (momentum at the end)
-//     lp1  = -1/2 sum theta1*(lam*theta1)                   (the target's log density at the end)
-// as quarter partials part[k][q][c]; combined ((p0+p1)+p2)+p3 (k_quarter_sums) they are, bit for
-// bit, what bk_leapfrog_finish and bk_target_*_gaussian_grad compute with their four wavefronts
-// per 64 chains -- which is why the walk is per quarter and in d order.  The momentum is read
-// either in the state layout (rho_in) or straight from the wavefront-per-chain generator's
-// chain-major normals (zt[c*ldz + d], rho0 = 0.0 + 1.0*z as numpy's random_normal); the final
-// momentum is never stored (HMC discards it).  HBM traffic: 8 D (theta) + 8 D (momentum) read,
-// 8 D (theta') written per chain -- against 32 D for the trajectory kernel above plus 32 D for
-// the two reductions it replaces.
-constexpr int TQ_ROWS = 8;
-template <bool HL, bool HM, bool ZT>
-__global__ __launch_bounds__(TG_BLOCK) void k_traj_gauss_q(const double* th_in, double* th_out, const double* rho_in,
-                                                           i64 ld, const double* zt, i64 ldz, const double* lam,
-                                                           const double* metric, double eps, int steps,
-                                                           double* part, i64 C, i64 D) {
-  const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;  // (64-thread workgroups for small launches)
-  const int q = blockIdx.y;
-  if (c >= C) return;
-  const i64 Dq = (D + 3) / 4;
-  const i64 dlo = q * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
-  const double half = 0.5 * eps;
-  double k0 = 0.0, k1 = 0.0, sl = 0.0;
-  for (i64 d0 = dlo; d0 < dhi; d0 += TQ_ROWS) {
-    double th[TQ_ROWS], r[TQ_ROWS], t[TQ_ROWS], l[TQ_ROWS], m[TQ_ROWS];
-#pragma unroll
-    for (int i = 0; i < TQ_ROWS; ++i) {
-      const i64 d = (d0 + i < dhi) ? d0 + i : dhi - 1;  // rows past the end recompute the last one, unused
-      th[i] = th_in[d * ld + c];
-      r[i] = ZT ? 0.0 + 1.0 * zt[c * ldz + d] : rho_in[d * ld + c];
-      l[i] = HL ? lam[d] : 1.0;
-      m[i] = HM ? metric[d] : 1.0;
-    }
-#pragma unroll
-    for (int i = 0; i < TQ_ROWS; ++i) {
-      if (d0 + i < dhi) {
-        const double mv = HM ? m[i] * r[i] : r[i];
-        k0 = k0 + r[i] * mv;
-      }
-      const double g = HL ? -(l[i] * th[i]) : -th[i];
-      t[i] = HM ? m[i] * g : g;
-      r[i] = r[i] + (-half) * t[i];  // hmc.py:46
-    }
-    for (int n = 0; n < steps; ++n) {
-#pragma unroll
-      for (int i = 0; i < TQ_ROWS; ++i) {
-        r[i] = r[i] + eps * t[i];    // hmc.py:48
-        th[i] = th[i] + eps * r[i];  // hmc.py:49
-        const double g = HL ? -(l[i] * th[i]) : -th[i];  // hmc.py:50
-        t[i] = HM ? m[i] * g : g;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < TQ_ROWS; ++i) {
-      r[i] = r[i] + half * t[i];  // hmc.py:52
-      if (d0 + i < dhi) {
-        th_out[(d0 + i) * ld + c] = th[i];
-        const double mv = HM ? m[i] * r[i] : r[i];
-        k1 = k1 + r[i] * mv;
-        const double lt = HL ? l[i] * th[i] : th[i];
-        sl = sl + th[i] * lt;
-      }
-    }
-  }
-  part[(0 * 4 + q) * C + c] = k0;
-  part[(1 * 4 + q) * C + c] = k1;
-  part[(2 * 4 + q) * C + c] = sl;
-}
-
-// ... and, when the caller hands over the rest of the accept test's inputs, the test itself
-// (hmc.py:60-63, the arithmetic of bk_mh_accept in HMC mode): one launch less per draw.
-__global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double* kin0, double* kin1, double* lp,
-                                                      double* lp_cur, const double* log_u, uint8_t* mask, double* ret,
-                                                      uint32_t* count, i64 C) {
-  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x;
-  bool acc = false;
-  if (c < C) {
-    double v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const double* p = part + (i64)k * 4 * C + c;
-      v[k] = ((p[0] + p[C]) + p[2 * C]) + p[3 * C];
-    }
-    const double a0 = 0.5 * v[0], a1 = 0.5 * v[1], l1 = -0.5 * v[2];
-    if (kin0) kin0[c] = a0;
-    kin1[c] = a1;
-    lp[c] = l1;
-    if (lp_cur) {
-      const double l0 = lp_cur[c];
-      const double h0 = l0 - a0, h1 = l1 - a1;  // hmc.py:36-38
-      acc = log_u[c] < h1 - h0;                 // hmc.py:60
-      if (mask) mask[c] = acc ? 1 : 0;
-      if (ret) ret[c] = acc ? h1 : h0;
-      if (acc) lp_cur[c] = l1;
-    }
-  }
-  if (lp_cur && count) {
-    unsigned long long b = __ballot(acc);
-    if ((threadIdx.x & (BK_WAVE - 1)) == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
-  }
-}
-
 // The separable Gaussians as a per-coordinate term (bk_elementwise.hpp): term = theta*(lam*theta) summed, log p = -1/2 sum.
 template <bool HL>
 struct GaussTerm {
@@ -581,29 +391,12 @@ int bk_target_diag_gaussian_grad_n(const double* theta, double* grad, double* lo
 int bk_hmc_trajectory_gaussian(const double* theta_in, double* theta_out, const double* rho_in,
                                double* rho_out, int64_t ld, const double* lam, const double* metric,
                                double eps, int64_t steps, int64_t C, int64_t D, void* stream) {
-  if (!theta_in || !theta_out || !rho_in || !rho_out || steps < 0 || steps > 0x7fffffff || C < 0 || D < 0)
-    return BK_E_ARG;
-  if (ld < C) return BK_E_ALIGN;
-  if (C == 0 || D == 0) return BK_OK;
-  hipStream_t s = bk_stream(stream);
-  if (C % 2 == 0 && ld % 2 == 0 && bk_aligned16(theta_in) && bk_aligned16(theta_out) && bk_aligned16(rho_in) &&
-      bk_aligned16(rho_out)) {
-    constexpr int TRAJ_ROWS = 4;  // 8 independent dependency chains per lane (1 / 2 / 4 rows: 1.01 / 0.93 / 0.90 ms)
-    dim3 grid((unsigned)bk_cdiv(C / 2, TG_BLOCK), (unsigned)bk_cdiv(D, TRAJ_ROWS));
-#define BK_TRAJ(HL, HM)                                                                                     \
-  k_traj_gauss<TRAJ_ROWS, HL, HM><<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, lam, \
-                                                                  metric, eps, (int)steps, C / 2, D)
-    if (lam && metric) BK_TRAJ(true, true);
-    else if (lam) BK_TRAJ(true, false);
-    else if (metric) BK_TRAJ(false, true);
-    else BK_TRAJ(false, false);
-#undef BK_TRAJ
-  } else {
-    dim3 grid((unsigned)bk_cdiv(C, TG_BLOCK), (unsigned)D);
-    k_traj_gauss_s<<<grid, dim3(TG_BLOCK), 0, s>>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps,
-                                                   (int)steps, C, D);
-  }
-  BK_RETURN_LAUNCH_STATUS();
+  // the library's whole-trajectory kernels (bk_elementwise.hpp) with the Gaussian term inlined
+  if (lam)
+    return bke::hmc_trajectory_launch<GaussTerm<true>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps, steps, C, D,
+                                                       stream);
+  return bke::hmc_trajectory_launch<GaussTerm<false>>(theta_in, theta_out, rho_in, rho_out, ld, lam, metric, eps, steps, C, D,
+                                                      stream);
 }
 
 int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in,
@@ -611,40 +404,12 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
                          int64_t steps, double* part, double* kin0, double* kin1, double* lp_out, double* lp_cur,
                          const double* log_u, uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C,
                          int64_t D, void* stream) {
-  if (!theta_in || !theta_out || (!rho_in && !zt) || (rho_in && zt) || !part || !kin1 || !lp_out || steps < 0 ||
-      steps > 0x7fffffff || C < 0 || D < 0 || (lp_cur && !log_u))
-    return BK_E_ARG;
-  if (ld < C || (zt && ldz < D)) return BK_E_ALIGN;
-  if (C == 0 || D == 0) return BK_OK;
-  static const bool generic = getenv("BK_GAUSS_GENERIC") != nullptr;
-  if (generic) {
-    if (lam)
-      return bke::hmc_draw_launch<GaussTerm<true>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
-                                                   kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
-    return bke::hmc_draw_launch<GaussTerm<false>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
-                                                  kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
-  }
-  hipStream_t s = bk_stream(stream);
-  // one wavefront per workgroup while that still leaves CUs idle (4096 chains: 256 workgroups instead of 64)
-  const int tq_block = C * 4 <= 256 * TG_BLOCK ? BK_WAVE : TG_BLOCK;
-  dim3 grid((unsigned)bk_cdiv(C, tq_block), 4);
-#define BK_TQ(HL, HM)                                                                                               \
-  do {                                                                                                              \
-    if (zt)                                                                                                         \
-      k_traj_gauss_q<HL, HM, true><<<grid, dim3(tq_block), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,    \
-                                                                   metric, eps, (int)steps, part, C, D);            \
-    else                                                                                                            \
-      k_traj_gauss_q<HL, HM, false><<<grid, dim3(tq_block), 0, s>>>(theta_in, theta_out, rho_in, ld, zt, ldz, lam,   \
-                                                                    metric, eps, (int)steps, part, C, D);           \
-  } while (0)
-  if (lam && metric) BK_TQ(true, true);
-  else if (lam) BK_TQ(true, false);
-  else if (metric) BK_TQ(false, true);
-  else BK_TQ(false, false);
-#undef BK_TQ
-  k_quarter_sums<<<dim3((unsigned)bk_cdiv(C, 256)), dim3(256), 0, s>>>(part, kin0, kin1, lp_out, lp_cur, log_u,
-                                                                       accept_mask, ret, accept_count, C);
-  BK_RETURN_LAUNCH_STATUS();
+  // the library's whole-draw kernels (bk_elementwise.hpp) with the Gaussian term inlined
+  if (lam)
+    return bke::hmc_draw_launch<GaussTerm<true>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
+                                                 kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
+  return bke::hmc_draw_launch<GaussTerm<false>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
+                                                kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
 }
 
 int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,

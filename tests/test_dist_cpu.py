@@ -46,3 +46,25 @@ def test_shard_arithmetic():
         for first, n in blocks:
             assert first == pos
             pos += n
+
+
+def test_single_rank_group_with_forced_collectives_over_gloo():
+    """The code path tests/test_gpu_multirank.py runs on RCCL, here on gloo: a one-rank group with the summaries'
+    collectives forced through it gives the no-group answers (all_gather lists, all_to_all_single with count lists,
+    the rank-normalised R-hat's sample sort with zero splitters)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update({"BK_TEST_BACKEND": "gloo", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "OMP_NUM_THREADS": "1"})
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "single_rank_group_worker.py")], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert r["ok"] and r["backend"] == "gloo" and r["collectives"]["all_to_all"] >= 5

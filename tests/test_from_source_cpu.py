@@ -44,7 +44,7 @@ def cache(tmp_path, monkeypatch):
 def exports(lib):
     h = ctypes.CDLL(lib)
     return {n for n in ("bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory",
-                        "bk_src_dr_proposal_job") if hasattr(h, n)}
+                        "bk_src_dr_proposal_job", "bk_src_leapfrog_step") if hasattr(h, n)}
 
 
 def test_every_form_compiles_and_exports_its_entry_points(cache):
@@ -53,9 +53,9 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     c = T._compile_source_target(CHAIN, "chain", False, 16, 0)
     assert exports(c) == {"bk_src_target", "bk_src_target_n"}
     l = T._compile_source_target(LANES, "lanes", False, 101, 1)
-    assert exports(l) == {"bk_src_target", "bk_src_target_n", "bk_src_dr_proposal_job"}
-    big = T._compile_source_target(LANES, "lanes", False, 300, 1)  # > 128 spread rows: gradient op only
-    assert exports(big) == {"bk_src_target", "bk_src_target_n"}
+    assert exports(l) == {"bk_src_target", "bk_src_target_n", "bk_src_dr_proposal_job", "bk_src_leapfrog_step"}
+    big = T._compile_source_target(LANES, "lanes", False, 300, 1)  # > 128 spread rows: gradient op + one-launch step
+    assert exports(big) == {"bk_src_target", "bk_src_target_n", "bk_src_leapfrog_step"}
     # the cache: 0700 directory, private files, a second request is served from it (same path, no temporaries left)
     assert stat.S_IMODE(os.lstat(cache).st_mode) == 0o700
     assert T._compile_source_target(TERM, "elementwise", False, 16, 0) == e
@@ -70,6 +70,7 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     assert hasattr(te, "bk_hmc_draw") and hasattr(te, "bk_hmc_trajectory") and not hasattr(te, "bk_dr_proposal")
     assert hasattr(tl, "bk_dr_proposal") and tl.bk_dr_proposal_supported() and not hasattr(tl, "bk_hmc_draw")
     assert not hasattr(tb, "bk_dr_proposal") and not hasattr(tc, "bk_dr_proposal") and not hasattr(tc, "bk_hmc_draw")
+    assert hasattr(tl, "bk_leapfrog_step") and hasattr(tb, "bk_leapfrog_step") and not hasattr(tc, "bk_leapfrog_step")
     assert all(t.bk_counted for t in (te, tl, tb, tc))
 
 

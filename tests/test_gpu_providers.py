@@ -221,22 +221,26 @@ def test_lanes_form_gradient_op_is_the_plugin_on_the_counted_path(ops):
     from tests.sampler_parity import check_many_chain
 
     args = (3, [0.2, 0.05, 0.0125], [5, 10, 20], 0.1)
-    for D, C in ((101, 2500), (40, 13000), (130, 800), (300, 500)):
+    for D, C, metric in ((101, 2500, None), (40, 13000, "m"), (130, 800, None), (300, 500, "m")):
         one = D - 1 <= 128
-        a = bk.DrGhmcDiag(funnel_lanes(D), *args, chains=C, seed=21, fuse_builtin=False)
-        p = bk.DrGhmcDiag(funnel_plugin(D), *args, chains=C, seed=21)
-        f = bk.DrGhmcDiag(funnel_lanes(D), *args, chains=C, seed=21) if one else None
+        kw = dict(chains=C, seed=21, metric_diag=None if metric is None else np.linspace(0.6, 1.7, D))
+        a = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, fuse_steps=False, **kw)  # gradient op per step
+        b = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, **kw)  # {gradient, kick, drift} ONE launch per step
+        h = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, device_counts=False, **kw)  # the same, host-sized
+        p = bk.DrGhmcDiag(funnel_plugin(D), *args, **kw)
+        f = bk.DrGhmcDiag(funnel_lanes(D), *args, **kw) if one else None
         assert a._dev_counts and a._use_graph and not a._one_launch and (f is None or f._one_launch)
+        assert b._step_hook and h._step_hook and not a._step_hook and not p._step_hook and b._dev_counts and not h._dev_counts
         if not one:
             assert not bk.DrGhmcDiag(funnel_lanes(D), *args, chains=64, seed=1)._one_launch
         for n in range(5):
             ta, la = a.sample()
             tp, lpp = p.sample()
             assert torch.equal(ta, tp) and torch.equal(la, lpp), (D, n)
-            if f is not None:
-                tf, _ = f.sample()
-                assert torch.equal(ta, tf), (D, n)
-        assert _same_state(a, p), D
+            for o in (b, h) + ((f,) if f is not None else ()):
+                to, _ = o.sample()
+                assert torch.equal(ta, to), (D, n)
+        assert _same_state(a, p) and _same_state(a, b) and torch.equal(a._rng_state, h._rng_state), D
     # the op on its own: every geometry (lane count on the host / on the device, small / mid / large sets), logp-only calls
     for D in (101, 7, 300):
         for n in (1, 63, 4608, 12288 + 5):
@@ -284,8 +288,8 @@ def test_lanes_form_hierarchical_model_with_two_head_coordinates(ops):
     m = np.linspace(0.7, 1.4, D)
     f = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31)
     c = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False)
-    h = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False, device_counts=False)
-    assert f._one_launch and c._dev_counts and not c._one_launch and not h._dev_counts
+    h = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False, device_counts=False, fuse_steps=False)
+    assert f._one_launch and c._dev_counts and not c._one_launch and not h._dev_counts and c._step_hook and not h._step_hook
     for n in range(6):
         tf, lf = f.sample()
         tc, lc = c.sample()

@@ -25,6 +25,12 @@ __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const doub
   if (g.wanted()) { g.set(0, ((-v / 9.0) - hn) + he * s); for (i64 d = 1; d < D; ++d) g.set(d, -(ev * th[d])); }
   return ((-(v * v) / 18.0) - hn * v) - he * s;
 }""", D, form="chain")
+elif opaque in ("lanes", "lanes_fused"):  # the funnel as a lane-spread density from source (bk_lanes.hpp); lanes: counted steps
+    sys.path.insert(0, ROOT)
+    import bench_secondary as bs
+    model = bk.CTarget.from_source(bs.FUNNEL_LANES_SRC, D, form="lanes", head=1)
+    if opaque == "lanes":
+        kw["fuse_builtin"] = False
 elif opaque != "0":
     kw["fuse_builtin"] = False
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,

@@ -24,14 +24,14 @@ starts = starts[-(want + 1):]
 draws = [rows[a:b] for a, b in zip(starts[:-1], starts[1:])]
 TAGS = {7: ["P0", "P1", "G0(P1)", "P2", "G0(P2)", "G1(P2)", "G0(G1(P2))"],
         4: ["P0", "P1+G0(P1)", "P2+G0(P2)", "G1(P2)+G0(G1(P2))"]}  # (a launch runs its lanes' first ghost too)
-tags = TAGS.get(sum("k_funnel_traj" in r["Kernel_Name"] for r in draws[-1]), TAGS[7])
+tags = TAGS.get(sum("k_lane_traj" in r["Kernel_Name"] for r in draws[-1]), TAGS[7])
 per_kernel, per_traj, spans, busy, launches = defaultdict(float), defaultdict(float), [], [], []
 for d in draws:
     t = 0
     for r in d:
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         per_kernel[short(r["Kernel_Name"])] += dur
-        if "k_funnel_traj" in r["Kernel_Name"]:
+        if "k_lane_traj" in r["Kernel_Name"]:
             per_traj[tags[t] if t < len(tags) else f"traj{t}"] += dur
             t += 1
     spans.append((int(d[-1]["End_Timestamp"]) - int(d[0]["Start_Timestamp"])) / 1e3)
@@ -44,4 +44,4 @@ print("| kernel | us per draw | % of busy |\n|---|---:|---:|")
 tot = sum(per_kernel.values())
 for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]):
     print(f"| {k} | {v / n:.1f} | {100 * v / tot:.1f} |")
-print("\nk_funnel_traj by trajectory (us, mean): " + " | ".join(f"{t} {per_traj[t] / n:.1f}" for t in tags if t in per_traj))
+print("\nk_lane_traj by trajectory (us, mean): " + " | ".join(f"{t} {per_traj[t] / n:.1f}" for t in tags if t in per_traj))

@@ -1,7 +1,7 @@
 """One leapfrog step of the counted (lane count on the device) model-opaque path -- gradient op + kick+drift --
 as a chain of REPS steps inside one hipGraph, over lane sets of several sizes inside a bound of C chains:
 microseconds per launch pair.  LANES=0 measures what a launch costs when every workgroup is surplus.
-usage: [C=32768] [D=101] [REPS=200] [PLUGIN=1] python tools/counted_step_bench.py"""
+usage: [C=32768] [D=101] [REPS=200] [PLUGIN=1 | SOURCE=lanes|chain] python tools/counted_step_bench.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
@@ -15,6 +15,11 @@ model = bk.Funnel(D)
 if os.environ.get("PLUGIN"):
     model = bk.CTarget(os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so"), "funnel_target", D,
                        counted_symbol="funnel_target_n")
+if os.environ.get("SOURCE"):  # the funnel from source: SOURCE=lanes | chain
+    sys.path.insert(0, ROOT)
+    import bench_secondary as bs
+    model = (bk.CTarget.from_source(bs.FUNNEL_LANES_SRC, D, form="lanes", head=1) if os.environ["SOURCE"] == "lanes"
+             else bk.CTarget.from_source(bs.FUNNEL_CHAIN_SRC, D, form="chain"))
 f64 = dict(dtype=torch.float64, device=dev)
 th, rho, g = (torch.randn((D, C), **f64) * 0.1 for _ in range(3))
 n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -47,6 +52,6 @@ for which in ("both", "grad", "kd"):
         e1.record()
         e1.synchronize()
         res.setdefault(lanes, {})[which] = round(1e3 * e0.elapsed_time(e1) / 5 / REPS, 2)
-print("us per step (both) / per launch (grad, kd), by lanes in the set; bound C =", C, "D =", D, "plugin" if os.environ.get("PLUGIN") else "builtin")
+print("us per step (both) / per launch (grad, kd), by lanes in the set; bound C =", C, "D =", D, "plugin" if os.environ.get("PLUGIN") else os.environ.get("SOURCE", "builtin"))
 for lanes, r in res.items():
     print(lanes, r)
