@@ -71,6 +71,7 @@ SIGNATURES = {
     "bk_target_iso_gaussian_grad_n": [P, P, P, I, I, I, P, P],
     "bk_target_diag_gaussian_grad_n": [P, P, P, I, P, I, I, P, P],
     "bk_target_funnel_grad_n": [P, P, P, I, I, I, P, P],
+    "bk_leapfrog_step_funnel": [P, P, I, P, F, I, I, P, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
@@ -530,6 +531,13 @@ class Ops:
             self._call("bk_target_funnel_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
         else:
             raise BkHipError(f"unknown built-in target {kind!r}")
+
+    def leapfrog_step_funnel(self, theta, rho, metric, h, n_dev=None):
+        """One leapfrog step {gradient, kick, drift} on the funnel in ONE launch, theta / rho [D, n] advanced in place."""
+        D, n = theta.shape
+        ld = _ld(theta)
+        assert _ld(rho) == ld
+        self._call("bk_leapfrog_step_funnel", ptr(theta), ptr(rho), ld, ptr(metric), h, n, D, ptr(n_dev), self._s())
 
     def hmc_trajectory_gaussian(self, theta_in, theta_out, rho_in, rho_out, lam, metric, eps, steps):
         D, C = theta_in.shape

@@ -136,6 +136,11 @@ class Funnel(_BuiltinTarget):
     def bk_dr_proposal_supported(self) -> bool:
         return self._D <= self._FUSED_MAX_D
 
+    def bk_leapfrog_step(self, theta, rho, metric, h, n_dev=None):
+        """One leapfrog step {gradient, kick, drift} (drghmc.py:280-283) as ONE launch, theta / rho advanced in place: what
+        the step-by-step paths call instead of {bk_eval, kick_drift} (any D)."""
+        self._get_ops().leapfrog_step_funnel(theta, rho, metric, h, n_dev=n_dev)
+
 
 class LogisticRegression(_BuiltinTarget):
     """Bayesian logistic regression, y_n ~ Bernoulli(sigmoid(x_n . theta)), theta ~ N(0, s^2 I)

@@ -601,25 +601,53 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
   BK_RETURN_LAUNCH_STATUS();
 }
 
-// ---- the same density as a gradient OP (plugin ABI bk_target_fn / bk_target_fn_n) ------------------------------
-// The rows of a chain are spread over LPC lanes of one wavefront exactly as in the trajectory kernel; theta is
-// read from and the gradient written to [D][ld] arrays.  SL > 0: a lane's rows sit in registers (one batch of
-// loads, no second pass: on a small lane set a launch is a chain of memory round trips).  SL = 0: any D, the
-// rows are walked twice (sums, then gradient).
-template <int LPC, int SL, int HEAD>
-struct GradCtx {
-  using G = Geo<LPC, (SL > 0 ? SL : 1)>;
+// ---- the same density as OPS on arrays in memory: gradient op and one-launch leapfrog step ---------------------------
+// A per-step launch lives on its loads and stores, not on its arithmetic, so these kernels use the geometry that gives
+// whole 512-byte row segments: LANE = CHAIN, a workgroup of 4 wavefronts serves 64 chains, wavefront w holds the class
+// group w (classes w, w+4, w+8, w+12: the row set lane position w of the 4-lane trajectory geometry holds, so all the
+// row bookkeeping is Geo<4, SL> with pos = w) and the four group sums meet in LDS:
+//     q[w] = ((cs[w] + cs[w+4]) + cs[w+8]) + cs[w+12]     in wavefront w
+//     s    = ((q[0] + q[1]) + q[2]) + q[3]                 in every wavefront, after one barrier
+// -- the canonical order, hence the same bits as the trajectory kernel.  (Spreading a chain over 16 lanes, as the
+// trajectory kernel does for sparse sets, makes every load and store a 32-byte piece: measured 7.6 us per gradient launch
+// against 5.2 in config 4's counted draws.)  A workgroup whose chains lie past the count exits as a whole, before the
+// barrier.  Successive sums alternate between two LDS buffers: one barrier per sum.
+struct CoopRed {
+  double (*part)[WAVES][BK_WAVE];  // [2][WAVES][64]
+  int w, lane, k;
+  __device__ __forceinline__ double operator()(const double* cs) {
+    double(&buf)[WAVES][BK_WAVE] = part[k & 1];
+    ++k;
+    buf[w][lane] = ((cs[0] + cs[1]) + cs[2]) + cs[3];
+    __syncthreads();
+    return ((buf[0][lane] + buf[1][lane]) + buf[2][lane]) + buf[3][lane];
+  }
+};
+
+// SL > 0: a wavefront's rows of its 64 chains sit in registers (one batch of loads, no second pass: on a small lane set a
+// launch is a chain of memory round trips).  SL = 0: any D, the rows are walked in memory (sums, then gradient).
+// STEP: the gradient is delivered INTO kick + drift, rho and theta rewritten in place (bk_leapfrog_step); else stored.
+template <int SL, bool HM, int HEAD, bool STEP>
+struct OpCtx {
+  using G = Geo<4, (SL > 0 ? SL : 1)>;
   static constexpr int NU = SL > 0 ? G::NU : 1, KC = G::KC;
-  const double* x;      // [NU] rows (SL > 0)
-  const double* v;      // [HEAD]
-  double* gv;           // [HEAD]
-  const bool* tail_ok;  // [KC] (SL > 0)
-  const double* th;     // column of this lane's chain: th[d * ld]
-  double* g;            // the same of the gradient (NULL: none wanted)
+  double* x;             // [NU] rows (SL > 0)
+  double* r;             // [NU] their momenta (STEP, SL > 0)
+  const double* v;       // [HEAD]
+  double* rv;            // [HEAD] (STEP)
+  double* gv;            // [HEAD]
+  const bool* tail_ok;   // [KC] (SL > 0)
+  const double* mvh;     // [HEAD] head metric entries (STEP)
+  const double* metric;  // device array or NULL (STEP)
+  double* th;            // column of this lane's chain: th[d * ld]
+  double* rho;           // the same of the momentum (STEP)
+  double* g;             // the same of the gradient (NULL: none wanted; !STEP)
   i64 ld;
-  int pos;
+  double h;
+  int pos;               // = wavefront index
   i64 D;
   bool on;
+  CoopRed red;
   bool rows_done;
 
   __device__ __forceinline__ i64 dims() const { return D; }
@@ -629,7 +657,7 @@ struct GradCtx {
 
   template <class F>
   __device__ __forceinline__ double sum(F&& f) {
-    if (rows_done) __builtin_trap();
+    if (rows_done) __builtin_trap();  // (folds away: the flag is a compile-time constant after inlining)
     double cs[KC];
     if constexpr (SL > 0) {
       class_sums<G, SL>(cs, tail_ok, [&](int u) { return f(x[u], row(u)); });
@@ -638,65 +666,119 @@ struct GradCtx {
       for (int k = 0; k < KC; ++k) {
         double acc = 0.0;
 #pragma unroll 4
-        for (i64 d = HEAD + pos + LPC * k; d < D; d += CLASSES) acc = acc + f(th[d * ld], d);
+        for (i64 d = HEAD + pos + 4 * k; d < D; d += CLASSES) acc = acc + f(th[d * ld], d);
         cs[k] = acc;
       }
     }
-    return reduce_lanes<LPC>(cs);
+    return red(cs);
   }
-  __device__ __forceinline__ void grad_head(int i, double gval) { gv[i] = gval; }
+  __device__ __forceinline__ void grad_head(int i, double gval) {
+    gv[i] = gval;
+    if (STEP) {
+      const double t = HM ? mvh[i] * gval : gval;
+      rv[i] = rv[i] + h * t;
+    }
+  }
   template <class F>
   __device__ __forceinline__ void grad(F&& f) {
     if (rows_done) __builtin_trap();
     rows_done = true;
-    if (!g) return;
+    if (!STEP && !g) return;
     if constexpr (SL > 0) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
         if (ok(u)) {
           const double gi = f(x[u], row(u));
-          if (on) g[row(u) * ld] = gi;
+          if (STEP) {
+            const double t = HM ? metric[row(u)] * gi : gi;
+            r[u] = r[u] + h * t;
+            x[u] = x[u] + h * r[u];
+          } else if (on) {
+            g[row(u) * ld] = gi;
+          }
         }
     } else {
 #pragma unroll 4
-      for (i64 d = HEAD + pos; d < D; d += LPC) {
-        const double gi = f(th[d * ld], d);
-        if (on) g[d * ld] = gi;
+      for (i64 d = HEAD + pos; d < D; d += 4) {
+        const double xd = th[d * ld];
+        const double gi = f(xd, d);
+        if (STEP) {
+          const double t = HM ? metric[d] * gi : gi;
+          const double rn = rho[d * ld] + h * t;
+          if (on) {
+            rho[d * ld] = rn;
+            th[d * ld] = xd + h * rn;
+          }
+        } else if (on) {
+          g[d * ld] = gi;
+        }
       }
     }
   }
 };
 
-template <class DEN, int LPC, int SL>
-__device__ __forceinline__ void grad_body(const double* th, double* g, double* logp, i64 ld, const double* params,
-                                          i64 n, i64 D, int lane, int wave) {
+// gradient op (STEP = false: g and / or logp out) or one leapfrog step in place (STEP = true) for min(n, *n_dev) chains
+template <class DEN, int SL, bool HM, bool STEP>
+__global__ __launch_bounds__(BLOCK) void k_lane_op(double* th, double* rho, double* g, double* logp, i64 ld, const double* metric,
+                                                   double h, const double* params, i64 n_host, i64 D, const uint32_t* n_dev) {
   constexpr int HEAD = DEN::HEAD;
-  using C = GradCtx<LPC, SL, HEAD>;
+  using C = OpCtx<SL, HM, HEAD, STEP>;
   using G = typename C::G;
-  constexpr int H1 = HEAD > 0 ? HEAD : 1;
-  const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;
-  if (j0 >= n) return;  // (whole wavefront past the set)
-  const int pos = lane & (LPC - 1);
-  const i64 j = j0 + lane / LPC;
+  constexpr int H1 = HEAD > 0 ? HEAD : 1, SLq = SL > 0 ? SL : 1;
+  __shared__ double part[2][WAVES][BK_WAVE];
+  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
+  const i64 n = bk_lanes(n_host, n_dev);
+  if ((i64)blockIdx.x * BK_WAVE >= n) return;  // (whole workgroup past the set: uniform, before any barrier)
+  const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
   const bool on = j < n;
-  const i64 col = on ? j : 0;  // (lanes past the set compute on chain 0 and store nothing: the DPP reduction wants all 64)
+  const i64 col = on ? j : 0;  // (lanes past the set compute on chain 0 and store nothing: every lane meets the barrier)
   bool tail_ok[G::KC];
-  double x[C::NU];
+  double x[C::NU], r[C::NU];
   if constexpr (SL > 0) {
 #pragma unroll
-    for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * (SL > 0 ? SL : 1) + (SL > 0 ? SL : 1) - 1) < D;
+    for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + w + G::off(k * SLq + SLq - 1) < D;
 #pragma unroll
     for (int u = 0; u < C::NU; ++u) {
-      const bool ok = !G::last_slot(u) || tail_ok[u / (SL > 0 ? SL : 1)];
-      x[u] = ok ? th[(i64)(HEAD + pos + G::off(u)) * ld + col] : 0.0;
+      const bool ok = !G::last_slot(u) || tail_ok[u / SLq];
+      const i64 o = (i64)(HEAD + w + G::off(u)) * ld + col;
+      x[u] = ok ? th[o] : 0.0;
+      if (STEP) r[u] = ok ? rho[o] : 0.0;
     }
   }
-  double v[H1], gv[H1];
+  double v[H1], rv[H1], mvh[H1], gv[H1];
 #pragma unroll
-  for (int i = 0; i < HEAD; ++i) v[i] = th[(i64)i * ld + col];
-  C c{x, v, gv, tail_ok, th + col, g ? g + col : nullptr, ld, pos, D, on, false};
+  for (int i = 0; i < HEAD; ++i) {
+    v[i] = th[(i64)i * ld + col];
+    if (STEP) {
+      rv[i] = rho[(i64)i * ld + col];
+      mvh[i] = HM ? metric[i] : 1.0;
+    }
+  }
+  C c{x, r, v, rv, gv, tail_ok, mvh, metric, th + col, STEP ? rho + col : nullptr, (!STEP && g) ? g + col : nullptr, ld, h, w, D, on,
+      CoopRed{part, w, lane, 0}, false};
   const double lp = DEN::eval(c, params);
-  if (on && pos == 0) {
+  // (a density without a sum() has no barrier of its own: every wavefront must have read the head coordinates before
+  // wavefront 0 rewrites them)
+  if (STEP && HEAD > 0) __syncthreads();
+  if (!on) return;
+  if (STEP) {
+    if constexpr (SL > 0) {
+#pragma unroll
+      for (int u = 0; u < C::NU; ++u)
+        if (!G::last_slot(u) || tail_ok[u / SLq]) {
+          const i64 o = (i64)(HEAD + w + G::off(u)) * ld + j;
+          rho[o] = r[u];
+          th[o] = x[u];
+        }
+    }
+    if (w == 0) {
+#pragma unroll
+      for (int i = 0; i < HEAD; ++i) {
+        rho[(i64)i * ld + j] = rv[i];
+        th[(i64)i * ld + j] = v[i] + h * rv[i];
+      }
+    }
+  } else if (w == 0) {
     if (logp) logp[j] = lp;
     if (g) {
 #pragma unroll
@@ -705,17 +787,29 @@ __device__ __forceinline__ void grad_body(const double* th, double* g, double* l
   }
 }
 
-template <class DEN, int LPC_ARG, int SL>
-__global__ __launch_bounds__(BLOCK) void k_lane_grad(const double* th, double* g, double* logp, i64 ld, const double* params,
-                                                     i64 n_host, i64 D, const uint32_t* n_dev) {
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
-  const i64 n = bk_lanes(n_host, n_dev);
-  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) grad_body<DEN, 4, SL>(th, g, logp, ld, params, n, D, lane, wave);
-  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) grad_body<DEN, 8, SL>(th, g, logp, ld, params, n, D, lane, wave);
-  else grad_body<DEN, 16, SL>(th, g, logp, ld, params, n, D, lane, wave);
+// slots per class for D, or 0 when the rows do not fit the registers
+template <int HEAD>
+static inline int op_slots(i64 D) {
+  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
+  if (need < 1) need = 1;
+  return need > MAX_SLOTS ? 0 : need;
 }
 
+#define BKL_OP_SWITCH(need, CALL) \
+  switch (need) {                 \
+    case 0: CALL(0); break;       \
+    case 1: CALL(1); break;       \
+    case 2: CALL(2); break;       \
+    case 3: CALL(3); break;       \
+    case 4: CALL(4); break;       \
+    case 5: CALL(5); break;       \
+    case 6: CALL(6); break;       \
+    case 7: CALL(7); break;       \
+    default: CALL(8); break;      \
+  }
+
 // Host side of the plugin ABI (bk_target_fn, and bk_target_fn_n with n_dev) for a lane-spread density.
+// SL_ONLY >= 0: only that slot count is instantiated (a generated translation unit knows its D).
 template <class DEN, int SL_ONLY = -1>
 static int target_launch(const double* theta, double* grad, double* logp, int64_t ld, const double* params, int64_t C,
                          int64_t D, const uint32_t* n_dev, void* stream) {
@@ -724,172 +818,27 @@ static int target_launch(const double* theta, double* grad, double* logp, int64_
   if (ld < C) return BK_E_ALIGN;
   if (C == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
-  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
-  if (need < 1) need = 1;
-  if (need > MAX_SLOTS) need = 0;  // rows walked in memory
+  const int need = op_slots<HEAD>(D);
   if (SL_ONLY >= 0 && need != SL_ONLY) return BK_E_ARG;
-  int geo;
-  if (n_dev) geo = C >= AUTO_MID ? 0 : 16;
-  else geo = C >= AUTO_WIDE ? 4 : (C >= AUTO_MID ? 8 : 16);
-  const unsigned blocks = blocks_for(C, geo);
-#define BKL_G(LPC, R) k_lane_grad<DEN, LPC, R><<<dim3(blocks), dim3(BLOCK), 0, s>>>(theta, grad, logp, ld, params, C, D, n_dev)
-#define BKL_G_ROWS(R)               \
-  do {                              \
-    if (geo == 16) BKL_G(16, R);    \
-    else if (geo == 4) BKL_G(4, R); \
-    else if (geo == 8) BKL_G(8, R); \
-    else BKL_G(0, R);               \
-  } while (0)
+  const dim3 grid((unsigned)bk_cdiv(C, BK_WAVE)), block(BLOCK);
+#define BKL_G(R)                                                                                                              \
+  k_lane_op<DEN, R, false, false><<<grid, block, 0, s>>>(const_cast<double*>(theta), nullptr, grad, logp, ld, nullptr, 0.0, params, \
+                                                         C, D, n_dev)
   if constexpr (SL_ONLY >= 0) {
-    BKL_G_ROWS(SL_ONLY);
+    BKL_G(SL_ONLY);
   } else {
-    switch (need) {
-      case 0: BKL_G_ROWS(0); break;
-      case 1: BKL_G_ROWS(1); break;
-      case 2: BKL_G_ROWS(2); break;
-      case 3: BKL_G_ROWS(3); break;
-      case 4: BKL_G_ROWS(4); break;
-      case 5: BKL_G_ROWS(5); break;
-      case 6: BKL_G_ROWS(6); break;
-      case 7: BKL_G_ROWS(7); break;
-      default: BKL_G_ROWS(8); break;
-    }
+    BKL_OP_SWITCH(need, BKL_G)
   }
-#undef BKL_G_ROWS
 #undef BKL_G
   BK_RETURN_LAUNCH_STATUS();
 }
 
 // ---- one leapfrog step {gradient, kick, drift} (drghmc.py:280-283) as ONE launch, state in memory ---------------------
-// For the step-by-step ("counted") path of a lane-spread density: theta and rho are advanced in place over min(n, *n_dev)
-// chains -- half the launches of {gradient op, bk_leapfrog_kick_drift}, and the gradient never travels through memory.  Same
-// arithmetic as those two launches (and as the trajectory kernel): bit-identical results.
-// SL > 0: a lane's rows in registers (TrajCtx).  SL = 0: any D; the rows are walked in memory, sums first, then
-// gradient + kick + drift row by row (every lane of a chain has finished its sums before the first row is rewritten: the lanes
-// of a chain share a wavefront, and sum() ends in a cross-lane reduction).
-template <int LPC, bool HM, int HEAD>
-struct MemStepCtx {
-  using G = Geo<LPC, 1>;
-  static constexpr int KC = G::KC;
-  const double* v;       // [HEAD]
-  double* rv;            // [HEAD]
-  double* gv;            // [HEAD]
-  const double* mvh;     // [HEAD]
-  const double* metric;  // device array (or NULL)
-  double* th;            // column of this lane's chain: th[d * ld]
-  double* rho;
-  i64 ld;
-  double hk, hd;
-  int pos;
-  i64 D;
-  bool on;
-  bool rows_done;
-
-  __device__ __forceinline__ i64 dims() const { return D; }
-  __device__ __forceinline__ double head(int i) const { return v[i]; }
-  template <class F>
-  __device__ __forceinline__ double sum(F&& f) {
-    if (rows_done) __builtin_trap();
-    double cs[KC];
-#pragma unroll
-    for (int k = 0; k < KC; ++k) {
-      double acc = 0.0;
-#pragma unroll 4
-      for (i64 d = HEAD + pos + LPC * k; d < D; d += CLASSES) acc = acc + f(th[d * ld], d);
-      cs[k] = acc;
-    }
-    return reduce_lanes<LPC>(cs);
-  }
-  __device__ __forceinline__ void grad_head(int i, double g) {
-    gv[i] = g;
-    const double t = HM ? mvh[i] * g : g;
-    rv[i] = rv[i] + hk * t;
-  }
-  template <class F>
-  __device__ __forceinline__ void grad(F&& f) {
-    if (rows_done) __builtin_trap();
-    rows_done = true;
-#pragma unroll 4
-    for (i64 d = HEAD + pos; d < D; d += LPC) {
-      const double x = th[d * ld];
-      const double gi = f(x, d);
-      const double t = HM ? metric[d] * gi : gi;
-      const double r = rho[d * ld] + hk * t;
-      if (on) {
-        rho[d * ld] = r;
-        th[d * ld] = x + hd * r;
-      }
-    }
-  }
-};
-
-template <class DEN, int LPC, int SL, bool HM>
-__device__ __forceinline__ void step_body(double* th, double* rho, i64 ld, const double* metric, double h, const double* params,
-                                          i64 n, i64 D, int lane, int wave) {
-  constexpr int HEAD = DEN::HEAD;
-  using G = Geo<LPC, (SL > 0 ? SL : 1)>;
-  constexpr int NU = SL > 0 ? G::NU : 1, H1 = HEAD > 0 ? HEAD : 1;
-  const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;
-  if (j0 >= n) return;  // (whole wavefront past the set)
-  const int pos = lane & (LPC - 1);
-  const i64 j = j0 + lane / LPC;
-  const bool on = j < n;
-  const i64 col = on ? j : 0;  // (lanes past the set compute on chain 0 and store nothing)
-  double v[H1], rv[H1], mvh[H1], gv[H1];
-#pragma unroll
-  for (int i = 0; i < HEAD; ++i) {
-    v[i] = th[(i64)i * ld + col];
-    rv[i] = rho[(i64)i * ld + col];
-    mvh[i] = HM ? metric[i] : 1.0;
-  }
-  if constexpr (SL > 0) {
-    bool tail_ok[G::KC];
-#pragma unroll
-    for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * SL + SL - 1) < D;
-    double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const bool ok = !G::last_slot(u) || tail_ok[u / SL];
-      const i64 o = (i64)(HEAD + pos + G::off(u)) * ld + col;
-      x[u] = ok ? th[o] : 0.0;
-      r[u] = ok ? rho[o] : 0.0;
-      if (HM && LPC == 16) mt[u] = ok ? metric[HEAD + pos + G::off(u)] : 1.0;
-    }
-    TrajCtx<LPC, SL, HM, HEAD, false, true> c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, h, h, pos, D, nullptr, 0, 0u, false, false};
-    DEN::eval(c, params);
-    if (on) {
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-        if (!G::last_slot(u) || tail_ok[u / SL]) {
-          const i64 o = (i64)(HEAD + pos + G::off(u)) * ld + j;
-          rho[o] = r[u];
-          th[o] = x[u];
-        }
-    }
-  } else {
-    MemStepCtx<LPC, HM, HEAD> c{v, rv, gv, mvh, metric, th + col, rho + col, ld, h, h, pos, D, on, false};
-    DEN::eval(c, params);
-  }
-  if (on && pos == 0) {
-#pragma unroll
-    for (int i = 0; i < HEAD; ++i) {
-      rho[(i64)i * ld + j] = rv[i];
-      th[(i64)i * ld + j] = v[i] + h * rv[i];
-    }
-  }
-}
-
-template <class DEN, int LPC_ARG, int SL, bool HM>
-__global__ __launch_bounds__(BLOCK) void k_lane_step(double* th, double* rho, i64 ld, const double* metric, double h,
-                                                     const double* params, i64 n_host, i64 D, const uint32_t* n_dev) {
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
-  const i64 n = bk_lanes(n_host, n_dev);
-  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) step_body<DEN, 4, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
-  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) step_body<DEN, 8, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
-  else step_body<DEN, 16, SL, HM>(th, rho, ld, metric, h, params, n, D, lane, wave);
-}
-
-// Host side: theta, rho [D][ld] advanced in place by one leapfrog step of size h over min(n, *n_dev) chains.
+// For the step-by-step ("counted") path of a lane-spread density: theta and rho [D][ld] are advanced in place by one step of
+// size h over min(n, *n_dev) chains -- half the launches of {gradient op, bk_leapfrog_kick_drift}, and the gradient never
+// travels through memory.  Same arithmetic as those two launches (and as the trajectory kernel): bit-identical results.
+// (SL = 0: every wavefront finishes its sums -- the barrier of the reduction -- before any row is rewritten, and a wavefront
+// rewrites only the rows it alone reads.)
 template <class DEN, int SL_ONLY = -1>
 static int step_launch(double* theta, double* rho, int64_t ld, const double* metric, double h, const double* params, int64_t n,
                        int64_t D, const uint32_t* n_dev, void* stream) {
@@ -898,49 +847,24 @@ static int step_launch(double* theta, double* rho, int64_t ld, const double* met
   if (ld < n) return BK_E_ALIGN;
   if (n == 0) return BK_OK;
   hipStream_t s = bk_stream(stream);
-  int need = (int)((D - HEAD + CLASSES - 1) / CLASSES);
-  if (need < 1) need = 1;
-  if (need > MAX_SLOTS) need = 0;
+  const int need = op_slots<HEAD>(D);
   if (SL_ONLY >= 0 && need != SL_ONLY) return BK_E_ARG;
-  int geo;
-  if (n_dev) geo = n >= AUTO_MID ? 0 : 16;
-  else geo = n >= AUTO_WIDE ? 4 : (n >= AUTO_MID ? 8 : 16);
-  const unsigned blocks = blocks_for(n, geo);
-#define BKL_S(LPC, R, M) k_lane_step<DEN, LPC, R, M><<<dim3(blocks), dim3(BLOCK), 0, s>>>(theta, rho, ld, metric, h, params, n, D, n_dev)
-#define BKL_S_ROWS(R)                    \
-  do {                                   \
-    if (geo == 16) {                     \
-      if (metric) BKL_S(16, R, true);    \
-      else BKL_S(16, R, false);          \
-    } else if (geo == 4) {               \
-      if (metric) BKL_S(4, R, true);     \
-      else BKL_S(4, R, false);           \
-    } else if (geo == 8) {               \
-      if (metric) BKL_S(8, R, true);     \
-      else BKL_S(8, R, false);           \
-    } else {                             \
-      if (metric) BKL_S(0, R, true);     \
-      else BKL_S(0, R, false);           \
-    }                                    \
+  const dim3 grid((unsigned)bk_cdiv(n, BK_WAVE)), block(BLOCK);
+#define BKL_S(R)                                                                                                               \
+  do {                                                                                                                         \
+    if (metric)                                                                                                                \
+      k_lane_op<DEN, R, true, true><<<grid, block, 0, s>>>(theta, rho, nullptr, nullptr, ld, metric, h, params, n, D, n_dev);  \
+    else                                                                                                                       \
+      k_lane_op<DEN, R, false, true><<<grid, block, 0, s>>>(theta, rho, nullptr, nullptr, ld, metric, h, params, n, D, n_dev); \
   } while (0)
   if constexpr (SL_ONLY >= 0) {
-    BKL_S_ROWS(SL_ONLY);
+    BKL_S(SL_ONLY);
   } else {
-    switch (need) {
-      case 0: BKL_S_ROWS(0); break;
-      case 1: BKL_S_ROWS(1); break;
-      case 2: BKL_S_ROWS(2); break;
-      case 3: BKL_S_ROWS(3); break;
-      case 4: BKL_S_ROWS(4); break;
-      case 5: BKL_S_ROWS(5); break;
-      case 6: BKL_S_ROWS(6); break;
-      case 7: BKL_S_ROWS(7); break;
-      default: BKL_S_ROWS(8); break;
-    }
+    BKL_OP_SWITCH(need, BKL_S)
   }
-#undef BKL_S_ROWS
 #undef BKL_S
   BK_RETURN_LAUNCH_STATUS();
 }
+#undef BKL_OP_SWITCH
 
 }  // namespace bkl

@@ -16,8 +16,6 @@ namespace {
 
 constexpr int TG_ROWS = 4;
 constexpr int TG_BLOCK = 256;
-constexpr int PC_BLOCK = 64;
-constexpr int PC_UNROLL = 8;
 
 // grad = -(lam*theta)  (lam NULL -> grad = -theta), two chains per lane
 typedef double dvec2 __attribute__((ext_vector_type(2)));
@@ -151,132 +149,6 @@ __global__ __launch_bounds__(RED_BLOCK) void k_gauss_logp_v2(const double* th, d
   }
 }
 
-// Neal's funnel, any D: one lane per chain, sequential in d
-__global__ __launch_bounds__(PC_BLOCK) void k_funnel(const double* th, double* g, double* logp, i64 ld,
-                                                     i64 C_host, i64 D, const uint32_t* n_dev) {
-  const i64 C = bk_lanes(C_host, n_dev);
-  i64 c = (i64)blockIdx.x * PC_BLOCK + threadIdx.x;
-  if (c >= C) return;
-  double v = th[c];
-  double s = 0.0;
-  for (i64 d0 = 1; d0 < D; d0 += PC_UNROLL) {
-    double t[PC_UNROLL];
-#pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) t[u] = th[(d0 + u) * ld + c];
-#pragma unroll
-    for (int u = 0; u < PC_UNROLL; ++u)
-      if (d0 + u < D) s = s + t[u] * t[u];
-  }
-  double ev = exp(-v);
-  double hn = 0.5 * (double)(D - 1);
-  double he = 0.5 * ev;
-  if (logp) logp[c] = ((-(v * v) / 18.0) - hn * v) - he * s;
-  if (g) {
-    g[c] = ((-v / 9.0) - hn) + he * s;
-    for (i64 d0 = 1; d0 < D; d0 += PC_UNROLL) {
-      double t[PC_UNROLL];
-#pragma unroll
-      for (int u = 0; u < PC_UNROLL; ++u)
-        if (d0 + u < D) t[u] = th[(d0 + u) * ld + c];
-#pragma unroll
-      for (int u = 0; u < PC_UNROLL; ++u)
-        if (d0 + u < D) g[(d0 + u) * ld + c] = -(ev * t[u]);
-    }
-  }
-}
-
-// Neal's funnel.  The only coupling between the coordinates of a chain is s = sum_{d>=1}
-// theta_d^2, so the ROWS of a chain are split over lanes and s is reduced across them.
-//
-// Canonical summation order (every funnel kernel below; results do not depend on how many chains
-// are in flight, on the grid, or on which geometry runs).  Row d belongs to class c = (d-1) mod 16,
-// slot i = (d-1) div 16:
-//     cs[c] = sum over i, in order, of x[1 + c + 16 i]^2              (16 class sums)
-//     q[g]  = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12],  g = 0..3     (4 group sums)
-//     s     = ((q[0] + q[1]) + q[2]) + q[3]
-// Geometries that produce exactly these values:
-//   * the gradient op (k_funnel_coop): a 4-wavefront workgroup, 64 chains, lane = chain; wavefront w owns
-//     the four classes of group w and contributes q[w] through LDS.
-//   * the trajectory kernel (bk_lanes.hpp, k_lane_traj<FunnelDensity, ...>): 4 / 8 / 16 adjacent lanes of ONE wavefront
-//     serve a chain, and s is reduced with DPP moves inside the wavefront (geometries described there).
-constexpr int FN_WAVES = 4;
-constexpr int FN_CLASSES = 16;
-constexpr int FN_MAX_SLOTS = 8;  // slots per class held in registers: D - 1 <= 128
-constexpr int FN_MAX_ROWS = FN_CLASSES * FN_MAX_SLOTS;
-constexpr int FN_BLOCK = FN_WAVES * BK_WAVE;
-
-struct FunnelLds {
-  double part[FN_WAVES][BK_WAVE];
-};
-
-// Geometry of the gradient op: register slot u = k*SL + i holds class w + 4k, slot i; chain = lane.
-template <int SL>
-struct FunnelGeo {
-  static constexpr int KC = 4;        // classes per lane
-  static constexpr int NU = KC * SL;  // register slots per lane
-  __device__ static __forceinline__ i64 row(int w, int lane, int u) {
-    return 1 + (w + 4 * (u / SL)) + (i64)FN_CLASSES * (u % SL);
-  }
-};
-
-// s (canonical order) for this lane's chain from the lane's class sums cs[4] (one use per launch)
-__device__ __forceinline__ double funnel_reduce_lds(FunnelLds& lds, int w, int lane, const double* cs) {
-  lds.part[w][lane] = ((cs[0] + cs[1]) + cs[2]) + cs[3];
-  __syncthreads();
-  return ((lds.part[0][lane] + lds.part[1][lane]) + lds.part[2][lane]) + lds.part[3][lane];
-}
-
-// class sums of `expr` over this lane's rows < D, each class sequential in its slots
-// (G::row(w, lane, u) with u = k*SL + i is the row of class slot (k, i))
-#define BK_FN_CLASS_SUMS(cs, expr)                                   \
-  _Pragma("unroll") for (int k = 0; k < G::KC; ++k) {                \
-    double acc_ = 0.0;                                               \
-    _Pragma("unroll") for (int i = 0; i < SL; ++i) {                 \
-      const int u = k * SL + i;                                      \
-      if (G::row(w, lane, u) < D) acc_ = acc_ + (expr);              \
-    }                                                                \
-    cs[k] = acc_;                                                    \
-  }
-
-// gradient / log density for n chains (chain j in column j)
-template <int SL>
-__global__ __launch_bounds__(FN_BLOCK) void k_funnel_coop(const double* th, double* g, double* logp, i64 ld,
-                                                          i64 n_host, i64 D, const uint32_t* n_dev) {
-  using G = FunnelGeo<SL>;
-  __shared__ FunnelLds lds;
-  const int lane = threadIdx.x & (BK_WAVE - 1), w = bk_wave_id();
-  const i64 n = bk_lanes(n_host, n_dev);
-  if ((i64)blockIdx.x * BK_WAVE >= n) return;  // (whole workgroup past the set: uniform)
-  const i64 j = (i64)blockIdx.x * BK_WAVE + lane;
-  const bool on = j < n;
-  double x[G::NU];
-#pragma unroll
-  for (int u = 0; u < G::NU; ++u) {
-    const i64 d = G::row(w, lane, u);
-    x[u] = (on && d < D) ? th[d * ld + j] : 0.0;
-  }
-  double cs[G::KC];
-  BK_FN_CLASS_SUMS(cs, x[u] * x[u])
-  double v = on ? th[j] : 0.0;
-  double s = funnel_reduce_lds(lds, w, lane, cs);
-  if (!on) return;
-  double ev = exp(-v);
-  double hn = 0.5 * (double)(D - 1);
-  double he = 0.5 * ev;
-  if (w == 0) {
-    if (logp) logp[j] = ((-(v * v) / 18.0) - hn * v) - he * s;
-    if (g) g[j] = ((-v / 9.0) - hn) + he * s;
-  }
-  if (g) {
-#pragma unroll
-    for (int u = 0; u < G::NU; ++u) {
-      const i64 d = G::row(w, lane, u);
-      if (d < D) g[d * ld + j] = -(ev * x[u]);
-    }
-  }
-}
-
 // The separable Gaussians as a per-coordinate term (bk_elementwise.hpp): term = theta*(lam*theta) summed, log p = -1/2 sum.
 template <bool HL>
 struct GaussTerm {
@@ -289,8 +161,11 @@ struct GaussTerm {
 };
 
 // Neal's funnel as a lane-spread density (bk_lanes.hpp): v = theta_0 is the head coordinate, the rows d >= 1 are
-// exchangeable given v.  The library's trajectory kernel k_lane_traj<FunnelDensity, ...> is the built-in
-// one-launch proposal; a CTarget.from_source(form="lanes") density goes through the same template.
+// exchangeable given v; the only coupling between the coordinates of a chain is s = sum_{d>=1} theta_d^2, summed in the
+// canonical order of bk_lanes.hpp (16 interleaved class sums -> 4 group sums -> total, for every D).  Every funnel entry
+// point -- gradient op (k_lane_op), one-launch leapfrog step, one-launch delayed-rejection proposal (k_lane_traj) -- is an
+// instantiation of the library's templates with this density; a CTarget.from_source(form="lanes") density goes through
+// the same templates.
 struct FunnelDensity {
   static constexpr int HEAD = 1;
   template <class L>
@@ -414,27 +289,17 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
 
 int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
                             int64_t D, const uint32_t* n_dev, void* stream) {
-  if (!theta || (!grad && !logp) || C < 0 || D < 1) return BK_E_ARG;
-  if (ld < C) return BK_E_ALIGN;
-  if (C == 0) return BK_OK;
-  if (D - 1 <= FN_MAX_ROWS) {
-    const int need = (int)((D - 1 + FN_CLASSES - 1) / FN_CLASSES);
-    dim3 grid((unsigned)bk_cdiv(C, BK_WAVE)), block(FN_BLOCK);
-    hipStream_t s = bk_stream(stream);
-    if (need <= 2) k_funnel_coop<2><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
-    else if (need <= 4) k_funnel_coop<4><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
-    else if (need <= 7) k_funnel_coop<7><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
-    else k_funnel_coop<8><<<grid, block, 0, s>>>(theta, grad, logp, ld, C, D, n_dev);
-  }
-  else
-    k_funnel<<<dim3((unsigned)bk_cdiv(C, PC_BLOCK)), dim3(PC_BLOCK), 0, bk_stream(stream)>>>(theta, grad, logp,
-                                                                                           ld, C, D, n_dev);
-  BK_RETURN_LAUNCH_STATUS();
+  return bkl::target_launch<FunnelDensity>(theta, grad, logp, ld, nullptr, C, D, n_dev, stream);
 }
 
 int bk_target_funnel_grad(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,
                           int64_t D, void* stream) {
-  return bk_target_funnel_grad_n(theta, grad, logp, ld, C, D, nullptr, stream);
+  return bkl::target_launch<FunnelDensity>(theta, grad, logp, ld, nullptr, C, D, nullptr, stream);
+}
+
+int bk_leapfrog_step_funnel(double* theta, double* rho, int64_t ld, const double* metric, double h, int64_t n, int64_t D,
+                            const uint32_t* n_dev, void* stream) {
+  return bkl::step_launch<FunnelDensity>(theta, rho, ld, metric, h, nullptr, n, D, n_dev, stream);
 }
 
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,

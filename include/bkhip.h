@@ -402,9 +402,10 @@ int bk_mala_step(const double* theta, double* theta_out, double* grad, double* t
  * inside the trajectory, hmc.py:45,50).  Operation order = oracle/models.py.
  *   iso     : logp = -0.5*sum th^2            grad = -th
  *   diag    : t = lam*th; logp = -0.5*sum th*t; grad = -t
- *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2 (for D-1 <= 128 summed
- *             as 4 interleaved partial sums -- rows 1+w, 5+w, ... for w = 0..3 -- then
- *             over w; sequentially in d otherwise)
+ *   funnel  : v = th[0], n = D-1, ev = exp(-v), s = sum_{i>=1} th_i^2 in the library's canonical order for
+ *             lane-spread densities (csrc/bk_lanes.hpp), for every D: row d is in class c = (d-1) mod 16;
+ *             cs[c] = the class's rows summed in order; q[g] = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12];
+ *             s = ((q[0] + q[1]) + q[2]) + q[3]
  *             logp = ((-(v*v)/18) - (0.5*n)*v) - (0.5*ev)*s
  *             grad0 = ((-v/9) - 0.5*n) + (0.5*ev)*s ; grad_i = -(ev*th_i)
  */
@@ -424,6 +425,14 @@ int bk_target_diag_gaussian_grad_n(const double* theta, double* grad, double* lo
                                    void* stream);
 int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld,
                             int64_t C, int64_t D, const uint32_t* n_dev, void* stream);
+
+/* One leapfrog step {gradient, kick, drift} (drghmc.py:280-283; hmc.py:48-50) of Neal's funnel as ONE launch:
+ * rho += h * (metric * grad(theta)); theta += h * rho, in place over chains [0, min(n, *n_dev)) (n_dev may be NULL).
+ * The same arithmetic as bk_target_funnel_grad_n followed by bk_leapfrog_kick_drift_n -- bit-identical -- in half the
+ * launches; the gradient never travels through memory.  (An instantiation of csrc/bk_lanes.hpp's k_lane_op, like the
+ * funnel's gradient op; CTarget.from_source(form="lanes") exports the same entry for a user density.) */
+int bk_leapfrog_step_funnel(double* theta, double* rho, int64_t ld, const double* metric, double h, int64_t n,
+                            int64_t D, const uint32_t* n_dev, void* stream);
 
 /* ---- user targets (plugin ABI) ------------------------------------------------------------
  * A model the USER compiles into their own shared library plugs in below the samplers through

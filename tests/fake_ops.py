@@ -286,6 +286,15 @@ class FakeOps:
         else:
             raise KeyError(kind)
 
+    def leapfrog_step_funnel(self, theta, rho, metric, h, n_dev=None):
+        """bk_leapfrog_step_funnel: {gradient, kick, drift} of one leapfrog step, in place."""
+        self._count("leapfrog_step_funnel")
+        import torch
+
+        g = torch.zeros_like(theta)
+        self.target_grad("funnel", None, theta, g, None, n_dev=n_dev)
+        self.kick_drift(theta, theta, rho, rho, g, metric, h, False, 0.0, True, h, n_dev=n_dev)
+
     def hmc_trajectory_gaussian(self, theta_in, theta_out, rho_in, rho_out, lam, metric, eps, steps):
         th, r = theta_in.numpy().copy(), rho_in.numpy().copy()
         lamv = None if lam is None else lam.numpy()[:, None]

@@ -68,11 +68,19 @@ __device__ __forceinline__ void bk_term(double th, i64 d, const double* lam, dou
 """
 
 FUNNEL_SRC = """
-// Neal's funnel, one chain per call, coordinates summed in order (bk.Funnel's order past 128 coordinates)
+// Neal's funnel, one chain per call, coordinates summed in the library's canonical class order (bk.Funnel's order:
+// 16 interleaved class sums -> 4 group sums -> total)
 __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* /*params*/) {
   const double v = th[0];
-  double s = 0.0;
-  for (i64 d = 1; d < D; ++d) { const double x = th[d]; s = s + x * x; }
+  double cs[16];
+  for (int c = 0; c < 16; ++c) {
+    double a = 0.0;
+    for (i64 d = 1 + c; d < D; d += 16) { const double x = th[d]; a = a + x * x; }
+    cs[c] = a;
+  }
+  double q[4];
+  for (int k = 0; k < 4; ++k) q[k] = ((cs[k] + cs[k + 4]) + cs[k + 8]) + cs[k + 12];
+  const double s = ((q[0] + q[1]) + q[2]) + q[3];
   const double ev = exp(-v), hn = 0.5 * (double)(D - 1), he = 0.5 * ev;
   if (g.wanted()) {
     g.set(0, ((-v / 9.0) - hn) + he * s);
@@ -88,7 +96,7 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     construction into the plugin ABI (both forms: host-sized and counted).  The elementwise form of the diagonal
     Gaussian is the built-in target bit for bit (same operation order, the library's own order for the per-chain
     sum) under HMC, MALA and DRGHMC -- incl. device-side lane counts inside one hipGraph; the per-chain form of
-    Neal's funnel is bk.Funnel's sequential-sum variant (D > 129) bit for bit."""
+    Neal's funnel, summed in the library's class order, is bk.Funnel bit for bit."""
     import torch
 
     D, C = 48, 1500

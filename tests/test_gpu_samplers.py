@@ -1014,23 +1014,26 @@ def test_drghmc_model_opaque_device_counts_equal_host_sized_and_one_launch(ops, 
     sizes, counts = [0.3, 0.1, 0.03, 0.01][:K], [3, 6, 12, 24][:K]
     for C in (700, 64):
         mk = lambda model, **kw: bk.DrGhmcDiag(model, K, sizes, counts, 0.3, chains=C, seed=5, **kw)  # noqa: E731
-        a = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False)   # host-sized, step by step
+        a = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False, fuse_steps=False)  # host-sized, gradient op per step
+        a1 = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False)  # host-sized, {gradient, kick, drift} one launch
+        e0 = mk(bk.Funnel(D), fuse_builtin=False, fuse_steps=False)     # counted, gradient op per step, one hipGraph
         f = mk(bk.Funnel(D)) if D <= 129 else None                       # one launch per proposal (+ graph)
         e = mk(bk.Funnel(D), fuse_builtin=False, graph=False)           # counted steps, eager
         g = mk(bk.Funnel(D), fuse_builtin=False)                        # counted steps, one hipGraph (the default)
         p = mk(funnel_plugin(D))                                        # the user's plugin, counted, one hipGraph
         h = mk(funnel_plugin(D), device_counts=False)                   # the plugin, host-sized
-        for s_ in (e, g, p):
+        for s_ in (e, g, p, e0):
             assert s_._dev_counts and not s_._one_launch and s_.host_syncs_per_draw == 0
+        assert g._step_hook and e._step_hook and a1._step_hook and not a._step_hook and not e0._step_hook and not p._step_hook
         assert g._use_graph and p._use_graph and not e._use_graph and not a._dev_counts and not h._dev_counts
         assert f is None or f._one_launch
-        # (past 128 coordinates the library's funnel sums sequentially and the plugin keeps its class order: two valid
-        # targets that differ in the last bit -- the plugin is then compared with itself, counted against host-sized)
-        same_order = D - 1 <= 128
+        # (the library's funnel and the plugin sum the coordinates in the same canonical class order for every D)
+        same_order = True
         for n in range(12):
             ta, la = a.sample()
             th_, lh_ = h.sample()
-            for name, s_ in (("one launch", f), ("eager", e), ("graph", g), ("plugin", p), ("plugin host-sized", h)):
+            for name, s_ in (("one launch", f), ("eager", e), ("graph", g), ("plugin", p), ("plugin host-sized", h),
+                             ("host-sized one-launch steps", a1), ("counted gradient op", e0)):
                 if s_ is None:
                     continue
                 if s_ is h:
