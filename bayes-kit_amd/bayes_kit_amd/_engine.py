@@ -462,7 +462,7 @@ class ManyChainSampler:
     # -- which allocation plays which role -------------------------------------------------------
     # The hot loops stream several arrays at equal offsets.  How fast that runs depends on where the
     # driver placed them RELATIVE to each other: the same kick+drift launch takes 414-484 us on
-    # different triples of identically sized allocations (6.5 -> 5.6 TB/s; tools/placement_probe.py arrays,
+    # different triples of identically sized allocations (6.5 -> 5.6 TB/s; tools/attic/placement_probe.py arrays,
     # examples/c_host/placement_probe.c), while each array alone streams at the same rate.  A process
     # cannot choose physical placement, but it can choose which of its allocations plays which role:
     # a few assignments of the scratch arrays (plus spare ones, freed afterwards) are timed with the

@@ -684,7 +684,7 @@ def _len(chain) -> int:
 # sums are O(N^2 / 64) for ALL lags.
 FFT_MIN_DRAWS = 16384
 # autocorr() wants ALL lags, which the direct sums pay O(N^2 / 64) for: the FFT is ahead from 256 draws on (4,096 chains:
-# 0.10 vs 0.13 ms at 256 draws, 0.40 vs 0.66 at 2,048, 0.55 vs 3.2 at 8,192; tools/autocorr_crossover.py)
+# 0.10 vs 0.13 ms at 256 draws, 0.40 vs 0.66 at 2,048, 0.55 vs 3.2 at 8,192; tools/attic/autocorr_crossover.py)
 AUTOCORR_FFT_MIN_DRAWS = 256
 _FFT_SCRATCH_BYTES = 2 << 30  # chains per FFT batch are chosen to keep the two complex scratch arrays below this
 

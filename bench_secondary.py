@@ -334,10 +334,17 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
                        "counted kick+drift launch per step, 2*sum(L)+O(1) = ~580 launches per draw, lane counts on the device)",
            "bound": "launch latency (dependent chain of ~580 small launches per draw inside one hipGraph)",
            "fused_one_launch_proposals_same_draws": fused}
-    so, r = run(bk.Funnel(D), draws, fuse_builtin=False)
+    so, r = run(bk.Funnel(D), draws, fuse_builtin=False, fuse_steps=False)
     r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
                                    and torch.equal(so._rng_state, ref._rng_state))
     out["builtin_gradient_op"] = r
+    del so
+    # the same path with a leapfrog step {gradient, kick, drift} as ONE launch (bk_leapfrog_step_funnel: the model's density
+    # inside the library's step kernel, csrc/bk_lanes.hpp) -- what the step-by-step path runs by default for a model that has it
+    so, r = run(bk.Funnel(D), draws, fuse_builtin=False)
+    r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
+                                   and torch.equal(so._rng_state, ref._rng_state))
+    out["builtin_one_launch_steps"] = r
     del so
     if os.path.exists(plugin_lib):
         so, r = run(bk.CTarget(plugin_lib, "funnel_target", D, counted_symbol="funnel_target_n"), draws)
@@ -363,7 +370,7 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
             out[key] = {"error": repr(e)}
     # the same draws with launches sized by host reads (three lane counts read back per draw; the path every model
     # had before the counted entry points, and the one PyTorch-autograd models still take)
-    so, r = run(bk.Funnel(D), 5, fuse_builtin=False, device_counts=False)
+    so, r = run(bk.Funnel(D), 5, fuse_builtin=False, fuse_steps=False, device_counts=False)
     out["host_sized_launches"] = r
     out["ms_per_draw"] = out["builtin_gradient_op"]["ms_per_draw"]
     return out

@@ -1,7 +1,7 @@
 """bk_autocorr_fft (long-chain autocorrelation, own Stockham passes) against the same formula through torch.fft
 (rocFFT; here for comparison only): time per call and agreement.  usage: autocorr_fft_bench.py [N=20000] [C=4096]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import numpy as np
 import torch

@@ -1,7 +1,7 @@
 """What the pieces of bench.py's config-4 loop cost per draw (un-profiled wall clock, 200 draws each):
 the replayed draw alone, + the returned copies, + the Welford update, + the tracked series."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

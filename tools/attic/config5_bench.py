@@ -3,7 +3,7 @@ torch seed 20243) -- gradient for C chains = two fp64 MFMA GEMMs; HMC with a den
 a short likelihood-annealed SMC with a Langevin move.  No reference oracle (tolerance parity
 in tests/); numbers are reported against the 78.6 TFLOP/s fp64 MFMA peak."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

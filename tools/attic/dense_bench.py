@@ -1,7 +1,7 @@
 """Dense mass matrix on the fp64 matrix cores: Y = M @ X at config-5 shape (D=512), timing
 and TFLOP/s vs the 78.6 TFLOP/s fp64 MFMA peak; also HMC steps/s with metric_dense."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -1,7 +1,7 @@
 """Diagnostics kernels at config-4 size (32,768 chains x 101 dims, 1000 draws of 4 tracked series), for
 rocprofv3: Welford updates, R-hat from the moments, ESS of stored series, split / rank-normalised R-hat."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -1,7 +1,7 @@
 """DRGHMC in the HBM-bound regime (config-3 target and shape, model-opaque gradient op):
 useful lane-steps/s of the lockstep state machine next to plain HMC's leapfrog steps/s."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

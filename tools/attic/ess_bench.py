@@ -1,7 +1,7 @@
 """bk_ess / bk_autocorr over [N, C] series (LDS-staged kernels): time per call.  usage: ess_bench.py [N C ...]
 BK_ESS_LANE_PER_CHAIN=1: the one-lane-per-chain kernels instead."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

@@ -1,7 +1,7 @@
 """bk_gemm_chains (k_dense_apply) over shapes: time, TFLOP/s and the time lost against the in-loop rate of long K.
 usage: gemm_k_sweep.py [shapes "R,K,C;R,K,C;..."]"""
 import os, sys, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

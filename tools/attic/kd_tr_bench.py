@@ -2,7 +2,7 @@
 returns by default), turned through 64 x 64 LDS tiles inside the kernel; against the chain-contiguous kernel
 on the same arrays.  40 D algorithmic bytes per chain-step either way."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

@@ -1,7 +1,7 @@
 """bk_target_diag_gaussian_grad WITH the log density (k_gauss_logp_v2: per-chain sums over D in the canonical quarter order) at
 config-3 size: microseconds per launch, alone.  The gradient-only streaming kernel beside it for scale."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

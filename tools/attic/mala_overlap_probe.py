@@ -5,7 +5,7 @@
     V3  with the step kernel, generator queued first
 Same draws in every variant (checked against V0)."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -3,7 +3,7 @@ arrays (theta, grad, theta', grad', z, theta_new) of 4,096 chains are 192 MiB, i
 the step kernel's reads of theta' / grad' -- written just before by the previous step / the gradient op -- could
 come from cache.  Wall time per draw of all 65,536 chains, against the one-tile sampler."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -2,7 +2,7 @@
 column-walking reductions (finish / kinetic energy, Gaussian gradient + log density) and the select / blend, with the rows
 at a 512-KiB pitch and PAD columns further apart.  usage: pitch_probe.py [PAD ...]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

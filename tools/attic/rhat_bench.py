@@ -1,6 +1,6 @@
 """rhat / split_rhat / rank_normalized_rhat of stored draws [N, C] (one parameter) and the Welford update of [D, C]: time per call."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -1,6 +1,6 @@
 """Isolated timing of the momentum-refresh (Philox + ziggurat) kernel."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

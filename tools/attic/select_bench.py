@@ -1,7 +1,7 @@
 """bk_select_columns at config-3 shape: 8-byte stores for half-accepted lane pairs vs full 16-byte
 re-writes (BK_AB_SELECT_FULL=1), with and without the fused output copy, at several accept rates."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

@@ -1,7 +1,7 @@
 """bk_sort_by_key (hand-written LSD radix sort of (double, int64) pairs) against torch.sort (vendor sort), time per call.
 usage: sort_bench.py [n ...]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 from bayes_kit_amd import _lib

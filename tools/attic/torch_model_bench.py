@@ -1,7 +1,7 @@
 """Config-3 workload with the gradient supplied by PyTorch autograd (TorchModel) instead of the
 C-ABI built-in target: what the model-opaque path costs when the model is user PyTorch code."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk

@@ -1,7 +1,7 @@
 """Launch-bound regime (config-2 shape: 4096 chains x D=128, L=32) with a USER PyTorch model:
 eager launches vs hipGraph replay of the whole draw (graph=True), autograd and analytic torch ops."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk
