@@ -72,6 +72,7 @@ SIGNATURES = {
     "bk_target_diag_gaussian_grad_n": [P, P, P, I, P, I, I, P, P],
     "bk_target_funnel_grad_n": [P, P, P, I, I, I, P, P],
     "bk_leapfrog_step_funnel": [P, P, I, P, F, I, I, P, P],
+    "bk_hmc_trajectory_funnel": [P, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
     "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
@@ -531,6 +532,14 @@ class Ops:
             self._call("bk_target_funnel_grad", ptr(theta), ptr(grad), ptr(logp), ld, C, D, self._s())
         else:
             raise BkHipError(f"unknown built-in target {kind!r}")
+
+    def hmc_trajectory_funnel(self, theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps):
+        """A whole HMC trajectory on the funnel in ONE launch (rho is overwritten)."""
+        D, C = theta_in.shape
+        ld = _ld(theta_in)
+        assert all(_ld(t) == ld for t in (rho, grad_in, theta_out, grad_out))
+        self._call("bk_hmc_trajectory_funnel", ptr(theta_in), ptr(rho), ptr(grad_in), ptr(theta_out), ptr(grad_out),
+                   ptr(logp_out), ptr(kin_out), ld, ptr(metric), eps, steps, C, D, self._s())
 
     def leapfrog_step_funnel(self, theta, rho, metric, h, n_dev=None):
         """One leapfrog step {gradient, kick, drift} on the funnel in ONE launch, theta / rho [D, n] advanced in place."""

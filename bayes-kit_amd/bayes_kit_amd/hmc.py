@@ -46,6 +46,7 @@ class HMCDiag(ManyChainSampler):
         chain_tile: Optional[int] = None,
         graph: Optional[bool] = None,
         fuse_builtin: bool = True,
+        fuse_steps: bool = True,
         prefetch_rng: Optional[bool] = None,
         metric_dense=None,
         tune_placement: Optional[bool] = None,
@@ -82,6 +83,12 @@ class HMCDiag(ManyChainSampler):
         # density), accept, select.  With Philox streams the momentum is consumed chain-major,
         # straight from the wavefront-per-chain generator: no transpose, no kinetic-energy pass.
         self._fused_draw = self._fused and hasattr(model, "bk_hmc_draw") and self.ENABLE_FUSED_DRAW
+        # ... a lane-spread density (bk.Funnel, CTarget.from_source(form="lanes")) runs the whole trajectory -- gradient
+        # inlined, theta / rho register-resident, the proposal's gradient, log density and kinetic energy out -- as ONE launch
+        # (bk_hmc_proposal: the delayed-rejection proposal kernel with hmc.py's first kick); the step-by-step path otherwise
+        # issues ONE launch per leapfrog step where the model has bk_leapfrog_step
+        self._lanes_traj = (bool(fuse_builtin) and self._batched and self._M is None and hasattr(model, "bk_hmc_proposal"))
+        self._step_hook = (bool(fuse_steps) and self._batched and self._M is None and hasattr(model, "bk_leapfrog_step"))
         self._fused_zt = (self._fused_draw and self._rng_kind == _lib.RNG_PHILOX and self._dim >= 32
                           and self.ENABLE_FUSED_ZT)
         D, C, dev = self._dim, self._C, self._ops.device
@@ -392,6 +399,17 @@ class HMCDiag(ManyChainSampler):
             self._take(th, thp)
             return
 
+        if self._lanes_traj and L >= 1:
+            if not self._have_cache:
+                self._materialize(self._eval_grad(th, self._grad, self._lp), self._grad)
+                self._have_cache = True
+            # [hmc.py:40-53, :59] in one launch; the proposal's gradient is kept for the chains that accept
+            if self._model.bk_hmc_proposal(th, rho, self._grad, thp, self._grad_p, self._lp_p, self._kin1, m, eps, L):
+                ops.mh_accept(_lib.ACCEPT_HMC, self._lp, kin0, self._lp_p, self._kin1, logu,
+                              self._mask, self._ret, self._accepted)                     # [hmc.py:60-63]
+                self._take(th, thp, self._grad, self._grad_p)
+                return
+
         if mirror:
             self._eval_logp(th, self._lp)                  # joint_logp(theta, rho)      [hmc.py:57]
             g = self._eval_grad(th, self._grad, None)       # leapfrog's first gradient   [hmc.py:45]
@@ -423,8 +441,15 @@ class HMCDiag(ManyChainSampler):
                     last = n == L - 1
                     if n == 0:
                         ops.kick_drift(th_t, thp_t, rho_t, rho_t, self._mg(g_t), m, eps, True, -half, True, eps)
+                    elif self._step_hook and not mirror:
+                        # {gradient at the point reached, kick, drift} of step n as ONE launch (the gradient op of step
+                        # n - 1 and this step's kick+drift, fused: the model's density inside the library's step kernel)
+                        self._grad_calls += 1
+                        self._model.bk_leapfrog_step(thp_t, rho_t, m, eps)
                     else:
                         ops.kick_drift(thp_t, thp_t, rho_t, rho_t, self._mg(gl), m, eps, False, 0.0, True, eps)
+                    if self._step_hook and not mirror and not last:
+                        continue  # (the next step's launch evaluates the gradient itself)
                     want_lp = lp_t if (last and not mirror) else None
                     gl = self._eval_grad(thp_t, gp_t, want_lp)
                 if tile:

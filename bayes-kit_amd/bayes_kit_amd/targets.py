@@ -141,6 +141,15 @@ class Funnel(_BuiltinTarget):
         the step-by-step paths call instead of {bk_eval, kick_drift} (any D)."""
         self._get_ops().leapfrog_step_funnel(theta, rho, metric, h, n_dev=n_dev)
 
+    def bk_hmc_proposal(self, theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps):
+        """A whole HMC trajectory (hmc.py:40-53) in ONE launch: theta_out, its gradient and log density, the end point's
+        kinetic energy; rho is overwritten.  False if the shape is unsupported (the sampler then steps)."""
+        strides = {_lib._ld(t) for t in (theta_in, rho, grad_in, theta_out, grad_out)}
+        if self._D > self._FUSED_MAX_D or steps < 1 or len(strides) != 1 or strides.pop() * 17 * 8 >= 2 ** 32:
+            return False
+        self._get_ops().hmc_trajectory_funnel(theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps)
+        return True
+
 
 class LogisticRegression(_BuiltinTarget):
     """Bayesian logistic regression, y_n ~ Bernoulli(sigmoid(x_n . theta)), theta ~ N(0, s^2 I)
@@ -495,6 +504,15 @@ extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, cons
                                                    stream);
 }
 #if %(sl)d > 0
+// a whole HMC trajectory per launch (the argument list of bk_hmc_trajectory_funnel + params)
+extern "C" int bk_src_hmc_trajectory_lanes(const double* theta_in, double* rho, const double* grad_in, double* theta_out,
+                                           double* grad_out, double* logp_out, double* kin_out, int64_t ld, const double* metric,
+                                           double eps, int64_t steps, int64_t C, int64_t D, const void* params, void* stream) {
+  return bkl::hmc_trajectory_launch<BkSrcDensity, BK_SRC_SL>(theta_in, rho, grad_in, ld, theta_out, grad_out, logp_out, kin_out, ld,
+                                                             metric, eps, steps, C, D, static_cast<const double*>(params), stream);
+}
+#endif
+#if %(sl)d > 0
 // one whole delayed-rejection proposal per launch with bk_lanes_density inlined: the argument list of
 // bk_dr_proposal_funnel_job (include/bkhip.h) + params
 extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
@@ -716,6 +734,23 @@ def _bind_source_fast_paths(t):
                   "bk_src_leapfrog_step")
 
         t.bk_leapfrog_step = types.MethodType(bk_leapfrog_step, t)
+    f_hmcl = export("bk_src_hmc_trajectory_lanes", [P, P, P, P, P, P, P, I, P, F, I, I, I, P, P])
+    if f_hmcl is not None:
+        def bk_hmc_proposal(self, theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps):
+            """A whole HMC trajectory (hmc.py:40-53) in ONE launch with the compiled density inlined (arguments as
+            Funnel.bk_hmc_proposal); False if the shape is unsupported."""
+            D, C = theta_in.shape
+            strides = {_lib._ld(x) for x in (theta_in, rho, grad_in, theta_out, grad_out)}
+            if steps < 1 or len(strides) != 1:
+                return False
+            ld = strides.pop()
+            if ld * (16 + self._head) * 8 >= 2 ** 32:
+                return False
+            check(f_hmcl(ptr(theta_in), ptr(rho), ptr(grad_in), ptr(theta_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld,
+                         ptr(metric), eps, steps, C, D, self._pp, stream(theta_in)), "bk_src_hmc_trajectory_lanes")
+            return True
+
+        t.bk_hmc_proposal = types.MethodType(bk_hmc_proposal, t)
     if f_traj is not None:
         def bk_hmc_trajectory(self, theta_in, theta_out, rho_in, rho_out, metric, eps, steps):
             """Whole leapfrog trajectory with the compiled term inlined (register-resident; bk_elementwise.hpp)."""

@@ -214,6 +214,7 @@ struct TrajArgs {
   const double* metric; double h; int steps; i64 n_host; i64 D; const uint32_t* n_dev; uint32_t* lanes_out;
   unsigned long long* lanes_total; double* H_out; double* hh_out; uint8_t* live_out; unsigned traj_blocks;
   const double* params;
+  int hmc_first;  // the FIRST kick as bayes_kit/hmc.py:46,48 writes it: (rho + (-h/2) t) + h t, instead of rho + (h/2) t
 };
 
 // One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE launch: gather chain
@@ -280,7 +281,12 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
     const double mi = (hm && BKL_OK(u)) ? metric[HEAD + pos + G::off(u)] : 1.0;
     if (HM && LPC == 16) mt[u] = mi;
     double t = hm ? mi * gin : gin;
-    r[u] = r[u] + half * t;
+    if (a.hmc_first) {
+      r[u] = r[u] + (-half) * t;  // hmc.py:46
+      r[u] = r[u] + h * t;        // hmc.py:48
+    } else {
+      r[u] = r[u] + half * t;
+    }
     x[u] = x[u] + h * r[u];
     // the gather is issued in batches of 8 rows: all 3*NU loads in flight at once would set the
     // kernel's register count (and so its occupancy for the whole trajectory)
@@ -294,7 +300,12 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
     mvh[i] = hm ? metric[i] : 1.0;
     const double gin = a.g_in[(i64)i * ld_in + src];
     const double t = hm ? mvh[i] * gin : gin;
-    rv[i] = rv[i] + half * t;
+    if (a.hmc_first) {
+      rv[i] = rv[i] + (-half) * t;
+      rv[i] = rv[i] + h * t;
+    } else {
+      rv[i] = rv[i] + half * t;
+    }
     v[i] = v[i] + h * rv[i];
   }
   using StepCtx = TrajCtx<LPC, SL, HM, HEAD, false, true>;
@@ -497,7 +508,7 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
                               int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
                               uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
                               const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, const bk_ghost0* g0_in,
-                              const double* params, void* stream) {
+                              const double* params, void* stream, bool hmc_first = false) {
   constexpr int HEAD = DEN::HEAD;
   if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < HEAD || D < 1)
@@ -563,7 +574,8 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
   const unsigned traj_blocks = n == 0 ? 0u : blocks_for(n, geo);
   const TrajArgs a = {theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out,
                       ld_out, metric, h, (int)steps, n, D, n_dev, lanes_out,
-                      reinterpret_cast<unsigned long long*>(lanes_total), H_out, h_out, live_out, traj_blocks, params};
+                      reinterpret_cast<unsigned long long*>(lanes_total), H_out, h_out, live_out, traj_blocks, params,
+                      hmc_first ? 1 : 0};
   dim3 grid(traj_blocks + job_blocks);
 #define BKL_FT(LPC, R, M) k_lane_traj<DEN, LPC, R, M><<<grid, dim3(BLOCK), 0, s>>>(a, job, ghost, g0)
 #define BKL_FT_ROWS(R)                 \
@@ -599,6 +611,19 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
 #undef BKL_FT_ROWS
 #undef BKL_FT
   BK_RETURN_LAUNCH_STATUS();
+}
+
+// A whole HMC trajectory (bayes_kit/hmc.py:40-53) of every chain in ONE launch, for any lane-spread density: the same kernel
+// with hmc.py's first kick.  In: theta, rho (overwritten with the end momentum, which HMC discards) and the cached gradient at
+// theta; out: theta', the gradient and log density there, and the end point's kinetic energy 1/2 rho.(metric rho)
+// (hmc.py:59 -> :37).  steps >= 1.
+template <class DEN, int SL_ONLY = 0>
+static int hmc_trajectory_launch(const double* theta_in, double* rho, const double* grad_in, int64_t ld_in, double* theta_out,
+                                 double* grad_out, double* logp_out, double* kin_out, int64_t ld_out, const double* metric,
+                                 double eps, int64_t steps, int64_t C, int64_t D, const double* params, void* stream) {
+  return dr_proposal_launch<DEN, SL_ONLY>(theta_in, rho, grad_in, ld_in, nullptr, theta_out, rho, grad_out, logp_out, kin_out,
+                                          ld_out, metric, eps, steps, C, D, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          nullptr, nullptr, nullptr, params, stream, true);
 }
 
 // ---- the same density as OPS on arrays in memory: gradient op and one-launch leapfrog step ---------------------------

@@ -302,6 +302,13 @@ int bk_leapfrog_step_funnel(double* theta, double* rho, int64_t ld, const double
   return bkl::step_launch<FunnelDensity>(theta, rho, ld, metric, h, nullptr, n, D, n_dev, stream);
 }
 
+int bk_hmc_trajectory_funnel(const double* theta_in, double* rho, const double* grad_in, double* theta_out, double* grad_out,
+                             double* logp_out, double* kin_out, int64_t ld, const double* metric, double eps, int64_t steps,
+                             int64_t C, int64_t D, void* stream) {
+  return bkl::hmc_trajectory_launch<FunnelDensity>(theta_in, rho, grad_in, ld, theta_out, grad_out, logp_out, kin_out, ld, metric,
+                                                   eps, steps, C, D, nullptr, stream);
+}
+
 int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
                               const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
                               double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,

@@ -434,6 +434,17 @@ int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int
 int bk_leapfrog_step_funnel(double* theta, double* rho, int64_t ld, const double* metric, double h, int64_t n,
                             int64_t D, const uint32_t* n_dev, void* stream);
 
+/* A whole HMC trajectory (hmc.py:40-53: backward half-kick, steps x {kick, drift, gradient}, forward half-kick) of every
+ * chain on Neal's funnel in ONE launch, the gradient inlined (an instantiation of csrc/bk_lanes.hpp's trajectory kernel -- the
+ * one behind bk_dr_proposal_funnel -- with hmc.py's first kick; requires D - 1 <= 128 and steps >= 1, BK_E_ARG otherwise).
+ * In: theta_in, the momentum rho (OVERWRITTEN with minus the end momentum, which HMC discards) and grad_in, the gradient at
+ * theta_in; out: theta_out, grad_out / logp_out there, kin_out = 1/2 sum rho*(metric*rho) at the end (hmc.py:59 -> :37).
+ * All [D][ld] arrays share ld.  Follow with bk_mh_accept(BK_ACCEPT_HMC, ...) and bk_select_columns (theta AND grad).
+ * CTarget.from_source(form="lanes") exports the same entry for a user density (bk_src_hmc_trajectory_lanes). */
+int bk_hmc_trajectory_funnel(const double* theta_in, double* rho, const double* grad_in, double* theta_out,
+                             double* grad_out, double* logp_out, double* kin_out, int64_t ld,
+                             const double* metric, double eps, int64_t steps, int64_t C, int64_t D, void* stream);
+
 /* ---- user targets (plugin ABI) ------------------------------------------------------------
  * A model the USER compiles into their own shared library plugs in below the samplers through
  * one exported function of this type: GradModel.log_density_gradient (typing.py:25-27) for all

@@ -286,6 +286,36 @@ class FakeOps:
         else:
             raise KeyError(kind)
 
+    def hmc_trajectory_funnel(self, theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps):
+        """bk_hmc_trajectory_funnel: hmc.py:40-53 on the funnel, energies of the end point; rho <- minus the end momentum."""
+        self._count("hmc_trajectory_funnel")
+        import torch
+
+        half = 0.5 * eps
+        th = theta_in.clone()
+        t = self._mt(metric, grad_in.numpy())
+        r = rho.numpy().copy()
+        r = r + (-half) * t
+        r = r + eps * t
+        th.numpy()[...] = th.numpy() + eps * r
+        g = torch.zeros_like(th)
+        for _ in range(int(steps) - 1):
+            self.target_grad("funnel", None, th, g, None)
+            t = self._mt(metric, g.numpy())
+            r = r + eps * t
+            th.numpy()[...] = th.numpy() + eps * r
+        self.target_grad("funnel", None, th, g, logp_out)
+        t = self._mt(metric, g.numpy())
+        r = -(r + half * t)
+        mr = r if metric is None else metric.numpy()[:, None] * r
+        kin = np.zeros(r.shape[1])
+        for d in range(r.shape[0]):
+            kin = kin + r[d] * mr[d]
+        kin_out.numpy()[...] = 0.5 * kin
+        rho.numpy()[...] = r
+        theta_out.numpy()[...] = th.numpy()
+        grad_out.numpy()[...] = g.numpy()
+
     def leapfrog_step_funnel(self, theta, rho, metric, h, n_dev=None):
         """bk_leapfrog_step_funnel: {gradient, kick, drift} of one leapfrog step, in place."""
         self._count("leapfrog_step_funnel")

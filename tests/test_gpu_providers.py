@@ -346,3 +346,54 @@ def test_elementwise_form_runs_the_whole_draw_hmc_kernel(ops):
 
     for name in ("hmc_diag1024_cfg3", "hmc_iso128_cfg2", "hmc_diag40_metric_steps1", "hmc_steps0"):
         check_many_chain(name, ops, model_factory=factory)
+
+
+def test_hmc_on_lane_spread_densities_one_launch_per_trajectory(ops):
+    """HMC (hmc.py:40-63) on a lane-spread density -- bk.Funnel, the funnel and a two-head hierarchical model from source: the
+    whole trajectory is ONE launch of the library's trajectory kernel with hmc.py's first kick (bk_hmc_proposal), and the
+    step-by-step path issues ONE launch per leapfrog step (bk_leapfrog_step).  Both give the draws of the path with the
+    gradient as a separate op per step, bit for bit (the returned joint log density to rounding: the fused kernel sums the
+    kinetic energy in its lanes' order), and those are the oracle's HMC on the NumPy funnel."""
+    from oracle import models as om
+    from oracle import samplers as osamp
+    from tests.sampler_parity import funnel_tol
+
+    yv = torch.linspace(-2.0, 3.0, 52, dtype=torch.float64, device=ops.device)
+    cases = [("funnel", lambda D: bk.Funnel(D), 101, 0.05, 12, None, 3000),
+             ("funnel", lambda D: bk.Funnel(D), 17, 0.1, 1, "m", 700),
+             ("funnel from source", funnel_lanes, 101, 0.05, 12, None, 3000),
+             ("funnel from source", funnel_lanes, 33, 0.08, 7, "m", 20000),
+             ("funnel, rows walked in memory", funnel_lanes, 300, 0.03, 5, None, 600),
+             ("hierarchical", lambda D: bk.CTarget.from_source(HIER_LANES_SRC, D, params=yv, form="lanes", head=2), 52, 0.04, 9, "m", 1800)]
+    for name, mk, D, eps, L, metric, C in cases:
+        m = None if metric is None else np.linspace(0.7, 1.4, D)
+        kw = dict(metric_diag=m, chains=C, seed=41)
+        f = bk.HMCDiag(mk(D), eps, L, **kw)                                         # one launch per trajectory
+        h = bk.HMCDiag(mk(D), eps, L, fuse_builtin=False, **kw)                     # one launch per leapfrog step
+        s = bk.HMCDiag(mk(D), eps, L, fuse_builtin=False, fuse_steps=False, **kw)   # gradient a separate op per step
+        g = bk.HMCDiag(mk(D), eps, L, graph=True, **kw)
+        one = D <= 129 or name == "hierarchical"
+        assert f._lanes_traj == one and h._step_hook and not h._lanes_traj and not s._step_hook and not s._lanes_traj, name
+        calls0 = s._grad_calls
+        for n in range(8):
+            tf, lf = f.sample()
+            th_, lh = h.sample()
+            ts, ls = s.sample()
+            tg, lg = g.sample()
+            assert torch.equal(th_, ts) and torch.equal(lh, ls), (name, D, n)
+            assert torch.equal(tf, ts) and torch.equal(tg, ts), (name, D, n, one)
+            torch.testing.assert_close(lf, ls, rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(f.rng_state(), s.rng_state())
+        assert h._grad_calls == s._grad_calls, name  # (one model evaluation per leapfrog step on both paths)
+        assert 0.2 < f.accept_rate() <= 1.0, (name, f.accept_rate())
+    # the oracle's HMC on the NumPy funnel, chain by chain
+    D, C, eps, L, seed = 21, 64, 0.1, 6, 77
+    f = bk.HMCDiag(bk.Funnel(D), eps, L, chains=C, seed=seed)
+    assert f._lanes_traj
+    draws = [f.sample() for _ in range(10)]
+    for c in range(0, C, 9):
+        o = osamp.HMCDiag(om.Funnel(D), eps, L, seed=np.random.Philox(key=[seed, c]))
+        for n in range(10):
+            oth, olp = o.sample()
+            np.testing.assert_allclose(draws[n][0][c].cpu().numpy(), oth, **funnel_tol(n))
+            np.testing.assert_allclose(float(draws[n][1][c]), olp, **funnel_tol(n))
