@@ -184,7 +184,11 @@ class _HMCKernel:
             h._materialize(h._eval_grad(h._theta_dc, h._grad, h._lp), h._grad)
             ll = self._target.ll_last if track else None
             if tg:
-                self._gll = self._target.gll_last.clone()
+                # (a copy with the STATE's row pitch: bk_retemper / select_columns walk it beside theta; clone() of a
+                # padded view would come back dense)
+                src = self._target.gll_last
+                self._gll = torch.empty_strided(src.shape, src.stride(), dtype=src.dtype, device=src.device)
+                self._gll.copy_(src)
         h._have_cache = True
         acc0 = int(h._accepted.item()) if hasattr(h, "_accepted") else 0
         for _ in range(self.draws):
@@ -229,6 +233,8 @@ def mala_kernel(epsilon: float, steps: int = 1) -> _MALAKernel:
 
 
 class TemperedLikelihoodSMC:
+    MIN_ADAPTIVE_STEP = 1e-12  # the adaptive ladder never advances by less (a degenerate weight set warns and takes this step)
+
     def __init__(self, model, M: int, N: int, sample_initial, kernel, *, seed=None, slot_id0: int = 0,
                  group=None, ops=None, adaptive=None, max_steps: int = 100000):
         """M = particles held by THIS rank.  Across ranks (one process per GPU) pass the rank's
@@ -349,6 +355,12 @@ class TemperedLikelihoodSMC:
             mmax = max(counts)
             pad = ll if ll.shape[0] == mmax else torch.cat([ll, ll.new_full((mmax - ll.shape[0],), float("-inf"))])
             ll = torch.cat([p[:c] for p, c in zip(_bkdist.all_gather(pad.contiguous(), self._group), counts)])
+        if not bool(torch.isfinite(ll).all().item()):
+            # (a NaN / inf log likelihood makes every ESS comparison below False: the ladder would creep forward by
+            # 2^-64 of the remaining way per temperature, a full HMC move each, until max_steps)
+            bad = int((~torch.isfinite(ll)).sum().item())
+            raise FloatingPointError(f"adaptive SMC ladder at t = {self.t}: {bad} of {ll.numel()} particles have a non-finite "
+                                     "log likelihood; the next temperature cannot be chosen")
         x = ll - ll.max()
         want = self.adaptive * x.shape[0]
 
@@ -365,7 +377,13 @@ class TemperedLikelihoodSMC:
         halves = room * torch.pow(torch.tensor(0.5, dtype=torch.float64, device=x.device),
                                   torch.arange(1, 65, dtype=torch.float64, device=x.device))
         ok = ess(halves) >= want
-        k = int(ok.to(torch.int64).argmax().item()) if bool(ok.any().item()) else 63
+        if not bool(ok.any().item()):
+            import warnings
+
+            warnings.warn(f"adaptive SMC ladder at t = {self.t}: no step down to 2^-64 of the remaining way keeps the ESS at "
+                          f"{self.adaptive} of the particles; taking the minimum step {self.MIN_ADAPTIVE_STEP:g}", stacklevel=2)
+            return min(room, self.MIN_ADAPTIVE_STEP)
+        k = int(ok.to(torch.int64).argmax().item())
         lo, hi = float(halves[k].item()), float(halves[k].item()) * 2.0  # (nothing passes: the smallest candidate; the ESS record shows it)
         for _ in range(2):
             cand = lo + (hi - lo) * torch.arange(1, 65, dtype=torch.float64, device=x.device) / 64.0

@@ -168,8 +168,10 @@ def _gpu_numa_node(index):
     try:
         import glob
 
-        cards = sorted(glob.glob("/sys/class/drm/renderD*/device/numa_node"),
-                       key=lambda p: int(p.split("renderD")[1].split("/")[0]))
+        # (AMD render nodes only: vendor 0x1002 -- a box may have other GPUs' render nodes as well)
+        cards = [p for p in sorted(glob.glob("/sys/class/drm/renderD*/device/numa_node"),
+                                   key=lambda p: int(p.split("renderD")[1].split("/")[0]))
+                 if open(os.path.join(os.path.dirname(p), "vendor")).read().strip().lower() == "0x1002"]
         node = int(open(cards[index]).read())
         return node if node >= 0 else None
     except (OSError, ValueError, IndexError):
@@ -216,6 +218,11 @@ def pin_rank(local_rank, world):
     record for the JSON line; BK_BENCH_NO_PIN=1 leaves the affinity alone."""
     if world <= 1 or os.environ.get("BK_BENCH_NO_PIN"):
         return None
+    masks = [v for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES") if os.environ.get(v)]
+    if masks:
+        # device index -> render node is the identity only without a visibility mask (and a reordered or partial list cannot
+        # be resolved without the HIP runtime, which must not start before the affinity is set): leave the affinity alone
+        return {"skipped": "visibility mask set (" + ", ".join(masks) + "): GPU -> NUMA node mapping not resolvable without HIP"}
     try:
         cpus = rank_cpu_set(local_rank, world)
         os.sched_setaffinity(0, cpus)

@@ -10,7 +10,7 @@ from bench_config import (C_CFG3, D_CFG3, EPS_CFG3, FP64_MFMA_PEAK_TFLOPS, FP64_
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def bench_cfg2(ctx, steps=60, warmup=6, chains=4096):
+def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
     """configs[1]: iso-Gaussian D=128, HMC L=32, 4096 chains: arrays of 4 MiB, cache-resident and
     launch/latency-bound.  Model-opaque (separate gradient op, hipGraph replay) and fused."""
     import torch
@@ -176,6 +176,10 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
         out["compiled_source_fused"] = bench_cfg4_compiled_source(ctx, C, D, warmup, draws)
     except Exception as e:  # context only
         out["compiled_source_fused"] = {"error": repr(e)}
+    try:
+        out["hmc_on_funnel"] = bench_hmc_lanes(ctx, C, D)
+    except Exception as e:  # context only
+        out["hmc_on_funnel"] = {"error": repr(e)}
     if spec_length and ctx.world == 1 and C >= 32768:
         try:
             out["spec_length"] = bench_cfg4_spec_length(ctx, C, D)
@@ -252,6 +256,35 @@ def bench_cfg4_compiled_source(ctx, C, D, warmup, draws):
     out["after_100_draws"] = {"ms_per_draw": 1e3 * els[chunks // 2] / per, "ms_per_draw_slowest_chunk": 1e3 * els[-1] / per,
                               "draws": chunks * per}
     return out
+
+
+def bench_hmc_lanes(ctx, C, D, eps=0.05, L=32, draws=20):
+    """Plain HMC (hmc.py:40-63) on the config-4 target through the lane-spread kernel templates: the whole trajectory as ONE
+    launch (built-in and from source), ONE launch per leapfrog step, and the gradient as a separate op per step -- same draws."""
+    import torch
+
+    import bayes_kit_amd as bk
+
+    kw = dict(chains=C, chain_id0=ctx.rank * C, seed=20244)
+    res = {"workload": f"HMC eps={eps} L={L} on Neal's funnel D={D}, {C} chains per GPU", "bound": "fp64 VALU / launch latency"}
+    ref = None
+    for key, mk, k2 in (("one_launch_trajectory", lambda: bk.Funnel(D), {}),
+                        ("one_launch_trajectory_from_source", lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1), {}),
+                        ("one_launch_per_step", lambda: bk.Funnel(D), dict(fuse_builtin=False)),
+                        ("gradient_separate_op", lambda: bk.Funnel(D), dict(fuse_builtin=False, fuse_steps=False))):
+        s = bk.HMCDiag(mk(), eps, L, **kw, **k2)
+        for _ in range(3):
+            s.sample()
+        el = ctx.timed_loop(s.sample, draws)
+        res[key] = {"ms_per_draw": 1e3 * el / draws, "steps_per_sec": C * ctx.world * L * draws / el, "accept_rate": s.accept_rate(),
+                    "hipgraph": bool(s._use_graph)}
+        if ref is None:
+            ref = s
+        else:
+            res[key]["identical_to_one_launch_trajectory"] = bool(torch.equal(s._theta_dc, ref._theta_dc)
+                                                                  and torch.equal(s._rng_state, ref._rng_state))
+            del s
+    return res
 
 
 def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=False):
