@@ -71,7 +71,8 @@ def launch_ranks(n, child_argv, extra_env=None, timeout=3000.0, out=None):
     for r in range(n):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
-                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                    "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         env.update(extra_env or {})
         procs.append(subprocess.Popen(list(child_argv), env=env, stdout=subprocess.PIPE, stderr=None, text=True))
     deadline = time.monotonic() + timeout
@@ -220,9 +221,11 @@ def pin_rank(local_rank, world):
         return None
     masks = [v for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES") if os.environ.get(v)]
     if masks:
-        # device index -> render node is the identity only without a visibility mask (and a reordered or partial list cannot
-        # be resolved without the HIP runtime, which must not start before the affinity is set): leave the affinity alone
-        return {"skipped": "visibility mask set (" + ", ".join(masks) + "): GPU -> NUMA node mapping not resolvable without HIP"}
+        # device index -> render node is the identity only without a visibility mask (and a reordered or partial list
+        # cannot be resolved without the HIP runtime, which must not start before the affinity is set): leave the
+        # affinity alone
+        return {"skipped": "visibility mask set (" + ", ".join(masks) + "): GPU -> NUMA node mapping "
+                                                                        "not resolvable without HIP"}
     try:
         cpus = rank_cpu_set(local_rank, world)
         os.sched_setaffinity(0, cpus)
@@ -346,7 +349,8 @@ def cpu_baseline():
         return sum(r[0] for r in res) / busy, wall
 
     chains_per_proc, draws = 8, 400  # 8 x 400 x 64 = 205k leapfrog steps per process
-    rate, wall = fan_out(P, lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
+    rate, wall = fan_out(P,
+                         lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
     out = {
         "value": rate,
         "unit": "leapfrog steps/sec",
@@ -459,9 +463,9 @@ class RankContext:
 # one rank
 # ---------------------------------------------------------------------------------------------
 def _claim_stdout():
-    """stdout must carry ONE JSON line.  Libraries write there too -- RCCL prints a version banner through C stdio, which
-    is flushed at exit when stdout is a pipe, i.e. AFTER the JSON line -- so from here on file descriptor 1 is stderr, and
-    the line goes to the saved descriptor at the very end (_emit)."""
+    """stdout must carry ONE JSON line.  Libraries write there too -- RCCL prints a version banner through C stdio,
+    which is flushed at exit when stdout is a pipe, i.e. AFTER the JSON line -- so from here on file descriptor 1 is
+    stderr, and the line goes to the saved descriptor at the very end (_emit)."""
     sys.stdout.flush()
     real = os.dup(1)
     os.dup2(2, 1)
@@ -532,8 +536,9 @@ def run_rank(args):
     event_stride, ops.timed_stride = ops.timed_stride, 1
     accept = s.accept_rate()
 
-    # an N > 1 run is a measurement only if every rank is really in the RCCL group: an all_reduce of ones that completed on it
-    # must count `world` ranks, or the run exits non-zero (ranks sharing a GPU over gloo are a code-path exercise and say so)
+    # an N > 1 run is a measurement only if every rank is really in the RCCL group: an all_reduce of ones that completed
+    # on it must count `world` ranks, or the run exits non-zero (ranks sharing a GPU over gloo are a code-path exercise
+    # and say so)
     rccl_ranks = ctx.collective_ranks() if ctx.backend == "nccl" else 0
     if world > 1 and not ctx.shared_gpu and rccl_ranks != world:
         sys.stderr.write(f"bench.py: {world} ranks were launched but the RCCL group counted {rccl_ranks}\n")
@@ -641,7 +646,8 @@ def run_rank(args):
             tot = bk.dist.sum_over_ranks(float(ess_min.sum().item()), device)
             tot2 = bk.dist.sum_over_ranks(float((ess_min * ess_min).sum().item()), device)
             n_ch = C * world
-            var_ch = max(0.0, (tot2 - tot * tot / n_ch) / max(1, n_ch - 1))  # between-chain variance of the per-chain ESS
+            # between-chain variance of the per-chain ESS
+            var_ch = max(0.0, (tot2 - tot * tot / n_ch) / max(1, n_ch - 1))
             out["ess"] = {"draws": N, "tracked": ["theta[0]", "theta[D/2]", "theta[D-1]", "logp"],
                           "ess_per_sec": tot / eel, "mean_min_ess_per_chain": tot / n_ch,
                           # Monte-Carlo standard error of the figure: the sum over n_ch independent chains of a
@@ -708,7 +714,8 @@ def run_rank(args):
                 "value": float(C) * world * L * args.steps / fel, "unit": "leapfrog steps/sec (whole job)",
                 "ms_per_step": 1e3 * fel / args.steps, "bound": "fp64 VALU (no FMA: bit parity)",
                 "trajectory_kernel_ms": tj_ms, "trajectory_kernel_tflops_fp64": flop / (tj_ms * 1e-3) / 1e12,
-                "trajectory_kernel_frac_of_no_fma_ceiling": flop / (tj_ms * 1e-3) / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2),
+                "trajectory_kernel_frac_of_no_fma_ceiling":
+                    flop / (tj_ms * 1e-3) / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2),
                 "draw_tflops_fp64": flop / (fel / args.steps) / 1e12,
                 "fp64_vector_peak_tflops_spec": FP64_VECTOR_PEAK_TFLOPS,
                 "flop_per_element_step": 5 if f._metric_identity else 6,
@@ -734,7 +741,8 @@ def run_rank(args):
         # cross-rank reduction (32,768 chains per rank, R-hat / ESS over the process group).
         from bench_secondary import run_secondary
 
-        out["secondary"] = run_secondary(ctx, ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"])
+        out["secondary"] = run_secondary(ctx,
+            ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"])
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if pinned is not None:

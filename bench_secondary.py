@@ -4,7 +4,8 @@ part of `value`; a failure here never costs the headline line."""
 import os
 import time
 
-from bench_config import (C_CFG3, D_CFG3, EPS_CFG3, FP64_MFMA_PEAK_TFLOPS, FP64_VECTOR_PEAK_TFLOPS, HBM_PEAK_GBPS,  # noqa: F401
+from bench_config import (C_CFG3, D_CFG3, EPS_CFG3, FP64_MFMA_PEAK_TFLOPS, FP64_VECTOR_PEAK_TFLOPS, HBM_PEAK_GBPS,
+                           # noqa: F401
                           L_CFG3, SEED_CFG3)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -18,7 +19,8 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
     import bayes_kit_amd as bk
 
     C, D, L = chains, 128, 32
-    res = {"workload": "BASELINE.json configs[1]: iso-Gaussian D=128, HMC L=32 eps=0.05, 4096 chains", "bound": "launch/latency",
+    res = {"workload": "BASELINE.json configs[1]: iso-Gaussian D=128, HMC L=32 eps=0.05, 4096 chains",
+           "bound": "launch/latency",
            "note": "4 MiB arrays live in L2 / Infinity Cache: an HBM fraction is not meaningful; us per leapfrog step "
                    "of all chains is the figure"}
     for name, fused in (("model_opaque", False), ("fused_builtin", True)):
@@ -31,14 +33,15 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
                      "steps_per_sec": C * ctx.world * L * steps / el, "accept_rate": s.accept_rate(),
                      "hipgraph": bool(s._use_graph)}
         del s
-    # The same target as five lines of HIP C++ handed to CTarget.from_source: the generated translation unit instantiates the
-    # library's whole-draw kernel (csrc/bk_elementwise.hpp) with the user's bk_term inlined -- the path the built-in takes,
-    # for ANY separable density.  Reported separately; never priced on the 56*D model.
+    # The same target as five lines of HIP C++ handed to CTarget.from_source: the generated translation unit
+    # instantiates the library's whole-draw kernel (csrc/bk_elementwise.hpp) with the user's bk_term inlined -- the path
+    # the built-in takes, for ANY separable density.  Reported separately; never priced on the 56*D model.
     try:
         t0 = time.perf_counter()
         model = bk.CTarget.from_source(ISO_TERM_SRC, D)
         build_s = time.perf_counter() - t0
-        ref = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240, chains=C,
+        ref = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
+                         chains=C,
                          chain_id0=ctx.rank * C, fuse_builtin=False)
         s = bk.HMCDiag(model, 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240, chains=C,
                        chain_id0=ctx.rank * C)
@@ -48,10 +51,12 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
         same = bool(torch.equal(s._theta_dc, ref._theta_dc) and torch.equal(s._rng_state, ref._rng_state))
         el = ctx.timed_loop(s.sample, steps)
         res["compiled_source_fused"] = {
-            "what": "CTarget.from_source(<bk_term of the iso Gaussian>): whole draw (trajectory + energies + accept) in the "
+            "what": "CTarget.from_source(<bk_term of the iso Gaussian>): whole draw (trajectory + "
+                    "energies + accept) in the "
                     "library's register-resident kernel with the compiled term inlined",
             "us_per_leapfrog_step": 1e6 * el / steps / L, "ms_per_draw": 1e3 * el / steps,
-            "steps_per_sec": C * ctx.world * L * steps / el, "accept_rate": s.accept_rate(), "hipgraph": bool(s._use_graph),
+            "steps_per_sec": C * ctx.world * L * steps / el, "accept_rate": s.accept_rate(),
+            "hipgraph": bool(s._use_graph),
             "fused_draw": bool(s._fused_draw), "identical_to_step_by_step_builtin": same,
             "construction_s_incl_hipcc_or_cache": build_s}
         del s, ref
@@ -152,9 +157,11 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
     calls = {k: bk.dist.collective_calls[k] - calls0[k] for k in calls0}
     flop_per_eval = 13.0 * D  # see DESIGN.md section 3: funnel gradient + kick + drift, per chain-step
     out = {"workload": "BASELINE.json configs[3]: Neal's funnel D=101, DRGHMC K=3 eps=(0.2,0.05,0.0125) L=(10,40,160) "
-                       f"damping 0.1, {C} chains per GPU (global chain ids rank*{C}..), Welford R-hat over all dims and "
+                       f"damping 0.1, {C} chains per GPU (global chain ids rank*{C}..), Welford "
+                       f"R-hat over all dims and "
                        "ALL ranks' chains + ESS of 3 dims and logp",
-           "bound": "fp64 VALU + exp latency (state register-resident inside a proposal; 26 MB arrays are cache-resident)",
+           "bound": "fp64 VALU + exp latency (state register-resident inside a proposal; 26 MB "
+                    "arrays are cache-resident)",
            "chains_per_gpu": C, "chains_total": C * ctx.world,
            "ms_per_draw": 1e3 * el / draws, "draws_per_sec": C * ctx.world * draws / el,
            "grad_evals_per_sec": lane_total / el, "mean_grad_evals_per_draw": lane_total / (C * ctx.world * draws),
@@ -163,8 +170,10 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
            "rhat_over_chains": C * ctx.world, "collectives_per_summary": calls, "summary_ms": 1e3 * summary_s,
            "summary_first_call_ms": 1e3 * first_s,
            "collective_backend": ctx.backend, "collective_ranks": ctx.collective_ranks(),
-           "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None), "hipgraph": bool(getattr(s, "_use_graph", False)),
-           "diagnostics": "Welford moments + tracked series updated inside the draw's hipGraph (attach), no returned copies "
+           "host_syncs_per_draw": getattr(s, "host_syncs_per_draw", None),
+           "hipgraph": bool(getattr(s, "_use_graph", False)),
+           "diagnostics": "Welford moments + tracked series updated inside the draw's hipGraph "
+                          "(attach), no returned copies "
                           "(advance)", "timed_draws_follow_warmup_draws": warmup}
     if full_rhat:
         out["rhat"] = [float(v) for v in rh]
@@ -183,8 +192,10 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
     if spec_length and ctx.world == 1 and C >= 32768:
         try:
             out["spec_length"] = bench_cfg4_spec_length(ctx, C, D)
-            out["spec_length"]["note"] = ("v = theta[0] mixes slowly at these settings (mean ESS per chain above): from N(0, I) "
-                                          "starts 1,100 draws do not reach v ~ N(0, 9); the run below starts from exact funnel draws")
+            out["spec_length"]["note"] = ("v = theta[0] mixes slowly at these settings (mean ESS per "
+                                          "chain above): from N(0, I) "
+                                          "starts 1,100 draws do not reach v ~ N(0, 9); the run below "
+                                          "starts from exact funnel draws")
             out["spec_length_stationary_start"] = bench_cfg4_spec_length(ctx, C, D, warmup=0, stationary_start=True)
         except Exception as e:  # context only
             out["spec_length"] = {"error": repr(e)}
@@ -205,7 +216,8 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
         els = sorted(ctx.timed_loop(s.advance, per) for _ in range(chunks))
         n2 = chunks * per
         ls2 = bk.dist.sum_over_ranks((float(s.lane_steps_total.item()) - b0) if on_device else float("nan"), ctx.device)
-        out["after_100_draws"] = {"ms_per_draw": 1e3 * els[chunks // 2] / per, "ms_per_draw_slowest_chunk": 1e3 * els[-1] / per,
+        out["after_100_draws"] = {"ms_per_draw": 1e3 * els[chunks // 2] / per,
+            "ms_per_draw_slowest_chunk": 1e3 * els[-1] / per,
                                   "draws": n2, "chunks": chunks, "mean_grad_evals_per_draw": ls2 / (C * ctx.world * n2),
                                   "grad_evals_per_sec": ls2 / n2 * per / els[chunks // 2],
                                   "diagnostics": "Welford moments inside the draw"}
@@ -219,9 +231,9 @@ CFG4_ARGS = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
 
 def bench_cfg4_compiled_source(ctx, C, D, warmup, draws):
     """Config 4 with the funnel given as SOURCE (CTarget.from_source(form="lanes")): the generated translation unit
-    instantiates the library's one-launch delayed-rejection proposal kernel (csrc/bk_lanes.hpp, the template bk.Funnel itself is
-    an instantiation of) with the user's density inlined.  Same warm-up and draws as the built-in figure; must end bit-identical
-    to it.  Also the stationary regime (draws 100..), like `after_100_draws`."""
+    instantiates the library's one-launch delayed-rejection proposal kernel (csrc/bk_lanes.hpp, the template bk.Funnel
+    itself is an instantiation of) with the user's density inlined.  Same warm-up and draws as the built-in figure;
+    must end bit-identical to it.  Also the stationary regime (draws 100..), like `after_100_draws`."""
     import torch
 
     import bayes_kit_amd as bk
@@ -242,7 +254,8 @@ def bench_cfg4_compiled_source(ctx, C, D, warmup, draws):
         ref.advance()
     same = bool(torch.equal(s._theta_dc, ref._theta_dc) and torch.equal(s._rho_dc, ref._rho_dc)
                 and torch.equal(s._rng_state, ref._rng_state))
-    out = {"what": "CTarget.from_source(<funnel as bk_lanes_density>, form='lanes', head=1): every delayed-rejection proposal ONE "
+    out = {"what": "CTarget.from_source(<funnel as bk_lanes_density>, form='lanes', head=1): every "
+                   "delayed-rejection proposal ONE "
                    "launch of the library's trajectory template with the compiled density inlined",
            "ms_per_draw": 1e3 * el / draws, "draws": draws, "grad_evals_per_sec": ls / el,
            "mean_grad_evals_per_draw": ls / (C * draws), "host_syncs_per_draw": s.host_syncs_per_draw,
@@ -253,30 +266,35 @@ def bench_cfg4_compiled_source(ctx, C, D, warmup, draws):
         s.advance()
     chunks, per = 5, 20
     els = sorted(ctx.timed_loop(s.advance, per) for _ in range(chunks))
-    out["after_100_draws"] = {"ms_per_draw": 1e3 * els[chunks // 2] / per, "ms_per_draw_slowest_chunk": 1e3 * els[-1] / per,
+    out["after_100_draws"] = {"ms_per_draw": 1e3 * els[chunks // 2] / per,
+        "ms_per_draw_slowest_chunk": 1e3 * els[-1] / per,
                               "draws": chunks * per}
     return out
 
 
 def bench_hmc_lanes(ctx, C, D, eps=0.05, L=32, draws=20):
-    """Plain HMC (hmc.py:40-63) on the config-4 target through the lane-spread kernel templates: the whole trajectory as ONE
-    launch (built-in and from source), ONE launch per leapfrog step, and the gradient as a separate op per step -- same draws."""
+    """Plain HMC (hmc.py:40-63) on the config-4 target through the lane-spread kernel templates: the whole trajectory
+    as ONE launch (built-in and from source), ONE launch per leapfrog step, and the gradient as a separate op per step
+    -- same draws."""
     import torch
 
     import bayes_kit_amd as bk
 
     kw = dict(chains=C, chain_id0=ctx.rank * C, seed=20244)
-    res = {"workload": f"HMC eps={eps} L={L} on Neal's funnel D={D}, {C} chains per GPU", "bound": "fp64 VALU / launch latency"}
+    res = {"workload": f"HMC eps={eps} L={L} on Neal's funnel D={D}, {C} chains per GPU",
+           "bound": "fp64 VALU / launch latency"}
     ref = None
     for key, mk, k2 in (("one_launch_trajectory", lambda: bk.Funnel(D), {}),
-                        ("one_launch_trajectory_from_source", lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1), {}),
+                        ("one_launch_trajectory_from_source",
+                         lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1), {}),
                         ("one_launch_per_step", lambda: bk.Funnel(D), dict(fuse_builtin=False)),
                         ("gradient_separate_op", lambda: bk.Funnel(D), dict(fuse_builtin=False, fuse_steps=False))):
         s = bk.HMCDiag(mk(), eps, L, **kw, **k2)
         for _ in range(3):
             s.sample()
         el = ctx.timed_loop(s.sample, draws)
-        res[key] = {"ms_per_draw": 1e3 * el / draws, "steps_per_sec": C * ctx.world * L * draws / el, "accept_rate": s.accept_rate(),
+        res[key] = {"ms_per_draw": 1e3 * el / draws, "steps_per_sec": C * ctx.world * L * draws / el,
+            "accept_rate": s.accept_rate(),
                     "hipgraph": bool(s._use_graph)}
         if ref is None:
             ref = s
@@ -300,7 +318,8 @@ def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=F
     if stationary_start:  # exact draws of the funnel: what 1,000 draws must leave invariant (tests/test_gpu_config4.py)
         g = torch.Generator().manual_seed(5)
         v0 = 3.0 * torch.randn(C, generator=g, dtype=torch.float64)
-        init = torch.cat([v0[:, None], torch.exp(0.5 * v0)[:, None] * torch.randn((C, D - 1), generator=g, dtype=torch.float64)], dim=1)
+        rows = torch.exp(0.5 * v0)[:, None] * torch.randn((C, D - 1), generator=g, dtype=torch.float64)
+        init = torch.cat([v0[:, None], rows], dim=1)
     s = bk.DrGhmcDiag(bk.Funnel(D), *CFG4_ARGS, chains=C, chain_id0=ctx.rank * C, seed=20242, init=init)
     for _ in range(warmup):
         s.advance()
@@ -324,9 +343,11 @@ def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=F
     v_mean, v_var = float(v.mean()), float(v.var())
     ess_v = float(per_series[0])
     names = ["theta[0] (v)", "theta[1]", f"theta[{D - 1}]", "joint logp"]
-    return {"what": f"configs[3] at its stated length: {draws} draws per chain after {warmup} burn-in draws, {C} chains, "
+    return {"what": f"configs[3] at its stated length: {draws} draws per chain after {warmup} "
+                    f"burn-in draws, {C} chains, "
                     "diagnostics inside the draw's hipGraph; start: "
-                    + ("exact draws of the funnel (invariance check)" if stationary_start else "N(0, I) as the reference (hmc.py:24-28)"),
+                    + ("exact draws of the funnel (invariance check)" if stationary_start
+                       else "N(0, I) as the reference (hmc.py:24-28)"),
             "draws": draws, "burn_in": warmup, "seconds": el, "ms_per_draw": 1e3 * el / draws,
             "grad_evals_per_sec": lane / el, "mean_grad_evals_per_draw": lane / (C * draws),
             "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "rhat_over_dims": int(rh.numel()),
@@ -342,7 +363,8 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
     """Config 4 through the interface north_star names: the gradient a SEPARATE device op called once per leapfrog
     step (drghmc.py:280-283) -- the library's own funnel op with fuse_builtin=False, and a user plugin behind the
     counted plugin ABI (bk_target_fn_n) -- every lane count on the device, the draw one hipGraph.  Same warm-up as the
-    fused figure above (draws 4..), so the two are comparable; the fused sampler run beside it must end bit-identical."""
+    fused figure above (draws 4..), so the two are comparable; the fused sampler run beside it must end
+    bit-identical."""
     import torch
 
     import bayes_kit_amd as bk
@@ -363,8 +385,10 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
                     "hipgraph": bool(so._use_graph), "device_counts": bool(so._dev_counts)}
 
     ref, fused = run(bk.Funnel(D), draws)
-    out = {"workload": "configs[3] with the gradient as a separate op per leapfrog step (one counted gradient launch + one "
-                       "counted kick+drift launch per step, 2*sum(L)+O(1) = ~580 launches per draw, lane counts on the device)",
+    out = {"workload": "configs[3] with the gradient as a separate op per leapfrog step (one "
+                       "counted gradient launch + one "
+                       "counted kick+drift launch per step, 2*sum(L)+O(1) = ~580 launches per draw, "
+                       "lane counts on the device)",
            "bound": "launch latency (dependent chain of ~580 small launches per draw inside one hipGraph)",
            "fused_one_launch_proposals_same_draws": fused}
     so, r = run(bk.Funnel(D), draws, fuse_builtin=False, fuse_steps=False)
@@ -372,8 +396,9 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
                                    and torch.equal(so._rng_state, ref._rng_state))
     out["builtin_gradient_op"] = r
     del so
-    # the same path with a leapfrog step {gradient, kick, drift} as ONE launch (bk_leapfrog_step_funnel: the model's density
-    # inside the library's step kernel, csrc/bk_lanes.hpp) -- what the step-by-step path runs by default for a model that has it
+    # the same path with a leapfrog step {gradient, kick, drift} as ONE launch (bk_leapfrog_step_funnel: the model's
+    # density inside the library's step kernel, csrc/bk_lanes.hpp) -- what the step-by-step path runs by default for a
+    # model that has it
     so, r = run(bk.Funnel(D), draws, fuse_builtin=False)
     r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
                                    and torch.equal(so._rng_state, ref._rng_state))
@@ -387,9 +412,11 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
         del so
     # the same density from SOURCE on the counted path: form="lanes" (a chain spread over 4 / 8 / 16 lanes, DPP sums;
     # fuse_builtin=False keeps it off its one-launch path) and form="chain" (one lane per chain walking D coordinates)
-    # ("_one_launch_steps": the lanes form also gives the step-by-step path {gradient, kick, drift} as ONE launch per leapfrog step)
-    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, dict(form="lanes", head=1), dict(fuse_steps=False)),
-                              ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, dict(form="lanes", head=1), {}),
+    # ("_one_launch_steps": the lanes form also gives the step-by-step path {gradient, kick, drift} as ONE launch per
+    # leapfrog step)
+    lanes = dict(form="lanes", head=1)
+    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(fuse_steps=False)),
+                              ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, lanes, {}),
                               ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
         try:
             so, r = run(bk.CTarget.from_source(src, D, **kws), draws, fuse_builtin=False, **k2)
@@ -424,7 +451,8 @@ def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
         s.sample()
     el = ctx.timed_loop(s.sample, draws)
     per = el / draws
-    return {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), model-opaque gradient op",
+    return {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), "
+                        "model-opaque gradient op",
             "bound": "hbm", "ms_per_draw": 1e3 * per, "draws_per_sec": C * ctx.world / per,
             "algorithmic_bytes_per_chain_draw": 88 * D, "achieved": 88.0 * D * C / per / 1e9, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": 88.0 * D * C / per / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate(),
@@ -451,7 +479,8 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
            "bound": "hbm (the model's own temporaries and extra passes, not the integrator)",
            "ms_per_draw": 1e3 * per, "steps_per_sec": C * ctx.world * L / per,
            "path_hbm_frac_56D_model": C * L / per * 56.0 * D / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate()}
-    # the same density written for the engine's own (D, C) layout: torch's contiguous kernels, a chain-contiguous gradient
+    # the same density written for the engine's own (D, C) layout: torch's contiguous kernels, a chain-contiguous
+    # gradient
     del s
     model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), D, layout="dc")
     s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
@@ -460,13 +489,14 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
     for _ in range(warmup):
         s.sample()
     per_dc = ctx.timed_loop(s.sample, draws) / draws
-    out["engine_layout"] = {"what": "TorchModel(fn, D, layout='dc'): fn takes the (D, C) array", "ms_per_draw": 1e3 * per_dc,
+    out["engine_layout"] = {"what": "TorchModel(fn, D, layout='dc'): fn takes the (D, C) array",
+        "ms_per_draw": 1e3 * per_dc,
                             "steps_per_sec": C * ctx.world * L / per_dc,
                             "path_hbm_frac_56D_model": C * L / per_dc * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
                             "accept_rate": s.accept_rate()}
     del s
-    # ... and with the gradient written out in torch ops as well (TorchModel(grad_fn=...)): no autograd graph, a leapfrog
-    # step is one torch kernel beside the engine's kick+drift
+    # ... and with the gradient written out in torch ops as well (TorchModel(grad_fn=...)): no autograd graph, a
+    # leapfrog step is one torch kernel beside the engine's kick+drift
     try:
         model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam[:, None]).sum(dim=0), D, layout="dc",
                               grad_fn=lambda Th: -(lam[:, None] * Th))
@@ -476,7 +506,8 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         for _ in range(warmup):
             s.sample()
         per_g = ctx.timed_loop(s.sample, draws) / draws
-        out["written_out_gradient"] = {"what": "TorchModel(fn, D, layout='dc', grad_fn=...): the gradient as torch ops, no autograd",
+        out["written_out_gradient"] = {"what": "TorchModel(fn, D, layout='dc', grad_fn=...): the gradient "
+                                               "as torch ops, no autograd",
                                        "ms_per_draw": 1e3 * per_g, "steps_per_sec": C * ctx.world * L / per_g,
                                        "path_hbm_frac_56D_model": C * L / per_g * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
                                        "accept_rate": s.accept_rate()}
@@ -486,28 +517,32 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
     # the same density as six lines of HIP C++ handed to CTarget.from_source: compiled with hipcc at construction into
     # the plugin ABI (bk_target_fn / bk_target_fn_n) -- what a Python user reaches without writing a build
     try:
-        src = ("__device__ __forceinline__ void bk_term(double th, i64 d, const double* lam, double& term, double& grad) {\n"
+        src = ("__device__ __forceinline__ void bk_term(double th, i64 d, const double* lam, "
+               "double& term, double& grad) {\n"
                "  const double t = lam[d] * th;\n  term = -0.5 * (th * t);\n  grad = -t;\n}\n")
         t0 = time.perf_counter()
         model = bk.CTarget.from_source(src, D, params=lam)
         build_s = time.perf_counter() - t0
         s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
-                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)  # (the model-opaque step-by-step path)
+                       # (the model-opaque step-by-step path)
+                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)
         s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             s.sample()
         n = max(draws, 5)
         per_src = ctx.timed_loop(s.sample, n) / n
-        out["compiled_source"] = {"what": "CTarget.from_source(<6 lines of HIP C++>, form='elementwise'): hipcc at construction, "
+        out["compiled_source"] = {"what": "CTarget.from_source(<6 lines of HIP C++>, "
+                                          "form='elementwise'): hipcc at construction, "
                                           "plugin ABI, streaming 16-byte-per-lane gradient kernel",
                                   "ms_per_draw": 1e3 * per_src, "steps_per_sec": C * ctx.world * L / per_src,
                                   "path_hbm_frac_56D_model": C * L / per_src * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
                                   "accept_rate": s.accept_rate(), "construction_s_incl_hipcc_or_cache": build_s}
     except Exception as e:  # context only
         out["compiled_source"] = {"error": repr(e)}
-    # TorchModel(compile=True): the SAME PyTorch lambda as the autograd figure above, read once with torch.fx, its per-coordinate
-    # term and hand-differentiated derivative emitted as bk_term source and compiled (trace.py): model-opaque step-by-step path
-    # (fuse_builtin=False: priced on the 56*D model like the headline) and the whole-draw kernel it also unlocks (separately)
+    # TorchModel(compile=True): the SAME PyTorch lambda as the autograd figure above, read once with torch.fx, its
+    # per-coordinate term and hand-differentiated derivative emitted as bk_term source and compiled (trace.py):
+    # model-opaque step-by-step path (fuse_builtin=False: priced on the 56*D model like the headline) and the whole-draw
+    # kernel it also unlocks (separately)
     try:
         t0 = time.perf_counter()
         model = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), D, compile=True)
@@ -527,7 +562,8 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         (g_auto,) = torch.autograd.grad((-0.5 * (x * x * lam).sum(dim=1)).sum(), x)
         _, g_c = model.log_density_gradient(Th)
         rel = float(((g_c - g_auto).abs().max() / g_auto.abs().max()).item())
-        out["traced_source"] = {"what": "TorchModel(fn, D, compile=True): the PyTorch lambda traced with torch.fx, bk_term (value + "
+        out["traced_source"] = {"what": "TorchModel(fn, D, compile=True): the PyTorch lambda traced with "
+                                        "torch.fx, bk_term (value + "
                                         "derivative) generated and compiled; step-by-step model-opaque path",
                                 "ms_per_draw": 1e3 * per_t, "steps_per_sec": C * ctx.world * L / per_t,
                                 "path_hbm_frac_56D_model": C * L / per_t * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
@@ -540,9 +576,11 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         for _ in range(3):
             f.sample()
         per_f = ctx.timed_loop(f.sample, 20) / 20
-        out["traced_source"]["whole_draw_kernel"] = {"what": "the same model through the whole-draw kernel (fp64-VALU bound; NOT on "
+        out["traced_source"]["whole_draw_kernel"] = {"what": "the same model through the whole-draw kernel "
+                                                             "(fp64-VALU bound; NOT on "
                                                              "the 56*D model)", "ms_per_draw": 1e3 * per_f,
-                                                     "steps_per_sec": C * ctx.world * L / per_f, "fused_draw": bool(f._fused_draw)}
+                                                     "steps_per_sec": C * ctx.world * L / per_f,
+                                                     "fused_draw": bool(f._fused_draw)}
         del f
     except Exception as e:  # context only
         out["traced_source"] = {"error": repr(e)}
@@ -571,7 +609,8 @@ def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
     el = ctx.timed_loop(lambda: model.bk_eval(th, grad, lp), grad_reps) / grad_reps
     el_g = ctx.timed_loop(lambda: model.bk_eval(th, grad, None), grad_reps) / grad_reps  # what a leapfrog step asks for
     flop = 2 * 2.0 * N * D * C  # Z = X Theta and G = X^T R
-    out = {"workload": f"BASELINE.json configs[4]: logistic regression N={N} D={D}, {C} chains per GPU (synthetic, torch "
+    out = {"workload": f"BASELINE.json configs[4]: logistic regression N={N} D={D}, {C} chains "
+                       f"per GPU (synthetic, torch "
                        "seed 20243), gradient = 2 fp64 MFMA GEMMs + residual pass",
            "bound": "mfma", "gradient_ms": 1e3 * el, "gradient_evals_per_sec": C * ctx.world / el,
            "achieved": flop / el / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -588,7 +627,8 @@ def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
     # per step: the gradient (4 N D) + M @ grad (2 D^2); per draw also chol(M) z and M^-1 rho twice
     hflop = C * (L * (4.0 * N * D + 2.0 * D * D) + 3 * 2.0 * D * D)
     out["hmc_dense_metric"] = {"leapfrog_steps": L, "ms_per_draw": 1e3 * el, "steps_per_sec": C * ctx.world * L / el,
-                               "tflops_fp64": hflop / el / 1e12, "frac_of_mfma_peak": hflop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                               "tflops_fp64": hflop / el / 1e12,
+                               "frac_of_mfma_peak": hflop / el / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                                "accept_rate": s.accept_rate()}
     del s
     # The reference's ladder t = n / N (smc.py:42-43) at this size, for the record: the first reweighting of an 8-step
@@ -613,18 +653,23 @@ def bench_cfg5(ctx, N=1_000_000, D=512, chains=2048, grad_reps=3):
     el = time.perf_counter() - t0
     T = smc.temperatures
     post = smc.thetas.mean(dim=0)
-    # evaluations of all particles: L per move (+ one at the very first temperature; afterwards the log density and gradient
-    # at a new temperature come from the untempered parts kept with each particle: bk_retemper, no pass over the data)
+    # evaluations of all particles: L per move (+ one at the very first temperature; afterwards the log density and
+    # gradient at a new temperature come from the untempered parts kept with each particle: bk_retemper, no pass over
+    # the data)
     evals = len(T) * L_smc + 1
-    out["annealed_smc"] = {"particles": C, "ladder": f"adaptive, ESS target {ess_target} x particles (extension; the reference "
+    out["annealed_smc"] = {"particles": C,
+        "ladder": f"adaptive, ESS target {ess_target} x particles (extension; the reference "
                                                      "has t = n/N)", "temperatures": len(T),
                            "first_temperatures": T[:3], "min_ess_over_ladder": min(smc.ess_history),
-                           "move": f"HMC eps={eps_smc} L={L_smc}, dense metric = particle variances, re-estimated per temperature",
-                           "accept_rate_min": min(kern.accept_rates), "accept_rate_mean": sum(kern.accept_rates) / len(T),
+                           "move": f"HMC eps={eps_smc} L={L_smc}, dense metric = particle variances, "
+                                   f"re-estimated per temperature",
+                           "accept_rate_min": min(kern.accept_rates),
+                           "accept_rate_mean": sum(kern.accept_rates) / len(T),
                            "seconds": el, "model_evaluations": evals,
                            "tflops_fp64": evals * 4.0 * N * D * C / el / 1e12,
                            "frac_of_mfma_peak": evals * 4.0 * N * D * C / el / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-                           "corr_posterior_mean_vs_truth": float(torch.corrcoef(torch.stack([post, tstar]))[0, 1].item()),
+                           "corr_posterior_mean_vs_truth":
+                               float(torch.corrcoef(torch.stack([post, tstar]))[0, 1].item()),
                            "rel_err_posterior_mean_vs_truth": float(((post - tstar).norm() / tstar.norm()).item())}
     return out
 
