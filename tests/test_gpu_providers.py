@@ -397,3 +397,24 @@ def test_hmc_on_lane_spread_densities_one_launch_per_trajectory(ops):
             oth, olp = o.sample()
             np.testing.assert_allclose(draws[n][0][c].cpu().numpy(), oth, **funnel_tol(n))
             np.testing.assert_allclose(float(draws[n][1][c]), olp, **funnel_tol(n))
+
+
+def test_hierarchical_example_converges():
+    """examples/hierarchical_model.py end to end: a user's hierarchical model from source under DRGHMC (one launch per proposal)
+    and HMC (one launch per trajectory), a PyTorch density traced and compiled: R-hat ~ 1, posterior where the data put it."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "hierarchical_model.py")], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    txt = out.stdout
+    assert "one launch per proposal: True | host syncs per draw: 0" in txt and "whole trajectory in one launch: True" in txt
+    assert "compiled = True" in txt and "whole-draw kernel: True" in txt
+    rh = [float(x) for x in re.search(r"R-hat: mu ([\d.]+)  log tau ([\d.]+)  max over rows ([\d.]+)", txt).groups()]
+    assert max(rh) < 1.05, rh
+    mu, ybar, tau, sd = [float(x) for x in re.search(r"mean of mu ([\d.]+) \(data mean ([\d.]+)\), of tau ([\d.]+) \(data sd ([\d.]+)\)", txt).groups()]
+    assert abs(mu - ybar) < 0.05 and abs(tau - (sd * sd - 1.0) ** 0.5) < 0.1, (mu, ybar, tau, sd)
