@@ -862,8 +862,12 @@ class TorchModel:
     compile=True: an autograd-free fast lane.  ``fn`` is read once with ``torch.fx``; if it is elementwise plus a sum over
     the coordinates (+ - * / neg exp log log1p expm1 pow sigmoid logsigmoid softplus tanh sqrt square abs sin cos, constants
     broadcast along the coordinate axis) its per-coordinate term and the hand-differentiated derivative are emitted as HIP
-    source and compiled by ``CTarget.from_source`` (``.traced_source``, ``.compiled``): the model is then a compiled target
-    like a built-in one.  Anything else warns (naming the node, ``.compile_note``) and keeps autograd.
+    source and compiled by ``CTarget.from_source`` (``.traced_source``, ``.compiled``, ``.compiled_form``): the model is then a
+    compiled target like a built-in one.  If it is instead a HIERARCHICAL density -- head coordinates ``Th[:, i]``, the rows
+    ``Th[:, H:]``, row expressions that may use head-derived values broadcast with ``[:, None]``, sums over ``dim=1``, any scalar
+    expression of heads and sums -- it is compiled into the lane-spread form (``trace_lanes.py``) and gets the one-launch HMC
+    trajectory / delayed-rejection proposal kernels ``bk.Funnel`` has.  Anything else warns (naming the node,
+    ``.compile_note``) and keeps autograd.
     """
 
     batched = True
@@ -894,15 +898,25 @@ class TorchModel:
 
         from . import trace
 
+        form, head = "elementwise", 0
         try:
             src, params, info = trace.term_source(self._fn, self._D, "dc" if self._dc else "cd")
         except trace.Unsupported as e:
-            self.compile_note = str(e)
-            warnings.warn(f"TorchModel(compile=True): not traceable ({e}); keeping autograd", stacklevel=3)
-            return
+            # not separable: a head-plus-sums (hierarchical) density?  (trace_lanes.py; the reference's (C, D) layout only)
+            try:
+                if self._dc:
+                    raise trace.Unsupported("head-plus-sums densities are traced in the (C, D) layout only")
+                from . import trace_lanes
+
+                src, head, params, info = trace_lanes.lanes_source(self._fn, self._D)
+                form = "lanes"
+            except trace.Unsupported as e2:
+                self.compile_note = f"as a sum over coordinates: {e}; as head coordinates plus sums over rows: {e2}"
+                warnings.warn(f"TorchModel(compile=True): not traceable ({self.compile_note}); keeping autograd", stacklevel=3)
+                return
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         p = None if params is None else params.to(dev)
-        target = CTarget.from_source(src, self._D, params=p, form="elementwise", contract=contract)
+        target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract)
         if dev.type == "cuda":
             note = self._check_compiled(target, dev)
             if note is not None:
@@ -912,7 +926,9 @@ class TorchModel:
         self.compiled, self.traced_source, self.trace_info = target, src, info
         # the hooks the samplers look for, straight to the compiled target
         self.bk_eval, self.bk_counted = target.bk_eval, target.bk_counted
-        for name in ("bk_hmc_draw", "bk_hmc_trajectory"):
+        self.compiled_form = form
+        for name in ("bk_hmc_draw", "bk_hmc_trajectory", "bk_leapfrog_step", "bk_hmc_proposal", "bk_dr_proposal",
+                     "bk_dr_proposal_supported"):
             if hasattr(target, name):
                 setattr(self, name, getattr(target, name))
         self.__dict__.pop("bk_gradient", None)

@@ -584,6 +584,42 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         del f
     except Exception as e:  # context only
         out["traced_source"] = {"error": repr(e)}
+    # ... and a HIERARCHICAL density written in PyTorch (Neal's funnel, config-4 shape): traced into the lane-spread
+    # form (trace_lanes.py), every delayed-rejection proposal one launch -- against the same function through autograd
+    try:
+        Df, Cf = 101, 32768
+
+        def funnel(Th):
+            v, x = Th[:, 0], Th[:, 1:]
+            return -(v * v) / 18.0 - 0.5 * (Df - 1) * v - 0.5 * torch.exp(-v) * (x * x).sum(dim=1)
+
+        args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
+        t0 = time.perf_counter()
+        traced = bk.TorchModel(funnel, Df, compile=True)
+        build_s = time.perf_counter() - t0
+        s = bk.DrGhmcDiag(traced, *args, chains=Cf, chain_id0=ctx.rank * Cf, seed=20242)
+        for _ in range(3):
+            s.advance()
+        per_l = ctx.timed_loop(s.advance, 40) / 40
+        a = bk.DrGhmcDiag(bk.TorchModel(funnel, Df), *args, chains=Cf, chain_id0=ctx.rank * Cf, seed=20242)
+        for _ in range(2):
+            a.sample()
+        per_a = ctx.timed_loop(a.sample, 3) / 3
+        out["traced_hierarchical"] = {"what": "Neal's funnel D=101 as a PyTorch function (Th[:, 0], Th[:, 1:], "
+                                              "a sum over rows), DRGHMC "
+                                              "K=3 on 32,768 chains: TorchModel(compile=True) -> lanes form "
+                                              "-> one launch per proposal",
+                                      "compiled_form": getattr(traced, "compiled_form", None),
+                                      "ms_per_draw": 1e3 * per_l,
+                                      "one_launch_proposals": bool(s._one_launch),
+                                      "host_syncs_per_draw": s.host_syncs_per_draw,
+                                      "autograd_ms_per_draw": 1e3 * per_a,
+                                      "autograd_host_syncs_per_draw": a.host_syncs_per_draw,
+                                      "speedup_vs_autograd": per_a / per_l,
+                                      "construction_s_incl_trace_hipcc_or_cache": build_s}
+        del s, a
+    except Exception as e:  # context only
+        out["traced_hierarchical"] = {"error": repr(e)}
     return out
 
 

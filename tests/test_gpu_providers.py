@@ -418,3 +418,60 @@ def test_hierarchical_example_converges():
     assert max(rh) < 1.05, rh
     mu, ybar, tau, sd = [float(x) for x in re.search(r"mean of mu ([\d.]+) \(data mean ([\d.]+)\), of tau ([\d.]+) \(data sd ([\d.]+)\)", txt).groups()]
     assert abs(mu - ybar) < 0.05 and abs(tau - (sd * sd - 1.0) ** 0.5) < 0.1, (mu, ybar, tau, sd)
+
+
+def test_torch_model_traces_hierarchical_densities_into_the_lanes_form(ops):
+    """TorchModel(fn, D, compile=True) on head-plus-sums densities written in PyTorch (trace_lanes.py): Neal's funnel and a
+    two-head hierarchical model become lane-spread compiled targets -- gradient equal to autograd, every DRGHMC proposal and
+    every HMC trajectory ONE launch, the three DRGHMC paths bit-identical among themselves, and the traced funnel tracks
+    bk.Funnel (the same density in another rounding) over the first draws."""
+    D = 101
+
+    def funnel(Th):
+        v, x = Th[:, 0], Th[:, 1:]
+        return -(v * v) / 18.0 - 0.5 * (D - 1) * v - 0.5 * torch.exp(-v) * (x * x).sum(dim=1)
+
+    Dh = 52
+    yv = torch.linspace(-2.0, 3.0, Dh, dtype=torch.float64, device=ops.device)[2:]
+
+    def hier(Th):
+        mu, lt, x = Th[:, 0], Th[:, 1], Th[:, 2:]
+        it2 = torch.exp(-2.0 * lt)
+        sq = ((x - mu[:, None]) ** 2).sum(dim=1)
+        sy = ((yv - x) ** 2).sum(dim=1)
+        return -0.5 * it2 * sq - (Dh - 2) * lt - 0.5 * sy - (mu * mu / 50.0 + 0.5 * lt * lt)
+
+    for fn, dims, head in ((funnel, D, 1), (hier, Dh, 2)):
+        m = bk.TorchModel(fn, dims, compile=True)
+        assert m.compiled is not None and m.compiled_form == "lanes" and m.compiled._head == head, m.compile_note
+        Th = 0.7 * torch.randn((777, dims), dtype=torch.float64, device=ops.device)
+        x = Th.clone().requires_grad_(True)
+        lp_t = fn(x)
+        (g_t,) = torch.autograd.grad(lp_t.sum(), x)
+        lp, g = m.log_density_gradient(Th)
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_t.detach().cpu().numpy(), rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=1e-10, atol=1e-11 * float(g_t.abs().max()))
+        args = (3, [0.15, 0.05, 0.02], [4, 8, 16], 0.2)
+        f = bk.DrGhmcDiag(m, *args, chains=1500, seed=51)
+        c = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, fuse_builtin=False)
+        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, fuse_builtin=False, fuse_steps=False,
+                           device_counts=False)
+        assert f._one_launch and f.host_syncs_per_draw == 0 and c._step_hook and not c._one_launch and not hs._dev_counts
+        for n in range(6):
+            tf, _ = f.sample()
+            tc, _ = c.sample()
+            th_, _ = hs.sample()
+            assert torch.equal(tf, tc) and torch.equal(tf, th_), (dims, n)
+        hm = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.05, 8, chains=1500, seed=52)
+        assert hm._lanes_traj
+        for _ in range(4):
+            th, lp = hm.sample()
+        assert torch.isfinite(th).all() and 0.3 < hm.accept_rate() <= 1.0
+    # the traced funnel against the built-in one: the same density, another rounding of the gradient
+    a = bk.DrGhmcDiag(bk.Funnel(D), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=512, seed=20242)
+    b = bk.DrGhmcDiag(bk.TorchModel(funnel, D, compile=True), 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=512, seed=20242)
+    for n in range(4):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=1e-8, atol=1e-9)
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())

@@ -117,11 +117,124 @@ def test_torch_model_compile_flag_on_the_build_box(tmp_path, monkeypatch):
     assert m.compiled is not None and m.compile_note is None and "bk_term" in m.traced_source
     assert m.bk_counted and hasattr(m, "bk_eval") and hasattr(m, "bk_hmc_draw") and hasattr(m, "bk_hmc_trajectory")
     assert os.path.exists(m.compiled.source_library)
-    with pytest.warns(UserWarning, match="getitem"):
-        u = bk.TorchModel(lambda Th: -0.5 * (Th[:, 1:] ** 2).sum(dim=1), D, compile=True)
-    assert u.compiled is None and "getitem" in u.compile_note and not hasattr(u, "bk_eval")
+    with pytest.warns(UserWarning, match="logsumexp"):
+        u = bk.TorchModel(lambda Th: torch.logsumexp(Th * lam, dim=1), D, compile=True)
+    assert u.compiled is None and "logsumexp" in u.compile_note and not hasattr(u, "bk_eval")
     lp, gr = u.log_density_gradient(torch.zeros((3, D), dtype=torch.float64))  # autograd still works
     assert lp.shape == (3,) and gr.shape == (3, D)
     # the namespaced gradient-only hook: a model's own `gradient` member is not what the engine calls
     w = bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(1), D, grad_fn=lambda Th: -Th)
     assert hasattr(w, "bk_gradient") and not hasattr(w, "gradient")
+
+
+# ---- head-plus-sums (hierarchical) densities -> the lane-spread form (trace_lanes.py) ------------------------------------
+LANES_HOST = """
+#include <math.h>
+#include <stdint.h>
+typedef int64_t i64;
+#define __device__
+%s
+struct HostCtx {   // one chain, the lane context's interface with plain loops (rows summed in order)
+  const double* th; double* g; i64 D; int H;
+  double head(int i) const { return th[i]; }
+  i64 dims() const { return D; }
+  template <class F> double sum(F&& f) { double s = 0.0; for (i64 d = H; d < D; ++d) s += f(th[d], d); return s; }
+  void grad_head(int i, double v) { g[i] = v; }
+  template <class F> void grad(F&& f) { for (i64 d = H; d < D; ++d) g[d] = f(th[d], d); }
+};
+extern "C" void eval_chains(const double* th, const double* P, long long C, long long D, int H, double* lp, double* g) {
+  for (long long c = 0; c < C; ++c) {
+    HostCtx ctx{th + c * D, g + c * D, D, H};
+    lp[c] = bk_lanes_density(ctx, P);
+  }
+}
+"""
+DL = 19
+yv = torch.randn(DL - 2, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+wv = torch.rand(DL - 1, generator=torch.Generator().manual_seed(4), dtype=torch.float64) + 0.5
+
+
+def t_funnel(Th):
+    v, x = Th[:, 0], Th[:, 1:]
+    return -(v * v) / 18.0 - 0.5 * (DL - 1) * v - 0.5 * torch.exp(-v) * (x * x).sum(dim=1)
+
+
+def t_funnel_inside(Th):  # the same density with the head-derived scale INSIDE the row expression, weighted rows
+    v = Th[:, 0]
+    r = Th[:, 1:] * torch.exp(-0.5 * v)[:, None]
+    return -(v * v) / 18.0 - 0.5 * (DL - 1) * v - 0.5 * (wv * r * r).sum(1)
+
+
+def t_hier(Th):
+    mu, lt, x = Th[:, 0], Th[:, 1], Th[:, 2:]
+    it2 = torch.exp(-2.0 * lt)
+    sq = ((x - mu[:, None]) ** 2).sum(dim=1)
+    sy = ((yv - x) ** 2).sum(dim=1)
+    return -0.5 * it2 * sq - (DL - 2) * lt - 0.5 * sy - (mu * mu / 50.0 + 0.5 * lt * lt)
+
+
+def t_logistic_scale(Th):  # rows through a sigmoid link with a shared slope (head 0) and offset (head 1), nonlinear in the sums
+    a, b, x = Th[:, 0], Th[:, 1], Th[:, 2:]
+    z = a.unsqueeze(1) * x + b[:, None]
+    ll = F.logsigmoid(z).sum(1)
+    pen = torch.log1p((x * x).sum(1))
+    return ll - 0.5 * pen * pen - 0.5 * (a * a + b * b)
+
+
+LANES = {"funnel": (t_funnel, 1), "funnel_scale_inside_rows": (t_funnel_inside, 1), "hierarchical_normal": (t_hier, 2),
+         "logistic_link_nonlinear_in_sums": (t_logistic_scale, 2)}
+
+
+@pytest.mark.parametrize("name", sorted(LANES))
+def test_lanes_source_value_and_gradient_match_autograd(name, tmp_path):
+    from bayes_kit_amd import trace_lanes
+
+    fn, H = LANES[name]
+    src, head, params, info = trace_lanes.lanes_source(fn, DL)
+    assert head == H and info["sums"] >= 1
+    cpp, lib = tmp_path / f"{name}.cpp", tmp_path / f"lib{name}.so"
+    cpp.write_text(LANES_HOST % src)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(cpp), "-o", str(lib)])
+    h = ctypes.CDLL(str(lib))
+    C = 33
+    Theta = 0.6 * torch.randn((C, DL), generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    x = Theta.clone().requires_grad_(True)
+    lp = fn(x)
+    (gr,) = torch.autograd.grad(lp.sum(), x)
+    th = np.ascontiguousarray(Theta.numpy())
+    P = np.zeros(1) if params is None else np.ascontiguousarray(params.numpy())
+    lp_c, g_c = np.empty(C), np.zeros((C, DL))
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    h.eval_chains(as_p(th), as_p(P), ctypes.c_longlong(C), ctypes.c_longlong(DL), ctypes.c_int(H), as_p(lp_c), as_p(g_c))
+    np.testing.assert_allclose(lp_c, lp.detach().numpy(), rtol=1e-12, atol=1e-12)
+    scale = np.abs(gr.numpy()).max()
+    np.testing.assert_allclose(g_c, gr.numpy(), rtol=1e-11, atol=1e-12 * scale)
+
+
+@pytest.mark.parametrize("fn, needle", [
+    (lambda Th: (Th[:, 1:] ** 2).sum(1) + (Th[:, 2:] ** 2).sum(1), "ONE slice"),
+    (lambda Th: (Th[:, 0] * Th[:, 1:]).sum(1), "without \\[:, None\\]"),
+    (lambda Th: ((Th[:, 1:] ** 2).sum(1)[:, None] * Th[:, 1:]).sum(1), "inside another row expression"),
+    (lambda Th: Th[:, 0] + Th[:, 3] + (Th[:, 2:] ** 2).sum(1), "inside the row slice"),
+    (lambda Th: (Th[:, 1:5] ** 2).sum(1), "indexed as"),
+    (lambda Th: Th[:, 0] * 2.0, "no row slice"),
+])
+def test_lanes_unsupported_shapes_name_the_reason(fn, needle):
+    from bayes_kit_amd import trace_lanes
+
+    with pytest.raises(trace.Unsupported, match=needle):
+        trace_lanes.lanes_source(fn, DL)
+
+
+def test_torch_model_compiles_a_hierarchical_density_into_the_lanes_form(tmp_path, monkeypatch):
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(tmp_path / "cache"))
+    m = bk.TorchModel(t_funnel, DL, compile=True)
+    assert m.compiled is not None and m.compiled_form == "lanes" and "bk_lanes_density" in m.traced_source
+    for hook in ("bk_eval", "bk_leapfrog_step", "bk_hmc_proposal", "bk_dr_proposal"):
+        assert hasattr(m, hook), hook
+    assert m.bk_dr_proposal_supported() and not hasattr(m, "bk_hmc_draw")
+    e = bk.TorchModel(lambda Th: -0.5 * (Th * Th).sum(1), DL, compile=True)
+    assert e.compiled_form == "elementwise"
+    with pytest.warns(UserWarning, match="as head coordinates plus sums over rows"):
+        u = bk.TorchModel(lambda Th: torch.logsumexp(Th, dim=1), DL, compile=True)
+    assert u.compiled is None
