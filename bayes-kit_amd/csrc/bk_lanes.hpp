@@ -230,8 +230,8 @@ constexpr i64 AUTO_MID = 4608, AUTO_WIDE = 12288;
 
 // Workgroups a launch needs for a set of at most n chains.  geo = 4 / 8 / 16: that many lanes per chain.  geo = 0 (the kernel
 // picks the geometry from the count on the device): the most any admissible count needs -- fewer than AUTO_MID chains at 16 per
-// workgroup, fewer than AUTO_WIDE at 32, n at 64 -- which is a quarter of sizing for 16 lanes per chain throughout (surplus
-// workgroups are not free: ~1.5 ns each on the dispatcher, 2.4 us per launch at a bound of 32,768 chains).
+// workgroup, fewer than AUTO_WIDE at 32, n at 64 -- a quarter of sizing for 16 lanes per chain throughout (surplus workgroups
+// exit after one scalar load and cost nothing measurable -- profiles/r5_cfg4_counted.md -- but fewer are never worse).
 static inline unsigned blocks_for(i64 n, int geo) {
   if (geo != 0) return (unsigned)bk_cdiv(n, WAVES * (BK_WAVE / geo));
   const i64 a = bk_cdiv(n < AUTO_MID ? n : AUTO_MID - 1, WAVES * (BK_WAVE / 16));
