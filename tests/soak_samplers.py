@@ -82,12 +82,24 @@ def funnel_paths(rng):
     b = mk(device_counts=True, graph=graph, fuse_first_ghost=fuse)
     # round 4: the gradient as a separate COUNTED op per leapfrog step (built-in op, or the user plugin), lane counts on
     # the device -- against the same host-sized path (step by step, so that the joint log densities agree bit for bit too)
-    opaque = str(rng.choice(["none", "builtin", "plugin"]))
+    # round 5: "builtin" runs {gradient, kick, drift} as ONE launch per step (bk_leapfrog_step), "builtin_op" keeps the gradient a
+    # separate op; "source" / "source_op": the funnel compiled from lanes-form source on the counted path, with / without the
+    # one-launch step; "source_fused": the same source through the one-launch proposal kernel (against the built-in's)
+    opaque = str(rng.choice(["none", "builtin", "builtin_op", "plugin", "source", "source_op", "source_fused"]))
     desc["opaque"] = opaque
     o = a2 = None
     if opaque != "none":
-        a2 = mk(device_counts=False, fuse_builtin=False)
-        if opaque == "plugin":
+        a2 = mk(device_counts=False, fuse_builtin=False, fuse_steps=bool(rng.integers(0, 2)))
+        if opaque.startswith("source"):
+            src = bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1)
+            kw = dict(source=dict(fuse_builtin=False), source_op=dict(fuse_builtin=False, fuse_steps=False), source_fused=dict())[opaque]
+            o = bk.DrGhmcDiag(src, K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed, prob_retry=pr,
+                              device_counts=True, graph=graph, **kw)
+            if opaque == "source_fused":
+                a2 = mk(device_counts=True, graph=graph)   # (the fused kernels sum the kinetic energy in their lanes' order)
+        elif opaque == "builtin_op":
+            o = mk(device_counts=True, graph=graph, fuse_builtin=False, fuse_steps=False)
+        elif opaque == "plugin":
             import os as _os
 
             lib = _os.path.join(ROOT, "examples", "plugin_target", "libfunnel_target.so")
@@ -115,8 +127,51 @@ def funnel_paths(rng):
     return "drfunnel"
 
 
+FUNNEL_LANES_SRC = """
+template <class L>
+__device__ double bk_lanes_density(L& c, const double* /*params*/) {
+  const double v = c.head(0);
+  const double s = c.sum([](double x, i64) { return x * x; });
+  const double ev = exp(-v);
+  const double hn = 0.5 * (double)(c.dims() - 1);
+  const double he = 0.5 * ev;
+  c.grad_head(0, ((-v / 9.0) - hn) + he * s);
+  c.grad([ev](double x, i64) { return -(ev * x); });
+  return ((-(v * v) / 18.0) - hn * v) - he * s;
+}
+"""
+
+
+def hmc_funnel(rng):
+    """Round 5: plain HMC on the funnel through the lane-spread kernels -- whole trajectory one launch (built-in or from source),
+    one launch per leapfrog step, gradient a separate op -- same draws bit for bit, whatever the step size does to the
+    trajectory (overflow to inf / NaN included); the watched chains against the oracle while the flow is still tame."""
+    D = int(rng.choice([2, 3, 11, 17, 33, 50, 101, 129, 200]))
+    C = int(rng.choice([1, 3, 64, 65, 700, 2100, 13000]))
+    eps = float(rng.uniform(0.02, 0.5))
+    L = int(rng.integers(1, 12))
+    metric = np.linspace(0.7, 1.4, D) if rng.random() < 0.4 else None
+    seed = int(rng.integers(1, 2**40))
+    N = int(rng.integers(2, 7))
+    graph = None if rng.integers(0, 2) else (bool(rng.integers(0, 2)) and not NO_GRAPH)
+    desc = dict(alg="hmcfunnel", D=D, C=C, eps=eps, L=L, metric=metric is not None, seed=seed, N=N, graph=graph)
+    model = (lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1)) if rng.integers(0, 2) else (lambda: bk.Funnel(D))
+    mk = lambda **kw: bk.HMCDiag(model(), eps, L, metric_diag=metric, chains=C, seed=seed, graph=graph, **kw)  # noqa: E731
+    f, h, s_ = mk(), mk(fuse_builtin=False), mk(fuse_builtin=False, fuse_steps=False)
+    for n in range(N):
+        tf, lf = f.sample()
+        th_, lh = h.sample()
+        ts, ls = s_.sample()
+        assert torch.equal(th_.nan_to_num(), ts.nan_to_num()) and torch.equal(lh.nan_to_num(), ls.nan_to_num()), ("step hook", desc, n)
+        assert torch.equal(tf.nan_to_num(), ts.nan_to_num()), ("one-launch trajectory", desc, n)
+    assert np.array_equal(f.rng_state(), s_.rng_state()) and np.array_equal(h.rng_state(), s_.rng_state()), ("stream", desc)
+    return "hmcfunnel"
+
+
 def one(rng, it):
-    alg = rng.choice(os.environ["ALGS"].split(",")) if os.environ.get("ALGS") else rng.choice(["hmc", "mala", "drghmc", "metropolis", "drfunnel"])
+    alg = rng.choice(os.environ["ALGS"].split(",")) if os.environ.get("ALGS") else rng.choice(["hmc", "mala", "drghmc", "metropolis", "drfunnel", "hmcfunnel"])
+    if alg == "hmcfunnel":
+        return hmc_funnel(rng)
     if alg == "drfunnel":
         return funnel_paths(rng)
     if alg == "torchgraph":
