@@ -441,9 +441,14 @@ extern "C" int bk_src_hmc_draw(const double* theta_in, double* theta_out, int64_
 
 _SRC_CHAIN = r"""
 // Accessors handed to the user's function: th[d] reads coordinate d of this lane's chain, g.set(d, v) writes its gradient
+typedef const __attribute__((address_space(3))) double* bk_lds_ptr;
 struct BkTheta {
   const double* p; i64 ld;
-  __device__ __forceinline__ double operator[](i64 d) const { return p[d * ld]; }
+  // the chain's coordinates staged by the kernel: mode 1 = a private array (registers), 2 = LDS ([d][lane]), 0 = not staged
+  const double* loc; bk_lds_ptr lds; int mode;
+  __device__ __forceinline__ double operator[](i64 d) const {
+    return mode == 1 ? loc[d] : (mode == 2 ? lds[d * 64] : p[d * ld]);
+  }
 };
 struct BkGrad {
   double* p; i64 ld;
@@ -456,14 +461,38 @@ struct BkGrad {
 %(user)s
 // -------------------------------------------------------------------------------------------------------------------
 namespace {
+constexpr i64 BK_SRC_D = %(dims)d;
+constexpr int BK_SRC_STAGE = %(stage)d;  // = D when a chain's coordinates fit the registers of its lane (D <= 128), else 0
+constexpr int BK_SRC_LDS = %(lds)d;    // = D when 64 chains' coordinates fit a workgroup's LDS instead (D <= 300), else 0
 __global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, double* logp, i64 ld, const double* params,
                                                   i64 C_host, i64 D, const uint32_t* n_dev) {
   const i64 C = bk_count(C_host, n_dev);
   const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
-  const BkTheta t = {th + c, ld};
   const BkGrad gr = {g ? g + c : nullptr, ld};
-  const double lp = bk_chain(t, gr, D, params);
+  double lp;
+  if (BK_SRC_STAGE > 0 && D == BK_SRC_D) {
+    // One lane walks a chain's coordinates.  Written against global memory, a loop that reads th[d] and sets the gradient is a
+    // chain of load -> store -> load round trips (the compiler must assume the two arrays alias; 24 us per call at D = 101).
+    // With the dimension a compile-time constant the coordinates are fetched ONCE, as one batch of loads, into a private
+    // array that the user's (now fully unrolled) loops read from registers; the gradient stores then pipeline.
+    double loc[BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1];
+#pragma unroll
+    for (int d = 0; d < BK_SRC_STAGE; ++d) loc[d] = th[(i64)d * ld + c];
+    const BkTheta t = {th + c, ld, loc, nullptr, 1};
+    lp = bk_chain(t, gr, BK_SRC_D, params);
+  } else if (BK_SRC_LDS > 0 && D == BK_SRC_D) {
+    // the same for a dimension too large for registers: the 64 chains' coordinates in LDS ([d][lane]: no bank conflicts);
+    // LDS reads cannot alias the gradient's global stores either
+    __shared__ double sh[(BK_SRC_LDS > 0 ? BK_SRC_LDS : 1) * 64];
+#pragma unroll 32
+    for (int d = 0; d < BK_SRC_LDS; ++d) sh[d * 64 + threadIdx.x] = th[(i64)d * ld + c];
+    const BkTheta t = {th + c, ld, nullptr, (bk_lds_ptr)(sh + threadIdx.x), 2};
+    lp = bk_chain(t, gr, BK_SRC_D, params);
+  } else {
+    const BkTheta t = {th + c, ld, nullptr, nullptr, 0};
+    lp = bk_chain(t, gr, D, params);
+  }
   if (logp) logp[c] = lp;
 }
 int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
@@ -637,7 +666,8 @@ def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
     elif form == "elementwise":
         body = _SRC_ELEMENTWISE % {"user": user_source}
     else:
-        body = _SRC_CHAIN % {"user": user_source}
+        body = _SRC_CHAIN % {"user": user_source, "dims": int(dims), "stage": int(dims) if int(dims) <= 128 else 0,
+                             "lds": int(dims) if 128 < int(dims) <= 300 else 0}
     return _SRC_PRELUDE + body + _SRC_EXPORTS
 
 
@@ -647,7 +677,6 @@ _SRC_REQUIRED_EXPORTS = ("bk_src_target", "bk_src_target_n")
 def _compile_source_target(user_source: str, form: str, contract: bool, dims: int = 1, head: int = 0) -> str:
     """hipcc the generated translation unit into a shared library (cached by content: the generated text, the flags and the
     library headers it includes); returns its path."""
-    import ctypes
     import hashlib
     import os
     import subprocess
@@ -657,6 +686,10 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
     inc = os.path.abspath(os.path.join(csrc, "..", "..", "include"))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
              "-ffp-contract=" + ("fast" if contract else "off")]
+    if form == "chain" and int(dims) <= 300:
+        # (the staged paths of k_src_chain want the user's loops over d unrolled completely: the private copy of the chain's
+        # coordinates then lives in registers, LDS reads are issued in batches; clang's default budget stops at trip counts of ~60)
+        flags += ["-mllvm", "-unroll-threshold=%d" % (4000 if int(dims) <= 128 else 10000)]
     h = hashlib.sha256((text + " ".join(flags)).encode())
     for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", os.path.join(inc, "bkhip.h")):
         with open(os.path.join(csrc, name), "rb") as f:
@@ -680,9 +713,12 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
         if r.returncode != 0:
             raise _lib.BkHipError("CTarget.from_source: hipcc failed\n" + r.stderr[-6000:])
         os.chmod(tmp, 0o700)
-        probe = ctypes.CDLL(tmp)
+        # (a build that was cut short must not be published: the export names have to be in the library's string table;
+        # checked on the bytes -- loading the temporary file would register its code objects a second time)
+        with open(tmp, "rb") as f:
+            blob = f.read()
         for name in _SRC_REQUIRED_EXPORTS:
-            if not hasattr(probe, name):
+            if b"\0" + name.encode() + b"\0" not in blob:
                 raise _lib.BkHipError(f"CTarget.from_source: the compiled library does not export {name}")
         os.replace(tmp, lib)
     finally:

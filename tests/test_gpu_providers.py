@@ -126,16 +126,23 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     assert torch.equal(g1, g2) and torch.equal(l1, l2)
     src().bk_eval(th, g2.zero_(), None)
     assert torch.equal(g1, g2)
-    # the per-chain form
-    Df = 150
-    fs = bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain")
-    a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
-    b = bk.DrGhmcDiag(fs, 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9)
-    assert b._dev_counts and b._use_graph
-    for n in range(8):
-        ta, la = a.sample()
-        tb, lb = b.sample()
-        assert torch.equal(ta, tb) and torch.equal(la, lb), ("funnel from source", n)
+    # the per-chain form: a chain's coordinates staged in its lane's registers (D <= 128), in LDS (D <= 300), or read from
+    # global memory as the user's loops ask for them (larger D) -- the same values
+    for Df in (150, 101, 17, 350):
+        fs = bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain")
+        a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
+        b = bk.DrGhmcDiag(fs, 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9)
+        assert b._dev_counts and b._use_graph
+        for n in range(8):
+            ta, la = a.sample()
+            tb, lb = b.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), ("funnel from source", Df, n)
+        # (a call with another D than the one compiled for takes the unstaged path)
+        th = torch.randn((Df - 1, 130), dtype=torch.float64, device=ops.device)
+        g1, g2 = torch.empty_like(th), torch.empty_like(th)
+        bk.Funnel(Df - 1).bk_eval(th, g1, None)
+        bk.CTarget(fs.source_library, "bk_src_target", Df - 1).bk_eval(th, g2, None)
+        assert torch.equal(g1, g2), Df
     # a source that does not compile says so (hipcc's message), it does not fall back to anything
     with pytest.raises(bk._lib.BkHipError):
         bk.CTarget.from_source("this is not C++", 3)
