@@ -452,8 +452,20 @@ struct BkTheta {
 };
 struct BkGrad {
   double* p; i64 ld;
-  __device__ __forceinline__ void set(i64 d, double v) const { if (p) p[d * ld] = v; }
-  __device__ __forceinline__ bool wanted() const { return p != nullptr; }
+  // step mode (bk_src_leapfrog_step): every entry is delivered INTO kick + drift of the lane's chain -- rho (staged in LDS)
+  // += h * (metric * v), theta (staged in registers) + h * rho -- and both are written back; set each entry exactly once
+  int step; double h; bk_lds_ptr metric; bk_lds_ptr rho_in; double* rho; double* th_out; const double* loc;
+  __device__ __forceinline__ void set(i64 d, double v) const {
+    if (step) {
+      const double t = metric ? metric[d] * v : v;
+      const double r = rho_in[d * 64] + h * t;
+      rho[d * ld] = r;
+      th_out[d * ld] = loc[d] + h * r;
+    } else if (p) {
+      p[d * ld] = v;
+    }
+  }
+  __device__ __forceinline__ bool wanted() const { return step != 0 || p != nullptr; }
 };
 // ---- user code: ONE CHAIN per call ----------------------------------------------------------------------------------
 //   __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, d
   const i64 C = bk_count(C_host, n_dev);
   const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
-  const BkGrad gr = {g ? g + c : nullptr, ld};
+  const BkGrad gr = {g ? g + c : nullptr, ld, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr};
   double lp;
   if (BK_SRC_STAGE > 0 && D == BK_SRC_D) {
     // One lane walks a chain's coordinates.  Written against global memory, a loop that reads th[d] and sets the gradient is a
@@ -495,6 +507,38 @@ __global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, d
   }
   if (logp) logp[c] = lp;
 }
+// One leapfrog step {gradient, kick, drift} (drghmc.py:280-283, hmc.py:48-50) as ONE launch for a per-chain density (D <= 128):
+// theta staged in the lane's registers, rho and the metric in LDS (reads that cannot alias the global stores), the user's
+// g.set(d, v) performs kick + drift of coordinate d and writes rho and theta back.  Same arithmetic as the gradient launch followed
+// by bk_leapfrog_kick_drift: bit-identical, half the launches, the gradient never travels through memory.
+__global__ __launch_bounds__(64) void k_src_chain_step(double* th, double* rho, i64 ld, const double* metric, double h,
+                                                       const double* params, i64 C_host, i64 D, const uint32_t* n_dev) {
+  constexpr int S = BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1;
+  __shared__ double srho[S * 64];
+  __shared__ double sm[S];
+  const i64 C = bk_count(C_host, n_dev);
+  if ((i64)blockIdx.x * 64 >= C) return;  // (whole workgroup past the set: uniform, before the barrier)
+  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  const bool on = c < C;
+  const i64 col = on ? c : 0;
+  if (metric)
+    for (int d = threadIdx.x; d < S; d += 64) sm[d] = metric[d];
+  double loc[S];
+  // (all 2 S loads of the lane in flight at once -- one wavefront per SIMD may hold them: 4 S registers -- rho then moves on to LDS)
+  double rl[S];
+#pragma unroll
+  for (int d = 0; d < S; ++d) {
+    loc[d] = th[(i64)d * ld + col];
+    rl[d] = rho[(i64)d * ld + col];
+  }
+#pragma unroll
+  for (int d = 0; d < S; ++d) srho[d * 64 + threadIdx.x] = rl[d];
+  __syncthreads();
+  if (!on) return;
+  const BkTheta t = {th + c, ld, loc, nullptr, 1};
+  const BkGrad gr = {nullptr, ld, 1, h, metric ? (bk_lds_ptr)sm : nullptr, (bk_lds_ptr)(srho + threadIdx.x), rho + c, th + c, loc};
+  bk_chain(t, gr, BK_SRC_D, params);
+}
 int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
            void* stream) {
   if (!th || (!g && !logp) || C < 0 || D < 0 || ld < C) return -1;
@@ -504,6 +548,16 @@ int launch(const double* th, double* g, double* logp, i64 ld, const void* params
   return (int)hipGetLastError();
 }
 }  // namespace
+#if %(stage)d > 0
+extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
+                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
+  if (!theta || !rho || n < 0 || D != BK_SRC_D || ld < n) return -1;
+  if (n == 0) return 0;
+  k_src_chain_step<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
+      theta, rho, ld, metric, h, static_cast<const double*>(params), n, D, n_dev);
+  return (int)hipGetLastError();
+}
+#endif
 """
 
 _SRC_LANES = r"""

@@ -417,7 +417,8 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
     lanes = dict(form="lanes", head=1)
     for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(fuse_steps=False)),
                               ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, lanes, {}),
-                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
+                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), dict(fuse_steps=False)),
+                              ("compiled_source_chain_one_launch_steps", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
         try:
             so, r = run(bk.CTarget.from_source(src, D, **kws), draws, fuse_builtin=False, **k2)
             same = torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc) and \

@@ -51,7 +51,8 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     e = T._compile_source_target(TERM, "elementwise", False, 16, 0)
     assert exports(e) == {"bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory"}
     c = T._compile_source_target(CHAIN, "chain", False, 16, 0)
-    assert exports(c) == {"bk_src_target", "bk_src_target_n"}
+    assert exports(c) == {"bk_src_target", "bk_src_target_n", "bk_src_leapfrog_step"}  # (D <= 128: the one-launch step)
+    assert exports(T._compile_source_target(CHAIN, "chain", False, 200, 0)) == {"bk_src_target", "bk_src_target_n"}
     l = T._compile_source_target(LANES, "lanes", False, 101, 1)
     assert exports(l) == {"bk_src_target", "bk_src_target_n", "bk_src_dr_proposal_job", "bk_src_leapfrog_step"}
     big = T._compile_source_target(LANES, "lanes", False, 300, 1)  # > 128 spread rows: gradient op + one-launch step
@@ -59,7 +60,8 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     # the cache: 0700 directory, private files, a second request is served from it (same path, no temporaries left)
     assert stat.S_IMODE(os.lstat(cache).st_mode) == 0o700
     assert T._compile_source_target(TERM, "elementwise", False, 16, 0) == e
-    assert sorted(os.listdir(cache)) == sorted(os.path.basename(p) for p in (e, c, l, big))
+    assert sorted(os.listdir(cache)) == sorted([os.path.basename(p) for p in (e, c, l, big)]
+                                                + [os.path.basename(T._compile_source_target(CHAIN, "chain", False, 200, 0))])
     for p in (e, c, l, big):
         assert not os.lstat(p).st_mode & 0o022
     # the objects: hooks the samplers look for exist exactly where the library exports them
@@ -70,7 +72,7 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     assert hasattr(te, "bk_hmc_draw") and hasattr(te, "bk_hmc_trajectory") and not hasattr(te, "bk_dr_proposal")
     assert hasattr(tl, "bk_dr_proposal") and tl.bk_dr_proposal_supported() and not hasattr(tl, "bk_hmc_draw")
     assert not hasattr(tb, "bk_dr_proposal") and not hasattr(tc, "bk_dr_proposal") and not hasattr(tc, "bk_hmc_draw")
-    assert hasattr(tl, "bk_leapfrog_step") and hasattr(tb, "bk_leapfrog_step") and not hasattr(tc, "bk_leapfrog_step")
+    assert hasattr(tl, "bk_leapfrog_step") and hasattr(tb, "bk_leapfrog_step") and hasattr(tc, "bk_leapfrog_step")
     assert all(t.bk_counted for t in (te, tl, tb, tc))
 
 

@@ -132,11 +132,21 @@ def test_density_compiled_from_source_under_every_sampler(ops):
         fs = bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain")
         a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
         b = bk.DrGhmcDiag(fs, 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9)
-        assert b._dev_counts and b._use_graph
+        b2 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
+                           fuse_steps=False, metric_diag=None)
+        hm = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4,
+                        metric_diag=np.linspace(0.8, 1.3, Df))
+        hs = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, fuse_steps=False,
+                        metric_diag=np.linspace(0.8, 1.3, Df))
+        assert b._dev_counts and b._use_graph and b._step_hook == (Df <= 128) and not b2._step_hook and hm._step_hook == (Df <= 128)
         for n in range(8):
             ta, la = a.sample()
             tb, lb = b.sample()
-            assert torch.equal(ta, tb) and torch.equal(la, lb), ("funnel from source", Df, n)
+            tb2, _ = b2.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb) and torch.equal(ta, tb2), ("funnel from source", Df, n)
+            t1, l1 = hm.sample()
+            t2, l2 = hs.sample()
+            assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source, one launch per step", Df, n)
         # (a call with another D than the one compiled for takes the unstaged path)
         th = torch.randn((Df - 1, 130), dtype=torch.float64, device=ops.device)
         g1, g2 = torch.empty_like(th), torch.empty_like(th)

@@ -28,6 +28,9 @@ h = 1e-4
 
 def chain(which):
     for _ in range(REPS):
+        if which == "step":  # {gradient, kick, drift} as ONE launch (models that have bk_leapfrog_step)
+            model.bk_leapfrog_step(th, rho, None, h, n_dev)
+            continue
         if which in ("both", "grad"):
             model.bk_eval(th, g, None, n_dev)
         if which in ("both", "kd"):
@@ -35,7 +38,7 @@ def chain(which):
 
 
 res = {}
-for which in ("both", "grad", "kd"):
+for which in ("both", "grad", "kd") + (("step",) if hasattr(model, "bk_leapfrog_step") else ()):
     chain(which)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
@@ -52,6 +55,6 @@ for which in ("both", "grad", "kd"):
         e1.record()
         e1.synchronize()
         res.setdefault(lanes, {})[which] = round(1e3 * e0.elapsed_time(e1) / 5 / REPS, 2)
-print("us per step (both) / per launch (grad, kd), by lanes in the set; bound C =", C, "D =", D, "plugin" if os.environ.get("PLUGIN") else os.environ.get("SOURCE", "builtin"))
+print("us per step (both; step = the one-launch step) / per launch (grad, kd), by lanes in the set; bound C =", C, "D =", D, "plugin" if os.environ.get("PLUGIN") else os.environ.get("SOURCE", "builtin"))
 for lanes, r in res.items():
     print(lanes, r)
