@@ -661,7 +661,7 @@ def test_randomised_sampler_configurations_against_the_oracle(ops):
     seen = set()
     for it in range(120):
         seen.add(str(mod.one(rng, it)))
-    assert seen == {"hmc", "mala", "drghmc", "metropolis", "drfunnel"}
+    assert seen == {"hmc", "mala", "drghmc", "metropolis", "drfunnel", "hmcfunnel"}
     assert set(mod.PROVIDERS_SEEN) == {"builtin", "torch", "row", "strided", "plugin"}, mod.PROVIDERS_SEEN
 
 
