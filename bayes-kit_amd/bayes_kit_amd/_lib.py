@@ -204,10 +204,12 @@ class RawDeviceArray:
 
     def __del__(self):
         p, self._ptr = getattr(self, "_ptr", None), None
-        if p and RawDeviceArray._hip is not None:
-            RawDeviceArray.live -= 1
+        cls = type(self)  # (at interpreter shutdown the module's globals -- the class name included -- are already None)
+        hip = getattr(cls, "_hip", None)
+        if p and hip is not None:
+            cls.live -= 1
             try:
-                RawDeviceArray._hip.hipFree(c_void_p(p))  # (hipFree waits for work in flight on the device)
+                hip.hipFree(ctypes.c_void_p(p))  # (hipFree waits for work in flight on the device)
             except Exception:  # interpreter shutdown
                 pass
 

@@ -445,12 +445,27 @@ class RankContext:
 
     def timed_loop(self, fn, steps):
         """EXACTLY `steps` calls of fn bracketed by barrier + synchronize; max over ranks."""
-        self.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0)
+        # No cyclic garbage collection inside the timed region: with PyTorch loaded a generation-2 collection is a 38-40 ms
+        # pause of the launching thread (measured: one draw's enqueue 1.5 -> 40 ms).  Mid-run the host is a draw or two ahead of
+        # the GPU and the pause is absorbed; right after the barrier it is not, and WHERE the collection lands depends on the
+        # allocation count since start-up (it moved into the first timed draw when the package grew: 38.2 -> 42 ms per draw over
+        # 10 draws, kernel times unchanged).  Collected before, switched off during, restored after.
+        import gc
+
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            self.barrier()
+            elapsed = time.perf_counter() - t0
+        finally:
+            if was_enabled:
+                gc.enable()
+        return self.max_over_ranks(elapsed)
 
     def close(self):
         import torch.distributed as dist
