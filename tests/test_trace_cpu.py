@@ -238,3 +238,133 @@ def test_torch_model_compiles_a_hierarchical_density_into_the_lanes_form(tmp_pat
     with pytest.warns(UserWarning, match="as head coordinates plus sums over rows"):
         u = bk.TorchModel(lambda Th: torch.logsumexp(Th, dim=1), DL, compile=True)
     assert u.compiled is None
+
+
+# ---- randomised expressions: every derivative rule of both tracers against autograd --------------------------------------
+def _random_expr(rng, depth, leaves):
+    """A random elementwise PyTorch expression (as a Python closure) over the supported operations, kept in a numerically tame
+    range (arguments of log / sqrt / pow are made positive, exponents bounded)."""
+    if depth == 0 or rng.random() < 0.15:
+        return leaves[int(rng.integers(0, len(leaves)))]
+    kind = rng.random()
+    a = _random_expr(rng, depth - 1, leaves)
+    if kind < 0.45:
+        b = _random_expr(rng, depth - 1, leaves)
+        op = int(rng.integers(0, 4))
+        if op == 0:
+            return lambda x: a(x) + b(x)
+        if op == 1:
+            return lambda x: a(x) - b(x)
+        if op == 2:
+            return lambda x: a(x) * b(x)
+        return lambda x: a(x) / (2.0 + torch.square(b(x)))
+    c = float(rng.uniform(0.3, 1.7))
+    u = int(rng.integers(0, 14))
+    table = [
+        lambda x: torch.exp(-torch.square(a(x)) * c), lambda x: torch.log(1.5 + torch.square(a(x))), lambda x: torch.log1p(torch.square(a(x)) * c),
+        lambda x: torch.expm1(-torch.abs(a(x))), lambda x: torch.sigmoid(a(x) * c), lambda x: F.logsigmoid(a(x)), lambda x: F.softplus(a(x) * c),
+        lambda x: torch.tanh(a(x)), lambda x: torch.sqrt(1.0 + torch.square(a(x))), lambda x: torch.square(a(x)), lambda x: torch.sin(a(x) * c),
+        lambda x: torch.cos(a(x)), lambda x: (1.0 + torch.square(a(x))) ** c, lambda x: -a(x) * c + 2.0 ** (0.3 * torch.tanh(a(x))),
+    ]
+    return table[u]
+
+
+def test_randomised_separable_densities_against_autograd(tmp_path):
+    """40 random elementwise expression trees (depth <= 4) over every supported operation, each summed over the coordinates:
+    value and hand-differentiated derivative of the generated bk_term against the function and autograd."""
+    rng = np.random.default_rng(20250)
+    pw = torch.rand(D, generator=torch.Generator().manual_seed(9), dtype=torch.float64) + 0.5
+    leaves = [lambda x: x, lambda x: x * pw, lambda x: x - a, lambda x: 0.5 * x + 0.25]
+    fns, srcs = [], []
+    for k in range(40):
+        e = _random_expr(rng, 4, leaves)
+        fn = (lambda e_: (lambda Th: e_(Th).sum(dim=1)))(e)
+        src, params, _ = trace.term_source(fn, D)
+        srcs.append((src.replace("bk_term(", f"bk_term_{k}("), params))
+        fns.append(fn)
+    body = "\n".join(s for s, _ in srcs)
+    calls = "\n".join(f"    case {k}: bk_term_{k}(th[i], d[i], P, term[i], grad[i]); break;" for k in range(len(fns)))
+    cpp = ("#include <math.h>\n#include <stdint.h>\ntypedef int64_t i64;\n#define __device__\n#define __forceinline__ inline\n" + body +
+           "\nextern \"C\" void eval_k(int k, const double* th, const long long* d, const double* P, long long n, double* term, double* grad) {\n"
+           "  for (long long i = 0; i < n; ++i) switch (k) {\n" + calls + "\n  }\n}\n")
+    (tmp_path / "rnd.cpp").write_text(cpp)
+    subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(tmp_path / "rnd.cpp"), "-o", str(tmp_path / "librnd.so")])
+    h = ctypes.CDLL(str(tmp_path / "librnd.so"))
+    C = 16
+    Theta = 0.8 * torch.randn((C, D), generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    th = np.ascontiguousarray(Theta.numpy().reshape(-1))
+    dd = np.ascontiguousarray(np.tile(np.arange(D, dtype=np.int64), C))
+    as_p = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for k, fn in enumerate(fns):
+        x = Theta.clone().requires_grad_(True)
+        lp = fn(x)
+        (gr,) = torch.autograd.grad(lp.sum(), x)
+        P = np.zeros(1) if srcs[k][1] is None else np.ascontiguousarray(srcs[k][1].numpy())
+        term, grad = np.empty(C * D), np.empty(C * D)
+        h.eval_k(ctypes.c_int(k), as_p(th), as_p(dd), as_p(P), ctypes.c_longlong(C * D), as_p(term), as_p(grad))
+        scale = max(1.0, float(np.abs(gr.numpy()).max()))
+        np.testing.assert_allclose(grad.reshape(C, D), gr.numpy(), rtol=1e-10, atol=1e-12 * scale, err_msg=f"expression {k}")
+        np.testing.assert_allclose(term.reshape(C, D).sum(axis=1), lp.detach().numpy(), rtol=1e-11, atol=1e-11, err_msg=f"expression {k}")
+
+
+def test_randomised_hierarchical_densities_against_autograd(tmp_path):
+    """25 random head-plus-sums densities: random row expressions that use two head coordinates through [:, None], two or three
+    sums, a random scalar expression of heads and sums at the end -- the symbolic derivatives of trace_lanes.py (incl. the extra
+    sums the head gradients need) against autograd."""
+    from bayes_kit_amd import trace_lanes
+
+    rng = np.random.default_rng(77)
+    n = DL - 2
+    pw = torch.rand(n, generator=torch.Generator().manual_seed(8), dtype=torch.float64) + 0.5
+    fns, srcs = [], []
+    for k in range(25):
+        def make():
+            row_leaves = lambda h0, h1: [lambda x: x, lambda x: x * pw, lambda x: x - h0, lambda x: x * torch.exp(-0.3 * h1), lambda x: 0.5 * x + h0 * 0.1]  # noqa: E731
+            seeds = [int(s) for s in rng.integers(0, 2 ** 31, size=3)]
+            nsum = int(rng.integers(2, 4))
+            mode = int(rng.integers(0, 3))
+
+            def fn(Th):
+                h0, h1, x = Th[:, 0], Th[:, 1], Th[:, 2:]
+                leaves = row_leaves(h0[:, None], h1[:, None])
+                sums = [_random_expr(np.random.default_rng(seeds[i]), 3, leaves)(x).sum(dim=1) for i in range(nsum)]
+                s = sums[0] - 0.5 * (h0 * h0 + h1 * h1)
+                if mode == 0:
+                    s = s + torch.tanh(sums[1] * 0.1) * torch.exp(-0.2 * h0)
+                elif mode == 1:
+                    s = s - torch.log1p(torch.square(sums[1])) * torch.sigmoid(h1)
+                else:
+                    s = s + sums[1] / (2.0 + torch.square(h0 - h1))
+                if nsum == 3:
+                    s = s - 0.3 * torch.sqrt(1.0 + torch.square(sums[2]))
+                return s
+            return fn
+        fn = make()
+        src, head, params, info = trace_lanes.lanes_source(fn, DL)
+        assert head == 2
+        srcs.append((src.replace("bk_lanes_density(", f"bk_lanes_density_{k}("), params))
+        fns.append(fn)
+    body = "\n".join(s for s, _ in srcs)
+    calls = "\n".join(f"      case {k}: lp[c] = bk_lanes_density_{k}(ctx, P); break;" for k in range(len(fns)))
+    host = LANES_HOST.split("extern \"C\"")[0] % body
+    cpp = host + ("extern \"C\" void eval_k(int k, const double* th, const double* P, long long C, long long D, int H, double* lp, double* g) {\n"
+                  "  for (long long c = 0; c < C; ++c) {\n    HostCtx ctx{th + c * D, g + c * D, D, H};\n    switch (k) {\n" + calls +
+                  "\n    }\n  }\n}\n")
+    (tmp_path / "rndl.cpp").write_text(cpp)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(tmp_path / "rndl.cpp"), "-o",
+                           str(tmp_path / "librndl.so")])
+    h = ctypes.CDLL(str(tmp_path / "librndl.so"))
+    C = 12
+    Theta = 0.6 * torch.randn((C, DL), generator=torch.Generator().manual_seed(6), dtype=torch.float64)
+    th = np.ascontiguousarray(Theta.numpy())
+    as_p = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    for k, fn in enumerate(fns):
+        x = Theta.clone().requires_grad_(True)
+        lp = fn(x)
+        (gr,) = torch.autograd.grad(lp.sum(), x)
+        P = np.zeros(1) if srcs[k][1] is None else np.ascontiguousarray(srcs[k][1].numpy())
+        lp_c, g_c = np.empty(C), np.zeros((C, DL))
+        h.eval_k(ctypes.c_int(k), as_p(th), as_p(P), ctypes.c_longlong(C), ctypes.c_longlong(DL), ctypes.c_int(2), as_p(lp_c), as_p(g_c))
+        scale = max(1.0, float(np.abs(gr.numpy()).max()))
+        np.testing.assert_allclose(lp_c, lp.detach().numpy(), rtol=1e-11, atol=1e-11, err_msg=f"density {k}")
+        np.testing.assert_allclose(g_c, gr.numpy(), rtol=1e-9, atol=1e-11 * scale, err_msg=f"density {k}")
