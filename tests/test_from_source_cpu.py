@@ -157,3 +157,33 @@ def test_missing_hipcc_says_so(cache, monkeypatch):
     monkeypatch.setenv("PATH", "")
     with pytest.raises(bk._lib.BkHipError, match="no hipcc was found"):
         bk.CTarget.from_source(TERM + "// never compiled before\n", 4)
+
+
+def test_generated_libraries_match_the_header_of_their_abi(cache):
+    """include/bkhip_source.h declares the C ABI of a generated library; every form exports a subset of exactly those names, and
+    every declared name is exported by some form."""
+    import re
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    src = open(os.path.join(root, "include", "bkhip_source.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"\bint\s+(bk_src_[a-z0-9_]+)\s*\(", src))
+    assert len(declared) == 7
+
+    def all_exports(lib):
+        with open(lib, "rb") as f:
+            blob = f.read()
+        return set(m.decode() for m in re.findall(rb"(?<=\x00)(bk_src_[a-z0-9_]+)(?=\x00)", blob))
+
+    seen = set()
+    for text, form, dims, head in ((TERM, "elementwise", 16, 0), (CHAIN, "chain", 16, 0), (CHAIN, "chain", 200, 0),
+                                   (LANES, "lanes", 101, 1), (LANES, "lanes", 300, 1)):
+        ex = all_exports(T._compile_source_target(text, form, False, dims, head))
+        assert ex <= declared and {"bk_src_target", "bk_src_target_n"} <= ex, (form, dims, ex - declared)
+        seen |= ex
+    assert seen == declared
+    # the header compiles as C
+    import subprocess
+
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "include", "bkhip_source.h")])
