@@ -78,3 +78,21 @@ class EngineTarget(Protocol):
     into the engine's [D, n] chain-contiguous buffers (either output may be None)."""
 
     def bk_eval(self, theta_dc, grad_out, logp_out) -> None: ...
+
+
+# Optional hooks a model may offer on top of ``bk_eval``; the samplers use the strongest one present (``hasattr``), all give the
+# same draws as the plain gradient-op path.  The library's targets and ``CTarget.from_source`` objects provide them; a
+# ``TorchModel(compile=True)`` forwards those of the target it was compiled into.
+#
+#   bk_counted = True, bk_eval(theta, grad, logp, n_dev)   the gradient op takes its chain count from device memory
+#                                                           (DrGhmcDiag: lane counts stay on the device, a draw is one hipGraph)
+#   bk_leapfrog_step(theta, rho, metric, h, n_dev=None)     one leapfrog step {gradient, kick, drift} as ONE launch, in place
+#                                                           (drghmc.py:280-283, hmc.py:48-50): the step-by-step paths of
+#                                                           DrGhmcDiag and HMCDiag issue one launch per step instead of two
+#   bk_hmc_trajectory / bk_hmc_draw                         whole HMC trajectory / whole draw of a separable density in registers
+#                                                           (hmc.py:40-63)
+#   bk_hmc_proposal(theta, rho, grad, theta_out, grad_out, logp_out, kin_out, metric, eps, steps) -> bool
+#                                                           whole HMC trajectory of a lane-spread density as ONE launch
+#   bk_dr_proposal(...) -> bool, bk_dr_proposal_supported() whole delayed-rejection proposal as ONE launch
+#                                                           (drghmc.py:253-289, 319-346, 391-446)
+#   bk_gradient(Theta)                                      the gradient alone through PyTorch ops (TorchModel(grad_fn=...))
