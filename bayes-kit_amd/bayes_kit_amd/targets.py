@@ -421,6 +421,43 @@ int launch(const double* th, double* g, double* logp, i64 ld, const void* params
   return (int)hipGetLastError();
 }
 }  // namespace
+// A separable density is also a lane-spread density without head coordinates (log p = ONE canonical-order sum of the terms, the
+// row gradient the term's derivative): through this adapter the translation unit instantiates the library's one-launch
+// delayed-rejection proposal kernel (D <= 128) and one-launch leapfrog step (csrc/bk_lanes.hpp) as well -- DrGhmcDiag on a
+// separable density is then 12 launches per draw at K = 3 instead of ~580.  theta and rho equal the step-by-step path's bit for
+// bit; the log density is the same terms summed in the lanes' class order instead of four quarters (last-bit differences).
+#include "bk_lanes.hpp"
+namespace {
+struct BkSrcLanesFromTerm {
+  static constexpr int HEAD = 0;
+  template <class L>
+  __device__ __forceinline__ static double eval(L& c, const double* params) {
+    const double lp = c.sum([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return t; });
+    c.grad([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return g; });
+    return lp;
+  }
+};
+constexpr int BK_SRC_SL = %(sl)d;  // slots per class for this D (0: D > 128)
+}  // namespace
+extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
+                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
+  return bkl::step_launch<BkSrcLanesFromTerm, BK_SRC_SL>(theta, rho, ld, metric, h, static_cast<const double*>(params), n, D,
+                                                         n_dev, stream);
+}
+#if %(sl)d > 0
+extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                                      const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
+                                      double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
+                                      int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
+                                      uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
+                                      const bk_scatter_job* job, const bk_ghost_link* ghost, const bk_ghost0* ghost0,
+                                      const void* params, void* stream) {
+  return bkl::dr_proposal_launch<BkSrcLanesFromTerm, BK_SRC_SL>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out,
+                                                                grad_out, logp_out, kin_out, ld_out, metric, h, steps, n, D,
+                                                                n_dev, lanes_out, lanes_total, H_out, h_out, live_out, job,
+                                                                ghost, ghost0, static_cast<const double*>(params), stream);
+}
+#endif
 // whole HMC trajectory / whole HMC draw with bk_term inlined: the argument lists of bk_hmc_trajectory_gaussian /
 // bk_hmc_draw_gaussian (include/bkhip.h) with `params` where those take `lam`
 extern "C" int bk_src_hmc_trajectory(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out,
@@ -718,7 +755,7 @@ def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
         sl = 0 if rows > _LANES_MAX_ROWS else max(1, -(-rows // 16))
         body = _SRC_LANES % {"user": user_source, "head": int(head), "sl": sl}
     elif form == "elementwise":
-        body = _SRC_ELEMENTWISE % {"user": user_source}
+        body = _SRC_ELEMENTWISE % {"user": user_source, "sl": 0 if dims > _LANES_MAX_ROWS else max(1, -(-dims // 16))}
     else:
         body = _SRC_CHAIN % {"user": user_source, "dims": int(dims), "stage": int(dims) if int(dims) <= 128 else 0,
                              "lds": int(dims) if 128 < int(dims) <= 300 else 0}

@@ -49,7 +49,8 @@ def exports(lib):
 
 def test_every_form_compiles_and_exports_its_entry_points(cache):
     e = T._compile_source_target(TERM, "elementwise", False, 16, 0)
-    assert exports(e) == {"bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory"}
+    assert exports(e) == {"bk_src_target", "bk_src_target_n", "bk_src_hmc_draw", "bk_src_hmc_trajectory", "bk_src_leapfrog_step",
+                          "bk_src_dr_proposal_job"}
     c = T._compile_source_target(CHAIN, "chain", False, 16, 0)
     assert exports(c) == {"bk_src_target", "bk_src_target_n", "bk_src_leapfrog_step"}  # (D <= 128: the one-launch step)
     assert exports(T._compile_source_target(CHAIN, "chain", False, 200, 0)) == {"bk_src_target", "bk_src_target_n"}
@@ -69,7 +70,8 @@ def test_every_form_compiles_and_exports_its_entry_points(cache):
     tl = bk.CTarget.from_source(LANES, 101, form="lanes", head=1)
     tb = bk.CTarget.from_source(LANES, 300, form="lanes", head=1)
     tc = bk.CTarget.from_source(CHAIN, 16, form="chain")
-    assert hasattr(te, "bk_hmc_draw") and hasattr(te, "bk_hmc_trajectory") and not hasattr(te, "bk_dr_proposal")
+    assert hasattr(te, "bk_hmc_draw") and hasattr(te, "bk_hmc_trajectory") and hasattr(te, "bk_dr_proposal")
+    assert hasattr(te, "bk_leapfrog_step") and te.bk_dr_proposal_supported()
     assert hasattr(tl, "bk_dr_proposal") and tl.bk_dr_proposal_supported() and not hasattr(tl, "bk_hmc_draw")
     assert not hasattr(tb, "bk_dr_proposal") and not hasattr(tc, "bk_dr_proposal") and not hasattr(tc, "bk_hmc_draw")
     assert hasattr(tl, "bk_leapfrog_step") and hasattr(tb, "bk_leapfrog_step") and hasattr(tc, "bk_leapfrog_step")

@@ -110,12 +110,24 @@ def test_density_compiled_from_source_under_every_sampler(ops):
         (bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5),
          bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5)),
     ]
-    assert pairs[2][1]._dev_counts and pairs[2][1]._use_graph and not pairs[2][1]._one_launch
-    for a, b in pairs:
+    # (round 5) a separable density is also a lane-spread one without head coordinates: DrGhmcDiag runs its proposals as ONE
+    # launch each (D <= 128); with fuse_builtin=False it steps, one launch per leapfrog step; fuse_steps=False: gradient op per step
+    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False)))
+    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False,
+                                             fuse_steps=False)))
+    assert pairs[2][1]._dev_counts and pairs[2][1]._use_graph and pairs[2][1]._one_launch and pairs[2][1].host_syncs_per_draw == 0
+    assert pairs[3][1]._step_hook and not pairs[3][1]._one_launch and not pairs[4][1]._step_hook
+    for i, (a, b) in enumerate(pairs):
+        if i >= 3:   # (pairs 3, 4 share their reference sampler with pair 2: a fresh one)
+            a = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5)
         for n in range(8):
             ta, la = a.sample()
             tb, lb = b.sample()
-            assert torch.equal(ta, tb) and torch.equal(la, lb), (type(a).__name__, n)
+            assert torch.equal(ta, tb), (i, type(a).__name__, n)
+            if i == 2:  # (the one-launch kernel sums the log density and the kinetic energy in its lanes' order)
+                torch.testing.assert_close(la, lb, rtol=1e-12, atol=1e-12)
+            else:
+                assert torch.equal(la, lb), (i, type(a).__name__, n)
         np.testing.assert_array_equal(a.rng_state(), b.rng_state())
     # odd chain counts and unaligned views take the one-chain-per-lane kernels
     th = torch.randn((D, 333), dtype=torch.float64, device=ops.device)
