@@ -432,7 +432,8 @@ struct BkSrcLanesFromTerm {
   static constexpr int HEAD = 0;
   template <class L>
   __device__ __forceinline__ static double eval(L& c, const double* params) {
-    const double lp = c.sum([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return t; });
+    // (the sum of the terms only makes up the VALUE: skipped where the caller discards it -- every step but a trajectory's last)
+    const double lp = c.wants_logp() ? c.sum([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return t; }) : 0.0;
     c.grad([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return g; });
     return lp;
   }

@@ -15,6 +15,7 @@
 //     c.sum(f)                  sum over the spread rows d >= HEAD of f(theta_d, d), in the library's canonical
 //                               order (below); the same value in every lane of the chain
 //     c.grad_head(i, g)         d log p / d theta_i
+//     c.wants_logp()            (optional) false where the returned value is discarded: sums that only feed it may be skipped
 //     c.grad(f)                 d log p / d theta_d = f(theta_d, d) for every spread row; call it ONCE and LAST
 //                               (a trajectory context advances the row as its gradient is delivered; a sum() after
 //                               grad() traps)
@@ -171,6 +172,9 @@ struct TrajCtx {
 
   __device__ __forceinline__ i64 dims() const { return D; }
   __device__ __forceinline__ double head(int i) const { return v[i]; }
+  // whether the returned log density is used (only at a trajectory's end point): a density whose gradient needs none of the
+  // sums that make up its value may skip them otherwise
+  __device__ __forceinline__ bool wants_logp() const { return STORE || !DRIFT; }
   __device__ __forceinline__ i64 row(int u) const { return (i64)(HEAD + pos + G::off(u)); }
   __device__ __forceinline__ bool ok(int u) const { return !G::last_slot(u) || tail_ok[u / SL]; }
   __device__ __forceinline__ double metric_of(int u) const { return MTR ? mt[MTR ? u : 0] : metric[HEAD + pos + G::off(u)]; }
@@ -672,11 +676,13 @@ struct OpCtx {
   int pos;               // = wavefront index
   i64 D;
   bool on;
+  bool want_lp;          // the launch was asked for the log density (!STEP)
   CoopRed red;
   bool rows_done;
 
   __device__ __forceinline__ i64 dims() const { return D; }
   __device__ __forceinline__ double head(int i) const { return v[i]; }
+  __device__ __forceinline__ bool wants_logp() const { return !STEP && want_lp; }
   __device__ __forceinline__ i64 row(int u) const { return (i64)(HEAD + pos + G::off(u)); }
   __device__ __forceinline__ bool ok(int u) const { return !G::last_slot(u) || tail_ok[u / (SL > 0 ? SL : 1)]; }
 
@@ -780,7 +786,7 @@ __global__ __launch_bounds__(BLOCK) void k_lane_op(double* th, double* rho, doub
     }
   }
   C c{x, r, v, rv, gv, tail_ok, mvh, metric, th + col, STEP ? rho + col : nullptr, (!STEP && g) ? g + col : nullptr, ld, h, w, D, on,
-      CoopRed{part, w, lane, 0}, false};
+      logp != nullptr, CoopRed{part, w, lane, 0}, false};
   const double lp = DEN::eval(c, params);
   // (a density without a sum() has no barrier of its own: every wavefront must have read the head coordinates before
   // wavefront 0 rewrites them)

@@ -525,8 +525,8 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         model = bk.CTarget.from_source(src, D, params=lam)
         build_s = time.perf_counter() - t0
         s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
-                       # (the model-opaque step-by-step path)
-                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)
+                       # (model-opaque: the gradient a separate op per step, priced on the 56 D model like the headline)
+                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False, fuse_steps=False)
         s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             s.sample()
@@ -551,7 +551,7 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         if model.compiled is None:
             raise RuntimeError("not traced: " + str(model.compile_note))
         s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
-                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)
+                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False, fuse_steps=False)
         s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             s.sample()
@@ -571,6 +571,20 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
                                 "accept_rate": s.accept_rate(), "gradient_max_rel_err_vs_autograd": rel,
                                 "construction_s_incl_trace_hipcc_or_cache": build_s}
         del s
+        # (the same model with {gradient, kick, drift} as ONE launch per leapfrog step: 32 D bytes per chain-step
+        # instead of 56 D, so NOT on the 56 D model either)
+        h1 = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
+                        metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)
+        h1._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
+        for _ in range(warmup + 1):
+            h1.sample()
+        per_h = ctx.timed_loop(h1.sample, n) / n
+        out["traced_source"]["one_launch_per_step"] = {
+            "what": "bk_leapfrog_step: gradient + kick + drift in one streaming launch (32 D "
+                    "algorithmic bytes per chain-step)",
+            "ms_per_draw": 1e3 * per_h, "steps_per_sec": C * ctx.world * L / per_h, "step_hook": bool(h1._step_hook),
+            "hbm_frac_32D_model": C * L / per_h * 32.0 * D / 1e9 / HBM_PEAK_GBPS}
+        del h1
         f = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
                        metric_diag=torch.ones(D, dtype=torch.float64))
         f._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
