@@ -248,6 +248,8 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
                    chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused,
+                   # (the headline's path: the gradient a SEPARATE op per leapfrog step, whatever the model offers)
+                   fuse_steps=fused,
                    prefetch_rng=prefetch_rng, tune_placement=tune_placement)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)
@@ -445,11 +447,12 @@ class RankContext:
 
     def timed_loop(self, fn, steps):
         """EXACTLY `steps` calls of fn bracketed by barrier + synchronize; max over ranks."""
-        # No cyclic garbage collection inside the timed region: with PyTorch loaded a generation-2 collection is a 38-40 ms
-        # pause of the launching thread (measured: one draw's enqueue 1.5 -> 40 ms).  Mid-run the host is a draw or two ahead of
-        # the GPU and the pause is absorbed; right after the barrier it is not, and WHERE the collection lands depends on the
-        # allocation count since start-up (it moved into the first timed draw when the package grew: 38.2 -> 42 ms per draw over
-        # 10 draws, kernel times unchanged).  Collected before, switched off during, restored after.
+        # No cyclic garbage collection inside the timed region: with PyTorch loaded a generation-2 collection is a 38-40
+        # ms pause of the launching thread (measured: one draw's enqueue 1.5 -> 40 ms).  Mid-run the host is a draw or
+        # two ahead of the GPU and the pause is absorbed; right after the barrier it is not, and WHERE the collection
+        # lands depends on the allocation count since start-up (it moved into the first timed draw when the package
+        # grew: 38.2 -> 42 ms per draw over 10 draws, kernel times unchanged).  Collected before, switched off during,
+        # restored after.
         import gc
 
         gc.collect()
