@@ -72,6 +72,8 @@ SIGNATURES = {
     "bk_target_diag_gaussian_grad_n": [P, P, P, I, P, I, I, P, P],
     "bk_target_funnel_grad_n": [P, P, P, I, I, I, P, P],
     "bk_leapfrog_step_funnel": [P, P, I, P, F, I, I, P, P],
+    "bk_leapfrog_step_gaussian": [P, P, I, P, P, F, I, I, P, P],
+    "bk_dr_proposal_gaussian_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "bk_hmc_trajectory_funnel": [P, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
@@ -594,6 +596,29 @@ class Ops:
         produced level by that launch (dr_proposal_funnel(ghost0=...))."""
         return Ghost0(float(h), int(steps), ptr(parent_a), float(prob_retry), ptr(next_index) or None,
                       ptr(next_count) or None, ptr(lanes_out) or None, ptr(lanes_total) or None)
+
+    def dr_proposal_gaussian(self, lam, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                             kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
+                             ghost=None, ghost0=None):
+        """dr_proposal_funnel for the separable Gaussians (lam None: isotropic); D <= 128."""
+        D, n = theta_out.shape
+        H, hh, live = level if level is not None else (None, None, None)
+        ld_in = _ld(theta_in)
+        assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
+        ld_out = _ld(theta_out)
+        assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
+        self._call("bk_dr_proposal_gaussian_job", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
+                   ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
+                   h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live),
+                   None if job is None else ctypes.byref(job), None if ghost is None else ctypes.byref(ghost),
+                   None if ghost0 is None else ctypes.byref(ghost0), ptr(lam), self._s())
+
+    def leapfrog_step_gaussian(self, lam, theta, rho, metric, h, n_dev=None):
+        """One leapfrog step {gradient, kick, drift} on a separable Gaussian in ONE launch, theta / rho advanced in place."""
+        D, n = theta.shape
+        ld = _ld(theta)
+        assert _ld(rho) == ld
+        self._call("bk_leapfrog_step_gaussian", ptr(theta), ptr(rho), ld, ptr(lam), ptr(metric), h, n, D, ptr(n_dev), self._s())
 
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,

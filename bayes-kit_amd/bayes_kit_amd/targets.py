@@ -67,7 +67,36 @@ class _BuiltinTarget:
         return lp, g.t()
 
 
-class IsoGaussian(_BuiltinTarget):
+class _GaussianLanes:
+    """The separable Gaussians through the lane-spread kernel templates (a separable density is a lanes-form density without
+    head coordinates): one launch per delayed-rejection proposal (D <= 128) and one launch per leapfrog step."""
+
+    _FUSED_MAX_D = 128
+
+    def _lam_or_none(self, device):
+        return None
+
+    def bk_dr_proposal(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                       kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
+                       ghost=None, ghost0=None):
+        """Whole delayed-rejection proposal in one launch (arguments as Funnel.bk_dr_proposal); False if unsupported."""
+        if self._D > self._FUSED_MAX_D or max(theta_in.stride(0), theta_out.stride(0)) * 16 * 8 >= 2 ** 32:
+            return False
+        self._get_ops().dr_proposal_gaussian(self._lam_or_none(theta_in.device), theta_in, rho_in, grad_in, src_index, theta_out,
+                                             rho_out, grad_out, logp_out, kin_out, metric, h, steps, n_dev=n_dev,
+                                             lanes_out=lanes_out, lanes_total=lanes_total, level=level, job=job, ghost=ghost,
+                                             ghost0=ghost0)
+        return True
+
+    def bk_dr_proposal_supported(self) -> bool:
+        return self._D <= self._FUSED_MAX_D
+
+    def bk_leapfrog_step(self, theta, rho, metric, h, n_dev=None):
+        """One leapfrog step {gradient, kick, drift} as ONE launch, theta / rho advanced in place (any D)."""
+        self._get_ops().leapfrog_step_gaussian(self._lam_or_none(theta.device), theta, rho, metric, h, n_dev=n_dev)
+
+
+class IsoGaussian(_GaussianLanes, _BuiltinTarget):
     """logp = -1/2 theta.theta (BASELINE.json config 2)."""
 
     _kind = "iso_gaussian"
@@ -82,10 +111,13 @@ class IsoGaussian(_BuiltinTarget):
                                           lp_out, accept)
 
 
-class DiagGaussian(_BuiltinTarget):
+class DiagGaussian(_GaussianLanes, _BuiltinTarget):
     """logp = -1/2 sum_i lam_i theta_i^2 (BASELINE.json config 3)."""
 
     _kind = "diag_gaussian"
+
+    def _lam_or_none(self, device):
+        return self._lam(device)
 
     def __init__(self, lam, ops=None):
         lam_t = torch.as_tensor(lam, dtype=torch.float64)

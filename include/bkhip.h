@@ -582,6 +582,21 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                           double* H_out, double* h_out, uint8_t* live_out, const bk_scatter_job* job,
                               const bk_ghost_link* ghost, const bk_ghost0* ghost0, void* stream);
 
+/* The separable Gaussians through the same kernel templates (a separable density is a lanes-form density without head
+ * coordinates): bk_dr_proposal_funnel_job and bk_leapfrog_step_funnel for logp = -1/2 sum th*(lam*th), lam NULL = the
+ * isotropic Gaussian.  D <= 128 for the proposal (BK_E_ARG otherwise), any D for the step.  theta and rho are bit-identical to
+ * the step-by-step path; the log density is summed in the lanes' class order (csrc/bk_lanes.hpp), not in four quarters. */
+int bk_dr_proposal_gaussian_job(const double* theta_in, const double* rho_in, const double* grad_in,
+                                int64_t ld_in, const int32_t* src_index, double* theta_out,
+                                double* rho_out, double* grad_out, double* logp_out, double* kin_out,
+                                int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
+                                int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
+                                double* H_out, double* h_out, uint8_t* live_out, const bk_scatter_job* job,
+                                const bk_ghost_link* ghost, const bk_ghost0* ghost0, const double* lam,
+                                void* stream);
+int bk_leapfrog_step_gaussian(double* theta, double* rho, int64_t ld, const double* lam, const double* metric,
+                              double h, int64_t n, int64_t D, const uint32_t* n_dev, void* stream);
+
 /* ---- dense mass matrix (no reference counterpart: parity unpinned) ----------------------------
  * Y[d*ld + c] = sum_k M[d*ldm + k] * X[k*ld + c] for all chains: one fp64 GEMM on the matrix
  * cores (v_mfma_f64_16x16x4_f64), 128 x 128 workgroup tiles, XCD-aware placement.  Used for

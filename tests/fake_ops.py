@@ -373,6 +373,24 @@ class FakeOps:
     def _lanes(n, n_dev):
         return n if n_dev is None else min(int(n), int(n_dev[0]))
 
+    _prop_target = ("funnel", None)  # (which target the shared proposal body evaluates)
+
+    def dr_proposal_gaussian(self, lam, *args, **kw):
+        """bk_dr_proposal_gaussian_job: the funnel proposal's body on a separable Gaussian."""
+        keep, self._prop_target = self._prop_target, (("iso_gaussian", None) if lam is None else ("diag_gaussian", lam))
+        try:
+            self.dr_proposal_funnel(*args, **kw)
+        finally:
+            self._prop_target = keep
+
+    def leapfrog_step_gaussian(self, lam, theta, rho, metric, h, n_dev=None):
+        self._count("leapfrog_step_gaussian")
+        import torch
+
+        g = torch.zeros_like(theta)
+        self.target_grad("iso_gaussian" if lam is None else "diag_gaussian", lam, theta, g, None, n_dev=n_dev)
+        self.kick_drift(theta, theta, rho, rho, g, metric, h, False, 0.0, True, h, n_dev=n_dev)
+
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
                            ghost=None, ghost0=None):
@@ -423,10 +441,11 @@ class FakeOps:
         if n == 0:
             return
         self.first_step_gather(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, metric, h, 0.5 * h)
+        kind, params = self._prop_target
         for _ in range(steps - 1):
-            self.target_grad("funnel", None, theta_out, grad_out, None)
+            self.target_grad(kind, params, theta_out, grad_out, None)
             self.kick_drift(theta_out, theta_out, rho_out, rho_out, grad_out, metric, h, False, 0.0, True, h)
-        self.target_grad("funnel", None, theta_out, grad_out, logp_out)
+        self.target_grad(kind, params, theta_out, grad_out, logp_out)
         self.leapfrog_finish(rho_out, rho_out, grad_out, metric, 0.5 * h, True, kin_out)
         if level is not None:
             self.dr_level_begin(lvl_logp, lvl_kin, level[0], level[1], level[2], n)

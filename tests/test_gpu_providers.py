@@ -118,8 +118,9 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     assert pairs[2][1]._dev_counts and pairs[2][1]._use_graph and pairs[2][1]._one_launch and pairs[2][1].host_syncs_per_draw == 0
     assert pairs[3][1]._step_hook and not pairs[3][1]._one_launch and not pairs[4][1]._step_hook
     for i, (a, b) in enumerate(pairs):
-        if i >= 3:   # (pairs 3, 4 share their reference sampler with pair 2: a fresh one)
-            a = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5)
+        if i >= 3:   # (pairs 3, 4 share their reference sampler with pair 2: a fresh one, stepping with the gradient op)
+            a = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False,
+                              fuse_steps=False)
         for n in range(8):
             ta, la = a.sample()
             tb, lb = b.sample()

@@ -1064,21 +1064,33 @@ def test_drghmc_model_opaque_device_counts_equal_host_sized_and_one_launch(ops, 
 
 
 def test_drghmc_counted_steps_on_gaussians_with_metric(ops):
-    """The counted step-by-step draw on the targets without a one-launch proposal (iso / diag Gaussian, with a
-    diagonal metric, without probabilistic retry) against the host-sized path; odd and even chain counts."""
-    for C, D in ((257, 16), (1024, 33)):
+    """The counted step-by-step draw on the separable Gaussians (with a diagonal metric, without probabilistic retry) --
+    gradient a separate op, and {gradient, kick, drift} one launch per step -- against the host-sized path, bit for bit; and
+    (round 5: a separable density is a lanes-form density without head coordinates) the one-launch proposals: same draws, the
+    joint log density to rounding (summed in the lanes' order); odd and even chain counts; D past 128 has no one-launch kernel."""
+    for C, D in ((257, 16), (1024, 33), (130, 200)):
         lam, met = np.linspace(0.5, 3.0, D), np.linspace(0.8, 1.3, D)
         for model, kw in ((lambda: bk.DiagGaussian(lam), dict(metric_diag=met)), (lambda: bk.IsoGaussian(D), dict(prob_retry=False))):
             mk = lambda **k2: bk.DrGhmcDiag(model(), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, chains=C, seed=3, **kw, **k2)  # noqa: E731
-            a, g = mk(device_counts=False), mk()
-            assert g._dev_counts and g._use_graph and not g._one_launch and not a._dev_counts
+            a = mk(device_counts=False, fuse_builtin=False, fuse_steps=False)
+            g = mk(fuse_builtin=False, fuse_steps=False)
+            h = mk(fuse_builtin=False)
+            f = mk()
+            assert g._dev_counts and g._use_graph and not g._one_launch and not a._dev_counts and h._step_hook and not g._step_hook
+            assert f._one_launch == (D <= 128) and f._dev_counts
             for n in range(10):
                 ta, la = a.sample()
                 tg, lg = g.sample()
+                th_, lh = h.sample()
+                tf, lf = f.sample()
                 assert torch.equal(ta, tg) and torch.equal(la, lg), (C, D, n)
-                assert a.last_stage_lanes == g.last_stage_lanes
-            assert torch.equal(a._rho, g._rho)
+                assert torch.equal(ta, th_) and torch.equal(la, lh), (C, D, n)
+                assert torch.equal(ta, tf), (C, D, n)
+                torch.testing.assert_close(la, lf, rtol=1e-12, atol=1e-12)
+                assert a.last_stage_lanes == g.last_stage_lanes == f.last_stage_lanes
+            assert torch.equal(a._rho, g._rho) and torch.equal(a._rho, f._rho)
             np.testing.assert_array_equal(a.rng_state(), g.rng_state())
+            np.testing.assert_array_equal(a.rng_state(), f.rng_state())
 
 
 def test_checkpoint_of_sampler_moments_recorder_and_draw_store(ops, tmp_path):

@@ -470,19 +470,27 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
 
 
 def test_drghmc_counted_steps_on_a_gaussian_with_metric_equal_host_sized_launches():
-    """The same for a target without a one-launch proposal (DiagGaussian), a diagonal metric and no
-    probabilistic retry: the counted step-by-step draw against the host-sized, stably compacted one."""
+    """The same on DiagGaussian with a diagonal metric and no probabilistic retry: the counted step-by-step draw (gradient a
+    separate op, and {gradient, kick, drift} as one launch per step) and the one-launch proposals (round 5: a separable density
+    is a lanes-form density without head coordinates) against the host-sized, stably compacted draw."""
     lam = np.linspace(0.5, 3.0, 9)
     met = np.linspace(0.8, 1.3, 9)
-    mk = lambda ops, dc: bk.DrGhmcDiag(bk.DiagGaussian(lam, ops=ops), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, metric_diag=met,
-                                       chains=33, seed=3, prob_retry=False, device_counts=dc, ops=ops)
-    a, o = mk(FakeOps(), False), mk(FakeOps(), True)
-    assert o._dev_counts and not o._one_launch and not a._dev_counts
+    mk = lambda ops, dc, **kw: bk.DrGhmcDiag(bk.DiagGaussian(lam, ops=ops), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, metric_diag=met,  # noqa: E731
+                                             chains=33, seed=3, prob_retry=False, device_counts=dc, ops=ops, **kw)
+    a = mk(FakeOps(), False, fuse_builtin=False, fuse_steps=False)
+    o = mk(FakeOps(), True, fuse_builtin=False, fuse_steps=False)
+    h = mk(FakeOps(), True, fuse_builtin=False)
+    f = mk(FakeOps(), True)
+    assert o._dev_counts and not o._one_launch and not a._dev_counts and h._step_hook and not o._step_hook and f._one_launch
     for n in range(12):
         ta, la = a.sample()
         to, lo = o.sample()
         assert np.array_equal(ta.numpy(), to.numpy()) and np.array_equal(la.numpy(), lo.numpy()), n
         assert a.last_stage_lanes == o.last_stage_lanes
+        for s_ in (h, f):
+            ts, ls = s_.sample()
+            assert np.array_equal(ta.numpy(), ts.numpy()) and np.array_equal(la.numpy(), ls.numpy()), n
+            assert a.last_stage_lanes == s_.last_stage_lanes
     assert np.array_equal(a._rho.numpy(), o._rho.numpy())
     np.testing.assert_array_equal(a.rng_state(), o.rng_state())
 
