@@ -472,10 +472,10 @@ struct BkSrcLanesFromTerm {
 };
 constexpr int BK_SRC_SL = %(sl)d;  // slots per class for this D (0: D > 128)
 }  // namespace
+// (the step of a separable density needs no sums: the streaming elementwise kernel, every (d, c) element on its own)
 extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
                                     int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
-  return bkl::step_launch<BkSrcLanesFromTerm, BK_SRC_SL>(theta, rho, ld, metric, h, static_cast<const double*>(params), n, D,
-                                                         n_dev, stream);
+  return bke::step_launch<BkSrcTerm>(theta, rho, ld, static_cast<const double*>(params), metric, h, n, D, n_dev, stream);
 }
 #if %(sl)d > 0
 extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,

@@ -205,6 +205,102 @@ __global__ __launch_bounds__(256) void k_quarter_sums(const double* part, double
   }
 }
 
+// One leapfrog step {gradient, kick, drift} (hmc.py:48-50, drghmc.py:280-283) of a separable density as ONE streaming launch:
+// rho += h * (metric * grad(theta)); theta += h * rho, in place.  Every element is independent: two chains (16 B) per lane,
+// ROWS rows per thread; 32 D algorithmic bytes per chain-step (read and write theta and rho) instead of the 56 D of a gradient
+// launch followed by bk_leapfrog_kick_drift, the same arithmetic (bit-identical), half the launches.
+template <class TERM, int ROWS, bool HM, bool NT>
+__global__ __launch_bounds__(BLOCK) void k_step(double* th, double* rho, i64 ld, const double* params, const double* metric,
+                                                double h, i64 C2, i64 D) {
+  const i64 c2 = (i64)blockIdx.x * BLOCK + threadIdx.x;
+  const i64 d0 = (i64)blockIdx.y * ROWS;
+  if (c2 >= C2) return;
+  dvec2 t[ROWS], r[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+    if (d0 + i < D) {
+      const dvec2* pt = reinterpret_cast<const dvec2*>(th + (d0 + i) * ld + 2 * c2);
+      const dvec2* pr = reinterpret_cast<const dvec2*>(rho + (d0 + i) * ld + 2 * c2);
+      t[i] = NT ? __builtin_nontemporal_load(pt) : *pt;
+      r[i] = NT ? __builtin_nontemporal_load(pr) : *pr;
+    }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+    if (d0 + i < D) {
+      double term, gx, gy;
+      TERM::eval(t[i].x, d0 + i, params, term, gx);
+      TERM::eval(t[i].y, d0 + i, params, term, gy);
+      const double m = HM ? metric[d0 + i] : 1.0;
+      const double tx = HM ? m * gx : gx, ty = HM ? m * gy : gy;
+      r[i].x = r[i].x + h * tx;
+      r[i].y = r[i].y + h * ty;
+      t[i].x = t[i].x + h * r[i].x;
+      t[i].y = t[i].y + h * r[i].y;
+      dvec2* qt = reinterpret_cast<dvec2*>(th + (d0 + i) * ld + 2 * c2);
+      dvec2* qr = reinterpret_cast<dvec2*>(rho + (d0 + i) * ld + 2 * c2);
+      if (NT) {
+        __builtin_nontemporal_store(r[i], qr);
+        __builtin_nontemporal_store(t[i], qt);
+      } else {
+        *qr = r[i];
+        *qt = t[i];
+      }
+    }
+}
+
+// one chain per lane: odd shapes, unaligned views, and every launch whose chain count lives on the device
+template <class TERM>
+__global__ __launch_bounds__(BLOCK) void k_step_s(double* th, double* rho, i64 ld, const double* params, const double* metric,
+                                                  double h, i64 C_host, i64 D, const uint32_t* n_dev) {
+  const i64 C = bk_lanes(C_host, n_dev);
+  const i64 c = (i64)blockIdx.x * BLOCK + threadIdx.x, d0 = (i64)blockIdx.y * 4;
+  if (c >= C) return;
+  double t[4], r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (d0 + i < D) {
+      t[i] = th[(d0 + i) * ld + c];
+      r[i] = rho[(d0 + i) * ld + c];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (d0 + i < D) {
+      double term, g;
+      TERM::eval(t[i], d0 + i, params, term, g);
+      const double tt = metric ? metric[d0 + i] * g : g;
+      r[i] = r[i] + h * tt;
+      rho[(d0 + i) * ld + c] = r[i];
+      th[(d0 + i) * ld + c] = t[i] + h * r[i];
+    }
+}
+
+// Host side: theta, rho [D][ld] advanced in place by one leapfrog step of size h over min(n, *n_dev) chains.
+template <class TERM>
+static int step_launch(double* theta, double* rho, int64_t ld, const double* params, const double* metric, double h, int64_t n,
+                       int64_t D, const uint32_t* n_dev, void* stream) {
+  if (!theta || !rho || n < 0 || D < 0) return BK_E_ARG;
+  if (ld < n) return BK_E_ALIGN;
+  if (n == 0 || D == 0) return BK_OK;
+  hipStream_t s = bk_stream(stream);
+  const bool vec = !n_dev && n % 2 == 0 && ld % 2 == 0 && bk_aligned16(theta) && bk_aligned16(rho);
+  if (vec) {
+    const bool nt = bk_streams_past_llc(4 * n * D) && D <= 65535;
+    if (nt) {
+      dim3 grid((unsigned)bk_cdiv(n / 2, BLOCK), (unsigned)D);
+      if (metric) k_step<TERM, 1, true, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+      else k_step<TERM, 1, false, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+    } else {
+      dim3 grid((unsigned)bk_cdiv(n / 2, BLOCK), (unsigned)bk_cdiv(D, 2));
+      if (metric) k_step<TERM, 2, true, false><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+      else k_step<TERM, 2, false, false><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+    }
+  } else {
+    dim3 grid((unsigned)bk_cdiv(n, BLOCK), (unsigned)bk_cdiv(D, 4));
+    k_step_s<TERM><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n, D, n_dev);
+  }
+  BK_RETURN_LAUNCH_STATUS();
+}
+
 // Host side of bk_hmc_trajectory_gaussian for any separable density (include/bkhip.h documents the arguments).
 template <class TERM>
 static int hmc_trajectory_launch(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out, int64_t ld,

@@ -5,6 +5,7 @@
 // for bit (the gradient is elementwise); the log density is the same terms summed in the lanes' class order instead of four
 // contiguous quarters (bk_target_*_gaussian_grad): last-bit differences.  A translation unit of its own: 130 kernel variants.
 #include "bk_common.hpp"
+#include "bk_elementwise.hpp"
 #include "bk_lanes.hpp"
 
 namespace {
@@ -19,6 +20,16 @@ struct GaussLanes {
     c.grad([lam](double x, i64 d) { const double lt = HL ? lam[d] * x : x; return -lt; });
     return -0.5 * s;
   }
+};
+
+template <bool HL>
+struct GaussStepTerm {
+  __device__ __forceinline__ static void eval(double th, i64 d, const double* lam, double& term, double& grad) {
+    const double lt = HL ? lam[d] * th : th;
+    term = th * lt;
+    grad = -lt;
+  }
+  __device__ __forceinline__ static double finish(double s) { return -0.5 * s; }
 };
 
 }  // namespace
@@ -41,10 +52,12 @@ int bk_dr_proposal_gaussian_job(const double* theta_in, const double* rho_in, co
                                                     lanes_total, H_out, h_out, live_out, job, ghost, ghost0, nullptr, stream);
 }
 
+// (the step of a separable density needs no sums: the streaming elementwise kernel of bk_elementwise.hpp, every (d, c) element
+// on its own -- 32 D bytes per chain-step -- rather than the lanes template's workgroup-per-64-chains op)
 int bk_leapfrog_step_gaussian(double* theta, double* rho, int64_t ld, const double* lam, const double* metric, double h,
                               int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
-  if (lam) return bkl::step_launch<GaussLanes<true>>(theta, rho, ld, metric, h, lam, n, D, n_dev, stream);
-  return bkl::step_launch<GaussLanes<false>>(theta, rho, ld, metric, h, nullptr, n, D, n_dev, stream);
+  if (lam) return bke::step_launch<GaussStepTerm<true>>(theta, rho, ld, lam, metric, h, n, D, n_dev, stream);
+  return bke::step_launch<GaussStepTerm<false>>(theta, rho, ld, nullptr, metric, h, n, D, n_dev, stream);
 }
 
 }  // extern "C"

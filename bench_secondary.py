@@ -23,9 +23,12 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
            "bound": "launch/latency",
            "note": "4 MiB arrays live in L2 / Infinity Cache: an HBM fraction is not meaningful; us per leapfrog step "
                    "of all chains is the figure"}
-    for name, fused in (("model_opaque", False), ("fused_builtin", True)):
+    # model_opaque: the gradient a separate op per leapfrog step; one_launch_per_step: {gradient, kick, drift} one
+    # launch (bk_leapfrog_step_gaussian); fused_builtin: the whole draw in registers
+    for name, fused, steps_fused in (("model_opaque", False, False), ("one_launch_per_step", False, True),
+                                     ("fused_builtin", True, True)):
         s = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
-                       chains=C, chain_id0=ctx.rank * C, fuse_builtin=fused)
+                       chains=C, chain_id0=ctx.rank * C, fuse_builtin=fused, fuse_steps=steps_fused)
         for _ in range(warmup):
             s.sample()
         el = ctx.timed_loop(s.sample, steps)
