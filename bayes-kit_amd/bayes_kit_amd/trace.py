@@ -9,9 +9,12 @@ expression symbolically (forward mode, one variable) and emits the ``bk_term`` s
 anything outside the supported set raises ``Unsupported`` naming the node, and ``TorchModel`` then keeps autograd.
 
 Supported: + - * / neg, ``**`` with a constant exponent or a constant base, exp, log, log1p, expm1, sigmoid, logsigmoid,
-softplus (beta = 1), tanh, sqrt, square, abs, sin, cos; tensor constants that broadcast along the coordinate axis
-(shape (D,) / (1, D) for the (C, D) layout, (D, 1) for the (D, C) layout) or are scalars; one ``sum`` over the coordinate
-axis per additive part; scalar multiples and sums of such parts after the sum.
+softplus (beta = 1), tanh, sinh, cosh, atan, erf, sqrt, rsqrt, reciprocal, square, abs, sin, cos; tensor constants that broadcast
+along the coordinate axis (shape (D,) / (1, D) for the (C, D) layout, (D, 1) for the (D, C) layout) or are scalars; one ``sum`` /
+``mean`` over the coordinate axis per additive part; scalar multiples and sums of such parts after the sum; ``.shape`` /
+``.size()`` of the coordinate axis; ``torch.broadcast_tensors``.  That set covers ``torch.distributions`` log_prob bodies such as
+Normal, StudentT, Laplace, Cauchy, Logistic with constant parameters (argument validation is data-dependent control flow, so it
+is switched off while the function is being read).
 """
 from __future__ import annotations
 
@@ -45,8 +48,13 @@ class _Chain:
 
 
 _UNARY = {"neg", "exp", "log", "log1p", "expm1", "sigmoid", "logsigmoid", "softplus", "tanh", "sqrt", "square", "abs", "sin",
-          "cos"}
-_BINARY = {"add", "sub", "mul", "div", "pow"}
+          "cos", "sinh", "cosh", "atan", "erf"}
+_HOST_UNARY = {"exp": math.exp, "log": math.log, "log1p": math.log1p, "expm1": math.expm1, "tanh": math.tanh, "sqrt": math.sqrt,
+               "square": lambda t: t * t, "abs": abs, "sin": math.sin, "cos": math.cos, "sinh": math.sinh, "cosh": math.cosh,
+               "atan": math.atan, "erf": math.erf, "neg": lambda t: -t}
+TWO_OVER_SQRT_PI = 2.0 / math.sqrt(math.pi)
+_BINARY = {"add", "sub", "mul", "div", "pow", "gt", "ge", "lt", "le", "maximum", "minimum"}
+_COMPARE = {"gt": ">", "ge": ">=", "lt": "<", "le": "<="}  # values 1.0 / 0.0; only ever the condition of a `where`
 
 
 def _function_table():
@@ -58,15 +66,64 @@ def _function_table():
         torch.negative: "neg", torch.exp: "exp", torch.log: "log", torch.log1p: "log1p", torch.expm1: "expm1",
         torch.sigmoid: "sigmoid", torch.special.expit: "sigmoid", F.sigmoid: "sigmoid", F.logsigmoid: "logsigmoid",
         F.softplus: "softplus", torch.tanh: "tanh", F.tanh: "tanh", torch.sqrt: "sqrt", torch.square: "square",
-        torch.pow: "pow", torch.abs: "abs", torch.sin: "sin", torch.cos: "cos", torch.sum: "sum",
+        torch.pow: "pow", torch.abs: "abs", torch.sin: "sin", torch.cos: "cos", torch.sum: "sum", torch.mean: "mean",
+        torch.sinh: "sinh", torch.cosh: "cosh", torch.atan: "atan", torch.arctan: "atan", torch.erf: "erf",
+        torch.special.erf: "erf", torch.reciprocal: "reciprocal", torch.rsqrt: "rsqrt", torch.special.log1p: "log1p",
+        torch.special.expm1: "expm1", torch.broadcast_tensors: "broadcast_tensors", getattr: "getattr",
+        operator.getitem: "getitem", torch.absolute: "abs", operator.gt: "gt", operator.ge: "ge", operator.lt: "lt",
+        operator.le: "le", torch.gt: "gt", torch.ge: "ge", torch.lt: "lt", torch.le: "le", torch.where: "where",
+        torch.maximum: "maximum", torch.minimum: "minimum", torch.relu: "relu", F.relu: "relu", torch.clamp: "clamp",
+        torch.clip: "clamp",
     }
     return t
 
 
+class no_distribution_validation:
+    """torch.distributions validates its arguments with data-dependent control flow (``if not valid.all(): raise``), which no
+    tracer can read; validation is off while the function is traced and restored afterwards."""
+
+    def __enter__(self):
+        from torch.distributions import Distribution
+
+        self.old = Distribution._validate_args
+        Distribution.set_default_validate_args(False)
+
+    def __exit__(self, *exc):
+        from torch.distributions import Distribution
+
+        Distribution.set_default_validate_args(self.old)
+        return False
+
+
 _METHODS = {"add": "add", "sub": "sub", "mul": "mul", "div": "div", "true_divide": "div", "neg": "neg", "exp": "exp",
             "log": "log", "log1p": "log1p", "expm1": "expm1", "sigmoid": "sigmoid", "tanh": "tanh", "sqrt": "sqrt",
-            "square": "square", "pow": "pow", "abs": "abs", "sin": "sin", "cos": "cos", "sum": "sum", "double": "id",
-            "float": None, "contiguous": "id", "clone": "id"}
+            "square": "square", "pow": "pow", "abs": "abs", "sin": "sin", "cos": "cos", "sum": "sum", "mean": "mean", "double": "id",
+            "float": None, "contiguous": "id", "clone": "id", "sinh": "sinh", "cosh": "cosh", "atan": "atan", "arctan": "atan",
+            "erf": "erf", "reciprocal": "reciprocal", "rsqrt": "rsqrt", "size": "size", "absolute": "abs", "gt": "gt", "ge": "ge",
+            "lt": "lt", "le": "le", "where": "where_method", "maximum": "maximum", "minimum": "minimum", "relu": "relu",
+            "clamp": "clamp", "clip": "clamp", "clamp_min": "clamp_min", "clamp_max": "clamp_max"}
+
+
+def piecewise_rewrite(name, args, kwargs, where):
+    """relu / clamp / x.where(...) as (operation, operands) over {where, maximum, minimum}; None for any other name."""
+    if name == "where_method":  # x.where(cond, other) == torch.where(cond, x, other)
+        if len(args) != 3:
+            raise Unsupported(f"{where}: where with {len(args)} operands")
+        return "where", [args[1], args[0], args[2]]
+    if name == "relu":
+        return "maximum", [args[0], 0.0]
+    if name in ("clamp", "clamp_min", "clamp_max"):
+        lo = kwargs.get("min", args[1] if len(args) > 1 and name != "clamp_max" else None)
+        hi = kwargs.get("max", args[1] if len(args) > 1 and name == "clamp_max" else (args[2] if len(args) > 2 else None))
+        for b in (lo, hi):
+            if b is not None and not isinstance(b, (int, float)):
+                raise Unsupported(f"{where}: clamp bounds must be Python numbers")
+        if lo is None and hi is None:
+            raise Unsupported(f"{where}: clamp without bounds")
+        if lo is not None and hi is not None:
+            return "minimum", [("maximum", [args[0], float(lo)]), float(hi)]
+        return ("maximum", [args[0], float(lo)]) if lo is not None else ("minimum", [args[0], float(hi)])
+    return None
 
 
 class _Tracer:
@@ -108,19 +165,16 @@ class _Tracer:
     # -- elementwise algebra with light constant folding -----------------------------------------------------------------
     def unary(self, op, a):
         if a.op == "c":
-            x = a.args[0]
             try:
-                f = {"neg": lambda: -x, "exp": lambda: math.exp(x), "log": lambda: math.log(x), "log1p": lambda: math.log1p(x),
-                     "expm1": lambda: math.expm1(x), "tanh": lambda: math.tanh(x), "sqrt": lambda: math.sqrt(x),
-                     "square": lambda: x * x, "abs": lambda: abs(x), "sin": lambda: math.sin(x), "cos": lambda: math.cos(x)}.get(op)
+                f = _HOST_UNARY.get(op)
                 if f is not None:
-                    return _const(f())
+                    return _const(f(a.args[0]))
             except (ValueError, OverflowError):
                 pass
         return _E(op, (a,), a.dep)
 
     def binary(self, op, a, b):
-        if a.op == "c" and b.op == "c":
+        if a.op == "c" and b.op == "c" and op in ("add", "sub", "mul", "div", "pow"):
             x, y = a.args[0], b.args[0]
             try:
                 return _const({"add": x + y, "sub": x - y, "mul": x * y, "div": x / y if y != 0 else float("nan"),
@@ -151,7 +205,8 @@ class _Tracer:
         import torch.fx as fx
 
         try:
-            gm = fx.symbolic_trace(fn)
+            with no_distribution_validation():
+                gm = fx.symbolic_trace(fn)
         except Exception as e:  # data-dependent control flow, in-place tricks, ...
             raise Unsupported(f"torch.fx could not trace the function: {type(e).__name__}: {e}") from e
         table = _function_table()
@@ -162,6 +217,8 @@ class _Tracer:
             where = f"node `{node.format_node()}`"
 
             def val(a):
+                if isinstance(a, (tuple, list)):
+                    return type(a)(val(x) for x in a)
                 return env[a] if isinstance(a, fx.Node) else a
 
             if node.op == "placeholder":
@@ -192,9 +249,41 @@ class _Tracer:
             raise Unsupported("the log density does not depend on theta")
         return out
 
+    def shape_of(self, v, where):
+        """The shape of a traced value with the chain count unknown (None: using it in arithmetic is an error)."""
+        if isinstance(v, _E) and v.dep:
+            return (self.D, None) if self.dc else (None, self.D)
+        if isinstance(v, _Chain):
+            return (None,)
+        if isinstance(v, torch.Tensor):
+            return tuple(v.shape)
+        raise Unsupported(f"{where}: shape of a value the tracer does not follow")
+
     def apply(self, name, args, kwargs, where):
         if name == "id":
             return args[0]
+        if name == "broadcast_tensors":  # (torch.distributions' broadcast_all): the operands themselves; every operation
+            return tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list)) else tuple(args)  # broadcasts anyway
+        if name == "getitem":
+            src, idx = args
+            if isinstance(src, (tuple, list)) and isinstance(idx, int):
+                return src[idx]
+            raise Unsupported(f"{where}: unsupported operation 'getitem' (indexing theta couples coordinates: not elementwise)")
+        if name == "getattr":
+            if args[1] == "shape":
+                return self.shape_of(args[0], where)
+            raise Unsupported(f"{where}: attribute {args[1]!r}")
+        if name == "size":
+            shp = self.shape_of(args[0], where)
+            return shp if len(args) == 1 else shp[args[1]]
+        if name in ("reciprocal", "rsqrt"):
+            if len(args) != 1 or kwargs:
+                raise Unsupported(f"{where}: {name} with extra arguments")
+            a = self.as_elem(args[0], where)
+            return self.binary("div", _const(1.0), a if name == "reciprocal" else self.unary("sqrt", a))
+        if name == "mean":
+            s = self.apply("sum", args, kwargs, where)
+            return self.chain_op("div", [s, float(self.D)], where)
         if name == "sum":
             x = args[0]
             dim = args[1] if len(args) > 1 else kwargs.get("dim", kwargs.get("axis"))
@@ -208,7 +297,10 @@ class _Tracer:
                 raise Unsupported(f"{where}: the sum must run over the coordinate axis only "
                                   f"(dim={'0' if self.dc else '1'}), got dim={dim!r}")
             return _Chain(x, 0.0)
-        if kwargs and not (name == "softplus" and set(kwargs) <= {"beta", "threshold"}):
+        if name == "relu" and kwargs.get("inplace") is False:
+            kwargs = {}
+        if kwargs and not (name == "softplus" and set(kwargs) <= {"beta", "threshold"}) \
+                and not (name.startswith("clamp") and set(kwargs) <= {"min", "max"}):
             raise Unsupported(f"{where}: keyword arguments {sorted(kwargs)}")
         if name == "softplus":
             beta = kwargs.get("beta", args[1] if len(args) > 1 else 1.0)
@@ -216,9 +308,20 @@ class _Tracer:
             if float(beta) != 1.0 or float(thr) != 20.0:
                 raise Unsupported(f"{where}: softplus with beta / threshold other than the defaults")
             args = args[:1]
+        rw = piecewise_rewrite(name, args, kwargs, where)
+        if rw is not None:
+            inner = [self.apply(a[0], a[1], {}, where) if isinstance(a, tuple) else a for a in rw[1]]
+            return self.apply(rw[0], inner, {}, where)
         chains = [a for a in args if isinstance(a, _Chain)]
         if chains:
             return self.chain_op(name, args, where)
+        if name == "where":
+            if len(args) != 3:
+                raise Unsupported(f"{where}: where with {len(args)} operands")
+            c, a, b = (self.as_elem(v, where) for v in args)
+            if c.op not in _COMPARE:
+                raise Unsupported(f"{where}: the condition of `where` must be a comparison (> >= < <=)")
+            return _E("where", (c, a, b), c.dep or a.dep or b.dep)
         if name in _UNARY:
             if len(args) != 1:
                 raise Unsupported(f"{where}: {name} with {len(args)} operands")
@@ -307,6 +410,12 @@ class _Emit:
         if op in _UNARY:
             a, da = self.gen(e.args[0])
             return self.unary(op, a, da)
+        if op == "where":
+            (c, _), (a, da), (b, db) = (self.gen(x) for x in e.args)
+            v = self.tmp(f"({c} != 0.0) ? {a} : {b}")
+            if da is None and db is None:
+                return v, None
+            return v, self.tmp(f"({c} != 0.0) ? {da or '0.0'} : {db or '0.0'}")
         a, da = self.gen(e.args[0])
         b, db = self.gen(e.args[1])
         return self.binary(op, a, da, b, db, e)
@@ -355,6 +464,14 @@ class _Emit:
             return T(f"sin({a})"), (None if da is None else self.mul(T(f"cos({a})"), da))
         if op == "cos":
             return T(f"cos({a})"), (None if da is None else self.mul(T(f"-sin({a})"), da))
+        if op == "sinh":
+            return T(f"sinh({a})"), (None if da is None else self.mul(T(f"cosh({a})"), da))
+        if op == "cosh":
+            return T(f"cosh({a})"), (None if da is None else self.mul(T(f"sinh({a})"), da))
+        if op == "atan":
+            return T(f"atan({a})"), (None if da is None else T(f"{da} / (1.0 + {a} * {a})"))
+        if op == "erf":
+            return T(f"erf({a})"), (None if da is None else self.mul(T(f"{_lit(TWO_OVER_SQRT_PI)} * exp(-({a} * {a}))"), da))
         raise AssertionError(op)
 
     def binary(self, op, a, da, b, db, e):
@@ -387,6 +504,15 @@ class _Emit:
             if da is None:
                 return v, T(f"-({v} * {db}) / {b}")
             return v, T(f"({da} - {v} * {db}) / {b}")
+        if op in _COMPARE:
+            return T(f"(double)({a} {_COMPARE[op]} {b})"), None
+        if op in ("maximum", "minimum"):  # torch: the derivative goes to the selected operand (ties: split evenly)
+            cmp = ">" if op == "maximum" else "<"
+            v = T(f"f{'max' if op == 'maximum' else 'min'}({a}, {b})")
+            if da is None and db is None:
+                return v, None
+            da, db = da or "0.0", db or "0.0"
+            return v, T(f"({a} {cmp} {b}) ? {da} : (({a} == {b}) ? 0.5 * ({da} + {db}) : {db})")
         if op == "pow":
             v = T(f"pow({a}, {b})")
             if da is None and db is None:

@@ -4,10 +4,11 @@
 
     log p(theta) = F( h_0 .. h_{H-1},  S_0 .. S_{K-1} ),      S_k = sum over rows d >= H of e_k(theta_d, h, params_d)
 
-i.e. a few leading "head" coordinates taken by integer index (``Th[:, 0]``), the remaining rows taken as ONE slice
-(``Th[:, H:]``), elementwise expressions of the rows that may use head-derived per-chain values broadcast with ``[:, None]``,
-sums of those over the row axis, and any scalar expression of heads and sums at the end.  Neal's funnel, hierarchical
-normal / logistic models with shared location and scale, are of this shape.
+i.e. a few leading "head" coordinates taken by integer index (``Th[:, 0]``), the remaining rows taken as slices (``Th[:, H:]``, or
+several groups ``Th[:, a:b]`` -- each sum then runs over its own group; ``Th`` itself when there are no heads), elementwise
+expressions of the rows that may use head-derived per-chain values broadcast with ``[:, None]``, sums (means) of those over the
+row axis, and any scalar expression of heads and sums at the end.  Neal's funnel, hierarchical normal / logistic models with shared
+location and scale -- written with arithmetic or with ``torch.distributions`` log_prob calls -- are of this shape.
 
 The function is read once with ``torch.fx`` into a hash-consed expression DAG, differentiated SYMBOLICALLY
 
@@ -25,7 +26,8 @@ import operator
 
 import torch
 
-from .trace import Unsupported, _function_table, _METHODS, _UNARY, _BINARY, _lit
+from .trace import (Unsupported, _function_table, _METHODS, _UNARY, _BINARY, _COMPARE, _HOST_UNARY, TWO_OVER_SQRT_PI, _lit,
+                    no_distribution_validation, piecewise_rewrite)
 
 
 # ---- hash-consed expression DAG ------------------------------------------------------------------------------------------
@@ -37,7 +39,8 @@ class _N:
 
 
 class _Dag:
-    """Nodes: ('c', value) | ('x',) row value | ('p', k) row constant | ('h', i) head | ('S', k) sum | (op, *children)."""
+    """Nodes: ('c', value) | ('x',) row value | ('p', k) row constant | ('h', i) head | ('S', k) sum | (op, *children) |
+    ('sel', e, lo, hi): e on the rows lo <= d < hi, 0 elsewhere."""
 
     def __init__(self):
         self.table = {}
@@ -54,6 +57,8 @@ class _Dag:
                       "S": frozenset({("S", args[0])} if op == "S" else ())}[op]
             else:
                 vs = frozenset().union(*[a.vars for a in args if isinstance(a, _N)])
+                if op == "sel":
+                    vs = vs | {"row"}  # (lives in a row lambda even when e is a constant: it reads the row index)
             n = _N(op, args, vs, len(self.table))
             self.table[key] = n
         return n
@@ -114,15 +119,20 @@ class _Dag:
         if op == "neg":
             return self.neg(a)
         if a.op == "c":
-            x = a.args[0]
             try:
-                f = {"exp": math.exp, "log": math.log, "log1p": math.log1p, "expm1": math.expm1, "tanh": math.tanh, "sqrt": math.sqrt,
-                     "square": lambda t: t * t, "abs": abs, "sin": math.sin, "cos": math.cos}.get(op)
+                f = _HOST_UNARY.get(op)
                 if f is not None:
-                    return self.const(f(x))
+                    return self.const(f(a.args[0]))
             except (ValueError, OverflowError):
                 pass
         return self.mk(op, a)
+
+    def sel(self, e, lo, hi):
+        if self.is_c(e, 0.0):
+            return e
+        if e.op == "sel" and e.args[1:] == (lo, hi):
+            return e
+        return self.mk("sel", e, lo, hi)
 
     def bin(self, op, a, b):
         if op == "add":
@@ -146,7 +156,14 @@ class _Dag:
                 if a.op == "c":
                     return self.const(a.args[0] ** b.args[0])
             return self.mk("pow", a, b)
+        if op in _COMPARE or op in ("maximum", "minimum"):
+            return self.mk(op, a, b)
         raise AssertionError(op)
+
+    def where(self, c, a, b):
+        if a is b:
+            return a
+        return self.mk("where", c, a, b)
 
     # -- symbolic derivative with respect to one variable -------------------------------------------------------------------
     def diff(self, e, var, memo=None):
@@ -166,6 +183,18 @@ class _Dag:
         if op in ("x", "h", "S"):
             return one
         d = lambda a: self.diff(a, var, memo)  # noqa: E731
+        if op == "sel":
+            return self.sel(d(e.args[0]), e.args[1], e.args[2])
+        if op == "where":
+            return self.where(e.args[0], d(e.args[1]), d(e.args[2]))
+        if op in ("maximum", "minimum"):  # torch: the derivative goes to the selected operand (ties: split evenly)
+            a, b = e.args
+            da, db = d(a), d(b)
+            first = self.mk("gt" if op == "maximum" else "lt", a, b)
+            tie = self.mul(self.const(0.5), self.add(da, db))
+            return self.where(first, da, self.where(self.mk("ge" if op == "maximum" else "le", a, b), tie, db))
+        if op in _COMPARE:
+            return zero
         if op == "add":
             return self.add(d(e.args[0]), d(e.args[1]))
         if op == "sub":
@@ -209,6 +238,14 @@ class _Dag:
             return self.mul(self.mk("cos", a), da)
         if op == "cos":
             return self.neg(self.mul(self.mk("sin", a), da))
+        if op == "sinh":
+            return self.mul(self.mk("cosh", a), da)
+        if op == "cosh":
+            return self.mul(self.mk("sinh", a), da)
+        if op == "atan":
+            return self.div(da, self.add(one, self.mul(a, a)))
+        if op == "erf":
+            return self.mul(self.mul(self.const(TWO_OVER_SQRT_PI), self.mk("exp", self.neg(self.mul(a, a)))), da)
         if op == "pow":
             b = e.args[1]
             if not b.vars:  # a^c
@@ -220,14 +257,17 @@ class _Dag:
 _C_UNARY = {"exp": "exp({a})", "log": "log({a})", "log1p": "log1p({a})", "expm1": "expm1({a})", "sigmoid": "1.0 / (1.0 + exp(-{a}))",
             "logsigmoid": "fmin({a}, 0.0) - log1p(exp(-fabs({a})))", "softplus": "({a} > 20.0) ? {a} : log1p(exp({a}))",
             "tanh": "tanh({a})", "sqrt": "sqrt({a})", "square": "{a} * {a}", "abs": "fabs({a})", "sin": "sin({a})", "cos": "cos({a})",
-            "neg": "-{a}", "sign": "(double)(({a} > 0.0) - ({a} < 0.0))"}
-_C_BINARY = {"add": "{a} + {b}", "sub": "{a} - {b}", "mul": "{a} * {b}", "div": "{a} / {b}", "pow": "pow({a}, {b})"}
+            "neg": "-{a}", "sign": "(double)(({a} > 0.0) - ({a} < 0.0))", "sinh": "sinh({a})", "cosh": "cosh({a})",
+            "atan": "atan({a})", "erf": "erf({a})"}
+_C_BINARY = {"add": "{a} + {b}", "sub": "{a} - {b}", "mul": "{a} * {b}", "div": "{a} / {b}", "pow": "pow({a}, {b})",
+             "maximum": "fmax({a}, {b})", "minimum": "fmin({a}, {b})", "gt": "(double)({a} > {b})", "ge": "(double)({a} >= {b})",
+             "lt": "(double)({a} < {b})", "le": "(double)({a} <= {b})"}
 
 
 # ---- values while walking the fx graph -------------------------------------------------------------------------------------
-class _Row:      # (C, D - H): an expression of the row value x, row constants and head-derived per-chain values
-    def __init__(self, e):
-        self.e = e
+class _Row:      # (C, hi - lo): an expression of the row value x, row constants and head-derived per-chain values on rows lo..hi
+    def __init__(self, e, lo, hi):
+        self.e, self.lo, self.hi = e, lo, hi
 
 
 class _Per:      # (C,) or, broadcast, (C, 1): an expression of heads and sums
@@ -235,32 +275,35 @@ class _Per:      # (C,) or, broadcast, (C, 1): an expression of heads and sums
         self.e, self.bcast = e, bcast
 
 
+class _RowConst:  # a tensor constant along the row axis, placed once its partner in an operation says which rows it spans
+    def __init__(self, t):
+        self.t = t
+
+
 class _LanesTracer:
     def __init__(self, D):
         self.D = int(D)
         self.g = _Dag()
-        self.H = None         # number of head coordinates: the start of the one row slice
+        self.ranges = set()   # row slices [lo, hi) the function takes
         self.max_head = -1
-        self.rows = []        # packed row constants, each (D,) on the host (entries < H unused)
-        self.sums = []        # e_k
+        self.rows = []        # packed row constants, each (D,) on the host (entries outside their slice unused)
+        self.sums = []        # (e_k, lo, hi)
 
-    def fix_head(self, start, where):
-        if self.H is None:
-            self.H = int(start)
-        elif self.H != int(start):
-            raise Unsupported(f"{where}: the rows must be taken as ONE slice Th[:, H:]; saw H = {self.H} and {start}")
+    @property
+    def H(self):
+        return min(lo for lo, _ in self.ranges) if self.ranges else None
 
-    def row_const(self, t, where):
-        if t.numel() == 1:
-            return self.g.const(float(t.reshape(()).item()))
-        if self.H is None:
-            raise Unsupported(f"{where}: a tensor constant is used before the row slice Th[:, H:] is known")
-        n = self.D - self.H
+    def take_rows(self, lo, hi):
+        self.ranges.add((lo, hi))
+        return _Row(self.g.mk("x"), lo, hi)
+
+    def row_const(self, t, lo, hi, where):
+        n = hi - lo
         if tuple(t.shape) not in ((n,), (1, n)):
             raise Unsupported(f"{where}: a tensor constant of shape {tuple(t.shape)} does not broadcast along the {n} rows "
-                              f"(expected a scalar or shape ({n},) / (1, {n}))")
+                              f"Th[:, {lo}:{hi}] (expected a scalar or shape ({n},) / (1, {n}))")
         row = torch.zeros(self.D, dtype=torch.float64)
-        row[self.H:] = t.detach().reshape(n).to(dtype=torch.float64, device="cpu")
+        row[lo:hi] = t.detach().reshape(n).to(dtype=torch.float64, device="cpu")
         for k, r in enumerate(self.rows):
             if torch.equal(r, row):
                 return self.g.mk("p", k)
@@ -271,11 +314,11 @@ class _LanesTracer:
         import torch.fx as fx
 
         try:
-            gm = fx.symbolic_trace(fn)
+            with no_distribution_validation():
+                gm = fx.symbolic_trace(fn)
         except Exception as e:
             raise Unsupported(f"torch.fx could not trace the function: {type(e).__name__}: {e}") from e
         table = dict(_function_table())
-        table[operator.getitem] = "getitem"
         table[torch.unsqueeze] = "unsqueeze"
         methods = dict(_METHODS, unsqueeze="unsqueeze")
         env, out, n_inputs = {}, None, 0
@@ -314,7 +357,7 @@ class _LanesTracer:
         if not isinstance(out, _Per) or out.bcast:
             raise Unsupported("the function does not end in a per-chain value built from head coordinates Th[:, i] and sums over "
                               "the rows Th[:, H:]")
-        if self.H is None or not self.sums:
+        if not self.ranges or not self.sums:
             raise Unsupported("no row slice Th[:, H:] summed over dim=1: not a head-plus-sums density")
         if self.max_head >= self.H:
             raise Unsupported(f"head index {self.max_head} lies inside the row slice Th[:, {self.H}:]")
@@ -322,10 +365,12 @@ class _LanesTracer:
             raise Unsupported(f"{self.H} head coordinates (the lane-spread kernels hold at most 8)")
         return out.e
 
-    def operand(self, v, where, want_row):
-        """A traced value as an operand of an elementwise operation; want_row: the operation's result is a row expression."""
-        if isinstance(v, (_Row, _Per)):
+    def operand(self, v, where, TH):
+        """A traced value as an operand of an elementwise operation."""
+        if isinstance(v, (_Row, _Per, _RowConst)):
             return v
+        if v is TH:
+            return self.take_rows(0, self.D)  # the whole state as rows: a density without head coordinates
         if isinstance(v, bool):
             raise Unsupported(f"{where}: boolean operand")
         if isinstance(v, (int, float)):
@@ -333,26 +378,50 @@ class _LanesTracer:
         if isinstance(v, torch.Tensor):
             if v.numel() == 1:
                 return _Per(self.g.const(float(v.reshape(()).item())), bcast=None)
-            return _Row(self.row_const(v, where))
+            return _RowConst(v)
         raise Unsupported(f"{where}: operand of type {type(v).__name__}")
+
+    def shape_of(self, v, where, TH):
+        if v is TH:
+            return (None, self.D)
+        if isinstance(v, _Row):
+            return (None, v.hi - v.lo)
+        if isinstance(v, _Per):
+            return (None, 1) if v.bcast else (None,)
+        if isinstance(v, torch.Tensor):
+            return tuple(v.shape)
+        raise Unsupported(f"{where}: shape of a value the tracer does not follow")
 
     def apply(self, name, args, kwargs, where, TH):
         g = self.g
         if name == "id":
             return args[0]
+        if name == "broadcast_tensors":  # (torch.distributions' broadcast_all): the operands themselves; every operation
+            return tuple(args[0]) if len(args) == 1 and isinstance(args[0], (tuple, list)) else tuple(args)  # broadcasts anyway
+        if name == "getattr":
+            if args[1] == "shape":
+                return self.shape_of(args[0], where, TH)
+            raise Unsupported(f"{where}: attribute {args[1]!r}")
+        if name == "size":
+            shp = self.shape_of(args[0], where, TH)
+            return shp if len(args) == 1 else shp[args[1]]
         if name == "getitem":
             src, idx = args
+            if isinstance(src, (tuple, list)) and isinstance(idx, int):
+                return src[idx]
             idx = idx if isinstance(idx, tuple) else (idx,)
             full = lambda s: s is Ellipsis or (isinstance(s, slice) and s == slice(None, None, None))  # noqa: E731
             if src is TH:
                 if len(idx) == 2 and full(idx[0]) and isinstance(idx[1], int) and not isinstance(idx[1], bool) and idx[1] >= 0:
                     self.max_head = max(self.max_head, idx[1])
                     return _Per(g.mk("h", idx[1]), bcast=False)
-                if len(idx) == 2 and full(idx[0]) and isinstance(idx[1], slice) and idx[1].stop is None and idx[1].step in (None, 1) \
-                        and isinstance(idx[1].start, int) and idx[1].start >= 0:
-                    self.fix_head(idx[1].start, where)
-                    return _Row(g.mk("x"))
-                raise Unsupported(f"{where}: theta may be indexed as Th[:, i] (a head coordinate) or Th[:, H:] (the rows) only")
+                if len(idx) == 2 and full(idx[0]) and isinstance(idx[1], slice) and idx[1].step in (None, 1):
+                    lo, hi = idx[1].start, idx[1].stop
+                    lo = 0 if lo is None else lo
+                    hi = self.D if hi is None else (hi + self.D if isinstance(hi, int) and hi < 0 else hi)
+                    if isinstance(lo, int) and isinstance(hi, int) and 0 <= lo < hi <= self.D:
+                        return self.take_rows(lo, hi)
+                raise Unsupported(f"{where}: theta may be indexed as Th[:, i] (a head coordinate) or Th[:, a:b] (rows) only")
             if isinstance(src, _Per) and src.bcast is False and len(idx) == 2 and full(idx[0]) and idx[1] is None:
                 return _Per(src.e, bcast=True)
             raise Unsupported(f"{where}: unsupported indexing")
@@ -362,20 +431,24 @@ class _LanesTracer:
             if isinstance(src, _Per) and src.bcast is False and dim in (1, -1):
                 return _Per(src.e, bcast=True)
             raise Unsupported(f"{where}: unsupported unsqueeze")
-        if name == "sum":
-            x = args[0]
+        if name in ("sum", "mean"):
+            x = self.operand(args[0], where, TH) if args[0] is TH else args[0]
             dim = args[1] if len(args) > 1 else kwargs.get("dim", kwargs.get("axis"))
             if isinstance(dim, (list, tuple)) and len(dim) == 1:
                 dim = dim[0]
             if kwargs.get("keepdim", False) or (len(args) > 2 and args[2]) or kwargs.get("dtype") not in (None, torch.float64):
-                raise Unsupported(f"{where}: sum(keepdim=True) / sum(dtype=...)")
+                raise Unsupported(f"{where}: {name}(keepdim=True) / {name}(dtype=...)")
             if not isinstance(x, _Row) or "x" not in x.e.vars and "row" not in x.e.vars:
-                raise Unsupported(f"{where}: sum of something that is not a row expression")
+                raise Unsupported(f"{where}: {name} of something that is not a row expression")
             if dim not in (1, -1):
-                raise Unsupported(f"{where}: the sum must run over the row axis (dim=1), got dim={dim!r}")
-            self.sums.append(x.e)
-            return _Per(g.mk("S", len(self.sums) - 1), bcast=False)
-        if kwargs and not (name == "softplus" and set(kwargs) <= {"beta", "threshold"}):
+                raise Unsupported(f"{where}: the {name} must run over the row axis (dim=1), got dim={dim!r}")
+            self.sums.append((x.e, x.lo, x.hi))
+            S = g.mk("S", len(self.sums) - 1)
+            return _Per(S if name == "sum" else g.div(S, g.const(float(x.hi - x.lo))), bcast=False)
+        if name == "relu" and kwargs.get("inplace") is False:
+            kwargs = {}
+        if kwargs and not (name == "softplus" and set(kwargs) <= {"beta", "threshold"}) \
+                and not (name.startswith("clamp") and set(kwargs) <= {"min", "max"}):
             raise Unsupported(f"{where}: keyword arguments {sorted(kwargs)}")
         if name == "softplus":
             beta = kwargs.get("beta", args[1] if len(args) > 1 else 1.0)
@@ -383,37 +456,65 @@ class _LanesTracer:
             if float(beta) != 1.0 or float(thr) != 20.0:
                 raise Unsupported(f"{where}: softplus with beta / threshold other than the defaults")
             args = args[:1]
+        if name in ("reciprocal", "rsqrt"):
+            if len(args) != 1:
+                raise Unsupported(f"{where}: {name} with {len(args)} operands")
+            den = args[0] if name == "reciprocal" else self.apply("sqrt", [args[0]], {}, where, TH)
+            return self.apply("div", [1.0, den], {}, where, TH)
         if name in _UNARY:
             if len(args) != 1:
                 raise Unsupported(f"{where}: {name} with {len(args)} operands")
-            a = self.operand(args[0], where, False)
+            a = self.operand(args[0], where, TH)
+            if isinstance(a, _RowConst):
+                raise Unsupported(f"{where}: {name} of a tensor constant inside the traced function (compute it outside)")
             e = g.un(name, a.e)
-            return _Row(e) if isinstance(a, _Row) else _Per(e, a.bcast)
-        if name in _BINARY:
-            if len(args) != 2:
+            return _Row(e, a.lo, a.hi) if isinstance(a, _Row) else _Per(e, a.bcast)
+        rw = piecewise_rewrite(name, args, kwargs, where)
+        if rw is not None:
+            inner = [self.apply(a[0], a[1], {}, where, TH) if isinstance(a, tuple) else a for a in rw[1]]
+            return self.apply(rw[0], inner, {}, where, TH)
+        if name in _BINARY or name == "where":
+            want = 3 if name == "where" else 2
+            if len(args) != want:
                 raise Unsupported(f"{where}: {name} with {len(args)} operands (alpha= / rounding_mode= are not supported)")
-            a, b = self.operand(args[0], where, False), self.operand(args[1], where, False)
-            e = g.bin(name, a.e, b.e)
-            if isinstance(a, _Row) or isinstance(b, _Row):
-                for o in (a, b):
+            ops = [self.operand(v, where, TH) for v in args]
+            if name == "where" and not (isinstance(ops[0], (_Row, _Per)) and ops[0].e.op in _COMPARE):
+                raise Unsupported(f"{where}: the condition of `where` must be a comparison (> >= < <=)")
+            build = (lambda es: g.where(*es)) if name == "where" else (lambda es: g.bin(name, *es))  # noqa: E731
+            rows = [o for o in ops if isinstance(o, _Row)]
+            if rows:
+                lo, hi = rows[0].lo, rows[0].hi
+                if any((o.lo, o.hi) != (lo, hi) for o in rows):
+                    raise Unsupported(f"{where}: rows of two different slices in one expression ("
+                                      + " and ".join(sorted({f"Th[:, {o.lo}:{o.hi}]" for o in rows}))
+                                      + "); each expression and its sum must stay within ONE slice")
+                es = []
+                for o in ops:
+                    if isinstance(o, _RowConst):
+                        es.append(self.row_const(o.t, lo, hi, where))
+                        continue
                     if isinstance(o, _Per):
                         if o.bcast is False:
                             raise Unsupported(f"{where}: a per-chain value meets a row expression without [:, None]")
                         if any(isinstance(v, tuple) and v[0] == "S" for v in o.e.vars):
                             raise Unsupported(f"{where}: a sum over the rows is used inside another row expression "
                                               "(rows may depend on head coordinates only)")
-                return _Row(e)
-            ba, bb = a.bcast, b.bcast
-            if ba is not None and bb is not None and ba != bb:
+                    es.append(o.e)
+                return _Row(build(es), lo, hi)
+            if any(isinstance(o, _RowConst) for o in ops):
+                raise Unsupported(f"{where}: a tensor constant meets a per-chain value before any row slice Th[:, a:b]: which rows it "
+                                  "spans is unknown (combine it with the rows first)")
+            shapes = {o.bcast for o in ops if o.bcast is not None}
+            if len(shapes) > 1:
                 raise Unsupported(f"{where}: a (C,) value meets a (C, 1) value")
-            return _Per(e, ba if ba is not None else bb)
+            return _Per(build([o.e for o in ops]), shapes.pop() if shapes else None)
         raise Unsupported(f"{where}: unsupported operation {name}")
 
 
 # ---- code generation: chain scope + row lambdas ----------------------------------------------------------------------------
 class _Gen:
-    def __init__(self, D):
-        self.D = D
+    def __init__(self, D, H):
+        self.D, self.H = D, H
         self.outer = []          # lines of the chain scope, in order
         self.names = {}          # node id -> name in the chain scope
         self.n = 0
@@ -439,7 +540,7 @@ class _Gen:
         elif e.op == "S":
             r = f"S{e.args[0]}"
         else:
-            r = self.tmp(self.outer, self.expr(e, [self.chain(a) for a in e.args]))
+            r = self.tmp(self.outer, self.expr(e, [self.chain(a) for a in e.args if isinstance(a, _N)]))
         self.names[e.id] = r
         return r
 
@@ -454,12 +555,18 @@ class _Gen:
         elif e.op == "p":
             r = self.tmp(lines, f"P[{e.args[0] * self.D} + d]")
         else:
-            r = self.tmp(lines, self.expr(e, [self.row(a, lines, memo) for a in e.args]))
+            r = self.tmp(lines, self.expr(e, [self.row(a, lines, memo) for a in e.args if isinstance(a, _N)]))
         memo[e.id] = r
         return r
 
-    @staticmethod
-    def expr(e, a):
+    def expr(self, e, a):
+        if e.op == "sel":
+            lo, hi = e.args[1], e.args[2]
+            if (lo, hi) == (self.H, self.D):
+                return a[0]
+            return f"(d >= {lo} && d < {hi}) ? {a[0]} : 0.0"
+        if e.op == "where":
+            return f"({a[0]} != 0.0) ? {a[1]} : {a[2]}"
         if e.op in _C_UNARY:
             return _C_UNARY[e.op].format(a=a[0])
         return _C_BINARY[e.op].format(a=a[0], b=a[1])
@@ -481,25 +588,26 @@ def lanes_source(fn, dims: int):
     g, H, K = tr.g, tr.H, len(tr.sums)
     if D - H < 1:
         raise Unsupported("no rows beyond the head coordinates")
+    sums = [g.sel(e, lo, hi) for e, lo, hi in tr.sums]  # each sum runs over ITS slice: zero on the other rows
     heads = sorted({v[1] for v in F.vars if isinstance(v, tuple) and v[0] == "h"}
-                   | {v[1] for e in tr.sums for v in e.vars if isinstance(v, tuple) and v[0] == "h"})
-    gen = _Gen(D)
+                   | {v[1] for e in sums for v in e.vars if isinstance(v, tuple) and v[0] == "h"})
+    gen = _Gen(D, H)
     out = []
     for i in range(H):
         gen.outer.append(f"  const double h{i} = c.head({i});")
     # the sums, then the extra sums T[k][i] = sum_d d e_k / d h_i
-    for k, e in enumerate(tr.sums):
+    for k, e in enumerate(sums):
         lam = gen.lam(e)
         gen.outer.append(f"  const double S{k} = c.sum({lam});")
     T = {}
-    for k, e in enumerate(tr.sums):
+    for k, e in enumerate(sums):
         for i in heads:
             de = g.diff(e, ("h", i))
             if g.is_c(de, 0.0):
                 continue
-            if not _Gen.row_level(de):
-                # a row-independent derivative summed over the rows: (D - H) copies of it
-                T[(k, i)] = g.mul(g.const(float(D - H)), de)
+            if de.op == "sel" and not _Gen.row_level(de.args[0]):
+                # a row-independent derivative summed over the slice: (hi - lo) copies of it
+                T[(k, i)] = g.mul(g.const(float(de.args[2] - de.args[1])), de.args[0])
                 continue
             lam = gen.lam(de)
             gen.outer.append(f"  const double T{k}_{i} = c.sum({lam});")
@@ -516,7 +624,7 @@ def lanes_source(fn, dims: int):
         gen.outer.append(f"  c.grad_head({i}, {gen.chain(gh)});")
     # d log p / d theta_d
     gx = g.const(0.0)
-    for k, e in enumerate(tr.sums):
+    for k, e in enumerate(sums):
         gx = g.add(gx, g.mul(FS[k], g.diff(e, "x")))
     if g.is_c(gx, 0.0):
         raise Unsupported("the log density does not depend on the rows")

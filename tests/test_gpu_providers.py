@@ -505,3 +505,70 @@ def test_torch_model_traces_hierarchical_densities_into_the_lanes_form(ops):
         tb, lb = b.sample()
         np.testing.assert_allclose(tb.cpu().numpy(), ta.cpu().numpy(), rtol=1e-8, atol=1e-9)
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+
+@pytest.mark.gpu
+def test_torch_model_traces_distributions_row_groups_and_piecewise_densities(ops):
+    """The wider traced shapes on the GPU: a funnel written with torch.distributions log_prob calls, row GROUPS (several slices
+    with their own hyper-parameters), a density with NO head coordinate but a nonlinear function of its sums, piecewise rows
+    (where / relu / clamp / maximum) and a separable sum of distribution bodies: gradient equal to autograd, DRGHMC one launch
+    per proposal bit-identical to the step-by-step paths, HMC sane."""
+    Normal, Laplace = torch.distributions.Normal, torch.distributions.Laplace
+    dev = ops.device
+    w = torch.linspace(0.5, 1.5, 40, dtype=torch.float64, device=dev)
+
+    def funnel_dist(Th):
+        v, x = Th[:, 0], Th[:, 1:]
+        return Normal(0.0, 3.0).log_prob(v) + Normal(0.0, torch.exp(0.5 * v)[:, None]).log_prob(x).sum(-1)
+
+    def groups(Th):
+        mu, lt = Th[:, 0], Th[:, 1]
+        ga, gb, gc = Th[:, 2:30], Th[:, 30:50], Th[:, 50:]
+        la = Normal(mu[:, None], torch.exp(lt)[:, None]).log_prob(ga).sum(-1)
+        lb = Laplace(0.0, 2.0).log_prob(gb - mu.unsqueeze(1)).sum(-1)
+        lc = -0.5 * (w * gc * gc).sum(-1) + 0.3 * torch.tanh(gc).mean(-1) * lt
+        return la + lb + lc - 0.5 * (mu * mu + lt * lt / 0.04)  # (a tight prior on the log scale: no funnel neck to fall into)
+
+    def no_heads(Th):
+        return -0.5 * (Th ** 2).sum(-1) - torch.log(torch.exp(Th).sum(-1))
+
+    def piecewise(Th):
+        s, x = Th[:, 0], Th[:, 1:]
+        z = x * torch.exp(-s)[:, None]
+        return (torch.where(z > 0.0, -z, 2.0 * z) - torch.relu(z - 0.5) ** 2 - torch.clamp(x, -0.4, 0.6) ** 2).sum(1) \
+            - 0.5 * s * s - 32.0 * torch.maximum(s, 0.1 * s)
+
+    def bodies(Th):
+        return (torch.distributions.StudentT(4.0).log_prob(Th) + torch.distributions.Gumbel(0.0, 1.0).log_prob(Th)
+                - torch.log(torch.cosh(0.5 * Th)) + 0.1 * torch.erf(Th)).sum(-1)
+
+    for fn, dims, head, form in ((funnel_dist, 101, 1, "lanes"), (groups, 90, 2, "lanes"), (no_heads, 64, 0, "lanes"),
+                                 (piecewise, 33, 1, "lanes"), (bodies, 48, None, "elementwise")):
+        m = bk.TorchModel(fn, dims, compile=True)
+        assert m.compiled is not None and m.compiled_form == form, (fn.__name__, m.compile_note)
+        if head is not None:
+            assert m.compiled._head == head
+        Th = 0.7 * torch.randn((777, dims), dtype=torch.float64, device=dev)
+        x = Th.clone().requires_grad_(True)
+        lp_t = fn(x)
+        (g_t,) = torch.autograd.grad(lp_t.sum(), x)
+        lp, g = m.log_density_gradient(Th)
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_t.detach().cpu().numpy(), rtol=1e-11, atol=1e-10, err_msg=fn.__name__)
+        np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=1e-10, atol=1e-11 * float(g_t.abs().max()),
+                                   err_msg=fn.__name__)
+        args = (3, [0.06, 0.025, 0.01], [4, 8, 16], 0.2)
+        th0 = 0.5 * torch.randn((1500, dims), dtype=torch.float64, device=dev)
+        f = bk.DrGhmcDiag(m, *args, chains=1500, seed=61, init=th0)
+        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=61, fuse_builtin=False, fuse_steps=False,
+                           device_counts=False, init=th0)
+        assert f._one_launch and f.host_syncs_per_draw == 0 and not hs._one_launch
+        for n in range(5):
+            tf, _ = f.sample()
+            th_, _ = hs.sample()
+            assert torch.isfinite(tf).all(), (fn.__name__, n)
+            assert torch.equal(tf, th_), (fn.__name__, n)
+        hm = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.03, 8, chains=1500, seed=62, init=th0)
+        for _ in range(4):
+            th, lp = hm.sample()
+        assert torch.isfinite(th).all() and 0.3 < hm.accept_rate() <= 1.0, (fn.__name__, hm.accept_rate())
+
+

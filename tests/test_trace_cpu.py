@@ -59,6 +59,18 @@ DENSITIES = {
                                - (torch.sqrt(1.0 + Th * Th) * lam[:, None]).sum(0) / 4.0 + 1.5, "dc"),
     "powers": (lambda Th: (-(1.0 + Th * Th) ** 1.5 + 0.1 * Th ** 3 - 2.0 ** (0.3 * Th) + torch.sin(Th) * torch.cos(b * Th)).sum(1),
                "cd"),
+    "distributions_bodies": (lambda Th: (torch.distributions.Normal(0.5, 2.0).log_prob(Th)
+                                         + torch.distributions.StudentT(4.0).log_prob(Th)
+                                         + torch.distributions.Cauchy(0.0, 1.5).log_prob(Th)
+                                         + torch.distributions.Laplace(0.25, 2.0).log_prob(Th)
+                                         + torch.distributions.Gumbel(0.0, 1.0).log_prob(Th)
+                                         + torch.distributions.LogNormal(0.0, 1.0).log_prob(torch.exp(Th))).sum(-1), "cd"),
+    "piecewise": (lambda Th: (torch.where(Th > a, -0.5 * Th * Th, -torch.abs(Th) * b) - F.relu(Th - 1.0) ** 2
+                              - torch.clamp(Th, -0.7, 0.9) ** 2 - Th.clamp(min=0.2) * 0.5 + torch.minimum(Th, a * Th) * 0.1
+                              - torch.maximum(Th * Th, b)).sum(1), "cd"),
+    "hyperbolic_erf": (lambda Th: (-torch.log(torch.cosh(Th)) + 0.1 * torch.sinh(0.5 * Th) + torch.atan(Th * b) * a
+                                   + torch.erf(Th) * 0.3 + torch.rsqrt(1.0 + Th * Th) + torch.reciprocal(2.0 + Th.square())).mean(1)
+                       * Th.shape[1], "cd"),
     "log_and_division": (lambda Th: (torch.log(1.0 + torch.exp(Th)) / (2.0 + torch.cos(Th)) - (a - Th) / b).sum(dim=1).neg(), "cd"),
 }
 
@@ -94,7 +106,8 @@ def test_constants_are_packed_once_and_the_source_is_plain(tmp_path):
 @pytest.mark.parametrize("fn, needle", [
     (lambda Th: -0.5 * (Th * Th), "does not end in a per-chain value"),
     (lambda Th: (Th[:, :3] ** 2).sum(1), "getitem"),
-    (lambda Th: torch.where(Th > 0, Th, -Th).sum(1), "unsupported operation"),
+    (lambda Th: torch.where(Th * Th, Th, -Th).sum(1), "must be a comparison"),
+    (lambda Th: torch.logsumexp(Th, 1), "unsupported operation"),
     (lambda Th: (Th * Th).sum(0), "coordinate axis"),
     (lambda Th: (Th * Th).sum(), "coordinate axis"),
     (lambda Th: torch.exp((Th * Th).sum(1)), "per-chain value"),
@@ -181,7 +194,34 @@ def t_logistic_scale(Th):  # rows through a sigmoid link with a shared slope (he
     return ll - 0.5 * pen * pen - 0.5 * (a * a + b * b)
 
 
-LANES = {"funnel": (t_funnel, 1), "funnel_scale_inside_rows": (t_funnel_inside, 1), "hierarchical_normal": (t_hier, 2),
+def t_funnel_distributions(Th):  # the funnel the way a PyTorch user writes it
+    Normal = torch.distributions.Normal
+    v, x = Th[:, 0], Th[:, 1:]
+    return Normal(0.0, 3.0).log_prob(v) + Normal(0.0, torch.exp(0.5 * v)[:, None]).log_prob(x).sum(-1)
+
+
+def t_groups(Th):  # two groups of rows with their own hyper-parameters, a third slice that overlaps neither
+    mu, lt = Th[:, 0], Th[:, 1]
+    ga, gb, gc = Th[:, 2:7], Th[:, 7:12], Th[:, 12:]
+    la = torch.distributions.Normal(mu[:, None], torch.exp(lt)[:, None]).log_prob(ga).sum(-1)
+    lb = torch.distributions.Laplace(0.0, 2.0).log_prob(gb - mu.unsqueeze(1)).sum(-1)
+    lc = -0.5 * (wv[:DL - 12] * gc * gc).sum(-1) / gc.shape[1] + 0.3 * torch.tanh(gc).mean(-1) * lt
+    return la + lb + lc - 0.5 * (mu * mu + lt * lt)
+
+
+def t_no_heads(Th):  # no head coordinate at all: a nonlinear function of two sums over the whole state
+    return -0.5 * (Th ** 2).sum(-1) - torch.log(torch.exp(Th).sum(-1)) + 0.1 * torch.tanh(Th[:, 0:].sum(1))
+
+
+def t_piecewise_rows(Th):
+    s, x = Th[:, 0], Th[:, 1:]
+    z = x * torch.exp(-s)[:, None]
+    return (torch.where(z > 0.0, -z, 2.0 * z) - F.relu(z - 0.5) ** 2 - torch.clamp(x, -0.4, 0.6) ** 2).sum(1) \
+        - 0.5 * s * s - (DL - 1) * torch.maximum(s, 0.1 * s)
+
+
+LANES = {"funnel_torch_distributions": (t_funnel_distributions, 1), "row_groups": (t_groups, 2), "no_heads": (t_no_heads, 0),
+         "piecewise_rows": (t_piecewise_rows, 1), "funnel": (t_funnel, 1), "funnel_scale_inside_rows": (t_funnel_inside, 1), "hierarchical_normal": (t_hier, 2),
          "logistic_link_nonlinear_in_sums": (t_logistic_scale, 2)}
 
 
@@ -212,11 +252,13 @@ def test_lanes_source_value_and_gradient_match_autograd(name, tmp_path):
 
 
 @pytest.mark.parametrize("fn, needle", [
-    (lambda Th: (Th[:, 1:] ** 2).sum(1) + (Th[:, 2:] ** 2).sum(1), "ONE slice"),
+    (lambda Th: (Th[:, 1:10] * Th[:, 10:]).sum(1), "ONE slice"),
     (lambda Th: (Th[:, 0] * Th[:, 1:]).sum(1), "without \\[:, None\\]"),
     (lambda Th: ((Th[:, 1:] ** 2).sum(1)[:, None] * Th[:, 1:]).sum(1), "inside another row expression"),
     (lambda Th: Th[:, 0] + Th[:, 3] + (Th[:, 2:] ** 2).sum(1), "inside the row slice"),
-    (lambda Th: (Th[:, 1:5] ** 2).sum(1), "indexed as"),
+    (lambda Th: (Th[:, 1:25] ** 2).sum(1), "indexed as"),
+    (lambda Th: (Th[:, 1::2] ** 2).sum(1), "indexed as"),
+    (lambda Th: ((yv - Th[:, 0][:, None]) ** 2).sum(1) + (Th[:, 2:] ** 2).sum(1), "which rows it"),
     (lambda Th: Th[:, 0] * 2.0, "no row slice"),
 ])
 def test_lanes_unsupported_shapes_name_the_reason(fn, needle):
@@ -259,8 +301,11 @@ def _random_expr(rng, depth, leaves):
             return lambda x: a(x) * b(x)
         return lambda x: a(x) / (2.0 + torch.square(b(x)))
     c = float(rng.uniform(0.3, 1.7))
-    u = int(rng.integers(0, 14))
+    u = int(rng.integers(0, 20))
     table = [
+        lambda x: torch.log(torch.cosh(a(x))), lambda x: torch.sinh(torch.tanh(a(x)) * c), lambda x: torch.atan(a(x) * c),
+        lambda x: torch.erf(a(x)), lambda x: torch.where(a(x) > 0.1 * c, torch.sin(a(x)), 0.5 * a(x)),
+        lambda x: torch.clamp(a(x), -c, c) * torch.minimum(a(x), 0.5 * a(x) + 0.1),
         lambda x: torch.exp(-torch.square(a(x)) * c), lambda x: torch.log(1.5 + torch.square(a(x))), lambda x: torch.log1p(torch.square(a(x)) * c),
         lambda x: torch.expm1(-torch.abs(a(x))), lambda x: torch.sigmoid(a(x) * c), lambda x: F.logsigmoid(a(x)), lambda x: F.softplus(a(x) * c),
         lambda x: torch.tanh(a(x)), lambda x: torch.sqrt(1.0 + torch.square(a(x))), lambda x: torch.square(a(x)), lambda x: torch.sin(a(x) * c),
