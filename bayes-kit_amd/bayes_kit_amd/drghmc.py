@@ -109,6 +109,9 @@ class DrGhmcDiag(ManyChainSampler):
         # ... and models whose leapfrog step {gradient, kick, drift} is one launch (bk_leapfrog_step: a lane-spread density
         # compiled from source): the step-by-step paths then issue one launch per step instead of two; same results
         self._step_hook = bool(fuse_steps) and self._batched and hasattr(model, "bk_leapfrog_step")
+        # ... and models whose whole trajectory {gathering first step .. last gradient + log density} is one launch
+        # (bk_leapfrog_trajectory: a per-chain density compiled from source): 2-3 launches per proposal; same results
+        self._traj_hook = bool(fuse_builtin) and self._step_hook and hasattr(model, "bk_leapfrog_trajectory")
         # Lane counts on the device: the sizes of the lane sets -- which depend on the draw's own accept / retry
         # decisions -- stay in device memory; every launch is sized for its parent set and surplus workgroups
         # exit at once.  No host read inside sample(), so the draw is a FIXED launch sequence and replays as one
@@ -328,6 +331,11 @@ class DrGhmcDiag(ManyChainSampler):
         if self._fused and self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, th, rho, gbuf,
                                                       dst.logp[:n], dst.kin[:n], m, h, steps):
             return
+        if self._traj_hook and self._model.bk_leapfrog_trajectory(src.theta, src.rho, src.grad, idx, th, rho, gbuf, dst.logp[:n],
+                                                                  m, h, steps):
+            self._grad_calls += steps
+            ops.leapfrog_finish(rho, rho, gbuf, m, 0.5 * h, True, dst.kin[:n])
+            return
         ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h)
         for _ in range(steps - 1):
             if self._step_hook:
@@ -525,14 +533,16 @@ class DrGhmcDiag(ManyChainSampler):
         ops, m, model, C = self._ops, self._metric_dev, self._model, self._C
         th, rho, g = dst.theta, dst.rho, dst.grad
         self._grad_calls += steps
-        ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h, n_dev=n_dev)   # :276-278
-        for _ in range(steps - 1):                                                                      # :280-283
-            if self._step_hook:
-                model.bk_leapfrog_step(th, rho, m, h, n_dev)
-                continue
-            model.bk_eval(th, g, None, n_dev)
-            ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h, n_dev=n_dev)
-        model.bk_eval(th, g, dst.logp, n_dev)                                                           # :285
+        if not (self._traj_hook and model.bk_leapfrog_trajectory(src.theta, src.rho, src.grad, idx, th, rho, g, dst.logp, m, h,
+                                                                 steps, n_dev=n_dev)):                  # :276-285, one launch
+            ops.first_step_gather(src.theta, src.rho, src.grad, idx, th, rho, m, h, 0.5 * h, n_dev=n_dev)   # :276-278
+            for _ in range(steps - 1):                                                                      # :280-283
+                if self._step_hook:
+                    model.bk_leapfrog_step(th, rho, m, h, n_dev)
+                    continue
+                model.bk_eval(th, g, None, n_dev)
+                ops.kick_drift(th, th, rho, rho, g, m, h, False, 0.0, True, h, n_dev=n_dev)
+            model.bk_eval(th, g, dst.logp, n_dev)                                                           # :285
         ops.leapfrog_finish(rho, rho, g, m, 0.5 * h, True, dst.kin, n_dev=n_dev,                        # :286, :345
                             level=(dst.logp, dst.H, dst.h, dst.live), lanes_out=self._slot_lanes[slot:slot + 1],
                             lanes_total=self._slot_lanes_total[slot:slot + 1])

@@ -89,6 +89,9 @@ class HMCDiag(ManyChainSampler):
         # issues ONE launch per leapfrog step where the model has bk_leapfrog_step
         self._lanes_traj = (bool(fuse_builtin) and self._batched and self._M is None and hasattr(model, "bk_hmc_proposal"))
         self._step_hook = (bool(fuse_steps) and self._batched and self._M is None and hasattr(model, "bk_leapfrog_step"))
+        # ... and ONE launch per trajectory where it has bk_leapfrog_trajectory (a per-chain density compiled from source:
+        # theta in registers, rho in LDS through all L steps), followed by the library's finish launch
+        self._traj_hook = (bool(fuse_builtin) and self._step_hook and hasattr(model, "bk_leapfrog_trajectory"))
         self._fused_zt = (self._fused_draw and self._rng_kind == _lib.RNG_PHILOX and self._dim >= 32
                           and self.ENABLE_FUSED_ZT)
         D, C, dev = self._dim, self._C, self._ops.device
@@ -427,6 +430,11 @@ class HMCDiag(ManyChainSampler):
             g_last = g
             if not mirror:
                 self._lp_p.copy_(self._lp)
+        elif (self._traj_hook and not mirror and self._chain_tile >= self._C
+              and self._model.bk_leapfrog_trajectory(th, rho, g, None, thp, rho, self._grad_p, self._lp_p, m, eps, L,
+                                                     hmc_first=True)):
+            self._grad_calls += L   # [hmc.py:45-50] in one launch: L gradients of the model's density
+            g_last = self._grad_p
         else:
             g_last = None
             T = self._chain_tile

@@ -520,14 +520,21 @@ struct BkTheta {
     return mode == 1 ? loc[d] : (mode == 2 ? lds[d * 64] : p[d * ld]);
   }
 };
+typedef __attribute__((address_space(3))) double* bk_lds_wptr;
 struct BkGrad {
   double* p; i64 ld;
-  // step mode (bk_src_leapfrog_step): every entry is delivered INTO kick + drift of the lane's chain -- rho (staged in LDS)
-  // += h * (metric * v), theta (staged in registers) + h * rho -- and both are written back; set each entry exactly once
-  int step; double h; bk_lds_ptr metric; bk_lds_ptr rho_in; double* rho; double* th_out; const double* loc;
+  // step mode 1 (bk_src_leapfrog_step): every entry is delivered INTO kick + drift of the lane's chain -- rho (staged in LDS)
+  // += h * (metric * v), theta (staged in registers) + h * rho -- and both are written back; set each entry exactly once.
+  // step mode 2 (bk_src_trajectory): the kick alone, rho updated in LDS; the kernel drifts after the call.
+  // hm: is there a metric (a compile-time fact in the kernels below, so that the user's unrolled loops stay one basic block)
+  int step; double h; bool hm; bk_lds_ptr metric; bk_lds_ptr rho_in; double* rho; double* th_out; const double* loc;
+  bk_lds_wptr rho_rw;
   __device__ __forceinline__ void set(i64 d, double v) const {
-    if (step) {
-      const double t = metric ? metric[d] * v : v;
+    if (step == 2) {
+      const double t = hm ? metric[d] * v : v;
+      rho_rw[d * 64] = rho_rw[d * 64] + h * t;
+    } else if (step) {
+      const double t = hm ? metric[d] * v : v;
       const double r = rho_in[d * 64] + h * t;
       rho[d * ld] = r;
       th_out[d * ld] = loc[d] + h * r;
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, d
   const i64 C = bk_count(C_host, n_dev);
   const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
   if (c >= C) return;
-  const BkGrad gr = {g ? g + c : nullptr, ld, 0, 0.0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const BkGrad gr = {g ? g + c : nullptr, ld, 0, 0.0, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double lp;
   if (BK_SRC_STAGE > 0 && D == BK_SRC_D) {
     // One lane walks a chain's coordinates.  Written against global memory, a loop that reads th[d] and sets the gradient is a
@@ -581,6 +588,7 @@ __global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, d
 // theta staged in the lane's registers, rho and the metric in LDS (reads that cannot alias the global stores), the user's
 // g.set(d, v) performs kick + drift of coordinate d and writes rho and theta back.  Same arithmetic as the gradient launch followed
 // by bk_leapfrog_kick_drift: bit-identical, half the launches, the gradient never travels through memory.
+template <bool HM>
 __global__ __launch_bounds__(64) void k_src_chain_step(double* th, double* rho, i64 ld, const double* metric, double h,
                                                        const double* params, i64 C_host, i64 D, const uint32_t* n_dev) {
   constexpr int S = BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1;
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(64) void k_src_chain_step(double* th, double* rho, 
   const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
   const bool on = c < C;
   const i64 col = on ? c : 0;
-  if (metric)
+  if (HM)
     for (int d = threadIdx.x; d < S; d += 64) sm[d] = metric[d];
   double loc[S];
   // (all 2 S loads of the lane in flight at once -- one wavefront per SIMD may hold them: 4 S registers -- rho then moves on to LDS)
@@ -606,8 +614,64 @@ __global__ __launch_bounds__(64) void k_src_chain_step(double* th, double* rho, 
   __syncthreads();
   if (!on) return;
   const BkTheta t = {th + c, ld, loc, nullptr, 1};
-  const BkGrad gr = {nullptr, ld, 1, h, metric ? (bk_lds_ptr)sm : nullptr, (bk_lds_ptr)(srho + threadIdx.x), rho + c, th + c, loc};
+  const BkGrad gr = {nullptr, ld, 1, h, HM, (bk_lds_ptr)sm, (bk_lds_ptr)(srho + threadIdx.x), rho + c, th + c, loc, nullptr};
   bk_chain(t, gr, BK_SRC_D, params);
+}
+// A whole leapfrog trajectory as ONE launch for a per-chain density (D <= 128): the gathering first step (drghmc.py:276-278, or
+// hmc.py:46-49 with hmc_first), (steps - 1) x {gradient, kick, drift} (drghmc.py:280-283), the last gradient + log density
+// (:285) -- theta in the lane's registers, rho and the metric in LDS for all of it, nothing through memory between the steps.
+// The caller's bk_leapfrog_finish does the last half-kick, the flip and the energies.  Same arithmetic per element as the
+// step-by-step launches: bit-identical.
+template <bool HM>
+__global__ __launch_bounds__(64) void k_src_chain_traj(const double* th_in, const double* rho_in, const double* g_in, i64 ld_in,
+                                                       const int32_t* idx, double* th_out, double* rho_out, double* g_out,
+                                                       double* logp_out, i64 ld_out, const double* metric, double h, int steps,
+                                                       int hmc_first, const double* params, i64 C_host, const uint32_t* n_dev) {
+  constexpr int S = BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1;
+  __shared__ double srho[S * 64];
+  __shared__ double sm[S];
+  const i64 C = bk_count(C_host, n_dev);
+  if ((i64)blockIdx.x * 64 >= C) return;  // (whole workgroup past the set: uniform, before the barrier)
+  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
+  const bool on = c < C;
+  const i64 col = on ? c : 0;
+  const i64 src = idx ? (i64)idx[col] : col;
+  const double half = 0.5 * h;
+  if (HM)
+    for (int d = threadIdx.x; d < S; d += 64) sm[d] = metric[d];
+  double loc[S];
+#pragma unroll
+  for (int d = 0; d < S; ++d) {
+    double x = th_in[(i64)d * ld_in + src], r = rho_in[(i64)d * ld_in + src];
+    const double gin = g_in[(i64)d * ld_in + src];
+    const double t = HM ? metric[d] * gin : gin;
+    if (hmc_first) {
+      r = r + (-half) * t;  // hmc.py:46
+      r = r + h * t;        // hmc.py:48
+    } else {
+      r = r + half * t;     // drghmc.py:276
+    }
+    x = x + h * r;
+    loc[d] = x;
+    srho[d * 64 + threadIdx.x] = r;
+    if ((d & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // (the gather in batches: 3 S loads in flight would set the register count)
+  }
+  __syncthreads();
+  const BkTheta t = {th_in, ld_in, loc, nullptr, 1};
+  const BkGrad kick = {nullptr, 0, 2, h, HM, (bk_lds_ptr)sm, nullptr, nullptr, nullptr, nullptr, (bk_lds_wptr)(srho + threadIdx.x)};
+  for (int s = 0; s + 1 < steps; ++s) {
+    bk_chain(t, kick, BK_SRC_D, params);
+#pragma unroll
+    for (int d = 0; d < S; ++d) loc[d] = loc[d] + h * srho[d * 64 + threadIdx.x];
+  }
+  if (!on) return;
+  const BkGrad gr = {g_out + c, ld_out, 0, 0.0, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  logp_out[c] = bk_chain(t, gr, BK_SRC_D, params);
+#pragma unroll
+  for (int d = 0; d < S; ++d) {
+    th_out[(i64)d * ld_out + c] = loc[d];
+    rho_out[(i64)d * ld_out + c] = srho[d * 64 + threadIdx.x];
+  }
 }
 int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
            void* stream) {
@@ -623,8 +687,32 @@ extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, cons
                                     int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
   if (!theta || !rho || n < 0 || D != BK_SRC_D || ld < n) return -1;
   if (n == 0) return 0;
-  k_src_chain_step<<<dim3((unsigned)((n + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
-      theta, rho, ld, metric, h, static_cast<const double*>(params), n, D, n_dev);
+  const dim3 grid((unsigned)((n + 63) / 64));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double* pp = static_cast<const double*>(params);
+  if (metric) k_src_chain_step<true><<<grid, dim3(64), 0, s>>>(theta, rho, ld, metric, h, pp, n, D, n_dev);
+  else k_src_chain_step<false><<<grid, dim3(64), 0, s>>>(theta, rho, ld, metric, h, pp, n, D, n_dev);
+  return (int)hipGetLastError();
+}
+// the whole trajectory of a proposal (gathering first step .. last gradient + log density) as one launch; src_index may be NULL
+// (lane j starts from chain j), n_dev NULL (n lanes); hmc_first: hmc.py's first kick.  Pair with bk_leapfrog_finish.
+extern "C" int bk_src_trajectory(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+                                 const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out, double* logp_out,
+                                 int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n, int64_t D,
+                                 const uint32_t* n_dev, int hmc_first, const void* params, void* stream) {
+  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || steps < 1 || steps > 0x7fffffff ||
+      n < 0 || D != BK_SRC_D || ld_out < n)
+    return -1;
+  if (n == 0) return 0;
+  const dim3 grid((unsigned)((n + 63) / 64));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double* pp = static_cast<const double*>(params);
+  if (metric)
+    k_src_chain_traj<true><<<grid, dim3(64), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                                                     ld_out, metric, h, (int)steps, hmc_first, pp, n, n_dev);
+  else
+    k_src_chain_traj<false><<<grid, dim3(64), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
+                                                      ld_out, metric, h, (int)steps, hmc_first, pp, n, n_dev);
   return (int)hipGetLastError();
 }
 #endif
@@ -894,6 +982,24 @@ def _bind_source_fast_paths(t):
                   "bk_src_leapfrog_step")
 
         t.bk_leapfrog_step = types.MethodType(bk_leapfrog_step, t)
+    f_ctraj = export("bk_src_trajectory", [P, P, P, I, P, P, P, P, P, I, P, F, I, I, I, P, ctypes.c_int, P, P])
+    if f_ctraj is not None:
+        def bk_leapfrog_trajectory(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out, metric, h,
+                                   steps, n_dev=None, hmc_first=False):
+            """The whole trajectory of a proposal -- gathering first step, (steps - 1) x {gradient, kick, drift}, last gradient +
+            log density (drghmc.py:276-285; hmc.py:46-50 with hmc_first) -- as ONE launch with the compiled per-chain density
+            inlined; the caller's leapfrog_finish does the last half-kick and the energies.  False if the shape is unsupported."""
+            D, n = theta_out.shape
+            ld_in, ld_out = _lib._ld(theta_in), _lib._ld(theta_out)
+            if steps < 1 or _lib._ld(rho_in) != ld_in or _lib._ld(grad_in) != ld_in or _lib._ld(rho_out) != ld_out \
+                    or _lib._ld(grad_out) != ld_out:
+                return False
+            check(f_ctraj(ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index), ptr(theta_out), ptr(rho_out),
+                          ptr(grad_out), ptr(logp_out), ld_out, ptr(metric), h, steps, n, D, ptr(n_dev), 1 if hmc_first else 0,
+                          self._pp, stream(theta_in)), "bk_src_trajectory")
+            return True
+
+        t.bk_leapfrog_trajectory = types.MethodType(bk_leapfrog_trajectory, t)
     f_hmcl = export("bk_src_hmc_trajectory_lanes", [P, P, P, P, P, P, P, I, P, F, I, I, I, P, P])
     if f_hmcl is not None:
         def bk_hmc_proposal(self, theta_in, rho, grad_in, theta_out, grad_out, logp_out, kin_out, metric, eps, steps):

@@ -418,12 +418,16 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
     # ("_one_launch_steps": the lanes form also gives the step-by-step path {gradient, kick, drift} as ONE launch per
     # leapfrog step)
     lanes = dict(form="lanes", head=1)
-    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(fuse_steps=False)),
-                              ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, lanes, {}),
-                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), dict(fuse_steps=False)),
-                              ("compiled_source_chain_one_launch_steps", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
+    # ("_one_launch_trajectories": the per-chain form -- ANY coupled density -- runs the whole trajectory of a proposal as one
+    # launch, theta in its lane's registers and rho in LDS through all the steps, followed by the library's finish launch)
+    off = dict(fuse_builtin=False)
+    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(off, fuse_steps=False)),
+                              ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, lanes, off),
+                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), dict(off, fuse_steps=False)),
+                              ("compiled_source_chain_one_launch_steps", FUNNEL_CHAIN_SRC, dict(form="chain"), off),
+                              ("compiled_source_chain_one_launch_trajectories", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
         try:
-            so, r = run(bk.CTarget.from_source(src, D, **kws), draws, fuse_builtin=False, **k2)
+            so, r = run(bk.CTarget.from_source(src, D, **kws), draws, **k2)
             same = torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc) and \
                 torch.equal(so._rng_state, ref._rng_state)
             # (the one-lane-per-chain form sums the coordinates in order: a different, equally valid rounding of s)

@@ -151,15 +151,31 @@ def test_density_compiled_from_source_under_every_sampler(ops):
                         metric_diag=np.linspace(0.8, 1.3, Df))
         hs = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, fuse_steps=False,
                         metric_diag=np.linspace(0.8, 1.3, Df))
+        # (D <= 128) the whole trajectory of a proposal is one launch (bk_leapfrog_trajectory: theta in registers, rho in LDS);
+        # fuse_builtin=False: one launch per leapfrog step; fuse_steps=False: gradient op + kick+drift per step
+        b3 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
+                           fuse_builtin=False)
+        b4 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
+                           device_counts=False)
+        h3 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, fuse_builtin=False,
+                        metric_diag=np.linspace(0.8, 1.3, Df))
         assert b._dev_counts and b._use_graph and b._step_hook == (Df <= 128) and not b2._step_hook and hm._step_hook == (Df <= 128)
+        assert b._traj_hook == (Df <= 128) and hm._traj_hook == (Df <= 128) and b4._traj_hook == (Df <= 128) and not b4._dev_counts
+        assert not b3._traj_hook and not h3._traj_hook and h3._step_hook == (Df <= 128)
         for n in range(8):
             ta, la = a.sample()
             tb, lb = b.sample()
             tb2, _ = b2.sample()
+            tb3, _ = b3.sample()
+            tb4, _ = b4.sample()
             assert torch.equal(ta, tb) and torch.equal(la, lb) and torch.equal(ta, tb2), ("funnel from source", Df, n)
+            assert torch.equal(ta, tb3) and torch.equal(ta, tb4), ("funnel from source, step / host-sized trajectory", Df, n)
             t1, l1 = hm.sample()
             t2, l2 = hs.sample()
-            assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source, one launch per step", Df, n)
+            t3, l3 = h3.sample()
+            assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source, one launch per trajectory", Df, n)
+            assert torch.equal(t1, t3) and torch.equal(l1, l3), ("HMC, per-chain source, one launch per step", Df, n)
+        assert b._grad_calls == b3._grad_calls == b2._grad_calls and hm._grad_calls == hs._grad_calls == h3._grad_calls
         # (a call with another D than the one compiled for takes the unstaged path)
         th = torch.randn((Df - 1, 130), dtype=torch.float64, device=ops.device)
         g1, g2 = torch.empty_like(th), torch.empty_like(th)
