@@ -87,6 +87,8 @@ class EngineTarget(Protocol):
 #   bk_counted = True, bk_eval(theta, grad, logp, n_dev)   the gradient op takes its chain count from device memory
 #                                                           (DrGhmcDiag: lane counts stay on the device, a draw is one hipGraph)
 #   bk_leapfrog_step(theta, rho, metric, h, n_dev=None)     one leapfrog step {gradient, kick, drift} as ONE launch, in place
+#   bk_leapfrog_trajectory(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out, metric, h, steps,
+#                          n_dev=None, hmc_first=False)   gathering first step .. last gradient + log density as ONE launch
 #                                                           (drghmc.py:280-283, hmc.py:48-50): the step-by-step paths of
 #                                                           DrGhmcDiag and HMCDiag issue one launch per step instead of two
 #   bk_hmc_trajectory / bk_hmc_draw                         whole HMC trajectory / whole draw of a separable density in registers
