@@ -340,448 +340,15 @@ class CTarget(_BuiltinTarget):
 # ---------------------------------------------------------------------------------------------------------------
 # CTarget.from_source: a density written as a few lines of HIP C++, compiled at construction
 # ---------------------------------------------------------------------------------------------------------------
-_SRC_PRELUDE = r"""
-// Generated by bayes_kit_amd.CTarget.from_source (plugin ABI bk_target_fn / bk_target_fn_n, include/bkhip.h).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <math.h>
-#include "bk_common.hpp"
-typedef double bk_dvec2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ i64 bk_count(i64 n, const uint32_t* n_dev) { return bk_lanes(n, n_dev); }
-"""
-
-_SRC_ELEMENTWISE = r"""
-// ---- user code: the density is a SUM OVER COORDINATES of bk_term ------------------------------------------------
-//   __device__ void bk_term(double th, i64 d, const double* params, double& term, double& grad)
-//   term = this coordinate's contribution to the log density, grad = d term / d th
-%(user)s
-// -------------------------------------------------------------------------------------------------------------------
-#include "bk_elementwise.hpp"
-namespace {
-// the library's whole-trajectory / whole-draw HMC kernels (bk_elementwise.hpp) see the density through this
-struct BkSrcTerm {
-  __device__ __forceinline__ static void eval(double th, i64 d, const double* params, double& term, double& grad) {
-    bk_term(th, d, params, term, grad);
-  }
-  __device__ __forceinline__ static double finish(double s) { return s; }
-};
-// gradient only (what a leapfrog step asks for): a streaming elementwise kernel, two chains (16 B) per lane
-template <int ROWS, bool NT>
-__global__ __launch_bounds__(256) void k_src_grad_v2(const double* th, double* g, i64 ld, const double* params, i64 C2, i64 D) {
-  const i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x, d0 = (i64)blockIdx.y * ROWS;
-  if (c2 >= C2) return;
-  bk_dvec2 t[ROWS];
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i)
-    if (d0 + i < D) {
-      const bk_dvec2* p = reinterpret_cast<const bk_dvec2*>(th + (d0 + i) * ld + 2 * c2);
-      t[i] = NT ? __builtin_nontemporal_load(p) : *p;
-    }
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i)
-    if (d0 + i < D) {
-      double term, gx, gy;
-      bk_term(t[i].x, d0 + i, params, term, gx);
-      bk_term(t[i].y, d0 + i, params, term, gy);
-      const bk_dvec2 o = {gx, gy};
-      bk_dvec2* q = reinterpret_cast<bk_dvec2*>(g + (d0 + i) * ld + 2 * c2);
-      if (NT) __builtin_nontemporal_store(o, q);
-      else *q = o;
-    }
+# The translation unit CTarget.from_source generates: the shape as macros, the library's prelude (csrc/bk_source_api.hpp: for
+# form="chain" the accessors bk_chain is written against), the user's function, the library's kernels and C entry points around
+# it (csrc/bk_source_kernels.hpp; ABI: include/bkhip_source.h).  The kernel text lives in those headers, not here.
+_SRC_USER_COMMENT = {
+    "elementwise": "// ---- user code: the density is a SUM OVER COORDINATES of bk_term ------------------------------------------------\n//   __device__ void bk_term(double th, i64 d, const double* params, double& term, double& grad)\n//   term = this coordinate's contribution to the log density, grad = d term / d th\n",
+    "lanes": '// ---- user code: ONE CHAIN, its coordinates spread over 4 / 8 / 16 lanes of a wavefront (bk_lanes.hpp) ---------------\n//   template <class L> __device__ double bk_lanes_density(L& c, const double* params)\n//   c.dims(), c.head(i), c.sum(f), c.grad_head(i, g), c.grad(f) with f(double theta_d, i64 d); returns the log density\n',
+    "chain": '// ---- user code: ONE CHAIN per call ----------------------------------------------------------------------------------\n//   __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)\n//   returns the log density; writes the gradient with g.set(d, value) (a no-op when none is wanted)\n',
 }
-// one chain per lane: odd shapes, unaligned views, and every launch whose chain count lives on the device
-__global__ __launch_bounds__(256) void k_src_grad_s(const double* th, double* g, i64 ld, const double* params, i64 C_host, i64 D,
-                                                    const uint32_t* n_dev) {
-  const i64 C = bk_count(C_host, n_dev);
-  const i64 c = (i64)blockIdx.x * 256 + threadIdx.x, d0 = (i64)blockIdx.y * 4;
-  if (c >= C) return;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    if (d0 + i < D) {
-      double term, gr;
-      bk_term(th[(d0 + i) * ld + c], d0 + i, params, term, gr);
-      g[(d0 + i) * ld + c] = gr;
-    }
-}
-// log density (+ gradient): 4 wavefronts per 64 chains, wavefront w sums its contiguous quarter of the coordinates
-// sequentially, the quarters are combined ((p0 + p1) + p2) + p3 -- the library's own order for per-chain sums
-__global__ __launch_bounds__(256) void k_src_logp(const double* th, double* g, double* logp, i64 ld, const double* params,
-                                                  i64 C_host, i64 D, const uint32_t* n_dev) {
-  __shared__ double part[4][64];
-  const i64 C = bk_count(C_host, n_dev);
-  if ((i64)blockIdx.x * 64 >= C) return;
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const i64 c = (i64)blockIdx.x * 64 + lane;
-  const i64 Dq = (D + 3) / 4, dlo = w * Dq, dhi = dlo + Dq < D ? dlo + Dq : D;
-  double s = 0.0;
-  if (c < C)
-    for (i64 d0 = dlo; d0 < dhi; d0 += 8) {
-      double t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (d0 + u < dhi) t[u] = th[(d0 + u) * ld + c];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (d0 + u < dhi) {
-          double term, gr;
-          bk_term(t[u], d0 + u, params, term, gr);
-          s = s + term;
-          if (g) g[(d0 + u) * ld + c] = gr;
-        }
-    }
-  part[w][lane] = s;
-  __syncthreads();
-  if (w == 0 && c < C) logp[c] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-}
-int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
-           void* stream) {
-  if (!th || (!g && !logp) || C < 0 || D < 0 || ld < C) return -1;
-  if (C == 0) return 0;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const double* p = static_cast<const double*>(params);
-  if (logp) {
-    k_src_logp<<<dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s>>>(th, g, logp, ld, p, C, D, n_dev);
-  } else if (D > 0) {
-    const bool vec = !n_dev && C %% 2 == 0 && ld %% 2 == 0 && (((uintptr_t)th | (uintptr_t)g) & 15u) == 0;
-    if (vec && 2 * C * D * 8 > ((i64)192 << 20) && D <= 65535)  // streams well past the Infinity Cache: one row per thread, non-temporal
-      k_src_grad_v2<1, true><<<dim3((unsigned)((C / 2 + 255) / 256), (unsigned)D), dim3(256), 0, s>>>(th, g, ld, p, C / 2, D);
-    else if (vec)
-      k_src_grad_v2<2, false><<<dim3((unsigned)((C / 2 + 255) / 256), (unsigned)((D + 1) / 2)), dim3(256), 0, s>>>(th, g, ld, p, C / 2, D);
-    else
-      k_src_grad_s<<<dim3((unsigned)((C + 255) / 256), (unsigned)((D + 3) / 4)), dim3(256), 0, s>>>(th, g, ld, p, C, D, n_dev);
-  }
-  return (int)hipGetLastError();
-}
-}  // namespace
-// A separable density is also a lane-spread density without head coordinates (log p = ONE canonical-order sum of the terms, the
-// row gradient the term's derivative): through this adapter the translation unit instantiates the library's one-launch
-// delayed-rejection proposal kernel (D <= 128) and one-launch leapfrog step (csrc/bk_lanes.hpp) as well -- DrGhmcDiag on a
-// separable density is then 12 launches per draw at K = 3 instead of ~580.  theta and rho equal the step-by-step path's bit for
-// bit; the log density is the same terms summed in the lanes' class order instead of four quarters (last-bit differences).
-#include "bk_lanes.hpp"
-namespace {
-struct BkSrcLanesFromTerm {
-  static constexpr int HEAD = 0;
-  template <class L>
-  __device__ __forceinline__ static double eval(L& c, const double* params) {
-    // (the sum of the terms only makes up the VALUE: skipped where the caller discards it -- every step but a trajectory's last)
-    const double lp = c.wants_logp() ? c.sum([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return t; }) : 0.0;
-    c.grad([params](double x, i64 d) { double t, g; bk_term(x, d, params, t, g); return g; });
-    return lp;
-  }
-};
-constexpr int BK_SRC_SL = %(sl)d;  // slots per class for this D (0: D > 128)
-}  // namespace
-// (the step of a separable density needs no sums: the streaming elementwise kernel, every (d, c) element on its own)
-extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
-                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
-  return bke::step_launch<BkSrcTerm>(theta, rho, ld, static_cast<const double*>(params), metric, h, n, D, n_dev, stream);
-}
-#if %(sl)d > 0
-extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
-                                      const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
-                                      double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
-                                      int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
-                                      uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
-                                      const bk_scatter_job* job, const bk_ghost_link* ghost, const bk_ghost0* ghost0,
-                                      const void* params, void* stream) {
-  return bkl::dr_proposal_launch<BkSrcLanesFromTerm, BK_SRC_SL>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out,
-                                                                grad_out, logp_out, kin_out, ld_out, metric, h, steps, n, D,
-                                                                n_dev, lanes_out, lanes_total, H_out, h_out, live_out, job,
-                                                                ghost, ghost0, static_cast<const double*>(params), stream);
-}
-#endif
-// whole HMC trajectory / whole HMC draw with bk_term inlined: the argument lists of bk_hmc_trajectory_gaussian /
-// bk_hmc_draw_gaussian (include/bkhip.h) with `params` where those take `lam`
-extern "C" int bk_src_hmc_trajectory(const double* theta_in, double* theta_out, const double* rho_in, double* rho_out,
-                                     int64_t ld, const void* params, const double* metric, double eps, int64_t steps,
-                                     int64_t C, int64_t D, void* stream) {
-  return bke::hmc_trajectory_launch<BkSrcTerm>(theta_in, theta_out, rho_in, rho_out, ld, static_cast<const double*>(params),
-                                               metric, eps, steps, C, D, stream);
-}
-extern "C" int bk_src_hmc_draw(const double* theta_in, double* theta_out, int64_t ld, const double* rho_in, const double* zt,
-                               int64_t ldz, const void* params, const double* metric, double eps, int64_t steps, double* part,
-                               double* kin0, double* kin1, double* lp_out, double* lp_cur, const double* log_u,
-                               uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C, int64_t D, void* stream) {
-  return bke::hmc_draw_launch<BkSrcTerm>(theta_in, theta_out, ld, rho_in, zt, ldz, static_cast<const double*>(params), metric,
-                                         eps, steps, part, kin0, kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count,
-                                         C, D, stream);
-}
-"""
-
-_SRC_CHAIN = r"""
-// Accessors handed to the user's function: th[d] reads coordinate d of this lane's chain, g.set(d, v) writes its gradient
-typedef const __attribute__((address_space(3))) double* bk_lds_ptr;
-struct BkTheta {
-  const double* p; i64 ld;
-  // the chain's coordinates staged by the kernel: mode 1 = a private array (registers), 2 = LDS ([d][lane]), 0 = not staged
-  const double* loc; bk_lds_ptr lds; int mode;
-  __device__ __forceinline__ double operator[](i64 d) const {
-    return mode == 1 ? loc[d] : (mode == 2 ? lds[d * 64] : p[d * ld]);
-  }
-};
-typedef __attribute__((address_space(3))) double* bk_lds_wptr;
-struct BkGrad {
-  double* p; i64 ld;
-  // step mode 1 (bk_src_leapfrog_step): every entry is delivered INTO kick + drift of the lane's chain -- rho (staged in LDS)
-  // += h * (metric * v), theta (staged in registers) + h * rho -- and both are written back; set each entry exactly once.
-  // step mode 2 (bk_src_trajectory): the kick alone, rho updated in LDS; the kernel drifts after the call.
-  // hm: is there a metric (a compile-time fact in the kernels below, so that the user's unrolled loops stay one basic block)
-  int step; double h; bool hm; bk_lds_ptr metric; bk_lds_ptr rho_in; double* rho; double* th_out; const double* loc;
-  bk_lds_wptr rho_rw;
-  __device__ __forceinline__ void set(i64 d, double v) const {
-    if (step == 2) {
-      const double t = hm ? metric[d] * v : v;
-      rho_rw[d * 64] = rho_rw[d * 64] + h * t;
-    } else if (step) {
-      const double t = hm ? metric[d] * v : v;
-      const double r = rho_in[d * 64] + h * t;
-      rho[d * ld] = r;
-      th_out[d * ld] = loc[d] + h * r;
-    } else if (p) {
-      p[d * ld] = v;
-    }
-  }
-  __device__ __forceinline__ bool wanted() const { return step != 0 || p != nullptr; }
-};
-// ---- user code: ONE CHAIN per call ----------------------------------------------------------------------------------
-//   __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)
-//   returns the log density; writes the gradient with g.set(d, value) (a no-op when none is wanted)
-%(user)s
-// -------------------------------------------------------------------------------------------------------------------
-namespace {
-constexpr i64 BK_SRC_D = %(dims)d;
-constexpr int BK_SRC_STAGE = %(stage)d;  // = D when a chain's coordinates fit the registers of its lane (D <= 128), else 0
-constexpr int BK_SRC_LDS = %(lds)d;    // = D when 64 chains' coordinates fit a workgroup's LDS instead (D <= 300), else 0
-__global__ __launch_bounds__(64) void k_src_chain(const double* th, double* g, double* logp, i64 ld, const double* params,
-                                                  i64 C_host, i64 D, const uint32_t* n_dev) {
-  const i64 C = bk_count(C_host, n_dev);
-  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
-  const BkGrad gr = {g ? g + c : nullptr, ld, 0, 0.0, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  double lp;
-  if (BK_SRC_STAGE > 0 && D == BK_SRC_D) {
-    // One lane walks a chain's coordinates.  Written against global memory, a loop that reads th[d] and sets the gradient is a
-    // chain of load -> store -> load round trips (the compiler must assume the two arrays alias; 24 us per call at D = 101).
-    // With the dimension a compile-time constant the coordinates are fetched ONCE, as one batch of loads, into a private
-    // array that the user's (now fully unrolled) loops read from registers; the gradient stores then pipeline.
-    double loc[BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1];
-#pragma unroll
-    for (int d = 0; d < BK_SRC_STAGE; ++d) loc[d] = th[(i64)d * ld + c];
-    const BkTheta t = {th + c, ld, loc, nullptr, 1};
-    lp = bk_chain(t, gr, BK_SRC_D, params);
-  } else if (BK_SRC_LDS > 0 && D == BK_SRC_D) {
-    // the same for a dimension too large for registers: the 64 chains' coordinates in LDS ([d][lane]: no bank conflicts);
-    // LDS reads cannot alias the gradient's global stores either
-    __shared__ double sh[(BK_SRC_LDS > 0 ? BK_SRC_LDS : 1) * 64];
-#pragma unroll 32
-    for (int d = 0; d < BK_SRC_LDS; ++d) sh[d * 64 + threadIdx.x] = th[(i64)d * ld + c];
-    const BkTheta t = {th + c, ld, nullptr, (bk_lds_ptr)(sh + threadIdx.x), 2};
-    lp = bk_chain(t, gr, BK_SRC_D, params);
-  } else {
-    const BkTheta t = {th + c, ld, nullptr, nullptr, 0};
-    lp = bk_chain(t, gr, D, params);
-  }
-  if (logp) logp[c] = lp;
-}
-// One leapfrog step {gradient, kick, drift} (drghmc.py:280-283, hmc.py:48-50) as ONE launch for a per-chain density (D <= 128):
-// theta staged in the lane's registers, rho and the metric in LDS (reads that cannot alias the global stores), the user's
-// g.set(d, v) performs kick + drift of coordinate d and writes rho and theta back.  Same arithmetic as the gradient launch followed
-// by bk_leapfrog_kick_drift: bit-identical, half the launches, the gradient never travels through memory.
-template <bool HM>
-__global__ __launch_bounds__(64) void k_src_chain_step(double* th, double* rho, i64 ld, const double* metric, double h,
-                                                       const double* params, i64 C_host, i64 D, const uint32_t* n_dev) {
-  constexpr int S = BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1;
-  __shared__ double srho[S * 64];
-  __shared__ double sm[S];
-  const i64 C = bk_count(C_host, n_dev);
-  if ((i64)blockIdx.x * 64 >= C) return;  // (whole workgroup past the set: uniform, before the barrier)
-  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
-  const bool on = c < C;
-  const i64 col = on ? c : 0;
-  if (HM)
-    for (int d = threadIdx.x; d < S; d += 64) sm[d] = metric[d];
-  double loc[S];
-  // (all 2 S loads of the lane in flight at once -- one wavefront per SIMD may hold them: 4 S registers -- rho then moves on to LDS)
-  double rl[S];
-#pragma unroll
-  for (int d = 0; d < S; ++d) {
-    loc[d] = th[(i64)d * ld + col];
-    rl[d] = rho[(i64)d * ld + col];
-  }
-#pragma unroll
-  for (int d = 0; d < S; ++d) srho[d * 64 + threadIdx.x] = rl[d];
-  __syncthreads();
-  if (!on) return;
-  const BkTheta t = {th + c, ld, loc, nullptr, 1};
-  const BkGrad gr = {nullptr, ld, 1, h, HM, (bk_lds_ptr)sm, (bk_lds_ptr)(srho + threadIdx.x), rho + c, th + c, loc, nullptr};
-  bk_chain(t, gr, BK_SRC_D, params);
-}
-// A whole leapfrog trajectory as ONE launch for a per-chain density (D <= 128): the gathering first step (drghmc.py:276-278, or
-// hmc.py:46-49 with hmc_first), (steps - 1) x {gradient, kick, drift} (drghmc.py:280-283), the last gradient + log density
-// (:285) -- theta in the lane's registers, rho and the metric in LDS for all of it, nothing through memory between the steps.
-// The caller's bk_leapfrog_finish does the last half-kick, the flip and the energies.  Same arithmetic per element as the
-// step-by-step launches: bit-identical.
-template <bool HM>
-__global__ __launch_bounds__(64) void k_src_chain_traj(const double* th_in, const double* rho_in, const double* g_in, i64 ld_in,
-                                                       const int32_t* idx, double* th_out, double* rho_out, double* g_out,
-                                                       double* logp_out, i64 ld_out, const double* metric, double h, int steps,
-                                                       int hmc_first, const double* params, i64 C_host, const uint32_t* n_dev) {
-  constexpr int S = BK_SRC_STAGE > 0 ? BK_SRC_STAGE : 1;
-  __shared__ double srho[S * 64];
-  __shared__ double sm[S];
-  const i64 C = bk_count(C_host, n_dev);
-  if ((i64)blockIdx.x * 64 >= C) return;  // (whole workgroup past the set: uniform, before the barrier)
-  const i64 c = (i64)blockIdx.x * 64 + threadIdx.x;
-  const bool on = c < C;
-  const i64 col = on ? c : 0;
-  const i64 src = idx ? (i64)idx[col] : col;
-  const double half = 0.5 * h;
-  if (HM)
-    for (int d = threadIdx.x; d < S; d += 64) sm[d] = metric[d];
-  double loc[S];
-#pragma unroll
-  for (int d = 0; d < S; ++d) {
-    double x = th_in[(i64)d * ld_in + src], r = rho_in[(i64)d * ld_in + src];
-    const double gin = g_in[(i64)d * ld_in + src];
-    const double t = HM ? metric[d] * gin : gin;
-    if (hmc_first) {
-      r = r + (-half) * t;  // hmc.py:46
-      r = r + h * t;        // hmc.py:48
-    } else {
-      r = r + half * t;     // drghmc.py:276
-    }
-    x = x + h * r;
-    loc[d] = x;
-    srho[d * 64 + threadIdx.x] = r;
-    if ((d & 15) == 15) __builtin_amdgcn_sched_barrier(0);  // (the gather in batches: 3 S loads in flight would set the register count)
-  }
-  __syncthreads();
-  const BkTheta t = {th_in, ld_in, loc, nullptr, 1};
-  const BkGrad kick = {nullptr, 0, 2, h, HM, (bk_lds_ptr)sm, nullptr, nullptr, nullptr, nullptr, (bk_lds_wptr)(srho + threadIdx.x)};
-  for (int s = 0; s + 1 < steps; ++s) {
-    bk_chain(t, kick, BK_SRC_D, params);
-#pragma unroll
-    for (int d = 0; d < S; ++d) loc[d] = loc[d] + h * srho[d * 64 + threadIdx.x];
-  }
-  if (!on) return;
-  const BkGrad gr = {g_out + c, ld_out, 0, 0.0, false, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  logp_out[c] = bk_chain(t, gr, BK_SRC_D, params);
-#pragma unroll
-  for (int d = 0; d < S; ++d) {
-    th_out[(i64)d * ld_out + c] = loc[d];
-    rho_out[(i64)d * ld_out + c] = srho[d * 64 + threadIdx.x];
-  }
-}
-int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
-           void* stream) {
-  if (!th || (!g && !logp) || C < 0 || D < 0 || ld < C) return -1;
-  if (C == 0) return 0;
-  k_src_chain<<<dim3((unsigned)((C + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream)>>>(
-      th, g, logp, ld, static_cast<const double*>(params), C, D, n_dev);
-  return (int)hipGetLastError();
-}
-}  // namespace
-#if %(stage)d > 0
-extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
-                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
-  if (!theta || !rho || n < 0 || D != BK_SRC_D || ld < n) return -1;
-  if (n == 0) return 0;
-  const dim3 grid((unsigned)((n + 63) / 64));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const double* pp = static_cast<const double*>(params);
-  if (metric) k_src_chain_step<true><<<grid, dim3(64), 0, s>>>(theta, rho, ld, metric, h, pp, n, D, n_dev);
-  else k_src_chain_step<false><<<grid, dim3(64), 0, s>>>(theta, rho, ld, metric, h, pp, n, D, n_dev);
-  return (int)hipGetLastError();
-}
-// the whole trajectory of a proposal (gathering first step .. last gradient + log density) as one launch; src_index may be NULL
-// (lane j starts from chain j), n_dev NULL (n lanes); hmc_first: hmc.py's first kick.  Pair with bk_leapfrog_finish.
-extern "C" int bk_src_trajectory(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
-                                 const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out, double* logp_out,
-                                 int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n, int64_t D,
-                                 const uint32_t* n_dev, int hmc_first, const void* params, void* stream) {
-  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || steps < 1 || steps > 0x7fffffff ||
-      n < 0 || D != BK_SRC_D || ld_out < n)
-    return -1;
-  if (n == 0) return 0;
-  const dim3 grid((unsigned)((n + 63) / 64));
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const double* pp = static_cast<const double*>(params);
-  if (metric)
-    k_src_chain_traj<true><<<grid, dim3(64), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                                                     ld_out, metric, h, (int)steps, hmc_first, pp, n, n_dev);
-  else
-    k_src_chain_traj<false><<<grid, dim3(64), 0, s>>>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                                                      ld_out, metric, h, (int)steps, hmc_first, pp, n, n_dev);
-  return (int)hipGetLastError();
-}
-#endif
-"""
-
-_SRC_LANES = r"""
-#include "bk_lanes.hpp"
-// ---- user code: ONE CHAIN, its coordinates spread over 4 / 8 / 16 lanes of a wavefront (bk_lanes.hpp) ---------------
-//   template <class L> __device__ double bk_lanes_density(L& c, const double* params)
-//   c.dims(), c.head(i), c.sum(f), c.grad_head(i, g), c.grad(f) with f(double theta_d, i64 d); returns the log density
-%(user)s
-// -------------------------------------------------------------------------------------------------------------------
-namespace {
-struct BkSrcDensity {
-  static constexpr int HEAD = %(head)d;
-  template <class L>
-  __device__ __forceinline__ static double eval(L& c, const double* params) { return bk_lanes_density(c, params); }
-};
-constexpr int BK_SRC_SL = %(sl)d;  // slots per class for this D (0: D - HEAD > 128, the gradient op walks the rows in memory)
-int launch(const double* th, double* g, double* logp, i64 ld, const void* params, i64 C, i64 D, const uint32_t* n_dev,
-           void* stream) {
-  return bkl::target_launch<BkSrcDensity, BK_SRC_SL>(th, g, logp, ld, static_cast<const double*>(params), C, D, n_dev, stream);
-}
-}  // namespace
-// one leapfrog step {gradient, kick, drift} per launch, theta and rho advanced in place (lane count optionally on the device):
-// what the step-by-step paths call instead of {bk_src_target_n, bk_leapfrog_kick_drift} -- half the launches
-extern "C" int bk_src_leapfrog_step(double* theta, double* rho, int64_t ld, const double* metric, double h, const void* params,
-                                    int64_t n, int64_t D, const uint32_t* n_dev, void* stream) {
-  return bkl::step_launch<BkSrcDensity, BK_SRC_SL>(theta, rho, ld, metric, h, static_cast<const double*>(params), n, D, n_dev,
-                                                   stream);
-}
-#if %(sl)d > 0
-// a whole HMC trajectory per launch (the argument list of bk_hmc_trajectory_funnel + params)
-extern "C" int bk_src_hmc_trajectory_lanes(const double* theta_in, double* rho, const double* grad_in, double* theta_out,
-                                           double* grad_out, double* logp_out, double* kin_out, int64_t ld, const double* metric,
-                                           double eps, int64_t steps, int64_t C, int64_t D, const void* params, void* stream) {
-  return bkl::hmc_trajectory_launch<BkSrcDensity, BK_SRC_SL>(theta_in, rho, grad_in, ld, theta_out, grad_out, logp_out, kin_out, ld,
-                                                             metric, eps, steps, C, D, static_cast<const double*>(params), stream);
-}
-#endif
-#if %(sl)d > 0
-// one whole delayed-rejection proposal per launch with bk_lanes_density inlined: the argument list of
-// bk_dr_proposal_funnel_job (include/bkhip.h) + params
-extern "C" int bk_src_dr_proposal_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
-                                      const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
-                                      double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
-                                      int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
-                                      uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out,
-                                      const bk_scatter_job* job, const bk_ghost_link* ghost, const bk_ghost0* ghost0,
-                                      const void* params, void* stream) {
-  return bkl::dr_proposal_launch<BkSrcDensity, BK_SRC_SL>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out,
-                                                          grad_out, logp_out, kin_out, ld_out, metric, h, steps, n, D, n_dev,
-                                                          lanes_out, lanes_total, H_out, h_out, live_out, job, ghost, ghost0,
-                                                          static_cast<const double*>(params), stream);
-}
-#endif
-"""
-
-_SRC_EXPORTS = r"""
-extern "C" int bk_src_target(const double* theta, double* grad, double* logp, int64_t ld, const void* params, int64_t C,
-                             int64_t D, void* stream) {
-  return launch(theta, grad, logp, ld, params, C, D, nullptr, stream);
-}
-extern "C" int bk_src_target_n(const double* theta, double* grad, double* logp, int64_t ld, const void* params, int64_t C,
-                               int64_t D, const uint32_t* n_dev, void* stream) {
-  if (!n_dev) return -1;
-  return launch(theta, grad, logp, ld, params, C, D, n_dev, stream);
-}
-"""
+_SRC_RULE = "// " + "-" * 115 + "\n"
 
 _LANES_MAX_ROWS = 128  # bk_lanes.hpp MAX_ROWS: spread rows a trajectory kernel keeps in registers
 _LANES_MAX_HEAD = 8
@@ -873,14 +440,18 @@ def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
         if dims < max(1, head):
             raise ValueError("dims must be at least max(1, head)")
         rows = dims - head
-        sl = 0 if rows > _LANES_MAX_ROWS else max(1, -(-rows // 16))
-        body = _SRC_LANES % {"user": user_source, "head": int(head), "sl": sl}
+        shape = {"HEAD": int(head), "SL": 0 if rows > _LANES_MAX_ROWS else max(1, -(-rows // 16))}
     elif form == "elementwise":
-        body = _SRC_ELEMENTWISE % {"user": user_source, "sl": 0 if dims > _LANES_MAX_ROWS else max(1, -(-dims // 16))}
+        shape = {"SL": 0 if dims > _LANES_MAX_ROWS else max(1, -(-dims // 16))}  # (slots per class; 0: no lane-spread kernels)
     else:
-        body = _SRC_CHAIN % {"user": user_source, "dims": int(dims), "stage": int(dims) if int(dims) <= 128 else 0,
-                             "lds": int(dims) if 128 < int(dims) <= 300 else 0}
-    return _SRC_PRELUDE + body + _SRC_EXPORTS
+        # STAGE = D when a chain's coordinates fit the registers of its lane (D <= 128), LDS = D when 64 chains' coordinates fit
+        # a workgroup's LDS instead (D <= 300)
+        shape = {"DIMS": int(dims), "STAGE": int(dims) if int(dims) <= 128 else 0, "LDS": int(dims) if 128 < int(dims) <= 300 else 0}
+    defines = "".join(f"#define BK_SOURCE_{k} {v}\n" for k, v in shape.items())
+    return (f"// Generated by bayes_kit_amd.CTarget.from_source(form=\"{form}\"): plugin ABI bk_target_fn / bk_target_fn_n "
+            "(include/bkhip.h) + the entry points of include/bkhip_source.h.\n"
+            f"#define BK_SOURCE_FORM_{form} 1\n" + defines + "#include \"bk_source_api.hpp\"\n"
+            + _SRC_USER_COMMENT[form] + user_source.rstrip("\n") + "\n" + _SRC_RULE + "#include \"bk_source_kernels.hpp\"\n")
 
 
 _SRC_REQUIRED_EXPORTS = ("bk_src_target", "bk_src_target_n")
@@ -903,7 +474,8 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
         # coordinates then lives in registers, LDS reads are issued in batches; clang's default budget stops at trip counts of ~60)
         flags += ["-mllvm", "-unroll-threshold=%d" % (4000 if int(dims) <= 128 else 10000)]
     h = hashlib.sha256((text + " ".join(flags)).encode())
-    for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", os.path.join(inc, "bkhip.h")):
+    for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_source_api.hpp", "bk_source_kernels.hpp",
+                 os.path.join(inc, "bkhip.h")):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     tag = h.hexdigest()[:20]
