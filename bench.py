@@ -348,11 +348,10 @@ def cpu_baseline():
             res.append((r["steps"], r["seconds"]))
         wall = time.perf_counter() - t0
         busy = max(r[1] for r in res)  # slowest worker's compute time (excludes process start-up)
-        return sum(r[0] for r in res) / busy, wall
+        return sum(r[0] for r in res) / busy, wall, sum(r[1] for r in res)
 
     chains_per_proc, draws = 8, 400  # 8 x 400 x 64 = 205k leapfrog steps per process
-    rate, wall = fan_out(P,
-                         lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
+    rate, wall, cpu_s = fan_out(P, lambda p: [p * chains_per_proc, chains_per_proc, draws, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3])
     out = {
         "value": rate,
         "unit": "leapfrog steps/sec",
@@ -363,14 +362,16 @@ def cpu_baseline():
         "cpu_model": _cpu_model(),
         "kind": "port",
         "sample": f"{P} procs x {chains_per_proc} chains x {draws} draws x L={L_CFG3} at D={D_CFG3} "
-                  f"(oracle/samplers.py HMCDiag, one object per chain); wall incl. spawn {wall:.1f}s",
+                  f"(oracle/samplers.py HMCDiag, one object per chain); {cpu_s:.0f} CPU-seconds of work in all, wall incl. "
+                  f"spawn {wall:.1f}s",
+        "cpu_seconds": cpu_s,
         "leg_seconds": wall,
     }
     if os.environ.get("BK_BENCH_BATCHED_NUMPY"):
         # context only (opt-in): the same arithmetic hand-vectorised over [D, C] arrays (not how the reference runs)
         try:
             bc, bd = 512, 6
-            brate, bwall = fan_out(P, lambda p: ["batched", bc, bd, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3 + 1 + p])
+            brate, bwall, _ = fan_out(P, lambda p: ["batched", bc, bd, D_CFG3, L_CFG3, EPS_CFG3, SEED_CFG3 + 1 + p])
             out["batched_numpy"] = {"value": brate, "unit": "leapfrog steps/sec", "cores": P,
                                     "sample": f"{P} procs x {bc} chains x {bd} draws, [D, C] arrays, in-place ufuncs; "
                                               f"wall incl. spawn {bwall:.1f}s"}
