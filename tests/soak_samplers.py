@@ -85,7 +85,10 @@ def funnel_paths(rng):
     # round 5: "builtin" runs {gradient, kick, drift} as ONE launch per step (bk_leapfrog_step), "builtin_op" keeps the gradient a
     # separate op; "source" / "source_op": the funnel compiled from lanes-form source on the counted path, with / without the
     # one-launch step; "source_fused": the same source through the one-launch proposal kernel (against the built-in's)
-    opaque = str(rng.choice(["none", "builtin", "builtin_op", "plugin", "source", "source_op", "source_fused"]))
+    # "chain" / "chain_step" / "chain_op": the funnel as a PER-CHAIN source (class-order sums: bk.Funnel's bits) with one launch per
+    # trajectory (bk_leapfrog_trajectory, D <= 128), one per leapfrog step, or the gradient a separate op; counted or host-sized
+    opaque = str(rng.choice(["none", "builtin", "builtin_op", "plugin", "source", "source_op", "source_fused", "chain", "chain_step",
+                             "chain_op"]))
     desc["opaque"] = opaque
     o = a2 = None
     if opaque != "none":
@@ -97,6 +100,14 @@ def funnel_paths(rng):
                               device_counts=True, graph=graph, **kw)
             if opaque == "source_fused":
                 a2 = mk(device_counts=True, graph=graph)   # (the fused kernels sum the kinetic energy in their lanes' order)
+        elif opaque.startswith("chain"):
+            src = bk.CTarget.from_source(FUNNEL_CHAIN_CLASS_ORDER_SRC, D, form="chain")
+            kw = dict(chain=dict(), chain_step=dict(fuse_builtin=False), chain_op=dict(fuse_steps=False))[opaque]
+            dc = bool(rng.integers(0, 2))
+            desc["chain_device_counts"] = dc
+            o = bk.DrGhmcDiag(src, K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed, prob_retry=pr,
+                              device_counts=dc, graph=graph and dc, **kw)
+            assert o._traj_hook == (opaque == "chain" and D <= 128), desc
         elif opaque == "builtin_op":
             o = mk(device_counts=True, graph=graph, fuse_builtin=False, fuse_steps=False)
         elif opaque == "plugin":
@@ -126,6 +137,27 @@ def funnel_paths(rng):
         assert np.array_equal(a.rng_state(), o.rng_state()), ("opaque stream", desc)
     return "drfunnel"
 
+
+FUNNEL_CHAIN_CLASS_ORDER_SRC = """
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* /*params*/) {
+  const double v = th[0];
+  double cs[16];
+  for (int c = 0; c < 16; ++c) {
+    double a = 0.0;
+    for (i64 d = 1 + c; d < D; d += 16) { const double x = th[d]; a = a + x * x; }
+    cs[c] = a;
+  }
+  double q[4];
+  for (int k = 0; k < 4; ++k) q[k] = ((cs[k] + cs[k + 4]) + cs[k + 8]) + cs[k + 12];
+  const double s = ((q[0] + q[1]) + q[2]) + q[3];
+  const double ev = exp(-v), hn = 0.5 * (double)(D - 1), he = 0.5 * ev;
+  if (g.wanted()) {
+    g.set(0, ((-v / 9.0) - hn) + he * s);
+    for (i64 d = 1; d < D; ++d) g.set(d, -(ev * th[d]));
+  }
+  return ((-(v * v) / 18.0) - hn * v) - he * s;
+}
+"""
 
 FUNNEL_LANES_SRC = """
 template <class L>
