@@ -285,10 +285,10 @@ static int step_launch(double* theta, double* rho, int64_t ld, const double* par
   const bool vec = !n_dev && n % 2 == 0 && ld % 2 == 0 && bk_aligned16(theta) && bk_aligned16(rho);
   if (vec) {
     const bool nt = bk_streams_past_llc(4 * n * D) && D <= 65535;
-    if (nt) {
-      dim3 grid((unsigned)bk_cdiv(n / 2, BLOCK), (unsigned)D);
-      if (metric) k_step<TERM, 1, true, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
-      else k_step<TERM, 1, false, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+    if (nt) {  // (two rows per thread: 0.82 of 8 TB/s at config-3 shape; one: 0.79, four: 0.70 -- tools/step_stream_bench.py)
+      dim3 grid((unsigned)bk_cdiv(n / 2, BLOCK), (unsigned)bk_cdiv(D, 2));
+      if (metric) k_step<TERM, 2, true, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
+      else k_step<TERM, 2, false, true><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
     } else {
       dim3 grid((unsigned)bk_cdiv(n / 2, BLOCK), (unsigned)bk_cdiv(D, 2));
       if (metric) k_step<TERM, 2, true, false><<<grid, dim3(BLOCK), 0, s>>>(theta, rho, ld, params, metric, h, n / 2, D);
