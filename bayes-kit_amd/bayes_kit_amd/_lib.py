@@ -65,6 +65,7 @@ SIGNATURES = {
     "bk_mala_single_draw": [c_int, P, I, P, P, P, P, P, P, P, I, P, P, F, F, I, c_int, F, P],
     "bk_mala_step_supported": [I, I, I],
     "bk_mala_step": [P, P, P, P, P, I, P, P, P, P, I, F, F, P, P, P, I, I, P],
+    "bk_mala_step_gaussian": [P, P, P, I, P, P, P, P, P, I, F, F, P, P, P, I, I, P],
     "bk_target_iso_gaussian_grad": [P, P, P, I, I, I, P],
     "bk_target_diag_gaussian_grad": [P, P, P, I, P, I, I, P],
     "bk_target_funnel_grad": [P, P, P, I, I, I, P],
@@ -508,6 +509,20 @@ class Ops:
         self._call("bk_mala_step", ptr(theta), ptr(theta_out), ptr(grad), ptr(theta_prop), ptr(grad_prop), ld,
                    ptr(lp), ptr(lp_prop), ptr(log_u), ptr(zt_next), ldz, eps, sqrt2eps, ptr(mask), ptr(ret),
                    ptr(count), C, D, self._s())
+
+    def mala_step_gaussian(self, lam, theta, theta_out, theta_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret,
+                           count):
+        """mala_step for the separable built-in Gaussians (lam None = identity): both gradients recomputed from theta /
+        theta_prop inside the kernel, none stored (bk_mala_step_gaussian)."""
+        D, C = theta.shape
+        ld = _ld(theta)
+        assert _ld(theta_out) == ld and _ld(theta_prop) == ld
+        ldz = 0
+        if zt_next is not None:
+            assert zt_next.shape[0] == C and zt_next.stride(1) == 1 and zt_next.shape[1] >= D
+            ldz = zt_next.stride(0)
+        self._call("bk_mala_step_gaussian", ptr(theta), ptr(theta_out), ptr(theta_prop), ld, ptr(lam), ptr(lp), ptr(lp_prop),
+                   ptr(log_u), ptr(zt_next), ldz, eps, sqrt2eps, ptr(mask), ptr(ret), ptr(count), C, D, self._s())
 
     # -- built-in targets -----------------------------------------------------------------------
     def target_grad(self, kind, params, theta, grad, logp, n_dev=None):

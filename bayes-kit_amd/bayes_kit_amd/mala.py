@@ -13,6 +13,10 @@ Two ways through the device:
   normals generated ahead on a side stream -- 88*D bytes of HBM traffic per chain-draw.  The
   state array is rebound every draw, as the reference rebinds ``_theta`` (mala.py:62): the
   tensor ``sample()`` returns IS the new state and is never written again.
+  For a model that is a SEPARABLE density the library can inline (``bk_mala_step``: the built-in Gaussians, an elementwise
+  ``CTarget.from_source`` / traced ``TorchModel``) the step kernel recomputes both gradients from theta and theta' and stores
+  none: the model's launch is its log density alone and a draw moves 56*D bytes; the same draws bit for bit
+  (``fuse_builtin=False`` keeps the model-opaque pair of launches).
 * **step by step** (everything else: a single-chain host model, PCG64 streams, odd shapes):
   proposal, gradient, proposal densities, accept and select as separate kernels.
 
@@ -42,7 +46,7 @@ class MALA(ManyChainSampler):
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
                  chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None,
                  tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None,
-                 single_launch: Optional[bool] = None, ops=None):
+                 single_launch: Optional[bool] = None, fuse_builtin: bool = True, ops=None):
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph, prefetch_rng)
@@ -80,6 +84,12 @@ class MALA(ManyChainSampler):
                              "of chains")
         self._two_pass = can_two_pass if two_pass is None else bool(two_pass)
         self.path = "two-pass (bk_mala_step)" if self._two_pass else "step-by-step"
+        # a separable density the library can inline: the step kernel recomputes the gradients (none is stored between draws;
+        # _grad is brought up to date when somebody asks for it)
+        self._sep_step = bool(fuse_builtin) and self._two_pass and hasattr(model, "bk_mala_step") and hasattr(model, "bk_eval")
+        self._grad_stale = False
+        if self._sep_step:
+            self.path = "two-pass, gradients recomputed in the step kernel (model.bk_mala_step)"
         nbuf = 2 if self._prefetch else 1
         if self._chain_major:
             dp = (D + 7) // 8 * 8
@@ -126,12 +136,20 @@ class MALA(ManyChainSampler):
         # mala.py:31-32: (logp, grad) at theta0
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
 
+    def _fresh_grad(self):
+        """The cached gradient of the current point; the separable step kernel does not keep it (recomputed on demand)."""
+        if self._grad_stale:
+            self._materialize(self._eval_grad(self._theta_dc, self._grad, None), self._grad)
+            self._grad_stale = False
+        return self._grad
+
     def refresh_cache(self):
         """Recompute the cached (logp, grad) of the current point (mala.py:31-32) after ``_theta`` was
         assigned or edited from outside, as the reference's constructor does for ``init``; a proposal
         made ahead from the old point is discarded (its normals are drawn again, same values)."""
         self._invalidate_pipe(restore_stream=True)
         self._materialize(self._eval_grad(self._theta_dc, self._grad, self._lp), self._grad)
+        self._grad_stale = False
 
     def _invalidate_pipe(self, restore_stream):
         if (self._two_pass or getattr(self, "_single", False)) and self._pipe_valid and restore_stream:
@@ -163,7 +181,7 @@ class MALA(ManyChainSampler):
                           "draw_kernels_ms_chosen": rep["ms_chosen"], "assignments_tried": rep["assignments_tried"]}
 
     def _state_tensors(self):
-        return {"theta": self._theta_dc, "grad": self._grad, "lp": self._lp, "accepted": self._accepted}
+        return {"theta": self._theta_dc, "grad": self._fresh_grad(), "lp": self._lp, "accepted": self._accepted}
 
     def _logical_rng(self):
         if getattr(self, "_single", False):
@@ -193,6 +211,7 @@ class MALA(ManyChainSampler):
         super().load_state_dict(sd)
 
     def _after_load(self):
+        self._grad_stale = False  # (the gradient of the restored point came with it)
         self._pf_event, self._pf_slot, self._pf_ready = None, 0, False
         self._invalidate_pipe(restore_stream=False)  # the stream was just restored to its logical position
 
@@ -292,7 +311,7 @@ class MALA(ManyChainSampler):
 
     @property
     def _log_p_grad_theta(self):
-        return self._grad.t() if self._batched else self._grad[:, 0].cpu().numpy()
+        return self._fresh_grad().t() if self._batched else self._grad[:, 0].cpu().numpy()
 
     def _graph_key(self):
         return float(self._epsilon)
@@ -334,6 +353,8 @@ class MALA(ManyChainSampler):
         if self._single:
             return self._sample_single()
         self._run_draw(self._draw2 if self._two_pass else self._draw)
+        if self._sep_step:
+            self._grad_stale = True  # (here, not in _draw2: a replayed hipGraph does not run the Python of the draw)
         self._join_side_stream()
         self._draws += 1
         if self._two_pass and not self._use_graph:
@@ -349,10 +370,15 @@ class MALA(ManyChainSampler):
             # this draw's proposal from the stream's next D normals (mala.py:41-45); later draws'
             # proposals are written by the previous draw's kernel
             ops.normals_chain_major(self._rng_kind, self._rng_state, self._zt_bufs[0], self._dim)
-            ops.mala_propose_from_normals(th, self._grad, self._z_bufs[0], thp, eps, s2)
+            ops.mala_propose_from_normals(th, self._fresh_grad(), self._z_bufs[0], thp, eps, s2)
             self._pipe_valid, self._unit_ready = True, False
         logu, zt_next = self._take_unit()
-        gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)   # mala.py:46-48
+        if self._sep_step:
+            self._eval_logp(thp, self._lp_p)                                                   # mala.py:46-48, log density
+            self._grad_calls += 1   # (the gradient of the same call is evaluated inside the step kernel)
+            gp = None
+        else:
+            gp = self._materialize(self._eval_grad(thp, self._grad_p, self._lp_p), self._grad_p)   # mala.py:46-48
         out = th if self._use_graph else self._new_state()
         with_step = self._prefetch and self.generate_with == "step"
         if self._prefetch and self.serialize_step and self._pf_event is not None and not with_step:
@@ -363,8 +389,12 @@ class MALA(ManyChainSampler):
             self._ev_ready[self._pf_slot].record(torch.cuda.current_stream())
             if not self.step_first:
                 self._start_unit(self._pf_slot, recorded=True)
-        ops.mala_step(th, out, self._grad, thp, gp, self._lp, self._lp_p, logu, zt_next, eps, s2,
-                      self._mask, self._ret, self._accepted)                                   # mala.py:50-66
+        if self._sep_step:
+            self._model.bk_mala_step(th, out, thp, self._lp, self._lp_p, logu, zt_next, eps, s2,
+                                     self._mask, self._ret, self._accepted)                    # mala.py:50-66
+        else:
+            ops.mala_step(th, out, self._grad, thp, gp, self._lp, self._lp_p, logu, zt_next, eps, s2,
+                          self._mask, self._ret, self._accepted)                               # mala.py:50-66
         if with_step and self.step_first:
             self._start_unit(self._pf_slot, recorded=True)
         self._theta_dc = out

@@ -95,6 +95,12 @@ class _GaussianLanes:
         """One leapfrog step {gradient, kick, drift} as ONE launch, theta / rho advanced in place (any D)."""
         self._get_ops().leapfrog_step_gaussian(self._lam_or_none(theta.device), theta, rho, metric, h, n_dev=n_dev)
 
+    def bk_mala_step(self, theta, theta_out, theta_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret, count):
+        """MALA's step kernel (proposal densities, accept, select, next proposal; mala.py:41-66) with the density's term inlined:
+        both gradients recomputed from theta / theta_prop, none stored (56 D bytes per chain-draw instead of 88 D)."""
+        self._get_ops().mala_step_gaussian(self._lam_or_none(theta.device), theta, theta_out, theta_prop, lp, lp_prop, log_u,
+                                           zt_next, eps, sqrt2eps, mask, ret, count)
+
 
 class IsoGaussian(_GaussianLanes, _BuiltinTarget):
     """logp = -1/2 theta.theta (BASELINE.json config 2)."""
@@ -474,7 +480,7 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
         # coordinates then lives in registers, LDS reads are issued in batches; clang's default budget stops at trip counts of ~60)
         flags += ["-mllvm", "-unroll-threshold=%d" % (4000 if int(dims) <= 128 else 10000)]
     h = hashlib.sha256((text + " ".join(flags)).encode())
-    for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_source_api.hpp", "bk_source_kernels.hpp",
+    for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_mala_step.hpp", "bk_source_api.hpp", "bk_source_kernels.hpp",
                  os.path.join(inc, "bkhip.h")):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
@@ -542,6 +548,22 @@ def _bind_source_fast_paths(t):
     f_draw = export("bk_src_hmc_draw", [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P])
     f_prop = export("bk_src_dr_proposal_job", [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P])
 
+    f_mala = export("bk_src_mala_step", [P, P, P, I, P, P, P, P, P, I, F, F, P, P, P, I, I, P])
+    if f_mala is not None:
+        def bk_mala_step(self, theta, theta_out, theta_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret, count):
+            """MALA's step kernel with the compiled term inlined (arguments as the built-in Gaussians' bk_mala_step)."""
+            D, C = theta.shape
+            ld = _lib._ld(theta)
+            assert _lib._ld(theta_out) == ld and _lib._ld(theta_prop) == ld
+            ldz = 0
+            if zt_next is not None:
+                assert zt_next.shape[0] == C and zt_next.stride(1) == 1 and zt_next.shape[1] >= D
+                ldz = zt_next.stride(0)
+            check(f_mala(ptr(theta), ptr(theta_out), ptr(theta_prop), ld, self._pp, ptr(lp), ptr(lp_prop), ptr(log_u),
+                         ptr(zt_next), ldz, eps, sqrt2eps, ptr(mask), ptr(ret), ptr(count), C, D, stream(theta)),
+                  "bk_src_mala_step")
+
+        t.bk_mala_step = types.MethodType(bk_mala_step, t)
     f_step = export("bk_src_leapfrog_step", [P, P, I, P, F, P, I, I, P, P])
     if f_step is not None:
         def bk_leapfrog_step(self, theta, rho, metric, h, n_dev=None):
@@ -765,8 +787,8 @@ class TorchModel:
         # the hooks the samplers look for, straight to the compiled target
         self.bk_eval, self.bk_counted = target.bk_eval, target.bk_counted
         self.compiled_form = form
-        for name in ("bk_hmc_draw", "bk_hmc_trajectory", "bk_leapfrog_step", "bk_hmc_proposal", "bk_dr_proposal",
-                     "bk_dr_proposal_supported"):
+        for name in ("bk_hmc_draw", "bk_hmc_trajectory", "bk_leapfrog_step", "bk_leapfrog_trajectory", "bk_hmc_proposal",
+                     "bk_dr_proposal", "bk_dr_proposal_supported", "bk_mala_step"):
             if hasattr(target, name):
                 setattr(self, name, getattr(target, name))
         self.__dict__.pop("bk_gradient", None)

@@ -87,6 +87,8 @@ class EngineTarget(Protocol):
 #   bk_counted = True, bk_eval(theta, grad, logp, n_dev)   the gradient op takes its chain count from device memory
 #                                                           (DrGhmcDiag: lane counts stay on the device, a draw is one hipGraph)
 #   bk_leapfrog_step(theta, rho, metric, h, n_dev=None)     one leapfrog step {gradient, kick, drift} as ONE launch, in place
+#   bk_mala_step(theta, theta_out, theta_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret, count)
+#                          MALA's step kernel with the (separable) density inlined: gradients recomputed, none stored
 #   bk_leapfrog_trajectory(theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out, metric, h, steps,
 #                          n_dev=None, hmc_first=False)   gathering first step .. last gradient + log density as ONE launch
 #                                                           (drghmc.py:280-283, hmc.py:48-50): the step-by-step paths of

@@ -9,6 +9,7 @@
 // per-chain sum runs sequentially over d in one lane.
 #include "bk_common.hpp"
 #include "bk_elementwise.hpp"
+#include "bk_mala_step.hpp"
 #include "bk_lanes.hpp"
 #include <stdlib.h>
 
@@ -285,6 +286,18 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
                                                  kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
   return bke::hmc_draw_launch<GaussTerm<false>>(theta_in, theta_out, ld, rho_in, zt, ldz, lam, metric, eps, steps, part, kin0,
                                                 kin1, lp_out, lp_cur, log_u, accept_mask, ret, accept_count, C, D, stream);
+}
+
+int bk_mala_step_gaussian(const double* theta, double* theta_out, double* theta_prop, int64_t ld, const double* lam,
+                          double* lp, const double* lp_prop, const double* log_u, const double* zt_next, int64_t ldz,
+                          double eps, double sqrt2eps, uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C,
+                          int64_t D, void* stream) {
+  // the library's MALA step kernel for separable densities (bk_mala_step.hpp) with the Gaussian term inlined
+  if (lam)
+    return bkm::mala_step_sep_launch<GaussTerm<true>>(theta, theta_out, theta_prop, ld, lam, lp, lp_prop, log_u, zt_next, ldz, eps,
+                                                      sqrt2eps, accept_mask, ret, accept_count, C, D, stream);
+  return bkm::mala_step_sep_launch<GaussTerm<false>>(theta, theta_out, theta_prop, ld, lam, lp, lp_prop, log_u, zt_next, ldz, eps,
+                                                     sqrt2eps, accept_mask, ret, accept_count, C, D, stream);
 }
 
 int bk_target_funnel_grad_n(const double* theta, double* grad, double* logp, int64_t ld, int64_t C,

@@ -445,26 +445,40 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
 
 
 def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
-    """MALA at config-3 shape: 88*D algorithmic bytes per chain-draw."""
+    """MALA at config-3 shape: 88*D algorithmic bytes per chain-draw with the model's gradient a separate op; beside
+    it the same draws with the separable density inlined into the step kernel (56*D), reported on its own model."""
     import torch
 
     import bayes_kit_amd as bk
 
     C, D = chains, D_CFG3
     lam = torch.logspace(0, 4, D, dtype=torch.float64)
-    s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, chain_id0=ctx.rank * C, seed=7)
-    s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(ctx.device)[:, None])
-    s.refresh_cache() if hasattr(s, "refresh_cache") else None
-    for _ in range(warmup):
-        s.sample()
-    el = ctx.timed_loop(s.sample, draws)
-    per = el / draws
-    return {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), "
-                        "model-opaque gradient op",
-            "bound": "hbm", "ms_per_draw": 1e3 * per, "draws_per_sec": C * ctx.world / per,
-            "algorithmic_bytes_per_chain_draw": 88 * D, "achieved": 88.0 * D * C / per / 1e9, "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": 88.0 * D * C / per / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate(),
-            "path": getattr(s, "path", None), "placement": s.placement}
+
+    def run(**kw):
+        s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, chain_id0=ctx.rank * C, seed=7, **kw)
+        s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(ctx.device)[:, None])
+        s.refresh_cache()
+        for _ in range(warmup):
+            s.sample()
+        return s, ctx.timed_loop(s.sample, draws) / draws
+
+    s, per = run(fuse_builtin=False)
+    out = {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), "
+                       "model-opaque gradient op",
+           "bound": "hbm", "ms_per_draw": 1e3 * per, "draws_per_sec": C * ctx.world / per,
+           "algorithmic_bytes_per_chain_draw": 88 * D, "achieved": 88.0 * D * C / per / 1e9, "peak": HBM_PEAK_GBPS,
+           "unit": "GB/s", "frac": 88.0 * D * C / per / 1e9 / HBM_PEAK_GBPS, "accept_rate": s.accept_rate(),
+           "path": getattr(s, "path", None), "placement": s.placement}
+    last = s._theta_dc.clone()
+    del s
+    f, per_f = run()
+    out["density_inlined"] = {
+        "what": "the same draws with the separable density inlined into the step kernel (model.bk_mala_step: both gradients "
+                "recomputed, none stored; the model's launch is its log density alone)",
+        "ms_per_draw": 1e3 * per_f, "draws_per_sec": C * ctx.world / per_f, "algorithmic_bytes_per_chain_draw": 56 * D,
+        "achieved": 56.0 * D * C / per_f / 1e9, "unit": "GB/s", "frac_56D_model": 56.0 * D * C / per_f / 1e9 / HBM_PEAK_GBPS,
+        "accept_rate": f.accept_rate(), "path": f.path, "identical_to_model_opaque": bool(torch.equal(f._theta_dc, last))}
+    return out
 
 
 def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):

@@ -500,6 +500,16 @@ int bk_hmc_draw_gaussian(const double* theta_in, double* theta_out, int64_t ld, 
                          double* lp_out, double* lp_cur, const double* log_u, uint8_t* accept_mask,
                          double* ret, uint32_t* accept_count, int64_t C, int64_t D, void* stream);
 
+/* bk_mala_step for a SEPARABLE built-in density (the Gaussians: lam NULL = identity): proposal densities, accept, select and
+ * the next draw's proposal (bayes_kit/mala.py:41-66) with both gradients RECOMPUTED from theta / theta_prop where bk_mala_step
+ * loads them, and the gradient at the new state never stored -- 56*D bytes per chain-draw with the log-density launch
+ * (lp_prop = bk_target_*_gaussian_grad with grad NULL) instead of 88*D.  Same arithmetic on the same values as
+ * {bk_target_*_gaussian_grad, bk_mala_step}: bit-identical draws.  Arguments as bk_mala_step without grad / grad_prop. */
+int bk_mala_step_gaussian(const double* theta, double* theta_out, double* theta_prop, int64_t ld, const double* lam,
+                          double* lp, const double* lp_prop, const double* log_u, const double* zt_next, int64_t ldz,
+                          double eps, double sqrt2eps, uint8_t* accept_mask, double* ret, uint32_t* accept_count, int64_t C,
+                          int64_t D, void* stream);
+
 /* One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) on Neal's funnel in a
  * single launch, gradient callback inlined: chain j of the outputs starts from chain
  * src_index[j] (NULL = j) of the source point (theta_in, rho_in and the source's cached

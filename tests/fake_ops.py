@@ -221,6 +221,16 @@ class FakeOps:
     def mala_step_supported(self, C, D, ld):
         return C % 2 == 0 and ld % 2 == 0 and 0 < D <= 1024
 
+    def mala_step_gaussian(self, lam, theta, theta_out, theta_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret, count):
+        self._count("mala_step_gaussian")
+        import torch
+
+        kind = "iso_gaussian" if lam is None else "diag_gaussian"
+        g, gp = torch.zeros_like(theta), torch.zeros_like(theta_prop)
+        self.target_grad(kind, lam, theta, g, None)
+        self.target_grad(kind, lam, theta_prop, gp, None)
+        self.mala_step(theta, theta_out, g, theta_prop, gp, lp, lp_prop, log_u, zt_next, eps, sqrt2eps, mask, ret, count)
+
     def mala_step(self, theta, theta_out, grad, theta_prop, grad_prop, lp, lp_prop, log_u, zt_next, eps, sqrt2eps,
                   mask, ret, count):
         self._count("mala_step")

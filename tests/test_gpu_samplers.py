@@ -774,6 +774,44 @@ def test_mala_two_pass_equals_step_by_step(ops, C, D):
         assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta) and torch.equal(a._log_p_theta, b._log_p_theta)
 
 
+@pytest.mark.parametrize("C,D", [(2, 32), (130, 129), (64, 200), (48, 1024), (18, 1000), (4096, 128)])
+def test_mala_step_kernel_with_the_density_inlined_equals_the_model_opaque_pair(ops, C, D):
+    """A separable density the library can inline (built-in Gaussians, an elementwise source, a traced PyTorch function): the
+    step kernel recomputes both gradients and stores none (model.bk_mala_step; 56 D bytes per chain-draw) -- the same draws,
+    masks, stream positions and, on request, cached gradient as the model-opaque pair {gradient op, bk_mala_step}."""
+    lam = np.logspace(0, 1.5, D)
+    lam_d = torch.from_numpy(lam).to(ops.device)
+    eps = 0.3 / D
+    src = "__device__ __forceinline__ void bk_term(double th, i64 d, const double* lam, double& term, double& grad) {\n" \
+          "  const double lt = lam[d] * th; term = -0.5 * (th * lt); grad = -lt; }\n"
+    models = [lambda: bk.DiagGaussian(lam), lambda: bk.IsoGaussian(D), lambda: bk.CTarget.from_source(src, D, params=lam_d)]
+    if D <= 200:
+        models.append(lambda: bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam_d).sum(dim=1), D, compile=True))
+    for mi, model_of in enumerate(models):
+        for kw in (dict(prefetch_rng=False, graph=False), dict(prefetch_rng=True, graph=False), dict(graph=True)):
+            a = bk.MALA(model_of(), eps, chains=C, seed=78, two_pass=True, fuse_builtin=False, prefetch_rng=False, graph=False)
+            b = bk.MALA(model_of(), eps, chains=C, seed=78, two_pass=True, **kw)
+            assert b._sep_step and not a._sep_step and "recomputed" in b.path, (mi, b.path)
+            for n in range(6):
+                ta, la = a.sample()
+                tb, lb = b.sample()
+                assert torch.equal(ta, tb) and torch.equal(la, lb), (mi, kw, n)
+                assert torch.equal(a.last_accept, b.last_accept)
+                if n == 2:
+                    assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta)
+                    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+            assert 0.05 < a.accept_rate() == b.accept_rate()
+            assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta) and torch.equal(a._log_p_theta, b._log_p_theta)
+            if mi == 0 and not kw.get("graph"):   # checkpoint of the inlined path -> resumed on the model-opaque one
+                sd = b.state_dict()
+                c = bk.MALA(model_of(), eps, chains=C, seed=1, two_pass=True, fuse_builtin=False, graph=False)
+                c.load_state_dict(sd)
+                for n in range(3):
+                    tb, lb = b.sample()
+                    tc, lc = c.sample()
+                    assert torch.equal(tb, tc) and torch.equal(lb, lc), n
+
+
 def test_whole_draw_hmc_rebinds_its_state_and_keeps_returned_draws(ops):
     """The one-pass HMC draw writes the blend of state and proposal to a fresh array that becomes the
     state (bk_blend_columns): draws handed out earlier are never written again, not by later draws and

@@ -8,7 +8,11 @@ C, D = int(os.environ.get("C", 65536)), int(os.environ.get("D", 1024))
 lam = torch.logspace(0, 4, D, dtype=torch.float64)
 s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, graph=os.environ.get("GRAPH", "0") == "1",
             prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None),
-            two_pass={"0": False, "1": True}.get(os.environ.get("TWO_PASS", ""), None))
+            two_pass={"0": False, "1": True}.get(os.environ.get("TWO_PASS", ""), None),
+            fuse_builtin=os.environ.get("INLINED", "1") == "1")  # INLINED=0: the model-opaque pair {gradient op, bk_mala_step}
+for k in ("serialize_step", "generate_with", "generator_workgroups"):   # e.g. serialize_step=0 generate_with=step
+    if os.environ.get(k):
+        setattr(s, k, os.environ[k] if k == "generate_with" else int(os.environ[k]))
 s._theta_dc.mul_((1.0 / torch.sqrt(lam)).to(s._theta_dc.device)[:, None])
 s.refresh_cache()
 for _ in range(3):
