@@ -726,8 +726,10 @@ class TorchModel:
     compiled target like a built-in one.  If it is instead a HIERARCHICAL density -- head coordinates ``Th[:, i]``, the rows
     ``Th[:, H:]``, row expressions that may use head-derived values broadcast with ``[:, None]``, sums over ``dim=1``, any scalar
     expression of heads and sums -- it is compiled into the lane-spread form (``trace_lanes.py``) and gets the one-launch HMC
-    trajectory / delayed-rejection proposal kernels ``bk.Funnel`` has.  Anything else warns (naming the node,
-    ``.compile_note``) and keeps autograd.
+    trajectory / delayed-rejection proposal kernels ``bk.Funnel`` has.  If its coordinates are COUPLED THROUGH SHIFTED SLICES
+    (``x[:, 1:] - phi[:, None] * x[:, :-1]``, ``torch.diff``: AR(1) and random-walk priors, state-space and stochastic-volatility
+    models) it is compiled into the per-chain form (``trace_chain.py``): compiled gradient op, one launch per leapfrog step and,
+    for D <= 128, one launch per trajectory.  Anything else warns (naming the node, ``.compile_note``) and keeps autograd.
     """
 
     batched = True
@@ -771,9 +773,19 @@ class TorchModel:
                 src, head, params, info = trace_lanes.lanes_source(self._fn, self._D)
                 form = "lanes"
             except trace.Unsupported as e2:
-                self.compile_note = f"as a sum over coordinates: {e}; as head coordinates plus sums over rows: {e2}"
-                warnings.warn(f"TorchModel(compile=True): not traceable ({self.compile_note}); keeping autograd", stacklevel=3)
-                return
+                # coordinates coupled through shifted slices (AR(1), random walks, state-space models)?  -> the per-chain form
+                try:
+                    if self._dc:
+                        raise trace.Unsupported("traced in the (C, D) layout only")
+                    from . import trace_chain
+
+                    src, params, info = trace_chain.chain_source(self._fn, self._D)
+                    form = "chain"
+                except trace.Unsupported as e3:
+                    self.compile_note = (f"as a sum over coordinates: {e}; as head coordinates plus sums over rows: {e2}; "
+                                         f"as sums over shifted slices: {e3}")
+                    warnings.warn(f"TorchModel(compile=True): not traceable ({self.compile_note}); keeping autograd", stacklevel=3)
+                    return
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         p = None if params is None else params.to(dev)
         target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract)

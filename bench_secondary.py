@@ -656,6 +656,45 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         del s, a
     except Exception as e:  # context only
         out["traced_hierarchical"] = {"error": repr(e)}
+    # (3) a density whose coordinates are COUPLED through shifted slices: an AR(1) state-space model (learned correlation and
+    # innovation scale, Gaussian observations) written with slices in PyTorch -> trace_chain.py -> the per-chain form: the whole
+    # trajectory of a proposal one launch -- against the same function through autograd
+    try:
+        Da, Ca = 101, 32768  # (config 4's shape)
+        ya = torch.sin(torch.linspace(0.0, 9.0, Da - 2, dtype=torch.float64, device=ctx.device))
+
+        def ar1(Th):
+            phi, ls, x = torch.tanh(Th[:, 0]), Th[:, 1], Th[:, 2:]
+            inn = x[:, 1:] - phi[:, None] * x[:, :-1]
+            return -0.5 * (inn * inn).sum(-1) * torch.exp(-2 * ls) - (Da - 3) * ls \
+                - 0.5 * x[:, 0] ** 2 * (1 - phi * phi) * torch.exp(-2 * ls) - 2.0 * ((ya - x) ** 2).sum(-1) \
+                - 0.5 * Th[:, 0] ** 2 - 0.5 * (ls + 1.0) ** 2 / 0.09
+
+        args = (3, [0.03, 0.012, 0.005], [10, 40, 160], 0.1)
+        th0 = 0.3 * torch.randn((Ca, Da), dtype=torch.float64, device=ctx.device)
+        t0 = time.perf_counter()
+        tm = bk.TorchModel(ar1, Da, compile=True)
+        build_s = time.perf_counter() - t0
+        rec = {"what": "AR(1) state-space model D=101 written with shifted slices in PyTorch, DRGHMC K=3 L=(10,40,160) on 32,768 "
+                       "chains: TorchModel(compile=True) -> per-chain form -> one launch per trajectory",
+               "compiled_form": getattr(tm, "compiled_form", None), "construction_s_incl_trace_hipcc_or_cache": build_s}
+        for key, kw in (("ms_per_draw", {}), ("ms_per_draw_one_launch_per_step", dict(fuse_builtin=False)),
+                        ("ms_per_draw_gradient_separate_op", dict(fuse_steps=False))):
+            s = bk.DrGhmcDiag(bk.TorchModel(ar1, Da, compile=True), *args, chains=Ca, seed=20246, init=th0, **kw)
+            for _ in range(3):
+                s.sample()
+            rec[key] = 1e3 * ctx.timed_loop(s.advance, 10) / 10
+            rec["host_syncs_per_draw"] = s.host_syncs_per_draw
+            del s
+        a = bk.DrGhmcDiag(bk.TorchModel(ar1, Da), *args, chains=Ca, seed=20246, init=th0)
+        a.sample()
+        per_a = ctx.timed_loop(a.sample, 2) / 2
+        rec.update(autograd_ms_per_draw=1e3 * per_a, autograd_host_syncs_per_draw=a.host_syncs_per_draw,
+                   speedup_vs_autograd=1e3 * per_a / rec["ms_per_draw"])
+        out["traced_coupled"] = rec
+        del a
+    except Exception as e:  # context only
+        out["traced_coupled"] = {"error": repr(e)}
     return out
 
 

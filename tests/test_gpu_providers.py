@@ -523,6 +523,65 @@ def test_torch_model_traces_hierarchical_densities_into_the_lanes_form(ops):
     np.testing.assert_array_equal(a.rng_state(), b.rng_state())
 
 @pytest.mark.gpu
+def test_torch_model_traces_coupled_densities_into_the_per_chain_form(ops):
+    """TorchModel(fn, D, compile=True) on densities whose coordinates are coupled through shifted slices (trace_chain.py): an AR(1)
+    state-space model with learned correlation and scale, a second-order random-walk prior, a stochastic-volatility model --
+    compiled into the per-chain form: gradient equal to autograd, one launch per trajectory == one launch per step == gradient a
+    separate op under DRGHMC (counted and host-sized) and HMC, bit for bit."""
+    dev = ops.device
+    D = 101
+    y = torch.sin(torch.linspace(0.0, 9.0, D - 2, dtype=torch.float64, device=dev))
+    y1 = torch.cat([y, y[:1]])
+
+    def ar1(Th):
+        phi, ls, x = torch.tanh(Th[:, 0]), Th[:, 1], Th[:, 2:]
+        inn = x[:, 1:] - phi[:, None] * x[:, :-1]
+        return -0.5 * (inn * inn).sum(-1) * torch.exp(-2 * ls) - (D - 3) * ls - 0.5 * x[:, 0] ** 2 * (1 - phi * phi) * torch.exp(-2 * ls) \
+            - 2.0 * ((y - x) ** 2).sum(-1) - 0.5 * Th[:, 0] ** 2 - 0.5 * (ls + 1.0) ** 2 / 0.09
+
+    def rw2(Th):
+        d2 = torch.diff(torch.diff(Th, dim=1), dim=1)
+        return -0.5 * (d2 ** 2).sum(1) * 4.0 - 0.05 * (Th ** 2).sum(1)
+
+    def sv(Th):
+        mu, h = Th[:, 0], Th[:, 1:]
+        return -0.5 * ((h[:, 1:] - mu[:, None] - 0.9 * (h[:, :-1] - mu[:, None])) ** 2).sum(-1) / 0.04 \
+            - 0.5 * (h + y1 * y1 * torch.exp(-h)).sum(-1) - 0.5 * mu * mu
+
+    for fn, dims in ((ar1, D), (rw2, 64), (sv, D), (rw2, 150)):
+        m = bk.TorchModel(fn, dims, compile=True)
+        assert m.compiled is not None and m.compiled_form == "chain", (fn.__name__, m.compile_note)
+        Th = 0.3 * torch.randn((777, dims), dtype=torch.float64, device=dev)
+        x = Th.clone().requires_grad_(True)
+        lp_t = fn(x)
+        (g_t,) = torch.autograd.grad(lp_t.sum(), x)
+        lp, g = m.log_density_gradient(Th)
+        np.testing.assert_allclose(lp.cpu().numpy(), lp_t.detach().cpu().numpy(), rtol=1e-11, atol=1e-10, err_msg=fn.__name__)
+        np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=1e-10, atol=1e-11 * float(g_t.abs().max()),
+                                   err_msg=fn.__name__)
+        args = (3, [0.03, 0.012, 0.005], [4, 8, 16], 0.2)
+        th0 = 0.3 * torch.randn((1500, dims), dtype=torch.float64, device=dev)
+        mk = lambda **kw: bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=71, init=th0, **kw)  # noqa: E731
+        f, c, op, hs = mk(), mk(fuse_builtin=False), mk(fuse_steps=False), mk(device_counts=False)
+        assert f._traj_hook == (dims <= 128) and c._step_hook == (dims <= 128) and not c._traj_hook and not op._step_hook
+        assert f._dev_counts and not hs._dev_counts and f.host_syncs_per_draw == 0
+        for n in range(5):
+            tf, lf = f.sample()
+            assert torch.isfinite(tf).all(), (fn.__name__, n)
+            for other in (c, op, hs):
+                to, lo = other.sample()
+                assert torch.equal(tf, to) and torch.equal(lf, lo), (fn.__name__, dims, n)
+        ha = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.02, 8, chains=1500, seed=72, init=th0)
+        hb = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.02, 8, chains=1500, seed=72, init=th0, fuse_steps=False)
+        assert ha._traj_hook == (dims <= 128)
+        for _ in range(4):
+            ta, la = ha.sample()
+            tb, lb = hb.sample()
+            assert torch.equal(ta, tb) and torch.equal(la, lb), fn.__name__
+        assert 0.3 < ha.accept_rate() <= 1.0, (fn.__name__, ha.accept_rate())
+
+
+@pytest.mark.gpu
 def test_torch_model_traces_distributions_row_groups_and_piecewise_densities(ops):
     """The wider traced shapes on the GPU: a funnel written with torch.distributions log_prob calls, row GROUPS (several slices
     with their own hyper-parameters), a density with NO head coordinate but a nonlinear function of its sums, piecewise rows

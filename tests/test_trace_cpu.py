@@ -282,6 +282,110 @@ def test_torch_model_compiles_a_hierarchical_density_into_the_lanes_form(tmp_pat
     assert u.compiled is None
 
 
+# ---- coordinates coupled through shifted slices -> the per-chain form (trace_chain.py) -----------------------------------
+CHAIN_HOST = """
+#include <math.h>
+#include <stdint.h>
+typedef int64_t i64;
+#define __device__
+struct BkTheta { const double* p; double operator[](i64 d) const { return p[d]; } void fence() const {} };
+#define __forceinline__ inline
+#define BK_CHAIN_PACE(i)
+#define BK_CHAIN_FORGET(p)
+struct BkGrad { double* p; bool wanted() const { return p != nullptr; } void set(i64 d, double v) const { p[d] = v; } };
+%s
+extern "C" void eval_chains(const double* th, const double* P, long long C, long long D, double* lp, double* g) {
+  for (long long c = 0; c < C; ++c) { BkTheta t{th + c * D}; BkGrad gr{g ? g + c * D : nullptr}; lp[c] = bk_chain(t, gr, D, P); }
+}
+"""
+DC = 24
+yc = torch.randn(DC - 2, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+yc1 = torch.cat([yc, yc[:1]])
+
+
+def c_ar1(Th):  # AR(1) latent path with a learned correlation and scale, Gaussian observations, stationary first state
+    phi, ls, x = torch.tanh(Th[:, 0]), Th[:, 1], Th[:, 2:]
+    inn = x[:, 1:] - phi[:, None] * x[:, :-1]
+    return -0.5 * (inn * inn).sum(-1) * torch.exp(-2 * ls) - (DC - 3) * ls - 0.5 * x[:, 0] ** 2 * (1 - phi * phi) * torch.exp(-2 * ls) \
+        - 0.5 * ((yc - x) ** 2).sum(-1) - 0.5 * Th[:, 0] ** 2 - 0.5 * ls * ls
+
+
+def c_rw2(Th):  # second-order random-walk (smoothness) prior on the whole state
+    d2 = torch.diff(torch.diff(Th, dim=1), dim=1)
+    return -0.5 * (d2 ** 2).sum(1) * 4.0 - 0.05 * (Th ** 2).sum(1)
+
+
+def c_stochastic_volatility(Th):  # h_t AR(1) around mu, y_t ~ N(0, exp(h_t))
+    mu, h = Th[:, 0], Th[:, 1:]
+    return -0.5 * ((h[:, 1:] - mu[:, None] - 0.9 * (h[:, :-1] - mu[:, None])) ** 2).sum(-1) / 0.04 \
+        - 0.5 * (h + yc1 * yc1 * torch.exp(-h)).sum(-1) - 0.5 * mu * mu
+
+
+def c_mixed_offsets(Th):  # several offsets, slices of computed vectors, scalars taken from the middle and the end, piecewise
+    inc = torch.diff(Th, dim=1)
+    return -torch.sqrt(1e-2 + inc ** 2).sum(-1) - 0.5 * ((Th[:, 3:] - Th[:, :-3]) ** 2).mean(-1) - 0.1 * Th[:, 5] ** 2 * Th[:, -1] \
+        - 0.5 * (Th * Th).sum(-1) - torch.relu(inc[:, 2:] * inc[:, :-2]).sum(1) - (inc * inc)[:, 4] * torch.tanh(Th[:, 0])
+
+
+CHAINS = {"ar1": c_ar1, "second_order_random_walk": c_rw2, "stochastic_volatility": c_stochastic_volatility,
+          "mixed_offsets": c_mixed_offsets}
+
+
+@pytest.mark.parametrize("name", sorted(CHAINS))
+def test_chain_source_value_and_gradient_match_autograd(name, tmp_path):
+    from bayes_kit_amd import trace_chain
+
+    fn = CHAINS[name]
+    src, params, info = trace_chain.chain_source(fn, DC)
+    assert info["sums"] >= 1 and info["gradient_blocks"] >= 2 and "#pragma unroll" in src
+    cpp, lib = tmp_path / f"{name}.cpp", tmp_path / f"lib{name}.so"
+    cpp.write_text(CHAIN_HOST % src)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(cpp), "-o", str(lib)])
+    h = ctypes.CDLL(str(lib))
+    C = 33
+    Theta = 0.6 * torch.randn((C, DC), generator=torch.Generator().manual_seed(2), dtype=torch.float64)
+    x = Theta.clone().requires_grad_(True)
+    lp = fn(x)
+    (gr,) = torch.autograd.grad(lp.sum(), x)
+    th = np.ascontiguousarray(Theta.numpy())
+    P = np.zeros(1) if params is None else np.ascontiguousarray(params.numpy())
+    lp_c, g_c = np.empty(C), np.zeros((C, DC))
+    as_p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+    h.eval_chains(as_p(th), as_p(P), ctypes.c_longlong(C), ctypes.c_longlong(DC), as_p(lp_c), as_p(g_c))
+    np.testing.assert_allclose(lp_c, lp.detach().numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g_c, gr.numpy(), rtol=1e-11, atol=1e-12 * np.abs(gr.numpy()).max())
+    lp_only = np.empty(C)   # (no gradient wanted: the log density alone)
+    h.eval_chains(as_p(th), as_p(P), ctypes.c_longlong(C), ctypes.c_longlong(DC), as_p(lp_only), None)
+    np.testing.assert_array_equal(lp_only, lp_c)
+
+
+@pytest.mark.parametrize("fn, needle", [
+    (lambda Th: (Th[:, 1:] * Th[:, :-2]).sum(1), "different lengths"),
+    (lambda Th: (Th[:, ::2] ** 2).sum(1), "strided"),
+    (lambda Th: ((Th ** 2).sum(1)[:, None] * Th).sum(1), "inside another vector expression"),
+    (lambda Th: (Th @ torch.ones(DC, DC, dtype=torch.float64)).sum(1), "unsupported operation"),
+    (lambda Th: torch.cumsum(Th, 1).sum(1), "unsupported operation"),
+    (lambda Th: (Th[:, 1:] * Th[:, 0]).sum(1), "without \\[:, None\\]"),
+])
+def test_chain_unsupported_shapes_name_the_reason(fn, needle):
+    from bayes_kit_amd import trace_chain
+
+    with pytest.raises(trace.Unsupported, match=needle):
+        trace_chain.chain_source(fn, DC)
+
+
+def test_torch_model_compiles_a_coupled_density_into_the_per_chain_form(tmp_path, monkeypatch):
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(tmp_path / "cache"))
+    m = bk.TorchModel(c_ar1, DC, compile=True)
+    assert m.compiled is not None and m.compiled_form == "chain" and "bk_chain" in m.traced_source, m.compile_note
+    for hook in ("bk_eval", "bk_leapfrog_step", "bk_leapfrog_trajectory"):
+        assert hasattr(m, hook), hook
+    assert m.bk_counted and not hasattr(m, "bk_dr_proposal")
+    with pytest.warns(UserWarning, match="as sums over shifted slices"):
+        u = bk.TorchModel(lambda Th: torch.cumsum(Th, 1).sum(1), DC, compile=True)
+    assert u.compiled is None
+
+
 # ---- randomised expressions: every derivative rule of both tracers against autograd --------------------------------------
 def _random_expr(rng, depth, leaves):
     """A random elementwise PyTorch expression (as a Python closure) over the supported operations, kept in a numerically tame
