@@ -812,6 +812,33 @@ def test_mala_step_kernel_with_the_density_inlined_equals_the_model_opaque_pair(
                     assert torch.equal(tb, tc) and torch.equal(lb, lc), n
 
 
+def test_mala_inlined_step_narrow_workgroups_give_the_same_draws():
+    """BK_MALA_STEP_PAIRS=4 (8 chains per workgroup, one wavefront per SIMD: the shape measured beside the generator in
+    profiles/r5_mala.md) keeps the summation order: the same draws as the model-opaque pair.  Own process: the choice is read once."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, torch, sys\n"
+        "sys.path.insert(0, 'bayes-kit_amd')\n"
+        "import bayes_kit_amd as bk\n"
+        "for C, D in ((130, 129), (48, 1024), (4096, 100)):\n"
+        "    lam = np.logspace(0, 1.5, D)\n"
+        "    a = bk.MALA(bk.DiagGaussian(lam), 0.3 / D, chains=C, seed=5, two_pass=True, fuse_builtin=False)\n"
+        "    b = bk.MALA(bk.DiagGaussian(lam), 0.3 / D, chains=C, seed=5, two_pass=True)\n"
+        "    assert b._sep_step and not a._sep_step\n"
+        "    for n in range(6):\n"
+        "        ta, la = a.sample(); tb, lb = b.sample()\n"
+        "        assert torch.equal(ta, tb) and torch.equal(la, lb), (C, D, n)\n"
+        "    assert np.array_equal(a.rng_state(), b.rng_state())\n"
+        "print('narrow ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, BK_MALA_STEP_PAIRS="4"), capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "narrow ok" in out.stdout, out.stderr[-3000:]
+
+
 def test_whole_draw_hmc_rebinds_its_state_and_keeps_returned_draws(ops):
     """The one-pass HMC draw writes the blend of state and proposal to a fresh array that becomes the
     state (bk_blend_columns): draws handed out earlier are never written again, not by later draws and
