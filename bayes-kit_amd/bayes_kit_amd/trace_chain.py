@@ -349,6 +349,7 @@ class _Gen:
         self.heads = set()
         self.n = 0
         self.loops = 0
+        self.heavy = False
 
     def tmp(self, lines, expr, indent="  "):
         name = f"t{self.n}"
@@ -400,7 +401,7 @@ class _Gen:
     def sum_loop(self, name, e, n, unroll):
         lines, memo = [], {}
         r = self.at_index(e, lines, memo, "    ")
-        if unroll and self.loops:
+        if unroll and self.heavy and self.loops:
             # (each pass over the coordinates recomputes what it needs: without this the compiler keeps the per-coordinate
             # subexpressions two unrolled loops share -- every residual, every exp -- alive from one to the other)
             self.outer.append("  th.fence(); BK_CHAIN_FORGET(P);")
@@ -411,7 +412,7 @@ class _Gen:
         self.outer.append(f"  for (i64 i = 0; i < {n}; ++i) {{")
         self.outer.extend(lines)
         self.outer.append(f"    {name} = {name} + {r};")
-        if unroll:
+        if unroll and self.heavy:
             self.outer.append("    BK_CHAIN_PACE(i);")
         self.outer.append("  }")
 
@@ -423,9 +424,16 @@ def chain_source(fn, dims: int):
     F = tr.run(fn)
     g, K = tr.g, len(tr.sums)
     unroll = D <= 128   # (the staged coordinates live in registers only under full unrolling: bk_source_kernels.hpp)
+    # Passes of a HEAVY function (transcendentals, divisions, vector constants) are separated by fences and handed to the
+    # scheduler four iterations at a time; a function of plain arithmetic is left alone (measured on the generated kernels'
+    # scratch use at D = 101: fences cut a stochastic-volatility model's spills by a third and triple a random walk's)
+    cheap = {"c", "x", "p", "h", "S", "add", "sub", "mul", "neg", "square", "abs", "sign", "where", "maximum", "minimum", "gt", "ge",
+             "lt", "le"}
+    gen_heavy = bool(tr.consts) or any(n.op not in cheap for n in g.table.values())
     heads = sorted({v[1] for v in F.vars if isinstance(v, tuple) and v[0] == "h"}
                    | {v[1] for e, _ in tr.sums for v in e.vars if isinstance(v, tuple) and v[0] == "h"})
     gen = _Gen(tr)
+    gen.heavy = gen_heavy and unroll
     for k, (e, n) in enumerate(tr.sums):
         gen.sum_loop(f"S{k}", e, n, unroll)
     val = gen.chain(F)
@@ -471,8 +479,9 @@ def chain_source(fn, dims: int):
     body = list(gen.outer[:pre_grad])
     body.append("  if (g.wanted()) {")
     body.extend("  " + ln for ln in gen.outer[pre_grad:])
-    if unroll:
+    if gen.heavy:
         body.append("    th.fence(); BK_CHAIN_FORGET(P);  // (the gradient pass recomputes / reloads what it needs: bk_source_api.hpp)")
+    if unroll:
         body.append("#pragma unroll")
     body.append(f"    for (i64 j = 0; j < {D}; ++j) {{")
     body.append("      double gj = 0.0;")
@@ -486,7 +495,7 @@ def chain_source(fn, dims: int):
     for i, name in sorted(gh.items()):
         body.append(f"      if (j == {i}) gj = gj + {name};")
     body.append("      g.set(j, gj);")
-    if unroll:
+    if gen.heavy:
         body.append("      BK_CHAIN_PACE(j);")
     body.append("    }")
     body.append("  }")
