@@ -435,7 +435,7 @@ def _find_hipcc():
                           "compiled yourself.")
 
 
-def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
+def _source_text(user_source: str, form: str, dims: int, head: int, stage: str = "auto") -> str:
     if form not in ("elementwise", "chain", "lanes"):
         raise ValueError("form must be 'elementwise' (bk_term: one coordinate's term and derivative), 'chain' "
                          "(bk_chain: one chain's log density and gradient, one lane per chain) or 'lanes' "
@@ -452,7 +452,14 @@ def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
     else:
         # STAGE = D when a chain's coordinates fit the registers of its lane (D <= 128), LDS = D when 64 chains' coordinates fit
         # a workgroup's LDS instead (D <= 300)
-        shape = {"DIMS": int(dims), "STAGE": int(dims) if int(dims) <= 128 else 0, "LDS": int(dims) if 128 < int(dims) <= 300 else 0}
+        if stage not in ("auto", "registers", "lds"):
+            raise ValueError("stage must be 'auto', 'registers' or 'lds'")
+        if stage == "lds" and int(dims) <= 128:
+            # theta in LDS in every kernel (the step and trajectory kernels too): for long functions, see bk_source_kernels.hpp
+            shape = {"DIMS": int(dims), "STAGE": 0, "LDS": int(dims), "THETA_LDS": 1}
+        else:
+            shape = {"DIMS": int(dims), "STAGE": int(dims) if int(dims) <= 128 else 0,
+                     "LDS": int(dims) if 128 < int(dims) <= 300 else 0}
     defines = "".join(f"#define BK_SOURCE_{k} {v}\n" for k, v in shape.items())
     return (f"// Generated by bayes_kit_amd.CTarget.from_source(form=\"{form}\"): plugin ABI bk_target_fn / bk_target_fn_n "
             "(include/bkhip.h) + the entry points of include/bkhip_source.h.\n"
@@ -463,14 +470,14 @@ def _source_text(user_source: str, form: str, dims: int, head: int) -> str:
 _SRC_REQUIRED_EXPORTS = ("bk_src_target", "bk_src_target_n")
 
 
-def _compile_source_target(user_source: str, form: str, contract: bool, dims: int = 1, head: int = 0) -> str:
+def _compile_source_target(user_source: str, form: str, contract: bool, dims: int = 1, head: int = 0, stage: str = "auto") -> str:
     """hipcc the generated translation unit into a shared library (cached by content: the generated text, the flags and the
     library headers it includes); returns its path."""
     import hashlib
     import os
     import subprocess
 
-    text = _source_text(user_source, form, int(dims), int(head))
+    text = _source_text(user_source, form, int(dims), int(head), stage)
     csrc = _csrc_dir()
     inc = os.path.abspath(os.path.join(csrc, "..", "..", "include"))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
@@ -664,7 +671,7 @@ def _bind_source_fast_paths(t):
 
 
 def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "elementwise", contract: bool = False,
-                         ops=None, head: int = 0):
+                         ops=None, head: int = 0, stage: str = "auto"):
     """A device model from a few lines of HIP C++, compiled with hipcc when the object is built (cached by content
     in a private per-user directory: $XDG_CACHE_HOME/bayes_kit_amd or ~/.cache/bayes_kit_amd, BK_SOURCE_TARGET_DIR
     overrides; a directory or cached library that another user could have written is refused) into the plugin ABI --
@@ -686,9 +693,13 @@ def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "
     ``DrGhmcDiag`` runs every delayed-rejection proposal as ONE launch (the path ``bk.Funnel`` has), else the counted
     step-by-step path.  form="chain": any density; ``source`` defines
         ``__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* params)``
-    called by one lane per chain (``th[d]``, ``g.set(d, v)``).  ``params``: a float64 device tensor (or None).
+    called by one lane per chain (``th[d]``, ``g.set(d, v)``); the chain's coordinates are staged before the call -- in the
+    lane's registers for dims <= 128 (the function's loops over d are then unrolled completely), in LDS for dims <= 300; ``stage="lds"``
+    stages them in LDS for dims <= 128 too, in the one-launch step and trajectory kernels as well: for LONG functions (many passes,
+    transcendentals, constants) whose unrolled form would not fit a lane's registers beside its coordinates -- their loops may then
+    stay rolled.  ``params``: a float64 device tensor (or None).
     contract=False compiles with -ffp-contract=off (every product and sum rounded, as NumPy does)."""
-    lib = _compile_source_target(source, form, contract, dims, head)
+    lib = _compile_source_target(source, form, contract, dims, head, stage)
     if params is not None and not (isinstance(params, torch.Tensor) and params.dtype == torch.float64):
         raise TypeError("params must be a float64 torch tensor (device memory the compiled function reads) or None")
     t = cls(lib, "bk_src_target", dims, params=params, ops=ops, counted_symbol="bk_src_target_n")
@@ -788,7 +799,8 @@ class TorchModel:
                     return
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         p = None if params is None else params.to(dev)
-        target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract)
+        stage = info.get("stage", "auto") if form == "chain" else "auto"
+        target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract, stage=stage)
         if dev.type == "cuda":
             note = self._check_compiled(target, dev)
             if note is not None:

@@ -176,6 +176,19 @@ def test_density_compiled_from_source_under_every_sampler(ops):
             assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source, one launch per trajectory", Df, n)
             assert torch.equal(t1, t3) and torch.equal(l1, l3), ("HMC, per-chain source, one launch per step", Df, n)
         assert b._grad_calls == b3._grad_calls == b2._grad_calls and hm._grad_calls == hs._grad_calls == h3._grad_calls
+        if Df <= 128:
+            # stage="lds": the coordinates staged in LDS in every kernel, the one-launch step and trajectory kernels included (for
+            # long functions; measured slower for this short one) -- the same draws
+            mk_l = lambda **kw: bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain", stage="lds"), 2, [0.3, 0.1], [3, 6],  # noqa: E731
+                                              0.3, chains=700, seed=9, **kw)
+            c0 = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
+            l1, l2, l3 = mk_l(), mk_l(fuse_builtin=False), mk_l(fuse_steps=False)
+            assert l1._traj_hook and l2._step_hook and not l2._traj_hook and not l3._step_hook
+            for n in range(5):
+                t0, p0 = c0.sample()
+                for o in (l1, l2, l3):
+                    to, po = o.sample()
+                    assert torch.equal(t0, to) and torch.equal(p0, po), ("stage=lds", Df, n)
         # (a call with another D than the one compiled for takes the unstaged path)
         th = torch.randn((Df - 1, 130), dtype=torch.float64, device=ops.device)
         g1, g2 = torch.empty_like(th), torch.empty_like(th)
