@@ -479,6 +479,28 @@ def test_hierarchical_example_converges():
     assert abs(mu - ybar) < 0.05 and abs(tau - (sd * sd - 1.0) ** 0.5) < 0.1, (mu, ybar, tau, sd)
 
 
+def test_state_space_example_converges():
+    """examples/state_space_model.py: an AR(1) state-space model written with shifted slices in PyTorch, traced into the per-chain
+    form, one launch per trajectory under DRGHMC: R-hat < 1.05, the posterior covers the truth, the path beats the observations."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "examples", "state_space_model.py")], capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    txt = out.stdout
+    assert "compiled form = chain" in txt and "one launch per trajectory: True | host syncs per draw: 0" in txt
+    assert "chains with a non-finite state: 0" in txt
+    rh = [float(x) for x in re.search(r"R-hat: a ([\d.]+)  log s ([\d.]+)  max over states ([\d.]+)", txt).groups()]
+    assert max(rh) < 1.05, rh
+    phi, sd, s_ = [float(x) for x in re.search(r"mean of phi ([\d.]+) \(sd ([\d.]+); truth 0.8\), of s ([\d.]+)", txt).groups()]
+    assert abs(phi - 0.8) < 3 * sd and abs(s_ - 0.5) < 0.15, (phi, sd, s_)
+    assert float(re.search(r"true states ([\d.]+)", txt).group(1)) < 0.5
+
+
 def test_torch_model_traces_hierarchical_densities_into_the_lanes_form(ops):
     """TorchModel(fn, D, compile=True) on head-plus-sums densities written in PyTorch (trace_lanes.py): Neal's funnel and a
     two-head hierarchical model become lane-spread compiled targets -- gradient equal to autograd, every DRGHMC proposal and
