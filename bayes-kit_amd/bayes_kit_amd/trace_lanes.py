@@ -97,6 +97,20 @@ class _Dag:
             return a
         if a.op == "c" and b.op == "c":
             return self.const(a.args[0] * b.args[0])
+        if a is b:
+            return self.un("square", a)   # (and its derivative 2 a a' instead of a' a + a a')
+        if self.is_c(a, -1.0):
+            return self.neg(b)
+        if self.is_c(b, -1.0):
+            return self.neg(a)
+        # constants gather: c1 * (c2 * x) -> (c1 c2) * x  (symbolic derivatives produce chains of them)
+        for c, o in ((a, b), (b, a)):
+            if c.op == "c" and o.op == "mul":
+                for k in (0, 1):
+                    if o.args[k].op == "c":
+                        return self.mul(self.const(c.args[0] * o.args[k].args[0]), o.args[1 - k])
+            if c.op == "c" and o.op == "neg":
+                return self.mul(self.const(-c.args[0]), o.args[0])
         return self.mk("mul", a, b)
 
     def div(self, a, b):
