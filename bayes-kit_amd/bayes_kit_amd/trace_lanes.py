@@ -21,9 +21,6 @@ shape raises ``trace.Unsupported`` naming the node.  Only the reference's (C, D)
 """
 from __future__ import annotations
 
-import math
-import operator
-
 import torch
 
 from .trace import (Unsupported, _function_table, _METHODS, _UNARY, _BINARY, _COMPARE, _HOST_UNARY, TWO_OVER_SQRT_PI, _lit,
