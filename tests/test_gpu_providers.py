@@ -141,7 +141,7 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     assert torch.equal(g1, g2)
     # the per-chain form: a chain's coordinates staged in its lane's registers (D <= 128), in LDS (D <= 300), or read from
     # global memory as the user's loops ask for them (larger D) -- the same values
-    for Df in (150, 101, 17, 350):
+    for Df in (150, 101, 17, 128, 350):
         fs = bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain")
         a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
         b = bk.DrGhmcDiag(fs, 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9)
