@@ -595,7 +595,9 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
 /* The separable Gaussians through the same kernel templates (a separable density is a lanes-form density without head
  * coordinates): bk_dr_proposal_funnel_job and bk_leapfrog_step_funnel for logp = -1/2 sum th*(lam*th), lam NULL = the
  * isotropic Gaussian.  D <= 128 for the proposal (BK_E_ARG otherwise), any D for the step.  theta and rho are bit-identical to
- * the step-by-step path; the log density is summed in the lanes' class order (csrc/bk_lanes.hpp), not in four quarters. */
+ * the step-by-step path; the log density is summed in the lanes' class order (csrc/bk_lanes.hpp), not in four quarters.
+ * The step of a separable density needs no sums: bk_leapfrog_step_gaussian is a STREAMING launch (csrc/bk_elementwise.hpp,
+ * every (d, c) element on its own, 16 bytes per lane): 32*D bytes per chain-step, min(n, *n_dev) chains. */
 int bk_dr_proposal_gaussian_job(const double* theta_in, const double* rho_in, const double* grad_in,
                                 int64_t ld_in, const int32_t* src_index, double* theta_out,
                                 double* rho_out, double* grad_out, double* logp_out, double* kin_out,
