@@ -440,6 +440,13 @@ def _source_text(user_source: str, form: str, dims: int, head: int, stage: str =
         raise ValueError("form must be 'elementwise' (bk_term: one coordinate's term and derivative), 'chain' "
                          "(bk_chain: one chain's log density and gradient, one lane per chain) or 'lanes' "
                          "(bk_lanes_density: one chain spread over the lanes of a wavefront)")
+    if stage not in ("auto", "registers", "lds"):
+        raise ValueError("stage must be 'auto', 'registers' or 'lds'")
+    if stage != "auto" and form != "chain":
+        raise ValueError("stage= applies to form='chain' only (where the kernels stage a chain's coordinates before the call)")
+    if (stage == "registers" and int(dims) > 128) or (stage == "lds" and int(dims) > 300):
+        raise ValueError("stage='registers' needs dims <= 128, stage='lds' dims <= 300 (the one-launch step and trajectory kernels: "
+                         "dims <= 128)")
     if form == "lanes":
         if not 0 <= int(head) <= _LANES_MAX_HEAD:
             raise ValueError(f"head must be 0..{_LANES_MAX_HEAD} (the coordinates every lane of a chain holds)")
@@ -452,8 +459,6 @@ def _source_text(user_source: str, form: str, dims: int, head: int, stage: str =
     else:
         # STAGE = D when a chain's coordinates fit the registers of its lane (D <= 128), LDS = D when 64 chains' coordinates fit
         # a workgroup's LDS instead (D <= 300)
-        if stage not in ("auto", "registers", "lds"):
-            raise ValueError("stage must be 'auto', 'registers' or 'lds'")
         if stage == "lds" and int(dims) <= 128:
             # theta in LDS in every kernel (the step and trajectory kernels too): for long functions, see bk_source_kernels.hpp
             shape = {"DIMS": int(dims), "STAGE": 0, "LDS": int(dims), "THETA_LDS": 1}

@@ -161,6 +161,17 @@ def test_missing_hipcc_says_so(cache, monkeypatch):
         bk.CTarget.from_source(TERM + "// never compiled before\n", 4)
 
 
+def test_stage_option_is_checked(cache):
+    for kw, needle in ((dict(form="elementwise", stage="lds"), "form='chain' only"), (dict(form="chain", stage="shared"), "stage must be"),
+                       (dict(form="chain", stage="registers", dims=200), "dims <= 128"), (dict(form="chain", stage="lds", dims=400), "dims <= 300")):
+        dims = kw.pop("dims", 16)
+        with pytest.raises(ValueError, match=needle):
+            T._source_text(CHAIN if kw["form"] == "chain" else TERM, kw["form"], dims, 0, kw["stage"])
+    text = T._source_text(CHAIN, "chain", 64, 0, "lds")
+    assert "#define BK_SOURCE_THETA_LDS 1" in text and "#define BK_SOURCE_STAGE 0" in text and "#define BK_SOURCE_LDS 64" in text
+    assert "BK_SOURCE_THETA_LDS" not in T._source_text(CHAIN, "chain", 64, 0)
+
+
 def test_generated_libraries_match_the_header_of_their_abi(cache):
     """include/bkhip_source.h declares the C ABI of a generated library; every form exports a subset of exactly those names, and
     every declared name is exported by some form."""
@@ -178,9 +189,12 @@ def test_generated_libraries_match_the_header_of_their_abi(cache):
         return set(m.decode() for m in re.findall(rb"(?<=\x00)(bk_src_[a-z0-9_]+)(?=\x00)", blob))
 
     seen = set()
-    for text, form, dims, head in ((TERM, "elementwise", 16, 0), (CHAIN, "chain", 16, 0), (CHAIN, "chain", 200, 0),
-                                   (LANES, "lanes", 101, 1), (LANES, "lanes", 300, 1)):
-        ex = all_exports(T._compile_source_target(text, form, False, dims, head))
+    for text, form, dims, head, stage in ((TERM, "elementwise", 16, 0, "auto"), (CHAIN, "chain", 16, 0, "auto"),
+                                          (CHAIN, "chain", 200, 0, "auto"), (CHAIN, "chain", 16, 0, "lds"),
+                                          (LANES, "lanes", 101, 1, "auto"), (LANES, "lanes", 300, 1, "auto")):
+        ex = all_exports(T._compile_source_target(text, form, False, dims, head, stage))
+        if form == "chain" and dims <= 128:
+            assert {"bk_src_leapfrog_step", "bk_src_trajectory"} <= ex, (stage, ex)
         assert ex <= declared and {"bk_src_target", "bk_src_target_n"} <= ex, (form, dims, ex - declared)
         seen |= ex
     assert seen == declared
