@@ -27,5 +27,3 @@ print("model-opaque, default schedule: %.3f ms" % run(False)[0])
 for ser, gw, wg in itertools.product((True, False), ("grad", "step"), (0, 256, 512)):
     ms, cs = run(True, serialize_step=ser, generate_with=gw, generator_workgroups=wg)
     print("inlined serialize_step=%s generate_with=%s generator_workgroups=%d: %.3f ms  (checksum %.6f)" % (ser, gw, wg, ms, cs))
-s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, prefetch_rng=False, graph=False)
-print("inlined, generator in line: %.3f ms" % run(True)[0])

@@ -17,6 +17,9 @@ run "counted_step_bench.py SOURCE=chain" env REPS=20 LANES=64,2228 SOURCE=chain 
 run "counted_step_bench.py PLUGIN=1" env REPS=20 LANES=64,2228 PLUGIN=1 python3 tools/counted_step_bench.py
 run "fused_hmc_profile_run.py" env N=3 python3 tools/fused_hmc_profile_run.py
 run "mala_bench.py" python3 tools/mala_bench.py
+run "mala_bench.py INLINED=0" env INLINED=0 python3 tools/mala_bench.py
+run "mala_inlined_schedules.py" python3 tools/mala_inlined_schedules.py
+run "step_stream_bench.py" python3 tools/step_stream_bench.py
 run "mala_two_pass/probe.py" python3 tools/mala_two_pass/probe.py
 run "cfg3_trajectory_length.py" env C=4096 DRAWS=10 python3 tools/cfg3_trajectory_length.py
 run "cfg4_damping_scan.py" env C=4096 DRAWS=50 python3 tools/cfg4_damping_scan.py
