@@ -176,6 +176,14 @@ def test_density_compiled_from_source_under_every_sampler(ops):
             assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source, one launch per trajectory", Df, n)
             assert torch.equal(t1, t3) and torch.equal(l1, l3), ("HMC, per-chain source, one launch per step", Df, n)
         assert b._grad_calls == b3._grad_calls == b2._grad_calls and hm._grad_calls == hs._grad_calls == h3._grad_calls
+        # a trajectory of ONE step (no in-kernel step loop: the gathering first step, then the last gradient) and of two
+        for L in (1, 2):
+            k1 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, L, chains=333, seed=14)
+            k2 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, L, chains=333, seed=14, fuse_steps=False)
+            for n in range(3):
+                t1, l1 = k1.sample()
+                t2, l2 = k2.sample()
+                assert torch.equal(t1, t2) and torch.equal(l1, l2), ("HMC, per-chain source", Df, L, n)
         if Df <= 128:
             # stage="lds": the coordinates staged in LDS in every kernel, the one-launch step and trajectory kernels included (for
             # long functions; measured slower for this short one) -- the same draws
