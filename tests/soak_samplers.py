@@ -187,7 +187,11 @@ def hmc_funnel(rng):
     N = int(rng.integers(2, 7))
     graph = None if rng.integers(0, 2) else (bool(rng.integers(0, 2)) and not NO_GRAPH)
     desc = dict(alg="hmcfunnel", D=D, C=C, eps=eps, L=L, metric=metric is not None, seed=seed, N=N, graph=graph)
-    model = (lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1)) if rng.integers(0, 2) else (lambda: bk.Funnel(D))
+    # (the funnel as a per-chain source too: one launch per trajectory for D <= 128 -- bk_leapfrog_trajectory --, per step, separate op)
+    kind = int(rng.integers(0, 3))
+    desc["model"] = ("builtin", "lanes source", "chain source")[kind]
+    model = (lambda: bk.Funnel(D), lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1),
+             lambda: bk.CTarget.from_source(FUNNEL_CHAIN_CLASS_ORDER_SRC, D, form="chain"))[kind]
     mk = lambda **kw: bk.HMCDiag(model(), eps, L, metric_diag=metric, chains=C, seed=seed, graph=graph, **kw)  # noqa: E731
     f, h, s_ = mk(), mk(fuse_builtin=False), mk(fuse_builtin=False, fuse_steps=False)
     for n in range(N):
