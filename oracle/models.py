@@ -122,3 +122,36 @@ class LogisticRegression:
         p = 1.0 / (1.0 + np.exp(-z))
         g = self._X.T @ (self._y - p) - self._inv_s2 * theta
         return np.sum(self._y * z - np.logaddexp(0.0, z)) + self.log_prior(theta), g
+
+
+class GaussPriorLik:
+    """A ``LogPriorLikelihoodModel`` (``bayes_kit/typing.py:37-42``) with elementwise parts, for the SMC fixtures:
+    prior theta ~ N(0, s0^2 I), likelihood y_d ~ N(theta_d, 1 / prec_d).
+
+    log_prior = (-0.5 / s0^2) * sum theta_d^2 ;  log_likelihood = -0.5 * sum prec_d (theta_d - y_d)^2
+    (sums are ``np.sum`` of the elementwise products)."""
+
+    def __init__(self, y, prec, prior_scale=1.0):
+        self._y = np.asarray(y, dtype=np.float64)
+        self._prec = np.asarray(prec, dtype=np.float64)
+        self._c0 = -0.5 / prior_scale**2
+
+    def dims(self) -> int:
+        return self._y.shape[0]
+
+    def log_prior(self, theta):
+        return self._c0 * np.sum(theta * theta)
+
+    def log_likelihood(self, theta):
+        r = theta - self._y
+        return -0.5 * np.sum(self._prec * (r * r))
+
+    def log_density(self, theta):
+        return self.log_likelihood(theta) + self.log_prior(theta)
+
+    def posterior_mean(self):
+        p0 = -2.0 * self._c0
+        return self._prec * self._y / (self._prec + p0)
+
+    def posterior_var(self):
+        return 1.0 / (self._prec - 2.0 * self._c0)

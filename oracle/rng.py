@@ -213,3 +213,146 @@ class PhiloxStream:
             "buffer": list(self.buffer),
             "buffer_pos": self.buffer_pos,
         }
+
+
+class LegacyStream:
+    """The process-global ``numpy.random`` stream the reference's SMC draws from (``bayes_kit/smc.py:73,81,85``):
+    ``numpy.random.RandomState`` = MT19937 (Matsumoto & Nishimura 1998; numpy ``random/src/mt19937/mt19937.c``) with
+    the LEGACY distributions of ``random/src/legacy/legacy-distributions.c`` -- frozen by NumPy's compatibility policy
+    (NEP 19), restated here on Python ints / floats:
+
+    * ``seed(s)``, 0 <= s < 2**32: Knuth's recurrence ``mt[i] = 1812433253 * (mt[i-1] ^ (mt[i-1] >> 30)) + i``;
+    * a 32-bit word: the standard tempering of the 624-word state, regenerated 624 words at a time;
+    * ``random_sample()`` / ``uniform()``: ``((a >> 5) * 2**26 + (b >> 6)) / 2**53`` from two words;
+    * ``normal()``: Marsaglia's polar method, ``x1, x2 = 2 u - 1`` until ``0 < r2 < 1``, ``f = sqrt(-2 log(r2) / r2)``,
+      returns ``f * x2`` and KEEPS ``f * x1`` for the next call (the cached value survives ``uniform()`` calls in
+      between: with D odd the second half of a pair crosses from one particle to the next);
+      ``normal(loc, scale) = loc + scale * gauss``;
+    * ``choice(n, size, replace=True, p)``: ``cdf = p.cumsum(); cdf /= cdf[-1]``, ``size`` doubles,
+      ``cdf.searchsorted(u, side="right")``.
+
+    ``tests/test_oracle_rng.py`` pins every piece against ``numpy.random.RandomState`` itself."""
+
+    N, M_ = 624, 397
+
+    def __init__(self, seed: int):
+        seed = int(seed)
+        if not 0 <= seed < (1 << 32):
+            raise ValueError("legacy integer seed must fit 32 bits")
+        mt = [0] * self.N
+        mt[0] = seed
+        for i in range(1, self.N):
+            mt[i] = (1812433253 * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+        self.mt, self.pos = mt, self.N
+        self.has_gauss, self.gauss = 0, 0.0
+
+    def _regenerate(self):
+        mt, N, M = self.mt, self.N, self.M_
+        for k in range(N):
+            y = (mt[k] & 0x80000000) | (mt[(k + 1) % N] & 0x7FFFFFFF)
+            mt[k] = mt[(k + M) % N] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+        self.pos = 0
+
+    def next_u32(self) -> int:
+        if self.pos == self.N:
+            self._regenerate()
+        y = self.mt[self.pos]
+        self.pos += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y
+
+    def random_sample(self) -> float:
+        a = self.next_u32() >> 5
+        b = self.next_u32() >> 6
+        return (a * 67108864.0 + b) / 9007199254740992.0
+
+    uniform = random_sample
+
+    def standard_normal(self) -> float:
+        if self.has_gauss:
+            self.has_gauss, g = 0, self.gauss
+            self.gauss = 0.0
+            return g
+        while True:
+            x1 = 2.0 * self.random_sample() - 1.0
+            x2 = 2.0 * self.random_sample() - 1.0
+            r2 = x1 * x1 + x2 * x2
+            if r2 < 1.0 and r2 != 0.0:
+                break
+        f = math.sqrt(-2.0 * math.log(r2) / r2)
+        self.gauss, self.has_gauss = f * x1, 1
+        return f * x2
+
+    def normal(self, loc, scale) -> np.ndarray:
+        """``np.random.normal(loc=array, scale=float)``: one gauss per element, ``loc + scale * gauss``."""
+        loc = np.atleast_1d(np.asarray(loc, dtype=np.float64))
+        return np.array([loc[i] + scale * self.standard_normal() for i in range(loc.shape[0])])
+
+    def choice_uniforms(self, m: int) -> np.ndarray:
+        return np.array([self.random_sample() for _ in range(m)])
+
+    def state(self):
+        """As ``RandomState.get_state(legacy=False)`` reports it."""
+        return dict(key=np.array(self.mt, dtype=np.uint32), pos=self.pos, has_gauss=self.has_gauss, gauss=self.gauss)
+
+
+def numpy_pairwise_sum(a) -> float:
+    """``np.sum`` of a contiguous float64 vector, restated: numpy's pairwise summation (``DOUBLE_pairwise_sum`` in
+    ``numpy/_core/src/umath/loops_utils.h.src``): fewer than 8 values -> a plain loop; up to 128 -> eight running
+    sums over strides of 8 combined ``((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))`` plus the remainder in order; beyond that
+    the vector is split at ``n/2`` rounded down to a multiple of 8 and the halves are summed recursively.  The
+    reduction machinery hands the inner loop at most 8,192 values at a time (its buffer size) and adds the pieces' sums
+    up in order -- probed against ``np.sum`` at lengths around and beyond 8,192 (``tests/test_oracle_rng.py``)."""
+    a = [float(v) for v in a]
+
+    def pw(lo, n):
+        if n < 8:
+            res = 0.0
+            for i in range(n):
+                res += a[lo + i]
+            return res
+        if n <= 128:
+            r = a[lo:lo + 8]
+            i = 8
+            while i < n - (n % 8):
+                for j in range(8):
+                    r[j] += a[lo + i + j]
+                i += 8
+            res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+            while i < n:
+                res += a[lo + i]
+                i += 1
+            return res
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pw(lo, n2) + pw(lo + n2, n - n2)
+
+    acc = pw(0, min(len(a), 8192))
+    for lo in range(8192, len(a), 8192):
+        acc = acc + pw(lo, min(8192, len(a) - lo))
+    return acc
+
+
+def legacy_choice(p, u) -> np.ndarray:
+    """Indices ``RandomState.choice(len(p), size=len(u), replace=True, p=p)`` returns when its uniforms are ``u``."""
+    cdf = np.empty(len(p))
+    acc = 0.0
+    for i, v in enumerate(p):
+        acc = acc + float(v) if i else float(v)
+        cdf[i] = acc
+    last = cdf[-1]
+    cdf = np.array([c / last for c in cdf])
+    out = np.empty(len(u), dtype=np.int64)
+    for j, x in enumerate(u):
+        lo, hi = 0, len(cdf)
+        while lo < hi:  # first index with cdf > x  (side="right")
+            mid = (lo + hi) // 2
+            if cdf[mid] <= x:
+                lo = mid + 1
+            else:
+                hi = mid
+        out[j] = lo
+    return out

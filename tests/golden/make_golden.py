@@ -277,6 +277,118 @@ SAMPLER_CASES = [
 ]
 
 
+def make_smc_model(spec):
+    if spec["kind"] == "ref_binomial":
+        from test.models.binomial import Binomial
+
+        return Binomial(alpha=2, beta=3, x=5, N=15, seed=spec["init_seed"])
+    if spec["kind"] == "gauss_prior_lik":
+        g = np.random.default_rng(spec["data_seed"])
+        D = spec["D"]
+        return models.GaussPriorLik(y=g.normal(size=D) * 1.5, prec=np.logspace(0, 1.5, D), prior_scale=spec["prior_scale"])
+    raise KeyError(spec)
+
+
+def smc_initial(case, model):
+    """Initial particles: the Binomial model's own ``initial_state`` (as test_tempered_smc.py:14-18 passes it); for the
+    Gaussian model prior draws from a seeded Generator."""
+    if case["model"]["kind"] == "ref_binomial":
+        return model.initial_state
+    g = np.random.default_rng(case["init_seed"])
+    init = g.normal(size=(case["M"], model.dims())) * case["model"]["prior_scale"]
+    return lambda i: init[i]
+
+
+def run_smc_case(case):
+    """The reference's TemperedLikelihoodSMC + metropolis_kernel (bayes_kit/smc.py:12-89) under ``np.random.seed``.
+    Stored: the particles after every move and after every resampling, the ancestor indices, and the values the
+    run took from the global stream in consumption order (per temperature: for every particle D standard normals and
+    one uniform, then choice's M uniforms) -- recorded by wrapping ``np.random.normal / uniform / choice`` with
+    pass-through recorders for the duration of the run."""
+    from bayes_kit.smc import TemperedLikelihoodSMC, metropolis_kernel
+
+    M, N, scale = case["M"], case["N"], case["scale"]
+    model = make_smc_model(case["model"])
+    smc = TemperedLikelihoodSMC(model, M, N, smc_initial(case, model), metropolis_kernel(scale))
+    D = smc.D
+    theta0 = smc.thetas.copy()
+    rec = dict(z=[], u=[], cu=[], idx=[])
+    orig = (np.random.normal, np.random.uniform, np.random.choice)
+
+    def normal(loc=0.0, scale=1.0, size=None):
+        out = orig[0](loc=loc, scale=scale, size=size)
+        rec["z"].append((np.asarray(out) - np.asarray(loc)) / scale)  # (diagnostic only; the exact values come below)
+        return out
+
+    def uniform(*a, **k):
+        out = orig[1](*a, **k)
+        rec["u"].append(out)
+        return out
+
+    def choice(a, size=None, replace=True, p=None):
+        st = np.random.get_state()
+        out = orig[2](a, size=size, replace=replace, p=p)
+        after = np.random.get_state()
+        np.random.set_state(st)
+        rec["cu"].append(np.random.random_sample(size))
+        np.random.set_state(after)
+        rec["idx"].append(np.asarray(out, dtype=np.int64))
+        return out
+
+    # the exact standard normals: the same seed replayed through a private RandomState in the same call pattern
+    shadow = np.random.RandomState(case["seed"])
+    z_exact = np.empty((N, M, D))
+    np.random.seed(case["seed"])
+    moved, after = np.empty((N, M, D)), np.empty((N, M, D))
+    np.random.normal, np.random.uniform, np.random.choice = normal, uniform, choice
+    try:
+        for n in range(1, N + 1):
+            pre = smc.thetas.copy()
+            # transition() overwrites thetas in place and then rebinds: capture the moved particles through choice()
+            smc.transition(n)
+            after[n - 1] = smc.thetas
+            for m in range(M):
+                z_exact[n - 1, m] = shadow.standard_normal(size=D)
+                assert shadow.uniform() == rec["u"][(n - 1) * M + m]
+            assert np.array_equal(shadow.random_sample(M), rec["cu"][n - 1])
+            del pre
+    finally:
+        np.random.normal, np.random.uniform, np.random.choice = orig
+    u = np.asarray(rec["u"]).reshape(N, M)
+    cu = np.stack(rec["cu"])
+    idx = np.stack(rec["idx"])
+    # the moved particles are not observable from outside transition(); recompute them as the reference's kernel
+    # does from the stored values and check them through the resampling: after[n] == moved[n][idx[n]]
+    cur = theta0.copy()
+    for n in range(N):
+        t = n / N
+        for m in range(M):
+            th = np.atleast_1d(cur[m])
+            prop = th + scale * z_exact[n, m]
+            lp = lambda x: model.log_likelihood(x) * t + model.log_prior(x)  # noqa: E731
+            cur[m] = prop if np.log(u[n, m]) < lp(prop) - lp(th) else th
+        moved[n] = cur
+        assert np.array_equal(cur[idx[n]], after[n]), n
+        cur = after[n].copy()
+    final_state = np.random.get_state(legacy=False)
+    # (the particles after resampling are moved[n][idx[n]] -- checked above -- and are not stored twice)
+    return dict(case=np.array(json.dumps(case)), theta0=theta0, moved=moved, idx=idx,
+                normals=z_exact, uniforms=u, choice_uniforms=cu,
+                final_pos=np.int64(final_state["state"]["pos"]), final_key=final_state["state"]["key"][:8].copy(),
+                final_has_gauss=np.int64(final_state["has_gauss"]))
+
+
+SMC_CASES = [
+    # the reference's own test (test/test_tempered_smc.py:8-30): Binomial model, M = 75, N = 15, scale 0.5
+    dict(name="smc_ref_binomial", model=dict(kind="ref_binomial", init_seed=11), M=75, N=15, scale=0.5, seed=20245),
+    # elementwise Gaussian prior / likelihood; D odd, so the polar method's cached second normal crosses particles
+    dict(name="smc_gauss5_m512", model=dict(kind="gauss_prior_lik", D=5, data_seed=3, prior_scale=2.0), M=512, N=8,
+         scale=0.35, seed=20246, init_seed=7),
+    dict(name="smc_gauss3_m2048", model=dict(kind="gauss_prior_lik", D=3, data_seed=4, prior_scale=1.5), M=2048, N=3,
+         scale=0.25, seed=20247, init_seed=8),
+]
+
+
 def ar1(rng, n, phi):
     x = np.empty(n)
     x[0] = rng.normal()
@@ -354,6 +466,14 @@ def main():
         np.savez_compressed(path, **res)
         print("%-28s draws %s  mean grad calls/draw %.1f  size %d B"
               % (case["name"], res["draws"].shape, res["grad_calls"].mean(), os.path.getsize(path)))
+    for case in SMC_CASES:
+        if only and case["name"] not in only:
+            continue
+        res = run_smc_case(case)
+        path = os.path.join(HERE, case["name"] + ".npz")
+        np.savez_compressed(path, **res)
+        print("%-28s particles %s  distinct ancestors at the end %d  size %d B"
+              % (case["name"], res["moved"].shape, len(np.unique(res["idx"][-1])), os.path.getsize(path)))
     if only and "diagnostics" not in only:
         return
     d = run_diagnostics()

@@ -128,3 +128,24 @@ def long_ar_chains(seed, n, phis):
             x[i] = phi * x[i - 1] + e[i]
         out.append(x)
     return out
+
+
+SMC_CASES = ["smc_ref_binomial", "smc_gauss5_m512", "smc_gauss3_m2048"]
+
+
+def smc_model(spec):
+    """The model of an SMC fixture (tests/golden/make_golden.py::make_smc_model), rebuilt without the reference."""
+    if spec["kind"] == "ref_binomial":
+        from tests.host_models import Binomial
+
+        return Binomial(alpha=2, beta=3, x=5, N=15)
+    if spec["kind"] == "gauss_prior_lik":
+        g = np.random.default_rng(spec["data_seed"])
+        D = spec["D"]
+        return omodels.GaussPriorLik(y=g.normal(size=D) * 1.5, prec=np.logspace(0, 1.5, D), prior_scale=spec["prior_scale"])
+    raise KeyError(spec)
+
+
+def smc_expected_thetas(z):
+    """The particles after every resampling: moved[n][idx[n]] (the generator checked this against the reference)."""
+    return np.stack([z["moved"][n][z["idx"][n]] for n in range(z["idx"].shape[0])])

@@ -172,3 +172,53 @@ def test_diagnostics_known_answers_from_reference_tests():
         od.ess([1.0, 2.0, 3.0])
     with pytest.raises(ValueError):
         od.autocorr([1.0])
+
+
+# ---- likelihood-tempered SMC (bayes_kit/smc.py:12-89 under np.random.seed) ----------------------------------------
+def _oracle_smc(case, z, stream):
+    from oracle import smc as osmc
+    from tests.helpers import smc_model
+
+    model = smc_model(case["model"])
+    return osmc.TemperedLikelihoodSMC(model, case["M"], case["N"], lambda i: z["theta0"][i],
+                                      osmc.metropolis_kernel(case["scale"], stream), stream)
+
+
+@pytest.mark.parametrize("source", ["restated_mt19937", "numpy_randomstate", "replay"])
+@pytest.mark.parametrize("name", ["smc_ref_binomial", "smc_gauss5_m512", "smc_gauss3_m2048"])
+def test_smc_matches_reference_bit_for_bit(name, source):
+    from oracle import smc as osmc
+    from oracle.rng import LegacyStream
+    from tests.helpers import smc_expected_thetas
+
+    case, z = load_case(name)
+    if source == "restated_mt19937":
+        stream = LegacyStream(case["seed"])
+    elif source == "numpy_randomstate":
+        stream = osmc.NumpyLegacySource(np.random.RandomState(case["seed"]))
+    else:
+        stream = osmc.ReplaySource(z["normals"], z["uniforms"], z["choice_uniforms"])
+    smc = _oracle_smc(case, z, stream)
+    want = smc_expected_thetas(z)
+    for n in range(1, case["N"] + 1):
+        smc.transition(n)
+        assert np.array_equal(smc.moved, z["moved"][n - 1]), (name, n)
+        assert np.array_equal(smc.idxs, z["idx"][n - 1]), (name, n)
+        assert np.array_equal(smc.thetas, want[n - 1]), (name, n)
+    if source == "restated_mt19937":
+        st = stream.state()
+        assert st["pos"] == int(z["final_pos"]) and st["has_gauss"] == int(z["final_has_gauss"])
+        assert np.array_equal(st["key"][:8], z["final_key"])
+
+
+def test_smc_fixture_reproduces_the_reference_test_moments():
+    # test/test_tempered_smc.py:8-30 asserts the Binomial posterior's moments at M = 75; the fixture is that run
+    from scipy import stats
+    from scipy.special import expit
+
+    from tests.helpers import smc_expected_thetas
+
+    case, z = load_case("smc_ref_binomial")
+    draws = expit(smc_expected_thetas(z)[-1])
+    post = stats.beta(2 + 5, 3 + 15 - 5)
+    assert abs(draws.mean() - post.mean()) < 0.05 and abs(draws.var(ddof=1) - post.var()) < 0.01

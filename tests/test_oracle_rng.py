@@ -60,3 +60,37 @@ def test_log1p_restatement_matches_libm():
         -rng.random(10000) * 2.0**-30, -rng.random(2000) * 2.0**-55, [0.0, -0.5, -0.2929, -0.29290001]])
     for x in xs:
         assert log1p_fdlibm(float(x)) == math.log1p(float(x)), x
+
+
+# ---- the legacy global stream of bayes_kit/smc.py:73,81,85 (numpy.random.RandomState) -------------------------------
+def test_legacy_mt19937_stream_matches_numpy_randomstate():
+    from oracle.rng import LegacyStream
+
+    for seed in (0, 1, 20245, 2**32 - 1):
+        rs, o = np.random.RandomState(seed), LegacyStream(seed)
+        assert np.array_equal(rs.get_state()[1], np.array(o.mt, dtype=np.uint32))
+        for k in range(400):  # D normals then one uniform, D odd and even: the cached gauss crosses the uniforms
+            D = 1 + k % 5
+            loc = np.arange(D) * 0.1
+            assert np.array_equal(rs.normal(loc=loc, scale=0.3), o.normal(loc, 0.3)), (seed, k)
+            assert rs.uniform() == o.uniform()
+        assert np.array_equal(rs.random_sample(700), o.choice_uniforms(700))  # crosses a 624-word refill
+        st = rs.get_state(legacy=False)
+        assert (st["has_gauss"], st["gauss"], st["state"]["pos"]) == (o.has_gauss, o.gauss, o.pos)
+        assert np.array_equal(st["state"]["key"], o.state()["key"])
+
+
+def test_numpy_sum_and_choice_restatements():
+    from oracle.rng import legacy_choice, numpy_pairwise_sum
+
+    g = np.random.default_rng(1)
+    for n in list(range(1, 140)) + [255, 256, 257, 511, 1000, 2048, 4097, 8191, 8192, 8193, 10000, 16385, 20000, 70001]:
+        w = np.exp(g.normal(size=n) * 3)
+        s = np.sum(w)
+        assert s == numpy_pairwise_sum(w), n
+        p = w / s
+        rs = np.random.RandomState(n)
+        st = rs.get_state()
+        idx = rs.choice(n, size=n, replace=True, p=p)
+        rs.set_state(st)
+        assert np.array_equal(idx, legacy_choice(p, rs.random_sample(n))), n
