@@ -9,11 +9,20 @@ one chain-contiguous ``[D, M]`` buffer (one particle per GPU lane); a temperatur
 1. the move kernel applied to every particle at temperature (n-1)/N       [smc.py:53-57]
 2. weights exp(lp_n - lp_{n-1}), multinomial resampling                   [smc.py:60, 64-75]
 
-The reference draws its random numbers from the process-global ``np.random`` (smc.py:73,
-81, 85), which cannot be seeded through its API, so parity is distributional (the moment
-test of test/test_tempered_smc.py).  Here every particle slot owns a Philox stream
-(key = (seed, slot)): proposal normals, the accept uniform and one resampling uniform per
-slot, which makes runs reproducible.
+Randomness, two modes:
+
+* default -- every particle slot owns a Philox stream (key = (seed, slot)): proposal normals, the
+  accept uniform and one resampling uniform per slot, generated on the device; reproducible, and
+  the same at any number of ranks.
+* **reference stream** (``seed=np.random``, a ``numpy.random.RandomState``, or any object with its
+  ``standard_normal(size=) / uniform() / random_sample(n)``): the reference draws from the
+  process-global legacy stream (smc.py:73, 81, 85), which ``np.random.seed(s)`` seeds.  In this
+  mode the host takes the values from that stream in the reference's own order -- per temperature,
+  for particle 0..M-1 {D normals, 1 uniform}, then ``choice``'s M uniforms -- and everything else
+  (proposal, densities, accept test, weights, ``choice``'s cdf and search, the gather) runs on the
+  device with the reference's arithmetic: after ``np.random.seed(s)`` the particles and ancestor
+  indices equal the reference's bit for bit (``tests/golden/smc_*.npz``).  Single rank,
+  ``metropolis_kernel`` (the reference's only move kernel).
 
 Model: the batched form of ``LogPriorLikelihoodModel`` (typing.py:37-42):
 ``log_prior(Theta) -> (M,)``, ``log_likelihood(Theta) -> (M,)`` on a (M, D) device view; for
@@ -40,6 +49,22 @@ class _RWMKernel:
         ops = smc._ops
         th, prop = smc._theta_dc, smc._prop_dc
         lp_cur = smc._tempered(th, t)
+        if smc._ref_stream is not None:
+            # the reference's stream in the reference's order: particle m takes D normals (smc.py:81), then one
+            # uniform (smc.py:85), before particle m + 1 takes any
+            rs, M, D = smc._ref_stream, smc.M, smc.D
+            z, u = np.empty((M, D)), np.empty(M)
+            for m in range(M):
+                z[m] = rs.standard_normal(size=D)
+                u[m] = rs.uniform()
+            z_dc = torch.as_tensor(np.ascontiguousarray(z.T)).to(th.device)
+            # normal(loc=theta, scale) = loc + scale * gauss: a rounded product, then a rounded sum
+            torch.add(th, z_dc * self.scale, out=prop)
+            smc._logu.copy_(torch.as_tensor(np.log(u)))
+            lp_prop = smc._tempered(prop, t)
+            ops.mh_accept(_lib.ACCEPT_MALA, lp_cur, None, lp_prop, None, smc._logu, smc._mask, None, smc._accepted)
+            ops.select_columns(smc._mask, th, prop)
+            return
         # theta* = normal(loc=theta, scale) [smc.py:81]
         ops.momentum_refresh(smc._rng_kind, smc._rng_state, th, 1.0, self.scale, prop, None, None,
                              None, getattr(smc, "_rng_work", None))
@@ -278,7 +303,20 @@ class TemperedLikelihoodSMC:
         f64 = dict(dtype=torch.float64, device=dev)
         self._theta_dc = init_t.t().contiguous().to(dev)
         self._prop_dc = torch.empty_like(self._theta_dc)
-        self._rng_kind, self._rng_state = make_streams(seed, self.M, self._slot0, False, dev)
+        # reference-stream mode: the randomness comes from numpy's legacy stream, in the reference's order
+        self._ref_stream = None
+        if seed is np.random or isinstance(seed, np.random.RandomState) or (
+                seed is not None and all(hasattr(seed, a) for a in ("standard_normal", "uniform", "random_sample"))
+                and not isinstance(seed, (np.random.Generator, np.random.BitGenerator))):
+            if not isinstance(kernel, _RWMKernel):
+                raise ValueError("the reference stream (seed=np.random / a RandomState) reproduces the reference's run, "
+                                 "whose only move kernel is metropolis_kernel(scale)")
+            if adaptive is not None or self._slot0 != 0:
+                raise ValueError("the reference stream is one sequential stream: t = n / N ladder, one rank")
+            self._ref_stream = seed
+            self._rng_kind = self._rng_state = None
+        else:
+            self._rng_kind, self._rng_state = make_streams(seed, self.M, self._slot0, False, dev)
         self._logu = torch.empty(self.M, **f64)
         self._u = torch.empty(self.M, **f64)
         self._cdf = torch.empty(self.M, **f64)
@@ -355,12 +393,16 @@ class TemperedLikelihoodSMC:
             mmax = max(counts)
             pad = ll if ll.shape[0] == mmax else torch.cat([ll, ll.new_full((mmax - ll.shape[0],), float("-inf"))])
             ll = torch.cat([p[:c] for p, c in zip(_bkdist.all_gather(pad.contiguous(), self._group), counts)])
-        if not bool(torch.isfinite(ll).all().item()):
-            # (a NaN / inf log likelihood makes every ESS comparison below False: the ladder would creep forward by
-            # 2^-64 of the remaining way per temperature, a full HMC move each, until max_steps)
-            bad = int((~torch.isfinite(ll)).sum().item())
-            raise FloatingPointError(f"adaptive SMC ladder at t = {self.t}: {bad} of {ll.numel()} particles have a non-finite "
-                                     "log likelihood; the next temperature cannot be chosen")
+        # -inf is a legitimate zero-weight particle (a hard constraint: exp(d * -inf) = 0 in the ESS and in the
+        # reweighting).  NaN / +inf make every ESS comparison below False: the ladder would creep forward by 2^-64 of
+        # the remaining way per temperature, a full move each, until max_steps -- as would a system with no finite
+        # particle left
+        broken = torch.isnan(ll) | (ll == float("inf"))
+        if bool(broken.any().item()) or not bool(torch.isfinite(ll).any().item()):
+            bad = int(broken.sum().item())
+            raise FloatingPointError(f"adaptive SMC ladder at t = {self.t}: {bad} of {ll.numel()} particles have a NaN / +inf "
+                                     f"log likelihood ({int((ll == float('-inf')).sum().item())} are -inf); the next "
+                                     "temperature cannot be chosen")
         x = ll - ll.max()
         want = self.adaptive * x.shape[0]
 
@@ -421,16 +463,22 @@ class TemperedLikelihoodSMC:
         # weights exp(lp - lpminus1) [smc.py:67-70], scaled by exp(-max) so that a large data set
         # (log-likelihood steps of 1e4 and more) cannot underflow every weight to zero; the
         # reference normalises by the sum (smc.py:73), so the common factor changes nothing
-        top = logw.max()
-        if multi:
-            dist.all_reduce(top, op=dist.ReduceOp.MAX, group=self._group)
-        w = torch.exp(logw - top).contiguous()
-        ops.uniform(self._rng_kind, self._rng_state, self._u)
+        if self._ref_stream is not None:
+            if multi:
+                raise RuntimeError("the reference stream is one sequential stream: one rank")
+            w = torch.exp(logw).contiguous()                      # smc.py:67-70 as written
+            self._u.copy_(torch.as_tensor(np.asarray(self._ref_stream.random_sample(self.M), dtype=np.float64)))
+        else:
+            top = logw.max()
+            if multi:
+                dist.all_reduce(top, op=dist.ReduceOp.MAX, group=self._group)
+            w = torch.exp(logw - top).contiguous()
+            ops.uniform(self._rng_kind, self._rng_state, self._u)
         if multi:
             self._resample_across_ranks(w, th)
         else:
             self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
-            ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73
+            ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73: choice(p = w / w.sum()), its arithmetic
             ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
             if hasattr(self.kernel, "resampled"):
                 self.kernel.resampled(self, self._idx)

@@ -1,41 +1,152 @@
-// Sequential Monte Carlo resampling (bayes_kit/smc.py:64-75): multinomial resampling of M
-// particles from unnormalised weights, as numpy's Generator.choice(p=...) does it -- inclusive
-// cumulative sum, normalise by the total, one uniform per draw, index = searchsorted(cdf, u,
-// side="right") -- followed by the gather of the chosen particles' columns.
+// Sequential Monte Carlo resampling (bayes_kit/smc.py:64-75): multinomial resampling of M particles from
+// unnormalised weights with EXACTLY the arithmetic of the reference's
+//     idxs = np.random.choice(M, size=M, replace=True, p=weights / weights.sum())          (smc.py:73)
+// from the weights on, so that the ancestor indices are bit-identical given the same uniforms:
+//   total = np.sum(weights)            numpy's pairwise summation, in pieces of 8,192 values added up in order
+//   p_i   = weights_i / total
+//   c_i   = c_{i-1} + p_i              np.cumsum: one sequential chain of rounded additions
+//   idx_j = #{ i : c_i / c_{n-1} <= u_j }   (RandomState.choice: cdf /= cdf[-1]; searchsorted(u, side="right"))
+// followed by the gather of the chosen particles' columns.  A chain of n dependent additions cannot be spread over
+// lanes without changing its roundings, so the cdf is built by ONE wavefront: the 64 lanes stage tiles through LDS
+// and sum the pairwise leaves, lane 0 runs the chains (n = 2,048: ~20 us; n = 65,536: ~0.5 ms).
 #include "bk_common.hpp"
 
 namespace {
 
-constexpr int SCAN_BLOCK = 1024;
+constexpr int NP_SUM_PIECE = 8192;  // numpy's reduction buffer: np.sum adds the pairwise sums of such pieces in order
+constexpr int NP_PW_BLOCK = 128;    // PW_BLOCKSIZE of numpy's pairwise sum
+constexpr int MAX_LEAVES = 128;     // a piece splits into leaves of 65..128 values
+constexpr int CDF_TILE = 4096;
 
-// inclusive scan of w[0..n) into cdf (one workgroup, chunked; wavefront shuffles + LDS)
-__global__ __launch_bounds__(SCAN_BLOCK) void k_cumsum(const double* w, double* cdf, i64 n) {
-  __shared__ double wave_tot[SCAN_BLOCK / BK_WAVE];
-  __shared__ double carry;
-  const int lane = threadIdx.x & (BK_WAVE - 1), wave = bk_wave_id();
-  if (threadIdx.x == 0) carry = 0.0;
-  __syncthreads();
-  for (i64 start = 0; start < n; start += SCAN_BLOCK) {
-    i64 i = start + threadIdx.x;
-    double v = i < n ? w[i] : 0.0;
-    // inclusive scan inside the wavefront
-#pragma unroll
-    for (int off = 1; off < BK_WAVE; off <<= 1) {
-      double t = __shfl_up(v, off);
-      if (lane >= off) v = v + t;
+// One piece (n <= 8192 values at a) summed as numpy's DOUBLE_pairwise_sum does; the whole wavefront calls it, the
+// result is valid in lane 0.
+__device__ double np_pairwise_piece(const double* a, int n, int* leaf_lo, int* leaf_n, double* leaf_sum, int* st_lo,
+                                    int* st_n, int* st_flag, double* vals, int* n_leaves) {
+  const int lane = threadIdx.x;
+  if (n < 8) {  // (only a piece shorter than 8: numpy's plain loop, starting from 0.0)
+    double res = 0.0;
+    if (lane == 0)
+      for (int i = 0; i < n; ++i) res = res + a[i];
+    return res;
+  }
+  // 1) the leaves of the recursion (split at n/2 rounded down to a multiple of 8 while n > 128), left to right
+  if (lane == 0) {
+    int top = 0, cnt = 0;
+    st_lo[0] = 0, st_n[0] = n, top = 1;
+    while (top > 0) {
+      --top;
+      const int lo = st_lo[top], m = st_n[top];
+      if (m <= NP_PW_BLOCK) {
+        leaf_lo[cnt] = lo, leaf_n[cnt] = m, ++cnt;
+      } else {
+        int h = m / 2;
+        h -= h % 8;
+        st_lo[top] = lo + h, st_n[top] = m - h, ++top;  // right half: after the left one
+        st_lo[top] = lo, st_n[top] = h, ++top;
+      }
     }
-    if (lane == BK_WAVE - 1) wave_tot[wave] = v;
+    *n_leaves = cnt;
+  }
+  __syncthreads();
+  const int L = *n_leaves;
+  // 2) leaf sums, eight leaves at a time: lane j of a group of 8 owns numpy's running sum r[j] (a[j], a[8+j], ...),
+  //    combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) -- additions commute, so the butterfly gives lane 0 of the
+  //    group that very value -- then the up-to-7 left-over values in order
+  for (int base = 0; base < L; base += 8) {
+    const int leaf = base + (lane >> 3), j = lane & 7;
+    const bool live = leaf < L;
+    const int lo = live ? leaf_lo[leaf] : 0, m = live ? leaf_n[leaf] : 0;
+    const int body = m - (m % 8);
+    double r = 0.0;
+    if (live) {
+      r = a[lo + j];
+      for (int i = 8; i < body; i += 8) r = r + a[lo + i + j];
+    }
+    r = r + __shfl_xor(r, 1);
+    r = r + __shfl_xor(r, 2);
+    r = r + __shfl_xor(r, 4);
+    if (live && j == 0) {
+      for (int i = body; i < m; ++i) r = r + a[lo + i];
+      leaf_sum[leaf] = r;
+    }
+  }
+  __syncthreads();
+  // 3) the recursion's additions, left + right, in its own order (a post-order walk with a value stack)
+  double res = 0.0;
+  if (lane == 0) {
+    int top = 0, vtop = 0, next = 0;
+    st_n[0] = n, st_flag[0] = 0, top = 1;
+    while (top > 0) {
+      --top;
+      const int m = st_n[top], flag = st_flag[top];
+      if (m <= NP_PW_BLOCK) {
+        vals[vtop++] = leaf_sum[next++];
+      } else if (!flag) {
+        int h = m / 2;
+        h -= h % 8;
+        st_n[top] = m, st_flag[top] = 1, ++top;
+        st_n[top] = m - h, st_flag[top] = 0, ++top;
+        st_n[top] = h, st_flag[top] = 0, ++top;
+      } else {
+        const double right = vals[--vtop], left = vals[--vtop];
+        vals[vtop++] = left + right;
+      }
+    }
+    res = vals[0];
+  }
+  __syncthreads();
+  return res;
+}
+
+// cdf[i] = cumsum(w / np.sum(w))[i]  (NOT yet divided by its last entry: k_search divides on the fly)
+__global__ __launch_bounds__(BK_WAVE) void k_choice_cdf(const double* w, double* cdf, i64 n) {
+  __shared__ double tile[CDF_TILE];
+  __shared__ double leaf_sum[MAX_LEAVES], vals[32];
+  __shared__ int leaf_lo[MAX_LEAVES], leaf_n[MAX_LEAVES], st_lo[32], st_n[32], st_flag[32], n_leaves;
+  __shared__ double total_s;
+  const int lane = threadIdx.x;
+  double total = 0.0;
+  for (i64 lo = 0; lo < n; lo += NP_SUM_PIECE) {
+    const int m = (int)(n - lo < NP_SUM_PIECE ? n - lo : NP_SUM_PIECE);
+    const double piece = np_pairwise_piece(w + lo, m, leaf_lo, leaf_n, leaf_sum, st_lo, st_n, st_flag, vals, &n_leaves);
+    total = lo == 0 ? piece : total + piece;
+  }
+  if (lane == 0) total_s = total;
+  __syncthreads();
+  total = total_s;
+  double carry = 0.0;
+  for (i64 lo = 0; lo < n; lo += CDF_TILE) {
+    const int m = (int)(n - lo < CDF_TILE ? n - lo : CDF_TILE);
+    for (int i = lane; i < m; i += BK_WAVE) tile[i] = w[lo + i] / total;
     __syncthreads();
-    double base = carry;
-    for (int k = 0; k < wave; ++k) base = base + wave_tot[k];
-    if (i < n) cdf[i] = base + v;
+    if (lane == 0) {
+      double c = carry;
+      int i = 0;
+      for (; i + 8 <= m; i += 8) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = tile[i + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          c = c + x[k];
+          x[k] = c;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tile[i + k] = x[k];
+      }
+      for (; i < m; ++i) {
+        c = c + tile[i];
+        tile[i] = c;
+      }
+      carry = c;
+    }
     __syncthreads();
-    if (threadIdx.x == SCAN_BLOCK - 1) carry = base + v;
+    for (int i = lane; i < m; i += BK_WAVE) cdf[lo + i] = tile[i];
     __syncthreads();
   }
 }
 
-// idx[j] = number of cdf entries <= u[j] * total   (searchsorted side="right" on cdf/total)
+// idx[j] = number of entries of cdf / cdf[n-1] that are <= u[j]   (searchsorted side="right" on the normalised cdf)
 __global__ __launch_bounds__(256) void k_search(const double* cdf, i64 n, const double* u, int32_t* idx, i64 m) {
   i64 j = (i64)blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
@@ -70,7 +181,7 @@ int bk_resample_indices(const double* weights, int64_t n, const double* u, int64
                         int32_t* idx_out, void* stream) {
   if (!weights || !u || !cdf_work || !idx_out || n < 1 || m < 0 || n > 0x7fffffff) return BK_E_ARG;
   hipStream_t s = bk_stream(stream);
-  k_cumsum<<<dim3(1), dim3(SCAN_BLOCK), 0, s>>>(weights, cdf_work, n);
+  k_choice_cdf<<<dim3(1), dim3(BK_WAVE), 0, s>>>(weights, cdf_work, n);
   if (m > 0) k_search<<<dim3((unsigned)bk_cdiv(m, 256)), dim3(256), 0, s>>>(cdf_work, n, u, idx_out, m);
   BK_RETURN_LAUNCH_STATUS();
 }

@@ -657,8 +657,12 @@ int bk_dot_columns(const double* x, const double* y, int64_t ld, double scale, d
                    int64_t C, int64_t D, void* stream);
 
 /* ---- sequential Monte Carlo resampling (smc.py:64-75) ---------------------------------------
- * Multinomial resampling as numpy's choice(M, size=m, p=w/sum(w)): cdf = cumsum(w) (written
- * to cdf_work[n]), idx_out[j] = searchsorted(cdf / cdf[n-1], u[j], side="right"). */
+ * Multinomial resampling with exactly the arithmetic of the reference's
+ *     np.random.choice(M, size=m, replace=True, p=weights / weights.sum())        (smc.py:73)
+ * from the weights on: total = np.sum(weights) (numpy's pairwise summation, pieces of 8,192 values added in order),
+ * p = weights / total, cdf = np.cumsum(p) as ONE sequential chain (written to cdf_work[n]),
+ * idx_out[j] = searchsorted(cdf / cdf[n-1], u[j], side="right").  Given the uniforms RandomState.choice would
+ * draw, the indices are bit-identical to the reference's (tests/golden/smc_*.npz). */
 int bk_resample_indices(const double* weights, int64_t n, const double* u, int64_t m,
                         double* cdf_work, int32_t* idx_out, void* stream);
 

@@ -501,7 +501,8 @@ class FakeOps:
         out.numpy()[...] = scale * np.einsum("dc,dc->c", x.numpy(), y.numpy())
 
     def resample_indices(self, weights, u, cdf_work, idx_out):
-        cdf = np.cumsum(weights.numpy())
+        w = weights.numpy()
+        cdf = np.cumsum(w / w.sum())   # RandomState.choice(p = w / w.sum()): cdf = p.cumsum(); cdf /= cdf[-1]
         cdf_work.numpy()[...] = cdf
         idx = np.searchsorted(cdf / cdf[-1], u.numpy(), side="right")
         idx_out.numpy()[...] = np.minimum(idx, len(cdf) - 1)

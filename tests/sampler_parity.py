@@ -456,3 +456,87 @@ def check_logistic_retemper(ops, N=3000, D=12, C=50):
         m.bk_retemper(th, gll, ll, t, gr, lr)
         assert torch.equal(gr, gf), t
         torch.testing.assert_close(lr, lf, rtol=1e-13, atol=1e-13)  # (the fresh call sums 256 segment partials, this one has their sum)
+
+
+class LegacyReplay:
+    """The values a reference SMC run took from numpy's global stream (tests/golden/smc_*.npz), handed out again
+    through RandomState's method names in the same order."""
+
+    def __init__(self, z):
+        self._z, self._u, self._c = z["normals"], z["uniforms"].reshape(-1), z["choice_uniforms"]
+        self._D = self._z.shape[-1]
+        self._z = self._z.reshape(-1, self._D)
+        self._iz = self._iu = self._ic = 0
+
+    def standard_normal(self, size):
+        assert size == self._D
+        self._iz += 1
+        return self._z[self._iz - 1]
+
+    def uniform(self):
+        self._iu += 1
+        return self._u[self._iu - 1]
+
+    def random_sample(self, n):
+        self._ic += 1
+        assert n == self._c.shape[1]
+        return self._c[self._ic - 1]
+
+
+def check_smc_reference_stream(ops, name, source):
+    """bayes_kit/smc.py:12-89 under np.random.seed(s), through the product: TemperedLikelihoodSMC in reference-stream
+    mode against the fixture of the REAL reference run -- the moved particles, the ancestor indices and the resampled
+    particles after every temperature, all bit-exact."""
+    import torch
+
+    from tests.helpers import load_case, smc_expected_thetas, smc_model
+
+    case, z = load_case(name)
+    M, N, spec = case["M"], case["N"], case["model"]
+    if spec["kind"] == "ref_binomial":
+        model = smc_model(spec)            # a reference-style host model: one particle per call (smc.py:28-32)
+    else:
+        om = smc_model(spec)               # the same densities as PyTorch functions of all particles at once
+        dev = ops.device
+        y, prec = (torch.as_tensor(v, dtype=torch.float64, device=dev) for v in (om._y, om._prec))
+        c0 = om._c0
+
+        def log_prior(Th):
+            return c0 * (Th * Th).sum(dim=1)
+
+        def log_lik(Th):
+            r = Th - y
+            return -0.5 * (prec * (r * r)).sum(dim=1)
+
+        model = bk.TorchPriorLikelihoodModel(log_prior, log_lik, spec["D"])
+    if source == "np.random":
+        np.random.seed(case["seed"])
+        stream = np.random
+    elif source == "RandomState":
+        stream = np.random.RandomState(case["seed"])
+    else:
+        stream = LegacyReplay(z)
+    smc = bk.TemperedLikelihoodSMC(model, M, N, z["theta0"], bk.metropolis_kernel(case["scale"]), seed=stream, ops=ops)
+    want = smc_expected_thetas(z)
+    for n in range(1, N + 1):
+        # the moved particles are what the resampling gathers from: read them between the two halves of transition()
+        seen = {}
+        gather = ops.gather_columns
+
+        def spy(index, src, dst, _seen=seen, _gather=gather):
+            _seen["moved"] = np.asarray(src.cpu()).T.copy()
+            _gather(index, src, dst)
+
+        ops.gather_columns = spy
+        try:
+            smc.transition(n)
+        finally:
+            del ops.gather_columns   # (the instance attribute: the class's method is visible again)
+        assert np.array_equal(seen["moved"], z["moved"][n - 1]), (name, source, n)
+        assert np.array_equal(np.asarray(smc._idx.cpu()), z["idx"][n - 1]), (name, source, n)
+        assert np.array_equal(np.asarray(torch.as_tensor(smc.thetas).cpu()), want[n - 1]), (name, source, n)
+    if source == "np.random":
+        st = np.random.get_state(legacy=False)
+        assert st["state"]["pos"] == int(z["final_pos"]) and st["has_gauss"] == int(z["final_has_gauss"])
+        assert np.array_equal(st["state"]["key"][:8], z["final_key"])
+    return smc

@@ -369,24 +369,26 @@ def test_dense_metric_apply_mfma(ops, D, C):
 
 
 def test_resample_indices_and_gather(ops):
+    """bk_resample_indices against numpy's own RandomState.choice(p = w / w.sum()) fed the same uniforms (smc.py:73):
+    indices BIT-EXACT, the cdf bit-exact (np.sum's pairwise pieces, np.cumsum's sequential chain)."""
     rng = np.random.default_rng(9)
-    for n in [1, 5, 1000, 1024, 1025, 50000]:
-        w = rng.uniform(0.0, 2.0, size=n)
+    for n in [1, 5, 7, 8, 9, 127, 128, 129, 1000, 1024, 1025, 4096, 4097, 8191, 8192, 8193, 8199, 20000, 50000, 70001]:
+        w = np.exp(rng.normal(size=n) * 3.0) if n % 2 else rng.uniform(0.0, 2.0, size=n)
         w[rng.uniform(size=n) < 0.1] = 0.0
         if w.sum() == 0:
             w[0] = 1.0
-        u = rng.uniform(size=n + 3)
+        p = w / w.sum()
+        rs = np.random.RandomState(n)
+        st = rs.get_state()
+        want = rs.choice(n, size=n + 3, replace=True, p=p)
+        rs.set_state(st)
+        u = rs.random_sample(n + 3)   # the uniforms choice() drew
         cdf = torch.empty(n, dtype=torch.float64, device=ops.device)
         idx = torch.empty(n + 3, dtype=torch.int32, device=ops.device)
         ops.resample_indices(dev(w, ops), dev(u, ops), cdf, idx)
-        c = np.cumsum(w)
-        np.testing.assert_allclose(cdf.cpu().numpy(), c, rtol=1e-13)
-        want = np.minimum(np.searchsorted(c / c[-1], u, side="right"), n - 1)
+        assert np.array_equal(cdf.cpu().numpy(), np.cumsum(p)), n
         got = idx.cpu().numpy()
-        # the device sums the cdf in a different order: indices may differ only where u sits
-        # within rounding of a cdf step
-        bad = got != want
-        assert bad.mean() < 1e-3
+        assert np.array_equal(got, want), n
         assert (w[got] > 0).all()  # zero-weight particles are never chosen
     D, M = 7, 300
     src = rng.normal(size=(D, M))

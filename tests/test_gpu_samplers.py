@@ -352,14 +352,51 @@ def test_dense_metric_hmc_vs_oracle(ops):
 
 
 def test_tempered_smc_binomial_moments(ops):
-    """test/test_tempered_smc.py:8-30 with many more particles (distributional parity: the
-    reference's SMC uses the unseedable global np.random)."""
+    """test/test_tempered_smc.py:8-30 with many more particles on the per-slot Philox streams (the pathwise pin to the
+    reference's own stream is test_tempered_smc_reference_stream_vs_reference_golden)."""
     from tests.sampler_parity import check_smc_binomial
 
     a = check_smc_binomial(ops, 8192, 15, bk.metropolis_kernel(0.5), mean_atol=0.006, var_atol=0.0012)
     b = check_smc_binomial(ops, 8192, 15, bk.metropolis_kernel(0.5), mean_atol=0.006, var_atol=0.0012)
     assert torch.equal(a.thetas, b.thetas)  # reproducible: every slot owns a Philox stream
     check_smc_binomial(ops, 8192, 10, bk.mala_kernel(0.2, 2), mean_atol=0.006, var_atol=0.0012)
+
+
+@pytest.mark.parametrize("source", ["np.random", "RandomState", "replay"])
+@pytest.mark.parametrize("name", ["smc_ref_binomial", "smc_gauss5_m512", "smc_gauss3_m2048"])
+def test_tempered_smc_reference_stream_vs_reference_golden(ops, name, source):
+    """bayes_kit/smc.py:12-89 run by the REAL reference under np.random.seed(s) (tests/golden/make_golden.py::
+    run_smc_case) against the device SMC fed the same stream: moved particles, ancestor indices (choice's cdf in
+    np.cumsum's order, np.sum's pairwise total) and resampled particles BIT-EXACT after every temperature."""
+    from tests.sampler_parity import check_smc_reference_stream
+
+    check_smc_reference_stream(ops, name, source)
+
+
+def test_tempered_smc_reference_stream_vs_oracle_other_seeds(ops):
+    """The same comparison against oracle/smc.py (pinned to the fixtures on the CPU) on seeds and sizes no fixture
+    holds, D even and odd."""
+    import torch
+
+    from oracle import models as om
+    from oracle import smc as osmc
+
+    for seed, M, D, N, scale in [(5, 300, 2, 5, 0.4), (6, 1000, 7, 3, 0.2), (7, 64, 1, 9, 0.8)]:
+        g = np.random.default_rng(seed)
+        y, prec = g.normal(size=D), np.logspace(0, 1, D)
+        host = om.GaussPriorLik(y, prec, prior_scale=1.3)
+        init = g.normal(size=(M, D)) * 1.3
+        stream = osmc.NumpyLegacySource(np.random.RandomState(seed))
+        o = osmc.TemperedLikelihoodSMC(host, M, N, lambda i: init[i], osmc.metropolis_kernel(scale, stream), stream)
+        yt, pt = (torch.as_tensor(v, dtype=torch.float64, device=ops.device) for v in (y, prec))
+        model = bk.TorchPriorLikelihoodModel(lambda T: host._c0 * (T * T).sum(dim=1),
+                                             lambda T: -0.5 * (pt * ((T - yt) * (T - yt))).sum(dim=1), D)
+        s = bk.TemperedLikelihoodSMC(model, M, N, init, bk.metropolis_kernel(scale), seed=np.random.RandomState(seed), ops=ops)
+        for n in range(1, N + 1):
+            o.transition(n)
+            s.transition(n)
+            assert np.array_equal(np.asarray(s._idx.cpu()), o.idxs), (seed, n)
+            assert np.array_equal(np.asarray(s.thetas.cpu()), o.thetas), (seed, n)
 
 
 def test_logistic_regression_target_and_annealed_smc(ops):

@@ -508,6 +508,45 @@ def test_recorder_dims_square_draws_padded_moments_and_attach_after_restore():
     check_recorder_and_moments_edges(FakeOps())
 
 
+@pytest.mark.parametrize("source", ["np.random", "replay"])
+@pytest.mark.parametrize("name", ["smc_ref_binomial", "smc_gauss5_m512"])
+def test_smc_reference_stream_host_logic(name, source):
+    # the driver's order of stream consumption and its arithmetic, on the CPU stand-in for the kernels
+    from tests.sampler_parity import check_smc_reference_stream
+
+    check_smc_reference_stream(FakeOps(), name, source)
+
+
+def test_smc_reference_stream_refuses_what_the_reference_cannot_do():
+    init = np.zeros((8, 2))
+    model = bk.TorchPriorLikelihoodModel(lambda T: -(T * T).sum(1), lambda T: -(T * T).sum(1), 2)
+    with pytest.raises(ValueError, match="metropolis_kernel"):
+        bk.TemperedLikelihoodSMC(model, 8, 3, init, bk.mala_kernel(0.1), seed=np.random, ops=FakeOps())
+    with pytest.raises(ValueError, match="one rank"):
+        bk.TemperedLikelihoodSMC(model, 8, 3, init, bk.metropolis_kernel(0.1), seed=np.random.RandomState(1), slot_id0=8,
+                                 ops=FakeOps())
+
+
+def test_adaptive_ladder_accepts_zero_weight_particles():
+    # a -inf log likelihood is a hard constraint (weight 0), not an error; NaN / +inf are
+    import torch
+
+    from bayes_kit_amd.smc import TemperedLikelihoodSMC
+
+    model = bk.TorchPriorLikelihoodModel(lambda T: -(T * T).sum(1), lambda T: -(T * T).sum(1), 1)
+    smc = TemperedLikelihoodSMC(model, 6, 3, np.zeros((6, 1)), bk.metropolis_kernel(0.1), seed=1, adaptive=0.5, ops=FakeOps())
+    ll = torch.tensor([-1.0, -2.0, float("-inf"), -0.5, -3.0, float("-inf")], dtype=torch.float64)
+    d = smc._next_temperature(ll)
+    assert 0.0 < d <= 1.0
+    for bad in (float("nan"), float("inf")):
+        ll2 = ll.clone()
+        ll2[0] = bad
+        with pytest.raises(FloatingPointError):
+            smc._next_temperature(ll2)
+    with pytest.raises(FloatingPointError):
+        smc._next_temperature(torch.full((6,), float("-inf"), dtype=torch.float64))
+
+
 def test_adaptive_smc_ladder_keeps_its_ess_and_finds_the_posterior():
     from tests.sampler_parity import check_adaptive_smc_ladder
 
