@@ -21,6 +21,10 @@ SOURCES = ["bk_rng.hip", "bk_integrator.hip", "bk_targets.hip", "bk_targets_gaus
 HEADERS = ["bk_common.hpp", "bk_rng.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_mala_step.hpp", "ziggurat_tables.inc", os.path.join("..", "..", "include", "bkhip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
+# Per-file flags.  bk_rng.hip: machine-level loop-invariant code motion lifts every constant of exp() / log1p() (the
+# rare ziggurat branches) out of the generator's pass loop into registers -- 149 instead of 93 VGPRs for k_zig_parallel<16>,
+# 3 instead of 5 wavefronts per SIMD, 332 instead of 286 us at 65,536 x 1024 (profiles/r6_generator.md).
+FILE_FLAGS = {"bk_rng.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _hipcc():
@@ -49,7 +53,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(OBJ_DIR, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

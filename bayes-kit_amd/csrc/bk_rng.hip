@@ -134,74 +134,114 @@ __global__ __launch_bounds__(RNG_BLOCK) void k_mala_propose(uint64_t* st, i64 ld
   g.store(st, ldr, c);
 }
 
-// ---- word-parallel ziggurat: one WAVEFRONT per chain ------------------------------------------
+// ---- word-parallel ziggurat: LPC lanes of a wavefront per chain -------------------------------
 // The one-lane-per-chain kernel above is latency bound: a chain's stream is consumed
 // sequentially, ~2,200 cycles per normal with one wavefront per SIMD, and with few chains most
 // SIMDs are idle (4096 chains = 64 wavefronts on 1024 SIMDs).  But Philox is counter based --
-// word v of a stream is block(counter0 + v/4)[v%4] -- and 98.5 % of the normals use exactly
-// one word.  So here the 64 lanes of a wavefront evaluate 256 consecutive words of ONE chain
-// at once: every lane generates one block, runs the ziggurat fast test on its 4 words and, for
-// the rare words that fail it, the complete slow path (wedge / tail) with positional access to
-// the following words.  Which words actually START a normal is then resolved exactly in
-// stream order: only the "exception" words can consume extra words, so a short scalar loop over
-// the exceptions (a few per 256 words) tracks the covered range; everything else is ballot /
-// popcount arithmetic.  The result is bit for bit the sequential stream, with C wavefronts of
-// parallelism instead of C/64.  Normals go to a chain-major scratch zt[c][d] (coalesced per
-// wavefront); k_refresh_apply transposes them into the [D][C] layout with loc + scale*z.
+// word v of a stream is block(counter0 + v/4)[v%4] -- and 98.8 % of the normals use exactly
+// one word.  So the LPC lanes of a segment evaluate 4 LPC consecutive words of ONE chain at
+// once: every lane generates one block and runs the ziggurat fast test on its 4 words; the rare
+// words that fail it get the complete slow path (wedge / tail) with positional access to the
+// following words.  Which words actually START a normal is then resolved exactly in stream
+// order: only the "exception" words can consume extra words, so a short scalar loop over the
+// exceptions (a few per window, and only when they interact) tracks the covered range;
+// everything else is ballot / scan arithmetic.  The result is bit for bit the sequential stream.
+// Normals go to a chain-major scratch zt[c][d]; k_refresh_apply* turn them into the [D][C]
+// layout with loc + scale*z.
+//
+// Round 6 (same stream, fewer instructions per pass; profiles/r6_generator.md):
+//   * the slow path runs ONCE per pass for the lanes' first failing word (a second time in the 6 % of passes where
+//     some lane has two) instead of once per word slot -- the wedge's exp() was executed 2.3 times per pass;
+//   * the words of the window are staged in LDS (two 16-byte writes per lane): "the word after mine" is one LDS read
+//     instead of eight ds_bpermute per pass and a select chain per access;
+//   * ki / wi share one 16-byte table entry (one LDS read per word), (double)rabs is an exponent OR and a subtraction;
+//   * a word's dimension comes from a DPP row scan of the lanes' emit counts with the running base folded into the
+//     segment's first lane, instead of four ballots and sixteen masked popcounts; positions are window-relative ints;
+//   * the end of the chain's last normal is broadcast once per launch, not once per pass.
 struct SlowRes {
   double val;
   int len;   // words consumed by the attempt that starts at this word (>= 2)
   bool emit; // false: rejected wedge attempt (its words are consumed, no normal is produced)
 };
 
-struct WordWindow {
-  uint64_t w0, w1, w2, w3, w4, w5, w6, w7;  // own block, next lane's block
-  bool has_next;
-  const bk::Philox* ph;  // key
-  uint64_t c0, c1, c2, c3;  // counter of the lane's own block
-  uint64_t e0, e1, e2, e3;  // on-demand block cache
-  int eblk;
-
-  __device__ uint64_t at(int j) {
-    if (j < 4) return j == 0 ? w0 : j == 1 ? w1 : j == 2 ? w2 : w3;
-    if (j < 8 && has_next) return j == 4 ? w4 : j == 5 ? w5 : j == 6 ? w6 : w7;
-    int blk = j >> 2;
-    if (blk != eblk) {
-      uint64_t a0, a1, a2, a3;
-      bk::Philox::ctr_add(c0, c1, c2, c3, (uint64_t)blk, a0, a1, a2, a3);
-      ph->block_at(a0, a1, a2, a3, e0, e1, e2, e3);
-      eblk = blk;
-    }
-    int k = j & 3;
-    return k == 0 ? e0 : k == 1 ? e1 : k == 2 ? e2 : e3;
-  }
-  __device__ double dbl(int j) { return (double)(at(j) >> 11) * (1.0 / 9007199254740992.0); }
+struct __align__(16) ZigKW {
+  uint64_t ki;
+  double wi;
 };
+struct ZigLds2 {
+  ZigKW kw[256];
+  double fi[256];
+};
+constexpr int ZP_WAVES = 4;  // wavefronts per workgroup
 
-// everything after a failed fast test for the word at offset k of the window (same arithmetic as
-// bk::zig_slow, with positional instead of sequential word access)
-__device__ SlowRes zig_slow_at(WordWindow& win, int k, int idx, uint64_t rabs, double x, const double* fi) {
+__device__ __forceinline__ void load_tables2(ZigLds2& t) {
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    t.kw[i].ki = d_zig_ki[i];
+    t.kw[i].wi = bk::u64_as_double(d_zig_wi[i]);
+    t.fi[i] = bk::u64_as_double(d_zig_fi[i]);
+  }
+  __syncthreads();
+}
+
+// the ziggurat's word-local part (bk::zig_fast) with the table entry fetched in one read and the integer -> double
+// conversion done by hand: rabs < 2^52, so 2^52 + rabs is the double with mantissa rabs and the subtraction is exact;
+// the product is >= 0, so the sign (bit 8 of the word) is inserted, not xor-ed
+__device__ __forceinline__ bool zig_fast2(uint64_t w, const ZigKW* kw, double& x) {
+  const ZigKW e = kw[(uint32_t)w & 0xffu];
+  const uint64_t rabs = (w >> 9) & 0x000fffffffffffffULL;
+  const double xd = bk::u64_as_double(rabs | 0x4330000000000000ULL) - 4503599627370496.0;
+  const uint64_t xm = bk::double_as_u64(xd * e.wi);
+  const uint32_t hi = ((uint32_t)w << 23 & 0x80000000u) | (uint32_t)(xm >> 32);
+  x = bk::u64_as_double(((uint64_t)hi << 32) | (uint32_t)xm);
+  return rabs < e.ki;  // 99.2 %
+}
+
+// Positional access to the words that follow a lane's own block: offset j counts from the lane's first word.  Words
+// of the segment's window come from the LDS copy; beyond it the block is generated on demand (a wedge on the last word
+// of a window: 3 % of the passes; a long tail attempt).  NOT inlined: inlined, the compiler hoists "the block after
+// mine" out of the branches that need it and every pass pays for a second Philox block (160 v_mad_u64_u32 in the
+// pass's main basic block instead of 80).
+// The ziggurat's tail (idx == 0: one word in 4,000): pairs of the words that follow until the tail test passes, read
+// from the segment's staged window (`mine` = the lane's first word there, `room` = words from it to the window's end).
+// len = 0: the window ran out before the test passed -- the caller starts the next window at this attempt instead.
+__device__ __forceinline__ SlowRes zig_tail_staged(const uint64_t* mine, int k, int room, uint64_t rabs) {
   const double zr = 3.6541528853610087963519472518, zinv = 0.27366123732975827203338247596;
   SlowRes r;
-  if (idx == 0) {
-    int j = k + 1;
-    for (;;) {
-      double xx = -zinv * bk::bk_log1p(-win.dbl(j));
-      double yy = -bk::bk_log1p(-win.dbl(j + 1));
-      j += 2;
-      if (yy + yy > xx * xx) {
-        r.val = ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
-        break;
-      }
+  r.val = 0.0, r.len = 0, r.emit = true;
+  for (int j = k + 1; j + 1 < room; j += 2) {
+    const double u1 = (double)(mine[j] >> 11) * (1.0 / 9007199254740992.0);
+    const double u2 = (double)(mine[j + 1] >> 11) * (1.0 / 9007199254740992.0);
+    const double xx = -zinv * bk::bk_log1p(-u1);
+    const double yy = -bk::bk_log1p(-u2);
+    if (yy + yy > xx * xx) {
+      r.val = ((rabs >> 8) & 1) ? -(zr + xx) : zr + xx;
+      r.len = j + 2 - k;
+      break;
     }
-    r.len = j - k;
-    r.emit = true;
-    return r;
   }
-  r.len = 2;
-  r.emit = (fi[idx - 1] - fi[idx]) * win.dbl(k + 1) + fi[idx] < exp(-0.5 * x * x);
-  r.val = x;
   return r;
+}
+
+constexpr int DPP_ROW_SHR_ = 0x110, DPP_ROW_ROR_ = 0x120, DPP_WAVE_ROR1_ = 0x13C, DPP_ROW_BCAST15_ = 0x142,
+              DPP_ROW_BCAST31_ = 0x143;
+
+// inclusive scan of v over every segment of LPC lanes (rows of 16 lanes by DPP row shifts, then the row totals)
+template <int LPC>
+__device__ __forceinline__ int seg_inclusive_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR_ + 1, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR_ + 2, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR_ + 4, 0xF, 0xF, false);
+  v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR_ + 8, 0xF, 0xF, false);
+  if (LPC >= 32) v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST15_, 0xA, 0xF, false);
+  if (LPC >= 64) v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_BCAST31_, 0xC, 0xF, false);
+  return v;
+}
+// the value of the segment's LAST lane, delivered to its FIRST lane (other lanes: unspecified)
+template <int LPC>
+__device__ __forceinline__ int seg_last_to_first(int v) {
+  if (LPC == 16) return __builtin_amdgcn_update_dpp(0, v, DPP_ROW_ROR_ + 1, 0xF, 0xF, false);
+  if (LPC == 64) return __builtin_amdgcn_update_dpp(0, v, DPP_WAVE_ROR1_, 0xF, 0xF, false);
+  return __shfl(v, ((int)(threadIdx.x & 63) | (LPC - 1)));
 }
 
 // LPC lanes per chain: a wavefront serves 64/LPC chains at once, each through a window of 4*LPC
@@ -212,10 +252,10 @@ __device__ SlowRes zig_slow_at(WordWindow& win, int k, int idx, uint64_t rabs, d
 // chain).  Fewer lanes per chain also mean fewer wavefronts, so small launches keep LPC = 64
 // (zp_lanes_per_chain).  The stream is the same whatever LPC is: every quantity below that was
 // wavefront-wide with LPC = 64 (ballots, ranks, the covered range) is per SEGMENT of LPC lanes.
-constexpr int ZP_WAVES = 4;  // wavefronts per workgroup
 template <int LPC>
 __device__ __forceinline__ void zig_parallel_wave(uint64_t* st, i64 ldr, double* zt, i64 ldz, i64 C, i64 D,
-                                                  uint64_t* snap, const ZigLds& tab, i64 wave_index);
+                                                  uint64_t* snap, const ZigLds2& tab, uint64_t* win_lds, uint64_t* rk_lds,
+                                                  i64 wave_index);
 
 // The grid may be SMALLER than the number of chain groups (a "background" launch: bk_normals_chain_major with
 // a bound on the workgroups): every workgroup then walks the groups blockIdx.x, blockIdx.x + gridDim.x, ...
@@ -225,17 +265,21 @@ template <int LPC>
 __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel(uint64_t* st, i64 ldr, double* zt, i64 ldz,
                                                                     i64 C, i64 D, uint64_t* snap) {
   constexpr int G = BK_WAVE / LPC;  // chains per wavefront
-  __shared__ ZigLds tab;
-  load_tables(tab);
+  __shared__ ZigLds2 tab;
+  __shared__ __align__(16) uint64_t win[ZP_WAVES][4 * BK_WAVE];
+  __shared__ __align__(16) uint64_t rkeys[ZP_WAVES][G][20];
+  load_tables2(tab);
   const i64 n_wg = (C + (i64)ZP_WAVES * G - 1) / ((i64)ZP_WAVES * G);
   for (i64 wg = blockIdx.x; wg < n_wg; wg += gridDim.x)
-    zig_parallel_wave<LPC>(st, ldr, zt, ldz, C, D, snap, tab, wg * ZP_WAVES + bk_wave_id());
+    zig_parallel_wave<LPC>(st, ldr, zt, ldz, C, D, snap, tab, win[bk_wave_id()], &rkeys[bk_wave_id()][0][0], wg * ZP_WAVES + bk_wave_id());
 }
 
 template <int LPC>
 __device__ __forceinline__ void zig_parallel_wave(uint64_t* st, i64 ldr, double* zt, i64 ldz, i64 C, i64 D,
-                                                  uint64_t* snap, const ZigLds& tab, i64 wave_index) {
+                                                  uint64_t* snap, const ZigLds2& tab, uint64_t* win_lds, uint64_t* rk_lds,
+                                                  i64 wave_index) {
   constexpr int G = BK_WAVE / LPC;  // chains per wavefront
+  constexpr int WW = 4 * LPC;       // words of a segment's window
   const int lane = threadIdx.x & (BK_WAVE - 1);
   const int seg = lane / LPC, l = lane % LPC;
   const i64 c = wave_index * G + seg;
@@ -243,141 +287,193 @@ __device__ __forceinline__ void zig_parallel_wave(uint64_t* st, i64 ldr, double*
   const bool live = c < C;     // (a wavefront's last segments may have no chain)
   const i64 cs = live ? c : C - 1;
   const unsigned long long segmask = (LPC == 64 ? ~0ULL : ((1ULL << (LPC & 63)) - 1)) << (seg * LPC);
-  const unsigned long long below = (lane == 0 ? 0ULL : (~0ULL >> (64 - lane))) & segmask;
   if (snap && live && l < BK_RNG_WORDS) snap[l * ldr + c] = st[l * ldr + c];  // the table before this call
   bk::Philox ph;
   ph.key0 = st[0 * ldr + cs];
   ph.key1 = st[1 * ldr + cs];
   const uint64_t k0 = st[2 * ldr + cs], k1 = st[3 * ldr + cs], k2 = st[4 * ldr + cs], k3 = st[5 * ldr + cs];
-  const i64 v0 = (i64)st[10 * ldr + cs];  // words of block `counter` already consumed (4 = all)
-  i64 cover_until = v0;                   // words below this position are consumed / not attempt starts
-  i64 d_base = live ? 0 : D, p_end = v0;
-  for (i64 t = 0; __any(d_base < D); ++t) {
-    // 1. one Philox block per lane: block (counter + LPC t + l), words v = 4 LPC t + 4 l + k
-    WordWindow win;
-    win.ph = &ph;
-    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)(LPC * t + l), win.c0, win.c1, win.c2, win.c3);
-    ph.block_at(win.c0, win.c1, win.c2, win.c3, win.w0, win.w1, win.w2, win.w3);
-    win.w4 = __shfl_down((unsigned long long)win.w0, 1);
-    win.w5 = __shfl_down((unsigned long long)win.w1, 1);
-    win.w6 = __shfl_down((unsigned long long)win.w2, 1);
-    win.w7 = __shfl_down((unsigned long long)win.w3, 1);
-    win.has_next = l < LPC - 1;
-    win.eblk = -1;
-    const i64 wbase = 4 * LPC * t;  // stream position of the window's first word
-    const i64 vbase = wbase + 4 * l;
-    // 2. fast test on the four words; 3. full slow path where it fails
-    double val[4];
-    int len[4];
-    bool okf[4], emitf[4];
-    const uint64_t wk[4] = {win.w0, win.w1, win.w2, win.w3};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double x;
-      int idx;
-      uint64_t rabs;
-      okf[k] = bk::zig_fast(wk[k], tab.ki, tab.wi, x, idx, rabs);
-      val[k] = x;
-      len[k] = 1;
-      emitf[k] = true;
-      if (!okf[k]) {
-        SlowRes r = zig_slow_at(win, k, idx, rabs, x, tab.fi);
-        val[k] = r.val;
-        len[k] = r.len;
-        emitf[k] = r.emit;
-      }
+  const int v0 = (int)st[10 * ldr + cs];  // words of block `counter` already consumed (4 = all)
+  const int Di = (int)D;
+  // the chain's ten pairs of Philox round keys, in LDS for the whole launch (written by the segment's first ten lanes)
+  uint64_t* const rk = rk_lds + 20 * seg;
+  if (l < 10) {
+    rk[2 * l] = ph.key0 + (uint64_t)l * 0x9E3779B97F4A7C15ULL;
+    rk[2 * l + 1] = ph.key1 + (uint64_t)l * 0xBB67AE8584CAA73BULL;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // output addresses: a wave-uniform base (scalar registers) + a 32-bit offset per lane
+  char* const zbase = reinterpret_cast<char*>(zt) + (size_t)((c - seg) * ldz) * sizeof(double);
+  const uint32_t zoff = (uint32_t)((size_t)((cs - (c - seg)) * ldz) * sizeof(double));
+  const uint64_t* const mine = win_lds + 4 * lane;  // the lane's four staged words, the segment's later ones behind them
+  const int rel = 4 * l;           // window-relative position of the lane's first word
+  int base = 0;                    // the segment's window starts at block `counter + base` ...
+  int carry = v0;                  // ... whose first `carry` words an earlier attempt (or pass) has consumed
+  int d_base = live ? 0 : Di;      // dimensions written so far (kept by the segment's first lane)
+  int last_end = -1, last_base = 0;  // this lane holds the word that produced dimension D - 1: its attempt ends at the
+                                     // window-relative position last_end of the pass that started at block last_base
+  while (__any(l == 0 && d_base < Di)) {
+    // 1. one Philox block per lane: block (counter + base + l), window-relative words 4 l + k
+    uint64_t c0, c1, c2, c3, w0, w1, w2, w3;
+    bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)(base + l), c0, c1, c2, c3);
+    bk::Philox::block_with_round_keys(rk, c0, c1, c2, c3, w0, w1, w2, w3);
+    {
+      ulonglong2* dst = reinterpret_cast<ulonglong2*>(win_lds + 4 * lane);
+      dst[0] = make_ulonglong2(w0, w1);
+      dst[1] = make_ulonglong2(w2, w3);
     }
-    // 4. which words start an attempt: scan the exceptions in stream order (lanes ascend within
-    //    every segment; segments are independent streams)
+    // 2. fast test on the four words
+    double val[4];
+    unsigned fail = 0;
+    {
+      const uint64_t wk[4] = {w0, w1, w2, w3};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (!zig_fast2(wk[k], tab.kw, val[k])) fail |= 1u << k;
+    }
+    // words consumed by an attempt of the previous window
+    unsigned cov = 0;  // bit k: word k of this lane is consumed by an earlier attempt, or left to the next pass
+    if (carry > rel) cov = carry - rel >= 4 ? 0xFu : (1u << (carry - rel)) - 1u;
+    // The slow path reads "the word after mine" from the staged window, so the window's LAST word cannot start one:
+    // when it fails the fast test (3 % of the passes) this pass leaves it alone and the next window starts at its
+    // block -- one block of sixteen generated twice, no code that generates words on demand.
+    int stop = WW;     // this pass handles the window-relative words below `stop` (the same in all lanes of a segment)
+    const bool defer = l == LPC - 1 && (fail & 8u);
+    if (defer) fail &= 7u, cov |= 8u;
+    if (__ballot(defer) & segmask) stop = WW - 1;
+    unsigned emitf = 0xFu;           // bit k: an attempt starting at word k produces a normal
+    unsigned lenp = 0x01010101u;     // byte k: words that attempt consumes (1; a wedge 2; a tail 3, 5, ...)
     unsigned long long ex[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ex[k] = __ballot(!okf[k]);
-    unsigned cov = 0;  // bit k: word k of this lane is consumed by an earlier attempt
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (vbase + k < cover_until) cov |= 1u << k;
+    for (int k = 0; k < 4; ++k) ex[k] = __ballot((fail >> k) & 1u);
     unsigned long long any = ex[0] | ex[1] | ex[2] | ex[3];
-    // The common window: every exception is a two-word attempt (wedge), none of them sits on a word that is
-    // already covered, no two are neighbours in the stream.  Then every exception starts an attempt, covers
-    // exactly the word behind it, and nothing has to be walked in order: a word is covered iff its
-    // predecessor in the segment is an exception (or the carry-in covers it).
+    int cover = carry;               // the words below this position are consumed
     if (any) {
-      bool odd = false;  // this lane holds an exception the shortcut cannot take
+      // 3. the full slow path, once for every lane's first failing word (again while some lane has another)
+      __builtin_amdgcn_wave_barrier();
+      bool tail_here = false;
+      int short_at = WW;             // a tail attempt starting here ran out of window
+      unsigned fm = fail;
+      do {
+        if (fm) {
+          const int k = __ffs((int)fm) - 1;
+          const uint64_t w = mine[k];
+          const int idx = (int)((uint32_t)w & 0xffu);
+          const uint64_t rabs = (w >> 9) & 0x000fffffffffffffULL;
+          if (idx == 0) {  // the tail: one word in 4,000
+            const SlowRes r = zig_tail_staged(mine, k, WW - rel, rabs);
+            if (r.len == 0) {
+              if (rel + k < short_at) short_at = rel + k;
+            } else {
+              if (r.len > 255) __builtin_trap();  // (cannot happen: WW <= 256; lenp holds bytes)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) odd |= !okf[k] && (len[k] != 2 || vbase + k < cover_until);
+              for (int kk = 0; kk < 4; ++kk)
+                if (kk == k) val[kk] = r.val;
+              lenp += (unsigned)(r.len - 1) << (8 * k);
+            }
+            tail_here = true;
+          } else {         // the wedge: |x| again from the word (x * x does not see the sign), one more word
+            const double xa = (bk::u64_as_double(rabs | 0x4330000000000000ULL) - 4503599627370496.0) * tab.kw[idx].wi;
+            const double u = (double)(mine[k + 1] >> 11) * (1.0 / 9007199254740992.0);
+            const bool emit = (tab.fi[idx - 1] - tab.fi[idx]) * u + tab.fi[idx] < exp(-0.5 * xa * xa);
+            if (!emit) emitf &= ~(1u << k);
+            lenp += 1u << (8 * k);
+          }
+          fm &= fm - 1;
+        }
+      } while (__any(fm != 0));
+      // a tail that ran out of window (one pass in ~10^4): the pass stops in front of it, the next window starts at its
+      // block.  A tail longer than a whole window (WW - 3 words: >= 30 rejected pairs in a row, p < 1e-40) cannot be
+      // served this way and aborts loudly.
+      const unsigned long long sm = __ballot(short_at < WW);
+      if (sm) {
+        if (sm & segmask) {
+          const int q = __shfl(short_at, __ffsll((long long)(sm & segmask)) - 1);  // (positions ascend with the lanes)
+          if (q < 4) __builtin_trap();
+          if (q < stop) stop = q;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if (rel + kk >= q) fail &= ~(1u << kk), cov |= 1u << kk;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ex[k] = __ballot((fail >> k) & 1u);
+        any = ex[0] | ex[1] | ex[2] | ex[3];
+      }
+      // 4. which words start an attempt.  The common window: every exception is a two-word attempt (wedge), none of
+      //    them sits on a word that is already covered, no two are neighbours in the stream.  Then every exception
+      //    starts an attempt, covers exactly the word behind it, and nothing has to be walked in order: a word is
+      //    covered iff its predecessor in the segment is an exception (or the carry-in covers it).
+      const bool odd = tail_here || (fail & cov) != 0;  // this lane holds an exception the shortcut cannot take
       // neighbours: words k, k+1 of one lane; word 3 of lane L and word 0 of lane L+1 of the same segment
       constexpr unsigned long long seg_last =  // lanes that are the last of their segment
           LPC == 64 ? 0x8000000000000000ULL : LPC == 32 ? 0x8000000080000000ULL : 0x8000800080008000ULL;
       const unsigned long long adj = (ex[0] & ex[1]) | (ex[1] & ex[2]) | (ex[2] & ex[3]) | (ex[3] & (ex[0] >> 1) & ~seg_last);
+      const unsigned long long mine_mask = any & segmask;
       if (!__any(odd) && !adj) {
-        const unsigned long long mine_mask = any & segmask;
         if (mine_mask) {
           // covered: the word behind an exception
-          if (!okf[0]) cov |= 1u << 1;
-          if (!okf[1]) cov |= 1u << 2;
-          if (!okf[2]) cov |= 1u << 3;
-          if (l > 0 && ((ex[3] >> (lane - 1)) & 1ULL)) cov |= 1u << 0;
-          // the last exception of the segment ends the covered range (its second word may be the next window's first)
+          cov |= (fail << 1) & 0xEu;
+          if (l > 0 && ((ex[3] >> (lane - 1)) & 1ULL)) cov |= 1u;
+          // the last exception of the segment ends the covered range
           const int Ll = 63 - __clzll((long long)mine_mask);  // last lane of the segment holding an exception
           int kl = 0;
 #pragma unroll
           for (int k = 1; k < 4; ++k)
             if ((ex[k] >> Ll) & 1ULL) kl = k;
-          cover_until = wbase + 4 * (Ll % LPC) + kl + 2;
+          cover = 4 * (Ll % LPC) + kl + 2;
         }
-        any = 0;
-      }
-    }
-    while (any) {
-      int L = __ffsll((long long)any) - 1;
-      any &= any - 1;
-      const bool mine = (L / LPC) == seg;
+      } else {
+        while (any) {
+          const int L = __ffsll((long long)any) - 1;
+          any &= any - 1;
+          const bool mine_l = (L / LPC) == seg;
+          const unsigned lens = (unsigned)__shfl((int)lenp, L);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((ex[k] >> L) & 1ULL) {
-          i64 pos = wbase + 4 * (L % LPC) + k;
-          int ln = __shfl(len[k], L);
-          if (mine && pos >= cover_until) {  // an actual attempt: it consumes words pos .. pos+ln-1
-            cover_until = pos + ln;
+          for (int k = 0; k < 4; ++k) {
+            if ((ex[k] >> L) & 1ULL) {
+              const int pos = 4 * (L % LPC) + k;
+              const int ln = (int)((lens >> (8 * k)) & 0xffu);
+              if (mine_l && pos >= cover) {  // an actual attempt: it consumes words pos .. pos+ln-1
+                cover = pos + ln;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-              if (vbase + kk > pos && vbase + kk < pos + ln) cov |= 1u << kk;
+                for (int kk = 0; kk < 4; ++kk)
+                  if (rel + kk > pos && rel + kk < pos + ln) cov |= 1u << kk;
+              }
+            }
           }
         }
       }
     }
     // 5./6. emitting words, their dimension index, output
-    bool em[4];
-    unsigned long long mk[4];
+    const unsigned em = ~cov & emitf & 0xFu;
+    const int cnt = __popc(em);
+    const int incl = seg_inclusive_scan<LPC>(cnt + (l == 0 ? d_base : 0));
+    int dim = incl - cnt;
+    if (incl < Di) {  // every word of this lane comes before the chain's last dimension
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      em[k] = !((cov >> k) & 1u) && emitf[k];
-      mk[k] = __ballot(em[k]);
-    }
-    i64 rank = __popcll(mk[0] & below) + __popcll(mk[1] & below) + __popcll(mk[2] & below) + __popcll(mk[3] & below);
-    bool last_here = false;
-    i64 my_end = 0;
+      for (int k = 0; k < 4; ++k)
+        if ((em >> k) & 1u) *reinterpret_cast<double*>(zbase + (zoff + 8u * (uint32_t)(dim++))) = val[k];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (em[k]) {
-        i64 dim = d_base + rank;
-        if (dim < D) zt[c * ldz + dim] = val[k];
-        if (dim == D - 1) {
-          last_here = true;
-          my_end = vbase + k + len[k];
+      for (int k = 0; k < 4; ++k) {
+        if ((em >> k) & 1u) {
+          if (dim < Di) *reinterpret_cast<double*>(zbase + (zoff + 8u * (uint32_t)dim)) = val[k];
+          if (dim == Di - 1) last_end = rel + k + (int)((lenp >> (8 * k)) & 0xffu), last_base = base;
+          ++dim;
         }
-        ++rank;
       }
     }
-    const unsigned long long lb = __ballot(last_here) & segmask;
-    const i64 end_of_seg = __shfl(my_end, lb ? __ffsll((long long)lb) - 1 : lane);
-    if (lb) p_end = end_of_seg;
-    d_base += __popcll(mk[0] & segmask) + __popcll(mk[1] & segmask) + __popcll(mk[2] & segmask) +
-              __popcll(mk[3] & segmask);
-    // an attempt that started in this window may reach into the next one: cover_until carries over
+    d_base = seg_last_to_first<LPC>(incl);
+    // the next window: behind this one, or at the block of the first word this pass left alone; an attempt that
+    // started in this window may reach into the next one
+    const int adv = stop >> 2;
+    carry = (cover > stop ? cover : stop) - 4 * adv;
+    base += adv;
   }
   // new stream position: p_end words into the block stream that starts at `counter`
-  if (l == 0 && live && p_end > v0) {
+  const unsigned long long lb = __ballot(last_end >= 0) & segmask;
+  const i64 my_end = 4 * (i64)last_base + last_end;
+  const i64 p_end = __shfl(my_end, lb ? __ffsll((long long)lb) - 1 : lane);
+  if (l == 0 && live && lb && p_end > v0) {
     i64 bf = (p_end - 1) / 4;
     uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
     bk::Philox::ctr_add(k0, k1, k2, k3, (uint64_t)bf, a0, a1, a2, a3);

@@ -51,6 +51,18 @@ BK_HD void mulhilo64(uint64_t a, uint64_t b, uint64_t& hi, uint64_t& lo) {
 #endif
 }
 
+// a ^ b ^ c: one V_BITOP3_B32 per 32-bit half on gfx950 (the compiler emits two v_xor_b32 per half otherwise:
+// 80 of the ~260 vector instructions of a Philox block)
+BK_HD uint64_t xor3_64(uint64_t a, uint64_t b, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint32_t lo = __builtin_amdgcn_bitop3_b32((uint32_t)a, (uint32_t)b, (uint32_t)c, 0x96);
+  const uint32_t hi = __builtin_amdgcn_bitop3_b32((uint32_t)(a >> 32), (uint32_t)(b >> 32), (uint32_t)(c >> 32), 0x96);
+  return ((uint64_t)hi << 32) | lo;
+#else
+  return a ^ b ^ c;
+#endif
+}
+
 BK_HD double u64_as_double(uint64_t u) {
   union { uint64_t u; double d; } x;
   x.u = u;
@@ -91,7 +103,24 @@ struct Philox {
       uint64_t hi0, lo0, hi1, lo1;
       mulhilo64(M0, x0, hi0, lo0);
       mulhilo64(M1, x2, hi1, lo1);
-      uint64_t y0 = hi1 ^ x1 ^ k0, y2 = hi0 ^ x3 ^ k1;
+      uint64_t y0 = xor3_64(hi1, x1, k0), y2 = xor3_64(hi0, x3, k1);
+      x0 = y0; x1 = lo1; x2 = y2; x3 = lo0;
+    }
+    o0 = x0; o1 = x1; o2 = x2; o3 = x3;
+  }
+
+  // The same block with the ten round keys read from a table (rk[2 r], rk[2 r + 1] = key0 + r W0, key1 + r W1):
+  // kernels that generate many blocks of ONE stream keep the table in LDS instead of 40 registers or 36 additions
+  // per block.
+  BK_HD static void block_with_round_keys(const uint64_t* rk, uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3,
+                                          uint64_t& o0, uint64_t& o1, uint64_t& o2, uint64_t& o3) {
+    const uint64_t M0 = 0xD2E7470EE14C6C93ULL, M1 = 0xCA5A826395121157ULL;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      uint64_t hi0, lo0, hi1, lo1;
+      mulhilo64(M0, x0, hi0, lo0);
+      mulhilo64(M1, x2, hi1, lo1);
+      uint64_t y0 = xor3_64(hi1, x1, rk[2 * r]), y2 = xor3_64(hi0, x3, rk[2 * r + 1]);
       x0 = y0; x1 = lo1; x2 = y2; x3 = lo0;
     }
     o0 = x0; o1 = x1; o2 = x2; o3 = x3;
@@ -143,8 +172,8 @@ struct Philox {
       mulhilo64(M0, y0, yh0, yl0);
       mulhilo64(M1, x2, xh1, xl1);
       mulhilo64(M1, y2, yh1, yl1);
-      uint64_t xa = xh1 ^ x1 ^ k0, xc = xh0 ^ x3 ^ k1;
-      uint64_t ya = yh1 ^ y1 ^ k0, yc = yh0 ^ y3 ^ k1;
+      uint64_t xa = xor3_64(xh1, x1, k0), xc = xor3_64(xh0, x3, k1);
+      uint64_t ya = xor3_64(yh1, y1, k0), yc = xor3_64(yh0, y3, k1);
       x0 = xa; x1 = xl1; x2 = xc; x3 = xl0;
       y0 = ya; y1 = yl1; y2 = yc; y3 = yl0;
     }
