@@ -268,18 +268,126 @@ def source_hash(path=None):
     return hashlib.sha256(region.encode()).hexdigest()[:16]
 
 
+LIB_FILE = os.path.join(ROOT, "bayes-kit_amd", "bayes_kit_amd", "lib", "libbkhip.so")
+
+
+def lib_hash(path=None):
+    """sha256 (16 hex digits) of the shared library the process loads: what the PMC passes were taken with."""
+    try:
+        h = hashlib.sha256()
+        with open(path or LIB_FILE, "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 20), b""):
+                h.update(chunk)
+        return h.hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _pmc_traffic(C, D):
-    """HBM bytes per kick+drift launch from the committed PMC passes (rocprofv3 cannot run inside
-    this process).  The file is stamped with the hash of the kernel's source file when the passes
-    were taken: None if the kernel source has changed since, or the profile is for another shape."""
+    """(HBM bytes per kick+drift launch, how the stamp matched) from the committed PMC passes (rocprofv3 cannot run
+    inside this process).  The file is stamped with the sha256 of the libbkhip.so the passes ran (`lib_sha256_16`) and
+    with the hash of the kernel's source text: the traffic is reported when the LIBRARY is the same binary
+    ("library"), or -- a rebuilt library whose kick+drift source is unchanged -- when the source text is
+    ("kernel source"); otherwise None."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
-        if t["chains"] == C and t["dims"] == D and t.get("source_sha256_16") == source_hash():
-            return t["traffic_bytes_per_launch"]
+        if t["chains"] == C and t["dims"] == D:
+            if t.get("lib_sha256_16") and t.get("lib_sha256_16") == lib_hash():
+                return t["traffic_bytes_per_launch"], "library"
+            if t.get("source_sha256_16") == source_hash():
+                return t["traffic_bytes_per_launch"], "kernel source"
     except (OSError, KeyError, ValueError):
         pass
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# which device, at which clocks (sysfs only: no HIP call, safe in the launcher too)
+# ---------------------------------------------------------------------------------------------
+def _amd_cards():
+    import glob
+
+    cards = []
+    for p in sorted(glob.glob("/sys/class/drm/renderD*/device"), key=lambda p: int(p.split("renderD")[1].split("/")[0])):
+        try:
+            if open(os.path.join(p, "vendor")).read().strip().lower() == "0x1002":
+                cards.append(p)
+        except OSError:
+            pass
+    return cards
+
+
+def _current_mhz(path):
+    """The starred level of a pp_dpm_* file, in MHz."""
+    try:
+        for line in open(path):
+            if "*" in line:
+                return float(line.split(":")[1].strip().split("M")[0].strip())
+    except (OSError, ValueError, IndexError):
+        pass
     return None
+
+
+def device_identity(index):
+    """PCI / unique id of the index-th AMD render node: lets two bench lines be told apart by box."""
+    try:
+        dev = _amd_cards()[index]
+    except IndexError:
+        return None
+    out = {}
+    for key, name in (("unique_id", "unique_id"), ("pci_device", "device"), ("pci_revision", "revision"),
+                      ("vbios", "vbios_version")):
+        try:
+            out[key] = open(os.path.join(dev, name)).read().strip()
+        except OSError:
+            out[key] = None
+    try:
+        out["pci_slot"] = os.path.basename(os.path.realpath(dev))
+    except OSError:
+        out["pci_slot"] = None
+    return out
+
+
+class ClockSampler:
+    """Shader / memory clock of one card sampled from sysfs by a sleeping thread while a timed region runs (a read every
+    `period` seconds: a few dozen samples per region, no HIP, nothing on the GPU's queues)."""
+
+    def __init__(self, index, period=0.02):
+        import threading
+
+        cards = _amd_cards()
+        self._dev = cards[index] if index < len(cards) else None
+        self._period, self._stop, self.sclk, self.mclk = period, threading.Event(), [], []
+        self._thread = threading.Thread(target=self._run, daemon=True) if self._dev else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            a = _current_mhz(os.path.join(self._dev, "pp_dpm_sclk"))
+            b = _current_mhz(os.path.join(self._dev, "pp_dpm_mclk"))
+            if a is not None:
+                self.sclk.append(a)
+            if b is not None:
+                self.mclk.append(b)
+            self._stop.wait(self._period)
+
+    def __enter__(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread:
+            self._stop.set()
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        def stat(v):
+            if not v:
+                return None
+            w = sorted(v)
+            return {"min": w[0], "median": w[len(w) // 2], "max": w[-1], "samples": len(w)}
+        return {"sclk_mhz": stat(self.sclk), "mclk_mhz": stat(self.mclk), "source": "sysfs pp_dpm_sclk / pp_dpm_mclk during the timed region"}
 
 
 def _cpu_model():
@@ -377,6 +485,60 @@ def cpu_baseline():
                                               f"wall incl. spawn {bwall:.1f}s"}
         except Exception as e:  # the context figure must not cost the baseline
             out["batched_numpy"] = {"error": repr(e)}
+    return out
+
+
+def strong_shard_entries(ctx, args, full_rate):
+    """The metric's OWN per-rank shard, on one GPU: BASELINE's metric is "65,536 chains whole node", so at N = 8 / 4 / 2
+    a GPU holds 8,192 / 16,384 / 32,768 chains x 1,024 -- 64 / 128 / 256 MiB per array, at or inside the 256-MiB Infinity
+    Cache, ~50-200 us per launch.  Same sampler, same path (gradient a separate op), chains = the FIRST shard's global
+    ids; per-launch times from HIP events.  `rate_vs_full_per_chain` = (steps/s per chain here) / (steps/s per chain at
+    65,536): what strong scaling keeps per GPU; `predicted_node_steps_per_s` = N x this GPU's rate -- a PREDICTION from
+    one GPU (no exchange on the path: chains are independent), not a measurement of N GPUs."""
+    import torch
+
+    out = {}
+    ops = None
+    for n_gpus in (8, 4, 2):
+        n = C_CFG3 // n_gpus
+        try:
+            ss = make_cfg3_sampler(n, 0, ctx.device)
+            ops = ss._ops
+            for _ in range(max(3, args.warmup)):
+                ss.sample()
+            steps = max(args.steps, 20)
+            el = ctx.timed_loop(ss.sample, steps)
+            ops.timed = {"bk_leapfrog_kick_drift": [], "bk_target_diag_gaussian_grad": []}
+            ops.timed_stride = 8
+            for _ in range(4):
+                ss.sample()
+            torch.cuda.synchronize()
+            timed, ops.timed, ops.timed_stride = ops.timed, None, 1
+            kd = [a.elapsed_time(b) for a, b in timed["bk_leapfrog_kick_drift"]]
+            gr = [a.elapsed_time(b) for a, b in timed["bk_target_diag_gaussian_grad"]]
+            rate = float(n) * L_CFG3 * steps / el
+            per_array_mib = n * D_CFG3 * 8 / 2**20
+            e = {"chains": n, "share_of": f"N = {n_gpus}", "ms_per_draw": 1e3 * el / steps, "value": rate,
+                 "unit": "leapfrog steps/sec (this GPU)", "us_per_leapfrog_step": 1e6 * el / steps / L_CFG3,
+                 "rate_vs_full_per_chain": (rate / n) / (full_rate / C_CFG3),
+                 "predicted_node_steps_per_s": rate * n_gpus, "predicted_speedup_vs_1gpu": rate * n_gpus / full_rate,
+                 "hipgraph": bool(ss._use_graph), "array_mib": per_array_mib,
+                 "regime": ("Infinity-Cache resident (3 arrays <= 256 MiB)" if 3 * per_array_mib <= 256 else
+                            "partly cache resident" if per_array_mib <= 256 else "HBM"),
+                 "path_bytes_model_GBps": rate * 56.0 * D_CFG3 / 1e9}
+            if kd:
+                e["kick_drift_us"] = 1e3 * sum(kd) / len(kd)
+                e["kick_drift_GBps"] = 40.0 * D_CFG3 * ss._chain_tile / (sum(kd) / len(kd) * 1e-3) / 1e9
+            if gr:
+                e["gradient_us"] = 1e3 * sum(gr) / len(gr)
+                e["gradient_GBps"] = 16.0 * D_CFG3 * ss._chain_tile / (sum(gr) / len(gr) * 1e-3) / 1e9
+            out[str(n)] = e
+            del ss
+            torch.cuda.empty_cache()
+        except Exception as ex:  # an extra must never cost the headline line
+            if ops is not None:
+                ops.timed, ops.timed_stride = None, 1
+            out[str(n)] = {"error": repr(ex)}
     return out
 
 
@@ -550,7 +712,8 @@ def run_rank(args):
         # every 8th launch of each is bracketed by HIP events (a sample spread evenly over the timed region): an event
         # record is a packet of its own on the queue, and 256 of them per draw cost the draw itself 4 %
         ops.timed_stride = int(os.environ.get("BK_BENCH_EVENT_STRIDE", "8"))
-    elapsed = ctx.timed_loop(s.sample, args.steps)
+    with ClockSampler(ctx.local) as clocks:
+        elapsed = ctx.timed_loop(s.sample, args.steps)
     timed, ops.timed = ops.timed, None
     event_stride, ops.timed_stride = ops.timed_stride, 1
     accept = s.accept_rate()
@@ -598,6 +761,9 @@ def run_rank(args):
         "placement": s.placement,  # which allocation plays which role was chosen by timing (HMCDiag._tune_placement)
         # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
         "path_hbm_frac": value / world * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
+        # which box and at which clocks (box-to-box spread of this pool is a few per cent: VERDICT r5 item 7)
+        "device": {"name": torch.cuda.get_device_name(ctx.local), "identity": device_identity(ctx.local),
+                   "clocks": clocks.summary(), "lib_sha256_16": lib_hash()},
     }
     if timed:
         kd = [a.elapsed_time(b) for a, b in timed["bk_leapfrog_kick_drift"]]
@@ -612,7 +778,8 @@ def run_rank(args):
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": _pmc_traffic(C, D),
+            "traffic": _pmc_traffic(C, D)[0],
+            "traffic_stamp": _pmc_traffic(C, D)[1],
             "avg_launch_ms": kd_ms,
             "launches": len(kd),
             "launches_in_timed_region": len(kd) * event_stride,
@@ -627,6 +794,10 @@ def run_rank(args):
                 "achieved": 16.0 * D * Ct / (g_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_per_launch": 16.0 * D * Ct,
             }
+            # (flat copies: a parser that keeps only the scalar keys of `roofline` still sees the second kernel)
+            out["roofline"]["gradient_avg_launch_ms"] = g_ms
+            out["roofline"]["gradient_achieved"] = 16.0 * D * Ct / (g_ms * 1e-3) / 1e9
+            out["roofline"]["gradient_frac"] = 16.0 * D * Ct / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         try:
             # context for `frac`: what a plain device-to-device copy of the same arrays sustains on this
             # box right now (the guide's measured copy ceiling is 6.29 TB/s = 79 % of the 8 TB/s spec)
@@ -704,6 +875,8 @@ def run_rank(args):
             out["value_strong"] = None
             out["strong"] = {"error": repr(e)}
 
+    if world == 1 and not args.no_strong_shard:
+        out["cfg3_strong_shard"] = strong_shard_entries(ctx, args, value)
     if not args.no_fused_extra:
         try:
             # Separately reported (never priced on the 56*D model): the same workload through the
@@ -790,6 +963,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-fused-extra", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' records (N=1 only)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N>1 only)")
+    ap.add_argument("--no-strong-shard", action="store_true",
+                    help="skip config 3 at the per-rank shard sizes of the metric (8,192 / 16,384 / 32,768 chains; N=1 only)")
     ap.add_argument("--ess-draws", type=int, default=200, help="extra draws for the ESS/sec figure (0 = skip)")
     args = ap.parse_args(argv)
     args.steps_given = any(a == "--steps" or a.startswith("--steps=") for a in (sys.argv[1:] if argv is None else argv))

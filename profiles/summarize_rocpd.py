@@ -26,6 +26,7 @@ def short(name):
 
 
 TRAFFIC = {}
+TRAFFIC_GRAD = {}
 
 
 def main():
@@ -55,16 +56,22 @@ def main():
             corr = b * 2 if ctr == "FETCH_SIZE" else b
             if "k_kick_drift_v2" in name:
                 TRAFFIC[ctr] = corr
+            if "k_gauss_grad_v2" in name:
+                TRAFFIC_GRAD[ctr] = corr
             print(f"| {short(name)} | {n} | {val:.1f} | {b:.4g} | {corr:.4g} | {dur / 1e3:.1f} |")
     if json_out and "FETCH_SIZE" in TRAFFIC and "WRITE_SIZE" in TRAFFIC:
         import json
 
+        rec = {"kernel": "k_kick_drift_v2", "chains": 65536, "dims": 1024,
+               "fetch_bytes_corrected": TRAFFIC["FETCH_SIZE"], "write_bytes": TRAFFIC["WRITE_SIZE"],
+               "traffic_bytes_per_launch": TRAFFIC["FETCH_SIZE"] + TRAFFIC["WRITE_SIZE"],
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"}
+        if "FETCH_SIZE" in TRAFFIC_GRAD and "WRITE_SIZE" in TRAFFIC_GRAD:
+            rec["gradient_kernel"] = {"kernel": "k_gauss_grad_v2", "fetch_bytes_corrected": TRAFFIC_GRAD["FETCH_SIZE"],
+                                      "write_bytes": TRAFFIC_GRAD["WRITE_SIZE"],
+                                      "traffic_bytes_per_launch": TRAFFIC_GRAD["FETCH_SIZE"] + TRAFFIC_GRAD["WRITE_SIZE"]}
         with open(json_out, "w") as f:
-            json.dump({"kernel": "k_kick_drift_v2", "chains": 65536, "dims": 1024,
-                       "fetch_bytes_corrected": TRAFFIC["FETCH_SIZE"], "write_bytes": TRAFFIC["WRITE_SIZE"],
-                       "traffic_bytes_per_launch": TRAFFIC["FETCH_SIZE"] + TRAFFIC["WRITE_SIZE"],
-                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH x2 (gfx950)"},
-                      f, indent=1)
+            json.dump(rec, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -28,18 +28,47 @@ def test_committed_traffic_matches_the_algorithmic_bytes(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
 
-    t = bench._pmc_traffic(65536, 1024)
-    assert t is not None  # the committed PMC passes are for the kernel source as it stands
+    t, stamp = bench._pmc_traffic(65536, 1024)
+    assert t is not None  # the committed PMC passes are for the library (or at least the kernel source) as it stands
+    assert stamp in ("library", "kernel source")
     algorithmic = 40.0 * 1024 * 65536
     assert abs(t / algorithmic - 1.0) < 0.02  # PMC traffic == algorithmic bytes (no re-reads)
-    assert bench._pmc_traffic(4096, 128) is None
+    assert bench._pmc_traffic(4096, 128) == (None, None)
     # the figure is tied to the kernel's source text: any edit of the kernel nulls it
     src = open(bench.KD_SOURCE).read()
     edited = tmp_path / "bk_integrator.hip"
     edited.write_text(src.replace("double t = has_m ? m * g : g;", "double t = has_m ? g * m : g;"))
     assert bench.source_hash(str(edited)) != bench.source_hash()
     monkeypatch.setattr(bench, "KD_SOURCE", str(edited))
-    assert bench._pmc_traffic(65536, 1024) is None
+    monkeypatch.setattr(bench, "LIB_FILE", str(tmp_path / "another_build.so"))   # ... and a different binary
+    assert bench._pmc_traffic(65536, 1024) == (None, None)
+
+
+def test_device_identity_and_clock_sampler_read_sysfs_only(tmp_path, monkeypatch):
+    """bench.py's box identity and clocks come from sysfs (no HIP): parsed from a fake card directory here."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    dev = tmp_path / "renderD128" / "device"
+    dev.mkdir(parents=True)
+    (dev / "vendor").write_text("0x1002\n")
+    (dev / "unique_id").write_text("abc123\n")
+    (dev / "device").write_text("0x75a3\n")
+    (dev / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 2104Mhz *\n2: 2400Mhz\n")
+    (dev / "pp_dpm_mclk").write_text("0: 900Mhz\n1: 2000Mhz *\n")
+    monkeypatch.setattr(bench, "_amd_cards", lambda: [str(dev)])
+    ident = bench.device_identity(0)
+    assert ident["unique_id"] == "abc123" and ident["pci_device"] == "0x75a3" and ident["vbios"] is None
+    assert bench.device_identity(1) is None
+    import time
+
+    with bench.ClockSampler(0, period=0.005) as c:
+        time.sleep(0.05)
+    sm = c.summary()
+    assert sm["sclk_mhz"]["median"] == 2104.0 and sm["mclk_mhz"]["max"] == 2000.0 and sm["sclk_mhz"]["samples"] >= 2
+    with bench.ClockSampler(3) as c:   # no such card: an empty summary, no thread
+        pass
+    assert c.summary()["sclk_mhz"] is None
 
 
 def test_launcher_starts_one_process_per_rank_and_relays_rank0(capsys):
