@@ -111,8 +111,9 @@ SIGNATURES = {
     "bk_host_normals": [c_int, P, P, I],
     "bk_host_uniforms": [c_int, P, P, I],
     "bk_host_log1p": [F],
+    "bk_host_exp": [F],
 }
-_RESTYPE = {"bk_gemm_chains_work_elems": c_int64, "bk_host_log1p": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64,
+_RESTYPE = {"bk_gemm_chains_work_elems": c_int64, "bk_host_log1p": c_double, "bk_host_exp": c_double, "bk_refresh_work_elems": c_int64, "bk_sort_by_key_work_bytes": c_int64,
              "bk_autocorr_fft_work_bytes": c_int64}
 
 

@@ -282,11 +282,13 @@ class MALA(ManyChainSampler):
             ev.record(self._side)
         self._pf_event = ev
 
-    # bk_mala_step's workgroups each take a whole CU's register file: next to the generator's
-    # wavefronts they cannot be scheduled, and the two kernels only slow each other down (1.52 ms per
-    # draw at 65,536 x 1024 against 1.3 when the generator overlaps the model's gradient op alone).
-    # With serialize_step the step kernel starts after the generator of the next unit has finished.
-    serialize_step = True
+    # Whether the step kernel waits for the generator of the next unit (queued on the side stream with the model's
+    # launch).  Rounds 2-5: yes -- the generator needed 169 registers per lane, could not sit beside a step workgroup
+    # (192 x 512 threads per CU), and the two only slowed each other down (1.52 against 1.3 ms per draw).  Round 6's
+    # generator needs 93 and finishes in 0.26-0.29 ms: letting its tail run under the step kernel is the fastest of the
+    # 32 schedules measured (65,536 x 1024, one box: model-opaque 1.124 ms against 1.152 serialized, density inlined
+    # 0.802 against 0.876; profiles/r6_mala.md).  Results do not depend on it (events order the data).
+    serialize_step = False
     # When the generator of the next unit starts: "grad" = with the model's gradient op (then, with
     # serialize_step, the step kernel waits for it), "step" = together with the step kernel, behind the
     # gradient op (the step kernel's workgroups are queued first and take one slot per CU; a generator

@@ -371,6 +371,22 @@ def _csrc_dir():
     raise _lib.BkHipError("CTarget.from_source: the library's kernel headers (csrc/bk_common.hpp) were not found")
 
 
+_HIPCC_VERSIONS = {}
+
+
+def _hipcc_version(hipcc):
+    """`hipcc --version` (once per process and compiler path); part of the from_source cache key."""
+    if hipcc not in _HIPCC_VERSIONS:
+        import subprocess
+
+        try:
+            r = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=120)
+            _HIPCC_VERSIONS[hipcc] = r.stdout.strip() if r.returncode == 0 else "unknown"
+        except (OSError, subprocess.SubprocessError):
+            _HIPCC_VERSIONS[hipcc] = "unknown"
+    return _HIPCC_VERSIONS[hipcc]
+
+
 def _check_private(path, what, want_dir):
     """Refuse a cache directory / cached library somebody else could have written: it must be a real directory / regular
     file (no symlink), owned by this user, without group or world write permission."""
@@ -491,9 +507,12 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
         # (the staged paths of k_src_chain want the user's loops over d unrolled completely: the private copy of the chain's
         # coordinates then lives in registers, LDS reads are issued in batches; clang's default budget stops at trip counts of ~60)
         flags += ["-mllvm", "-unroll-threshold=%d" % (4000 if int(dims) <= 128 else 10000)]
-    h = hashlib.sha256((text + " ".join(flags)).encode())
+    # the cache key: the generated text, the flags, every library header the translation unit can include, and the
+    # COMPILER (path + `--version` text: a toolchain upgrade must not serve a library built by the old one)
+    hipcc = _find_hipcc()
+    h = hashlib.sha256((text + " ".join(flags) + "\0" + hipcc + "\0" + _hipcc_version(hipcc)).encode())
     for name in ("bk_common.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_mala_step.hpp", "bk_source_api.hpp", "bk_source_kernels.hpp",
-                 os.path.join(inc, "bkhip.h")):
+                 os.path.join(inc, "bkhip.h"), os.path.join(inc, "bkhip_source.h"), os.path.join(inc, "bkhip_math.h")):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     tag = h.hexdigest()[:20]
@@ -502,7 +521,6 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
     if os.path.lexists(lib):
         _check_private(lib, "the cached library", False)
         return lib
-    hipcc = _find_hipcc()
     # (several ranks may compile the same source at once: everything is written under per-process names, the finished
     # library is checked for its exports and only then published with an atomic rename)
     src = os.path.join(root, f"t_{tag}.{os.getpid()}.hip")

@@ -432,7 +432,7 @@ class _Emit:
         if op == "neg":
             return T(f"-{a}"), (None if da is None else T(f"-{da}"))
         if op == "exp":
-            v = T(f"exp({a})")
+            v = T(f"bk_exp({a})")   # (the library's exp: the same double as the built-in funnel's, on host and device)
             return v, self.mul(v, da)
         if op == "log":
             return T(f"log({a})"), (None if da is None else T(f"{da} / {a}"))

@@ -265,7 +265,7 @@ class _Dag:
         raise AssertionError(op)
 
 
-_C_UNARY = {"exp": "exp({a})", "log": "log({a})", "log1p": "log1p({a})", "expm1": "expm1({a})", "sigmoid": "1.0 / (1.0 + exp(-{a}))",
+_C_UNARY = {"exp": "bk_exp({a})", "log": "log({a})", "log1p": "log1p({a})", "expm1": "expm1({a})", "sigmoid": "1.0 / (1.0 + exp(-{a}))",
             "logsigmoid": "fmin({a}, 0.0) - log1p(exp(-fabs({a})))", "softplus": "({a} > 20.0) ? {a} : log1p(exp({a}))",
             "tanh": "tanh({a})", "sqrt": "sqrt({a})", "square": "{a} * {a}", "abs": "fabs({a})", "sin": "sin({a})", "cos": "cos({a})",
             "neg": "-{a}", "sign": "(double)(({a} > 0.0) - ({a} < 0.0))", "sinh": "sinh({a})", "cosh": "cosh({a})",

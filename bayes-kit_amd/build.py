@@ -18,7 +18,8 @@ OUT_DIR = os.path.join(HERE, "bayes_kit_amd", "lib")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libbkhip.so")
 SOURCES = ["bk_rng.hip", "bk_integrator.hip", "bk_targets.hip", "bk_targets_gauss_lanes.hip", "bk_diag.hip", "bk_dr.hip", "bk_dense.hip", "bk_smc.hip", "bk_mala.hip", "bk_sort.hip", "bk_fft.hip"]
-HEADERS = ["bk_common.hpp", "bk_rng.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_mala_step.hpp", "ziggurat_tables.inc", os.path.join("..", "..", "include", "bkhip.h")]
+HEADERS = ["bk_common.hpp", "bk_rng.hpp", "bk_lanes.hpp", "bk_elementwise.hpp", "bk_mala_step.hpp", "ziggurat_tables.inc", os.path.join("..", "..", "include", "bkhip.h"),
+           os.path.join("..", "..", "include", "bkhip_math.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
 # Per-file flags.  bk_rng.hip: machine-level loop-invariant code motion lifts every constant of exp() / log1p() (the

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/bkhip.h"
+#include "../../include/bkhip_math.h"
 
 typedef int64_t i64;
 

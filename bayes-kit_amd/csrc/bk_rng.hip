@@ -991,5 +991,6 @@ int bk_host_uniforms(int rng_kind, uint64_t* w, double* out, int64_t n) {
 }
 
 double bk_host_log1p(double x) { return bk::bk_log1p(x); }
+double bk_host_exp(double x) { return bk_exp(x); }
 
 }  // extern "C"

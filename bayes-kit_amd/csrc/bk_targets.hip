@@ -173,7 +173,7 @@ struct FunnelDensity {
   __device__ __forceinline__ static double eval(L& c, const double*) {
     const double v = c.head(0);
     const double s = c.sum([](double x, i64) { return x * x; });
-    const double ev = exp(-v);
+    const double ev = bk_exp(-v);  // (the library's own exp: include/bkhip_math.h -- the same double on host and device)
     const double hn = 0.5 * (double)(c.dims() - 1);
     const double he = 0.5 * ev;
     c.grad_head(0, ((-v / 9.0) - hn) + he * s);

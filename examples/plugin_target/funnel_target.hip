@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/bkhip_math.h"  // bk_exp: the library's exp (the built-in funnel uses it; same double, same draws)
+
 namespace {
 
 constexpr int WAVES = 4;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_funnel_plugin(const double* thet
   __syncthreads();
   if (!on) return;
   const double s = ((q[0][lane] + q[1][lane]) + q[2][lane]) + q[3][lane];
-  const double ev = exp(-v);
+  const double ev = bk_exp(-v);
   const double hn = 0.5 * (double)(D - 1);
   const double he = 0.5 * ev;
   if (w == 0) {

@@ -155,3 +155,30 @@ class GaussPriorLik:
 
     def posterior_var(self):
         return 1.0 / (self._prec - 2.0 * self._c0)
+
+
+class FunnelCanonical(Funnel):
+    """The funnel with sum x^2 taken in the HIP library's canonical order (csrc/bk_lanes.hpp: 16 interleaved class sums
+    -> 4 group sums -> total) instead of ``np.dot``: class c = (d - 1) mod 16 of row d >= 1 is summed in row order,
+    q[g] = ((cs[g] + cs[g+4]) + cs[g+8]) + cs[g+12], s = ((q[0] + q[1]) + q[2]) + q[3].  With this model the oracle and
+    the device evaluate the SAME sequence of rounded operations except inside exp(); the comparison between them is
+    then held to SURVEY 8c's 1e-9 over every draw, and the chaos-widened bound stays where it belongs: between this
+    order and the reference's own ``np.dot`` (tests/test_oracle_golden.py).
+
+    exp() is the library's ``bk_exp`` (``oracle.rng.exp_fdlibm``): with the summation order AND the exponential shared,
+    the device and this oracle run the same sequence of rounded operations and agree BIT FOR BIT."""
+
+    def _parts(self, theta):
+        v = theta[0]
+        x = theta[1:]
+        cs = [0.0] * 16
+        for i, xi in enumerate(x):
+            cs[i % 16] = cs[i % 16] + xi * xi
+        q = [((cs[g] + cs[g + 4]) + cs[g + 8]) + cs[g + 12] for g in range(4)]
+        s = ((q[0] + q[1]) + q[2]) + q[3]
+        from .rng import exp_fdlibm
+
+        ev = exp_fdlibm(-v)
+        hn = 0.5 * (self._D - 1)
+        he = 0.5 * ev
+        return v, x, ev, s, hn, he

@@ -356,3 +356,57 @@ def legacy_choice(p, u) -> np.ndarray:
                 hi = mid
         out[j] = lo
     return out
+
+
+def exp_fdlibm(x: float) -> float:
+    """The HIP library's ``bk_exp`` (``include/bkhip_math.h``: Sun fdlibm 5.3 ``e_exp.c``) restated operation for
+    operation on Python floats -- every ``*`` and ``+`` one IEEE rounding, as in the library (-ffp-contract=off) -- so
+    that an oracle-side density with an exp() inside can be evaluated with the device's own double
+    (``oracle.models.FunnelCanonical``).  ``tests/test_abi.py`` checks it against the library's host build of the same
+    header."""
+    one, huge, twom1000 = 1.0, 1.0e300, 9.33263618503218878990e-302
+    o_threshold, u_threshold = 7.09782712893383973096e02, -7.45133219101941108420e02
+    ln2HI, ln2LO, invln2 = 6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.44269504088896338700e00
+    P1, P2, P3 = 1.66666666666666019037e-01, -2.77777777770155933842e-03, 6.61375632143793436117e-05
+    P4, P5 = -1.65339022054652515390e-06, 4.13813679705723846039e-08
+    x = float(x)
+    bits = struct.unpack("<Q", struct.pack("<d", x))[0]
+    hx, lx = bits >> 32, bits & 0xFFFFFFFF
+    xsb = (hx >> 31) & 1
+    hx &= 0x7FFFFFFF
+    hi = lo = 0.0
+    k = 0
+    if hx >= 0x40862E42:
+        if hx >= 0x7FF00000:
+            if ((hx & 0xFFFFF) | lx) != 0:
+                return x + x
+            return x if xsb == 0 else 0.0
+        if x > o_threshold:
+            return float("inf")
+        if x < u_threshold:
+            return 0.0
+    if hx > 0x3FD62E42:
+        if hx < 0x3FF0A2B2:
+            hi = x + ln2HI if xsb else x - ln2HI
+            lo = -ln2LO if xsb else ln2LO
+            k = 1 - xsb - xsb
+        else:
+            k = int(invln2 * x + (-0.5 if xsb else 0.5))  # (C's conversion truncates toward zero, as int() does)
+            t = float(k)
+            hi = x - t * ln2HI
+            lo = t * ln2LO
+        x = hi - lo
+    elif hx < 0x3E300000:
+        if huge + x > one:
+            return one + x
+    t = x * x
+    c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))))
+    if k == 0:
+        return one - ((x * c) / (c - 2.0) - x)
+    y = one - ((lo - (x * c) / (2.0 - c)) - hi)
+    bits = struct.unpack("<Q", struct.pack("<d", y))[0]
+    if k >= -1021:
+        bits = (bits + (k << 52)) & M64
+        return struct.unpack("<d", struct.pack("<Q", bits))[0]
+    bits = (bits + ((k + 1000) << 52)) & M64
+    return struct.unpack("<d", struct.pack("<Q", bits))[0] * twom1000

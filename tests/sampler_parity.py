@@ -540,3 +540,35 @@ def check_smc_reference_stream(ops, name, source):
         assert st["state"]["pos"] == int(z["final_pos"]) and st["has_gauss"] == int(z["final_has_gauss"])
         assert np.array_equal(st["state"]["key"][:8], z["final_key"])
     return smc
+
+
+def check_funnel_vs_canonical_oracle(name, ops, model_factory=None, **extra):
+    """The funnel fixtures' configurations, HIP against the ORACLE WITH THE LIBRARY'S SUMMATION ORDER AND THE LIBRARY'S
+    exp (oracle.models.FunnelCanonical: 16-class sums of csrc/bk_lanes.hpp, bk_exp of include/bkhip_math.h restated in
+    oracle/rng.py): the two run the same sequence of rounded operations, so theta and the momentum are required to be
+    BIT-IDENTICAL over all draws (60 of funnel11_k3, 40 of funnel101_cfg4), the joint log density to 1e-12 (the
+    kinetic-energy sum's order), the stream state exact.  SURVEY 8c asks for rel 1e-9; this is zero.  (Against the
+    reference's own np.dot + libm exp the chaotic flow amplifies last-bit differences: that comparison, with its
+    widening bound, is the CPU test of this oracle against the golden, tests/test_oracle_golden.py.)"""
+    from oracle import models as om
+    from tests.helpers import oracle_sampler, rng_state_words
+
+    case, z = load_case(name)
+    N, C, D = z["draws"].shape
+    assert case["model"]["kind"] == "funnel"
+    model = (model_factory or product_model)(case["model"], ops)
+    s = build_sampler(case, model, ops, case["seed"], chains=C, **extra)
+    oracles = [oracle_sampler(case, c, model=om.FunnelCanonical(D)) for c in range(C)]
+    for n in range(N):
+        th, lp = s.sample()
+        th, lp = th.cpu().numpy(), lp.cpu().numpy()
+        for c, o in enumerate(oracles):
+            oth, olp = o.sample()
+            assert np.array_equal(th[c], oth), (name, c, n, float(np.abs(th[c] - oth).max()))
+            np.testing.assert_allclose(lp[c], olp, rtol=LOGP_RTOL, atol=1e-12, err_msg=f"{name} chain {c} draw {n} logp")
+    st = s.rng_state().T
+    rho = s._rho.cpu().numpy()
+    for c, o in enumerate(oracles):
+        np.testing.assert_array_equal(st[c], rng_state_words(o._rng))
+        assert np.array_equal(rho[c], o._rho), (name, c)
+    return s

@@ -150,7 +150,7 @@ __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const doub
   double q[4];
   for (int k = 0; k < 4; ++k) q[k] = ((cs[k] + cs[k + 4]) + cs[k + 8]) + cs[k + 12];
   const double s = ((q[0] + q[1]) + q[2]) + q[3];
-  const double ev = exp(-v), hn = 0.5 * (double)(D - 1), he = 0.5 * ev;
+  const double ev = bk_exp(-v), hn = 0.5 * (double)(D - 1), he = 0.5 * ev;
   if (g.wanted()) {
     g.set(0, ((-v / 9.0) - hn) + he * s);
     for (i64 d = 1; d < D; ++d) g.set(d, -(ev * th[d]));
@@ -164,7 +164,7 @@ template <class L>
 __device__ double bk_lanes_density(L& c, const double* /*params*/) {
   const double v = c.head(0);
   const double s = c.sum([](double x, i64) { return x * x; });
-  const double ev = exp(-v);
+  const double ev = bk_exp(-v);
   const double hn = 0.5 * (double)(c.dims() - 1);
   const double he = 0.5 * ev;
   c.grad_head(0, ((-v / 9.0) - hn) + he * s);

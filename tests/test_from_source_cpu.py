@@ -26,7 +26,7 @@ LANES = """
 template <class L> __device__ double bk_lanes_density(L& c, const double*) {
   const double v = c.head(0);
   const double s = c.sum([](double x, i64) { return x * x; });
-  const double ev = exp(-v);
+  const double ev = bk_exp(-v);
   c.grad_head(0, -v / 9.0 + 0.5 * ev * s);
   c.grad([ev](double x, i64) { return -(ev * x); });
   return -(v * v) / 18.0 - 0.5 * ev * s;

@@ -362,6 +362,20 @@ def test_tempered_smc_binomial_moments(ops):
     check_smc_binomial(ops, 8192, 10, bk.mala_kernel(0.2, 2), mean_atol=0.006, var_atol=0.0012)
 
 
+@pytest.mark.parametrize("path", ["one_launch", "counted_steps"])
+@pytest.mark.parametrize("name", ["drghmc_funnel11_k3", "drghmc_funnel101_cfg4", "drghmc_funnel17_k4",
+                                  "drghmc_funnel33_k2_metric_noretry", "drghmc_funnel129_k3", "drghmc_funnel130_k2"])
+def test_funnel_fixtures_bit_identical_to_the_canonical_order_oracle(ops, name, path):
+    """SURVEY 8c's funnel bar is theta rel 1e-9 over <= 50 draws.  HIP against the oracle that sums in the library's
+    canonical order and uses the library's exp (the same rounded operations on both sides): theta and momentum
+    BIT-IDENTICAL over all draws of every funnel fixture, decisions and stream state exact -- through the one-launch
+    proposal kernel and through counted leapfrog steps."""
+    from tests.sampler_parity import check_funnel_vs_canonical_oracle
+
+    extra = {} if path == "one_launch" else dict(fuse_builtin=False)
+    check_funnel_vs_canonical_oracle(name, ops, **extra)
+
+
 @pytest.mark.parametrize("source", ["np.random", "RandomState", "replay"])
 @pytest.mark.parametrize("name", ["smc_ref_binomial", "smc_gauss5_m512", "smc_gauss3_m2048"])
 def test_tempered_smc_reference_stream_vs_reference_golden(ops, name, source):
