@@ -721,6 +721,12 @@ def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "
     stages them in LDS for dims <= 128 too, in the one-launch step and trajectory kernels as well: for LONG functions (many passes,
     transcendentals, constants) whose unrolled form would not fit a lane's registers beside its coordinates -- their loops may then
     stay rolled.  ``params``: a float64 device tensor (or None).
+    **Contract of ``bk_chain``: whenever ``g.wanted()`` it calls ``g.set(d, v)`` for EVERY d in [0, D), exactly once each,
+    with the final value** -- in the one-launch step and trajectory kernels ``set`` is not a store but the kick (and
+    drift) of coordinate d, so a second ``set`` of the same d kicks twice and a skipped d is left un-kicked; the function
+    must also not read back what it has set.  When the object is built on a box with a GPU the two kernels are checked
+    against {gradient op, library kick + drift} on random points and are DROPPED (with a warning; the samplers then run the
+    gradient as a separate op) if they disagree: ``chain_hooks_note`` says what happened.
     contract=False compiles with -ffp-contract=off (every product and sum rounded, as NumPy does)."""
     lib = _compile_source_target(source, form, contract, dims, head, stage)
     if params is not None and not (isinstance(params, torch.Tensor) and params.dtype == torch.float64):
@@ -730,7 +736,73 @@ def _ctarget_from_source(cls, source: str, dims: int, params=None, form: str = "
     t.source_form = form
     t._head = int(head)
     _bind_source_fast_paths(t)
+    t.chain_hooks_note = _check_chain_hooks(t) if form == "chain" else None
     return t
+
+
+def _check_chain_hooks(t, chains: int = 70, h: float = 0.0137):
+    """The one-launch leapfrog step and trajectory of a per-chain density deliver every gradient entry INTO the integrator
+    (csrc/bk_source_api.hpp: BkGrad::set is a kick, not a store): a bk_chain that sets an entry twice, or skips one, gives
+    silently wrong trajectories there while its gradient op looks fine.  Run both kernels once against the composition
+    {gradient op, the library's kick + drift arithmetic} on random points; any difference drops the hooks."""
+    import warnings
+
+    hooks = [n for n in ("bk_leapfrog_step", "bk_leapfrog_trajectory") if hasattr(t, n)]
+    if not hooks:
+        return "no one-launch kernels for this shape"
+    if not torch.cuda.is_available():
+        return "not checked (no GPU where the object was built)"
+    D, C = t.dims(), chains
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(20246)
+    rnd = lambda *shape, scale=1.0: (torch.randn(*shape, generator=g, dtype=torch.float64) * scale).to(dev)  # noqa: E731
+    metric = (torch.rand(D, generator=g, dtype=torch.float64) + 0.5).to(dev)
+
+    def grad_of(theta, want_lp=False):
+        gr = torch.empty_like(theta)
+        lp = torch.empty(theta.shape[1], dtype=torch.float64, device=dev) if want_lp else None
+        t.bk_eval(theta, gr, lp)
+        return gr, lp
+
+    def kick_drift(theta, rho, gr, hk):   # rho + hk * (metric * grad), then theta + h * rho: every product and sum rounded
+        r = rho + hk * (metric[:, None] * gr)
+        return theta + h * r, r
+
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, nan=1.25e300), torch.nan_to_num(b, nan=1.25e300))  # noqa: E731
+    bad = []
+    try:
+        theta, rho = rnd(D, C, scale=0.4), rnd(D, C)
+        g0, _ = grad_of(theta)
+        if not bool(torch.isfinite(g0).any()):
+            return "not checked (the gradient is not finite at the random test points)"
+        if "bk_leapfrog_step" in hooks:
+            th1, r1 = theta.clone(), rho.clone()
+            t.bk_leapfrog_step(th1, r1, metric, h)
+            th_ref, r_ref = kick_drift(theta, rho, g0, h)
+            if not (same(th1, th_ref) and same(r1, r_ref)):
+                bad.append("bk_leapfrog_step")
+        if "bk_leapfrog_trajectory" in hooks:
+            tho, ro, go = torch.empty_like(theta), torch.empty_like(theta), torch.empty_like(theta)
+            lpo = torch.empty(C, dtype=torch.float64, device=dev)
+            if t.bk_leapfrog_trajectory(theta, rho, g0, None, tho, ro, go, lpo, metric, h, 2) is not False:
+                th_a, r_a = kick_drift(theta, rho, g0, 0.5 * h)   # drghmc.py:276-278
+                g1, _ = grad_of(th_a)
+                th_b, r_b = kick_drift(th_a, r_a, g1, h)          # drghmc.py:280-283
+                g2, lp2 = grad_of(th_b, want_lp=True)
+                if not (same(tho, th_b) and same(ro, r_b) and same(go, g2) and same(lpo, lp2)):
+                    bad.append("bk_leapfrog_trajectory")
+        torch.cuda.synchronize()
+    except _lib.BkHipError as e:
+        return f"not checked ({e})"
+    if not bad:
+        return "checked: one-launch step / trajectory == gradient op + kick + drift on random points"
+    for name in hooks:   # (a function that breaks the contract in one kernel is not trusted in the other)
+        delattr(t, name)
+    note = ("dropped " + ", ".join(hooks) + ": " + ", ".join(bad) + " differ(s) from {gradient op, kick + drift} -- bk_chain must "
+            "call g.set(d, v) exactly once for every d, with the final value, and not read it back (CTarget.from_source docstring)")
+    warnings.warn("CTarget.from_source(form='chain'): " + note + "; the samplers will run the gradient as a separate op",
+                  stacklevel=3)
+    return note
 
 
 CTarget.from_source = classmethod(_ctarget_from_source)

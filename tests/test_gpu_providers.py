@@ -690,3 +690,58 @@ def test_torch_model_traces_distributions_row_groups_and_piecewise_densities(ops
         assert torch.isfinite(th).all() and 0.3 < hm.accept_rate() <= 1.0, (fn.__name__, hm.accept_rate())
 
 
+
+
+CHAIN_GOOD = """
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* lam) {
+  double s = 0.0;
+  for (i64 d = 0; d < D; ++d) { const double t = lam[d] * th[d]; s = s + th[d] * t; if (g.wanted()) g.set(d, -t); }
+  return -0.5 * s;
+}"""
+CHAIN_SETS_TWICE = """
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* lam) {
+  double s = 0.0;
+  if (g.wanted()) for (i64 d = 0; d < D; ++d) g.set(d, -(0.5 * lam[d]) * th[d]);   // "a first part, overwritten below": breaks the contract
+  for (i64 d = 0; d < D; ++d) { const double t = lam[d] * th[d]; s = s + th[d] * t; if (g.wanted()) g.set(d, -t); }
+  return -0.5 * s;
+}"""
+CHAIN_SKIPS_ONE = """
+__device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const double* lam) {
+  double s = 0.0;
+  for (i64 d = 0; d < D; ++d) { const double t = lam[d] * th[d]; s = s + th[d] * t; if (g.wanted() && (d != 3 || t != 0.0)) g.set(d, -t); }
+  return -0.5 * s;   // (entry 3 is skipped when its gradient is zero: "nothing to add")
+}"""
+
+
+def test_chain_form_step_kernels_are_checked_against_the_gradient_op_when_the_object_is_built(ops):
+    """ADVICE r5 (medium): in the one-launch step / trajectory kernels of form="chain" BkGrad::set is a kick, not a store.
+    from_source runs both against {gradient op, kick + drift} on random points: a function that keeps the contract keeps
+    its kernels; one that sets entries twice loses them (with a warning) and the samplers fall back to the separate
+    gradient op -- same draws as the well-behaved source, bit for bit."""
+    import warnings
+
+    D = 24
+    lam = torch.linspace(0.5, 3.0, D, dtype=torch.float64, device=ops.device)
+    good = bk.CTarget.from_source(CHAIN_GOOD, D, params=lam, form="chain")
+    assert good.chain_hooks_note.startswith("checked") and hasattr(good, "bk_leapfrog_step") and hasattr(good, "bk_leapfrog_trajectory")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        twice = bk.CTarget.from_source(CHAIN_SETS_TWICE, D, params=lam, form="chain")
+    assert any("exactly once" in str(x.message) for x in w)
+    assert twice.chain_hooks_note.startswith("dropped") and "bk_leapfrog_trajectory" in twice.chain_hooks_note
+    assert not hasattr(twice, "bk_leapfrog_step") and not hasattr(twice, "bk_leapfrog_trajectory")
+    # (the skipping variant keeps the contract at the random test points -- no gradient entry is exactly zero there -- and is
+    # indistinguishable from a correct function: the check is a net for systematic violations, the contract is the documentation)
+    skip = bk.CTarget.from_source(CHAIN_SKIPS_ONE, D, params=lam, form="chain")
+    assert skip.chain_hooks_note.startswith("checked")
+    # the dropped hooks change the route, not the draws
+    mk = lambda m: bk.DrGhmcDiag(m, 2, [0.3, 0.1], [3, 6], 0.3, chains=500, seed=11)   # noqa: E731
+    a, b = mk(good), mk(twice)
+    for _ in range(6):
+        ta, la = a.sample()
+        tb, lb = b.sample()
+        assert torch.equal(ta, tb) and torch.equal(la, lb)
+    h1 = bk.HMCDiag(good, 0.1, 7, chains=333, seed=5)
+    h2 = bk.HMCDiag(twice, 0.1, 7, chains=333, seed=5)
+    for _ in range(4):
+        assert torch.equal(h1.sample()[0], h2.sample()[0])
