@@ -895,10 +895,20 @@ class TorchModel:
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         p = None if params is None else params.to(dev)
         stage = info.get("stage", "auto") if form == "chain" else "auto"
-        target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract, stage=stage)
+        try:
+            target = CTarget.from_source(src, self._D, params=p, form=form, head=head, contract=contract, stage=stage)
+        except _lib.BkHipError as e:
+            # no hipcc on this box, a compiler error on the generated text, a refused cache directory, ...: the promise is
+            # "anything else warns and keeps autograd", for these as well
+            self.compile_note = f"traced as form={form!r}, but the source could not be built: {e}"
+            self.traced_source = src
+            warnings.warn(f"TorchModel(compile=True): {self.compile_note}; keeping autograd", stacklevel=3)
+            return
         if dev.type == "cuda":
             note = self._check_compiled(target, dev)
-            if note is not None:
+            if note is not None and note.startswith("not verified"):
+                self.compile_note = note    # (accepted: the function could not be evaluated here; say so)
+            elif note is not None:
                 self.compile_note = note
                 warnings.warn(f"TorchModel(compile=True): {note}; keeping autograd", stacklevel=3)
                 return
@@ -923,8 +933,8 @@ class TorchModel:
                 lp = self._fn(x)
                 (gr,) = torch.autograd.grad(lp.sum(), x)
             gr = gr.t() if self._dc else gr
-        except Exception:  # the function cannot be evaluated here (e.g. its constants live elsewhere): nothing to compare
-            return None
+        except Exception as e:  # the function cannot be evaluated here (e.g. its constants live elsewhere): nothing to compare
+            return f"not verified against the function on random points (evaluating it on {dev} raised {type(e).__name__}: {e})"
         lp_c, g_c = target.log_density_gradient(Theta)
         ok = (torch.allclose(lp_c, lp.detach(), rtol=1e-9, atol=1e-9, equal_nan=True)
               and torch.allclose(g_c, gr, rtol=1e-9, atol=1e-9, equal_nan=True))

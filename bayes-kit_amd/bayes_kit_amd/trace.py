@@ -104,14 +104,25 @@ _METHODS = {"add": "add", "sub": "sub", "mul": "mul", "div": "div", "true_divide
             "clamp": "clamp", "clip": "clamp", "clamp_min": "clamp_min", "clamp_max": "clamp_max"}
 
 
+def expand_rewrite(rw, apply):
+    """Evaluate a (possibly nested) rewrite (operation, operands) bottom-up with apply(operation, operands)."""
+    def ex(a):
+        return apply(a[0], [ex(x) for x in a[1]]) if isinstance(a, tuple) else a
+    return ex(rw)
+
+
 def piecewise_rewrite(name, args, kwargs, where):
-    """relu / clamp / x.where(...) as (operation, operands) over {where, maximum, minimum}; None for any other name."""
+    """relu / clamp / x.where(...) as (operation, operands) over `where` and comparisons; None for any other name.
+
+    PyTorch's conventions, which a rewrite to maximum / minimum does not have (their tie rule splits the derivative 0.5 /
+    0.5): relu'(0) = 0 and clamp' = 1 AT a bound (autograd: `x > 0`, `lo <= x <= hi`), and NaN goes through both (every
+    comparison with NaN is false, so the `where`s below hand x itself on)."""
     if name == "where_method":  # x.where(cond, other) == torch.where(cond, x, other)
         if len(args) != 3:
             raise Unsupported(f"{where}: where with {len(args)} operands")
         return "where", [args[1], args[0], args[2]]
     if name == "relu":
-        return "maximum", [args[0], 0.0]
+        return "where", [("le", [args[0], 0.0]), 0.0, args[0]]
     if name in ("clamp", "clamp_min", "clamp_max"):
         lo = kwargs.get("min", args[1] if len(args) > 1 and name != "clamp_max" else None)
         hi = kwargs.get("max", args[1] if len(args) > 1 and name == "clamp_max" else (args[2] if len(args) > 2 else None))
@@ -120,9 +131,11 @@ def piecewise_rewrite(name, args, kwargs, where):
                 raise Unsupported(f"{where}: clamp bounds must be Python numbers")
         if lo is None and hi is None:
             raise Unsupported(f"{where}: clamp without bounds")
-        if lo is not None and hi is not None:
-            return "minimum", [("maximum", [args[0], float(lo)]), float(hi)]
-        return ("maximum", [args[0], float(lo)]) if lo is not None else ("minimum", [args[0], float(hi)])
+        x = args[0]
+        if lo is not None and hi is not None:   # (torch.clamp with lo > hi returns hi everywhere: the outer test decides)
+            return "where", [("gt", [x, float(hi)]), float(hi), ("where", [("lt", [x, float(lo)]), float(lo), x])] \
+                if float(lo) <= float(hi) else ("where", [("le", [x, x]), float(hi), x])
+        return ("where", [("lt", [x, float(lo)]), float(lo), x]) if lo is not None else ("where", [("gt", [x, float(hi)]), float(hi), x])
     return None
 
 
@@ -310,8 +323,7 @@ class _Tracer:
             args = args[:1]
         rw = piecewise_rewrite(name, args, kwargs, where)
         if rw is not None:
-            inner = [self.apply(a[0], a[1], {}, where) if isinstance(a, tuple) else a for a in rw[1]]
-            return self.apply(rw[0], inner, {}, where)
+            return expand_rewrite(rw, lambda n, a: self.apply(n, a, {}, where))
         chains = [a for a in args if isinstance(a, _Chain)]
         if chains:
             return self.chain_op(name, args, where)

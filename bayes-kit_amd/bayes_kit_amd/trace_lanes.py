@@ -24,7 +24,7 @@ from __future__ import annotations
 import torch
 
 from .trace import (Unsupported, _function_table, _METHODS, _UNARY, _BINARY, _COMPARE, _HOST_UNARY, TWO_OVER_SQRT_PI, _lit,
-                    no_distribution_validation, piecewise_rewrite)
+                    no_distribution_validation, piecewise_rewrite, expand_rewrite)
 
 
 # ---- hash-consed expression DAG ------------------------------------------------------------------------------------------
@@ -482,8 +482,7 @@ class _LanesTracer:
             return _Row(e, a.lo, a.hi) if isinstance(a, _Row) else _Per(e, a.bcast)
         rw = piecewise_rewrite(name, args, kwargs, where)
         if rw is not None:
-            inner = [self.apply(a[0], a[1], {}, where, TH) if isinstance(a, tuple) else a for a in rw[1]]
-            return self.apply(rw[0], inner, {}, where, TH)
+            return expand_rewrite(rw, lambda n, a: self.apply(n, a, {}, where, TH))
         if name in _BINARY or name == "where":
             want = 3 if name == "where" else 2
             if len(args) != want:

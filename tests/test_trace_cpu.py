@@ -13,9 +13,11 @@ import bayes_kit_amd as bk
 from bayes_kit_amd import trace
 
 F = torch.nn.functional
+_BKHIP_MATH_H = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "include", "bkhip_math.h")   # bk_exp
 HOST = """
 #include <math.h>
 #include <stdint.h>
+#include "BKHIP_MATH_H_PATH"
 typedef int64_t i64;
 #define __device__
 #define __forceinline__ inline
@@ -29,7 +31,7 @@ extern "C" void eval_terms(const double* th, const long long* d, const double* P
 def host_eval(src, params, Theta, tmp_path, tag):
     """log density (C,) and gradient (C, D) of the generated bk_term, evaluated on the host."""
     cpp, lib = tmp_path / f"{tag}.cpp", tmp_path / f"lib{tag}.so"
-    cpp.write_text(HOST % src)
+    cpp.write_text((HOST % src).replace("BKHIP_MATH_H_PATH", _BKHIP_MATH_H))
     subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(cpp), "-o", str(lib)])
     h = ctypes.CDLL(str(lib))
     C, D = Theta.shape
@@ -93,6 +95,30 @@ def test_generated_term_and_derivative_match_autograd(name, tmp_path):
     np.testing.assert_allclose(lp_c, lp.detach().numpy(), rtol=1e-12, atol=1e-12)
 
 
+def test_relu_and_clamp_follow_autograd_at_the_ties_and_hand_nan_on(tmp_path):
+    """relu'(0) = 0 and clamp' = 1 AT a bound are PyTorch's conventions (a maximum / minimum rewrite splits the
+    derivative 0.5 / 0.5 there -- and theta = 0 is a common start); NaN goes through relu and clamp, it is not dropped."""
+    def fn(Th):
+        return (2.0 * F.relu(Th) + 3.0 * torch.clamp(Th, -0.5, 0.5) + 5.0 * Th.clamp_min(-1.0) + 7.0 * Th.clamp(max=1.5)
+                - 0.5 * Th * Th).sum(1)
+
+    src, params, _ = trace.term_source(fn, D, "cd")
+    ties = torch.tensor([0.0, -0.0, 0.5, -0.5, -1.0, 1.5, 0.3, -0.7, 2.0, -2.0], dtype=torch.float64)
+    Theta = ties.repeat((D + len(ties) - 1) // len(ties))[:D].repeat(3, 1).clone()
+    Theta[1] = Theta[1].flip(0)
+    Theta[2] = torch.randn(D, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    x = Theta.clone().requires_grad_(True)
+    lp = fn(x)
+    (gr,) = torch.autograd.grad(lp.sum(), x)
+    lp_c, g_c = host_eval(src, params, Theta, tmp_path, "ties")
+    np.testing.assert_allclose(g_c, gr.numpy(), rtol=1e-13, atol=1e-13)   # (a wrong tie rule is an error of 1 .. 3.5 here)
+    np.testing.assert_allclose(lp_c, lp.detach().numpy(), rtol=1e-13)
+    nan = Theta.clone()
+    nan[0, 4] = float("nan")
+    lp_n, g_n = host_eval(src, params, nan, tmp_path, "ties_nan")
+    assert np.isnan(lp_n[0]) and np.isnan(g_n[0, 4]) and np.isfinite(g_n[0, :4]).all() and np.isfinite(lp_n[1:]).all()
+
+
 def test_constants_are_packed_once_and_the_source_is_plain(tmp_path):
     src, params, info = trace.term_source(lambda Th: (lam * Th * Th + lam * Th).sum(1), D)
     assert info["param_rows"] == 1 and params.shape == (D,) and torch.equal(params, lam)
@@ -122,6 +148,25 @@ def test_unsupported_functions_name_the_reason(fn, needle):
         trace.term_source(fn, D)
 
 
+def test_torch_model_compile_keeps_autograd_when_the_source_cannot_be_built(tmp_path, monkeypatch):
+    """"anything else warns and keeps autograd" also when the traced source cannot be BUILT (no hipcc on the
+    box, a refused cache directory): construction must not raise."""
+    from bayes_kit_amd import _lib, targets
+
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(tmp_path / "cache"))
+
+    def no_hipcc():
+        raise _lib.BkHipError("no hipcc was found (test)")
+
+    monkeypatch.setattr(targets, "_find_hipcc", no_hipcc)
+    with pytest.warns(UserWarning, match="could not be built"):
+        m = bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam).sum(dim=1), D, compile=True)
+    assert m.compiled is None and "no hipcc" in m.compile_note and "bk_term" in m.traced_source
+    Th = torch.randn(3, D, dtype=torch.float64)
+    lp, g = m.log_density_gradient(Th)      # autograd still serves the model
+    assert torch.allclose(g, -(Th * lam)) and lp.shape == (3,)
+
+
 def test_torch_model_compile_flag_on_the_build_box(tmp_path, monkeypatch):
     """compile=True: a traceable function becomes a compiled target (hipcc cross-compiles here; no compute without a GPU);
     an untraceable one warns, names the node, and stays an autograd model."""
@@ -144,6 +189,7 @@ def test_torch_model_compile_flag_on_the_build_box(tmp_path, monkeypatch):
 LANES_HOST = """
 #include <math.h>
 #include <stdint.h>
+#include "BKHIP_MATH_H_PATH"
 typedef int64_t i64;
 #define __device__
 %s
@@ -233,7 +279,7 @@ def test_lanes_source_value_and_gradient_match_autograd(name, tmp_path):
     src, head, params, info = trace_lanes.lanes_source(fn, DL)
     assert head == H and info["sums"] >= 1
     cpp, lib = tmp_path / f"{name}.cpp", tmp_path / f"lib{name}.so"
-    cpp.write_text(LANES_HOST % src)
+    cpp.write_text((LANES_HOST % src).replace("BKHIP_MATH_H_PATH", _BKHIP_MATH_H))
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(cpp), "-o", str(lib)])
     h = ctypes.CDLL(str(lib))
     C = 33
@@ -286,6 +332,7 @@ def test_torch_model_compiles_a_hierarchical_density_into_the_lanes_form(tmp_pat
 CHAIN_HOST = """
 #include <math.h>
 #include <stdint.h>
+#include "BKHIP_MATH_H_PATH"
 typedef int64_t i64;
 #define __device__
 struct BkTheta { const double* p; double operator[](i64 d) const { return p[d]; } void fence() const {} };
@@ -339,7 +386,7 @@ def test_chain_source_value_and_gradient_match_autograd(name, tmp_path):
     src, params, info = trace_chain.chain_source(fn, DC)
     assert info["sums"] >= 1 and info["gradient_blocks"] >= 2 and "#pragma unroll" in src
     cpp, lib = tmp_path / f"{name}.cpp", tmp_path / f"lib{name}.so"
-    cpp.write_text(CHAIN_HOST % src)
+    cpp.write_text((CHAIN_HOST % src).replace("BKHIP_MATH_H_PATH", _BKHIP_MATH_H))
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(cpp), "-o", str(lib)])
     h = ctypes.CDLL(str(lib))
     C = 33
@@ -433,10 +480,10 @@ def test_randomised_separable_densities_against_autograd(tmp_path):
         fns.append(fn)
     body = "\n".join(s for s, _ in srcs)
     calls = "\n".join(f"    case {k}: bk_term_{k}(th[i], d[i], P, term[i], grad[i]); break;" for k in range(len(fns)))
-    cpp = ("#include <math.h>\n#include <stdint.h>\ntypedef int64_t i64;\n#define __device__\n#define __forceinline__ inline\n" + body +
+    cpp = ("#include <math.h>\n#include <stdint.h>\n#include \"BKHIP_MATH_H_PATH\"\ntypedef int64_t i64;\n#define __device__\n#define __forceinline__ inline\n" + body +
            "\nextern \"C\" void eval_k(int k, const double* th, const long long* d, const double* P, long long n, double* term, double* grad) {\n"
            "  for (long long i = 0; i < n; ++i) switch (k) {\n" + calls + "\n  }\n}\n")
-    (tmp_path / "rnd.cpp").write_text(cpp)
+    (tmp_path / "rnd.cpp").write_text(cpp.replace("BKHIP_MATH_H_PATH", _BKHIP_MATH_H))
     subprocess.check_call(["g++", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(tmp_path / "rnd.cpp"), "-o", str(tmp_path / "librnd.so")])
     h = ctypes.CDLL(str(tmp_path / "librnd.so"))
     C = 16
@@ -499,7 +546,7 @@ def test_randomised_hierarchical_densities_against_autograd(tmp_path):
     cpp = host + ("extern \"C\" void eval_k(int k, const double* th, const double* P, long long C, long long D, int H, double* lp, double* g) {\n"
                   "  for (long long c = 0; c < C; ++c) {\n    HostCtx ctx{th + c * D, g + c * D, D, H};\n    switch (k) {\n" + calls +
                   "\n    }\n  }\n}\n")
-    (tmp_path / "rndl.cpp").write_text(cpp)
+    (tmp_path / "rndl.cpp").write_text(cpp.replace("BKHIP_MATH_H_PATH", _BKHIP_MATH_H))
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-shared", "-fPIC", str(tmp_path / "rndl.cpp"), "-o",
                            str(tmp_path / "librndl.so")])
     h = ctypes.CDLL(str(tmp_path / "librndl.so"))
