@@ -125,8 +125,49 @@ def numpy_generator_from_words(kind: int, w: np.ndarray) -> np.random.Generator:
 # ---------------------------------------------------------------------------------------
 # engine base
 # ---------------------------------------------------------------------------------------
+PATHS = ("auto", "step", "opaque")
+
+
 class ManyChainSampler:
-    """Common state of the HIP samplers (not part of the reference's API surface)."""
+    """Common state of the HIP samplers (not part of the reference's API surface).
+
+    Engine options shared by HMCDiag / MALA / DrGhmcDiag (keyword-only, after the reference's own arguments):
+
+    ``chains``, ``chain_id0``   number of chains of a batched device model; global id of the first (Philox key =
+                                (seed, global chain id): the same chain at any number of ranks)
+    ``path``                    HOW a model's launches are composed; every path gives the same draws bit for bit:
+        "auto"    (default) everything the model offers: whole-draw / whole-trajectory / whole-proposal kernels with the
+                  density inlined, else one launch per leapfrog step, else the gradient as a separate op
+        "step"    no whole-trajectory kernels: one launch per leapfrog step where the model has ``bk_leapfrog_step``
+                  (density inlined in the library's step kernel), else the gradient as a separate op
+        "opaque"  the gradient ALWAYS a separate device op, whatever the model offers: the model-opaque path BASELINE's
+                  56 D bytes per chain-step are counted on (bench.py's headline)
+    ``tuning``                  a dict of engine knobs for experiments and bisection (they may also be given as plain
+                                keywords); none of them changes a result.  Each class lists its own (``TUNING``).
+    ``ops``                     the kernel library object (tests inject a CPU stand-in)
+    """
+
+    TUNING: tuple = ()
+
+    @staticmethod
+    def _resolve_path(path):
+        """path -> (fuse_builtin, fuse_steps): whole-trajectory kernels allowed; one-launch steps allowed."""
+        if path not in PATHS:
+            raise ValueError(f"path must be one of {PATHS}, got {path!r}")
+        return {"auto": (True, True), "step": (False, True), "opaque": (False, False)}[path]
+
+    def _resolve_tuning(self, tuning, knobs):
+        """One dict from `tuning=` and loose keywords; unknown names are refused with the list of known ones."""
+        out = dict(tuning or {})
+        for k, v in knobs.items():
+            if k in out and out[k] is not v:
+                raise TypeError(f"tuning knob {k!r} given twice")
+            out[k] = v
+        bad = sorted(set(out) - set(self.TUNING))
+        if bad:
+            raise TypeError(f"{type(self).__name__}: unknown option(s) {bad}; engine options are chains, chain_id0, path, "
+                            f"tuning, ops and the tuning knobs {sorted(self.TUNING)}")
+        return out
 
     def _setup(self, model, metric_diag, init, seed, chains, chain_id0, ops):
         self._model = model

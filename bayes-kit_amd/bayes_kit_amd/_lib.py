@@ -35,10 +35,9 @@ SIGNATURES = {
     "bk_log_uniform": [c_int, P, I, P, P, I, P],
     "bk_uniform": [c_int, P, I, P, P, I, P],
     "bk_leapfrog_kick_drift": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P],
-    "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P],
     "bk_leapfrog_finish": [P, P, I, P, I, I, P, F, c_int, P, I, I, P],
     "bk_leapfrog_kick_drift_n": [P, P, P, P, I, P, I, I, P, F, c_int, F, c_int, F, I, I, P, P],
-    "bk_leapfrog_first_step_gather_n": [P, P, P, I, P, P, P, I, P, F, F, I, I, P, P],
+    "bk_leapfrog_first_step_gather": [P, P, P, I, P, P, P, I, P, F, F, I, I, P, P],
     "bk_leapfrog_finish_level": [P, P, I, P, I, I, P, F, c_int, P, I, I, P, P, P, P, P, P, P, P],
     "bk_mh_accept": [c_int, P, P, P, P, P, P, P, P, I, P],
     "bk_select_columns": [P, P, P, P, P, P, I, I, I, P],
@@ -59,8 +58,7 @@ SIGNATURES = {
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
     "bk_mala_propose": [c_int, P, I, P, P, P, I, F, F, I, I, P],
     "bk_mala_propose_from_normals": [P, P, P, I, I, P, I, F, F, I, I, P],
-    "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P, P],
-    "bk_normals_chain_major_bg": [c_int, P, I, P, I, I, I, P, I, P],
+    "bk_normals_chain_major": [c_int, P, I, P, I, I, I, P, I, P],
     "bk_mala_logq": [P, P, P, P, I, F, P, P, I, I, P],
     "bk_mala_single_draw": [c_int, P, I, P, P, P, P, P, P, P, I, P, P, F, F, I, c_int, F, P],
     "bk_mala_step_supported": [I, I, I],
@@ -74,12 +72,11 @@ SIGNATURES = {
     "bk_target_funnel_grad_n": [P, P, P, I, I, I, P, P],
     "bk_leapfrog_step_funnel": [P, P, I, P, F, I, I, P, P],
     "bk_leapfrog_step_gaussian": [P, P, I, P, P, F, I, I, P, P],
-    "bk_dr_proposal_gaussian_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
+    "bk_dr_proposal_gaussian": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "bk_hmc_trajectory_funnel": [P, P, P, P, P, P, P, I, P, F, I, I, I, P],
     "bk_hmc_trajectory_gaussian": [P, P, P, P, I, P, P, F, I, I, I, P],
     "bk_hmc_draw_gaussian": [P, P, I, P, P, I, P, P, F, I, P, P, P, P, P, P, P, P, P, I, I, P],
-    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P],
-    "bk_dr_proposal_funnel_job": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P],
+    "bk_dr_proposal_funnel": [P, P, P, I, P, P, P, P, P, P, I, P, F, I, I, I, P, P, P, P, P, P, P, P, P, P],
     "bk_dense_metric_apply": [P, I, P, P, I, I, I, P],
     "bk_gemm_chains": [P, I, I, I, P, I, P, I, I, P, I, P],
     "bk_gemm_chains_work_elems": [I, I, I],
@@ -89,8 +86,7 @@ SIGNATURES = {
     "bk_resample_indices": [P, I, P, I, P, P, P],
     "bk_gather_columns": [P, P, I, P, I, I, I, P],
     "bk_relayout": [P, I, I, P, I, I, I, I, P],
-    "bk_welford_update": [P, P, P, I, I, I, I, P],
-    "bk_welford_update_ld": [P, P, I, P, I, I, I, I, P],
+    "bk_welford_update": [P, P, I, P, I, I, I, I, P],
     "bk_record_series": [P, I, P, I, P, P, I, I, I, P],
     "bk_record_series_dev": [P, I, P, I, P, P, I, P, I, I, P],
     "bk_welford_update_dev": [P, P, I, P, I, P, I, I, I, P],
@@ -333,7 +329,7 @@ class Ops:
         D, n = theta_out.shape
         ld_in = _ld(theta_in)
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in and _ld(rho_out) == _ld(theta_out)
-        self._call("bk_leapfrog_first_step_gather_n", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in,
+        self._call("bk_leapfrog_first_step_gather", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in,
                    ptr(src_index), ptr(theta_out), ptr(rho_out), _ld(theta_out), ptr(metric), eps, pre,
                    n, D, ptr(n_dev), self._s())
 
@@ -475,16 +471,12 @@ class Ops:
     def normals_chain_major(self, kind, state, zt, D, snapshot=None, max_workgroups=0):
         """zt[c, :D] = the next D standard normals of chain c; `snapshot` (optional, a table like
         `state`) receives the stream table as it was before the call; max_workgroups > 0: a background launch
-        of at most that many workgroups (bk_normals_chain_major_bg)."""
+        of at most that many workgroups (bk_normals_chain_major)."""
         C = zt.shape[0]
         assert zt.stride(1) == 1 and zt.shape[1] >= D
         assert snapshot is None or (snapshot.shape == state.shape and snapshot.stride(0) == state.stride(0))
-        if max_workgroups:
-            self._call("bk_normals_chain_major_bg", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
-                       ptr(snapshot), int(max_workgroups), self._s())
-        else:
-            self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
-                       ptr(snapshot), self._s())
+        self._call("bk_normals_chain_major", kind, ptr(state), state.stride(0), ptr(zt), zt.stride(0), C, D,
+                   ptr(snapshot), int(max_workgroups or 0), self._s())
 
     def mala_logq(self, theta, grad, theta_prop, grad_prop, eps, lp_forward, lp_reverse):
         D, C = theta.shape
@@ -623,7 +615,7 @@ class Ops:
         assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
         ld_out = _ld(theta_out)
         assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
-        self._call("bk_dr_proposal_gaussian_job", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
+        self._call("bk_dr_proposal_gaussian", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                    ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                    h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live),
                    None if job is None else ctypes.byref(job), None if ghost is None else ctypes.byref(ghost),
@@ -652,12 +644,9 @@ class Ops:
         args = (ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                 ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                 h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live))
-        if job is None and ghost is None and ghost0 is None:
-            self._call("bk_dr_proposal_funnel", *args, self._s())
-        else:
-            self._call("bk_dr_proposal_funnel_job", *args, None if job is None else ctypes.byref(job),
-                       None if ghost is None else ctypes.byref(ghost),
-                       None if ghost0 is None else ctypes.byref(ghost0), self._s())
+        self._call("bk_dr_proposal_funnel", *args, None if job is None else ctypes.byref(job),
+                   None if ghost is None else ctypes.byref(ghost),
+                   None if ghost0 is None else ctypes.byref(ghost0), self._s())
 
     def dense_metric_apply(self, M, X, Y):
         D, C = X.shape
@@ -721,7 +710,7 @@ class Ops:
         """theta may have a row pitch of its own (padded sampler state); mean and m2 share theirs."""
         D, C = theta.shape
         assert _ld(m2) == _ld(mean)
-        self._call("bk_welford_update_ld", ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), n, C, D, self._s())
+        self._call("bk_welford_update", ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), n, C, D, self._s())
 
     def record_series(self, theta, dims, logp, series, row):
         """series[k, row, :] = theta[dims[k], :] (k < K), series[K, row, :] = logp: one launch."""

@@ -52,6 +52,8 @@ class _Level:
 
 
 class DrGhmcDiag(ManyChainSampler):
+    TUNING = ("graph", "device_counts", "fuse_first_ghost", "tune_placement")
+
     def __init__(
         self,
         model,
@@ -66,14 +68,19 @@ class DrGhmcDiag(ManyChainSampler):
         *,
         chains: Optional[int] = None,
         chain_id0: int = 0,
-        fuse_builtin: bool = True,
-        tune_placement: Optional[bool] = None,
-        device_counts: Optional[bool] = None,
-        graph: Optional[bool] = None,
-        fuse_first_ghost: bool = True,
-        fuse_steps: bool = True,
+        path: str = "auto",
+        tuning: Optional[dict] = None,
         ops=None,
+        **knobs,
     ):
+        """The reference's arguments (drghmc.py:37-48), then the engine's (ManyChainSampler: chains, chain_id0, path, tuning,
+        ops).  Tuning knobs (none changes a result): ``graph`` (replay a draw as one hipGraph; default on where the draw is a
+        fixed launch sequence), ``device_counts`` (lane-set sizes stay on the device; default on where the model allows),
+        ``fuse_first_ghost`` (the first ghost proposal inside the stage's launch), ``tune_placement``."""
+        fuse_builtin, fuse_steps = self._resolve_path(path)
+        tn = self._resolve_tuning(tuning, knobs)
+        tune_placement, device_counts, graph = tn.get("tune_placement"), tn.get("device_counts"), tn.get("graph")
+        fuse_first_ghost = tn.get("fuse_first_ghost", True)
         self._max_proposals = max_proposals
         self._leapfrog_step_sizes = leapfrog_step_sizes
         self._leapfrog_step_counts = leapfrog_step_counts

@@ -29,6 +29,7 @@ from ._engine import ManyChainSampler
 
 
 class HMCDiag(ManyChainSampler):
+    TUNING = ("graph", "prefetch_rng", "tune_placement", "chain_tile")
     ENABLE_FUSED_DRAW = True  # experiments / bisection: the one-pass draw kernel for built-in targets
     ENABLE_FUSED_ZT = True    # ... and its chain-major momentum input
 
@@ -43,15 +44,21 @@ class HMCDiag(ManyChainSampler):
         *,
         chains: Optional[int] = None,
         chain_id0: int = 0,
-        chain_tile: Optional[int] = None,
-        graph: Optional[bool] = None,
-        fuse_builtin: bool = True,
-        fuse_steps: bool = True,
-        prefetch_rng: Optional[bool] = None,
+        path: str = "auto",
         metric_dense=None,
-        tune_placement: Optional[bool] = None,
+        tuning: Optional[dict] = None,
         ops=None,
+        **knobs,
     ):
+        """The reference's arguments (hmc.py:9-17), then the engine's (ManyChainSampler: chains, chain_id0, path, tuning,
+        ops) and ``metric_dense`` (extension: a dense velocity covariance, fp64 MFMA GEMMs).  Tuning knobs (none changes a
+        result): ``graph`` (replay a draw as one hipGraph; default: small launch-bound shapes), ``prefetch_rng`` (the next
+        draw's randomness on a side stream; default on), ``tune_placement`` (time which allocation plays which role),
+        ``chain_tile`` (chains per Infinity-Cache tile)."""
+        fuse_builtin, fuse_steps = self._resolve_path(path)
+        tn = self._resolve_tuning(tuning, knobs)
+        chain_tile, graph = tn.get("chain_tile"), tn.get("graph")
+        prefetch_rng, tune_placement = tn.get("prefetch_rng"), tn.get("tune_placement")
         self._stepsize = stepsize
         self._steps = steps
         self._setup(model, metric_diag, init, seed, chains, chain_id0, ops)

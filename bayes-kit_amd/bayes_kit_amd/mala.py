@@ -16,7 +16,7 @@ Two ways through the device:
   For a model that is a SEPARABLE density the library can inline (``bk_mala_step``: the built-in Gaussians, an elementwise
   ``CTarget.from_source`` / traced ``TorchModel``) the step kernel recomputes both gradients from theta and theta' and stores
   none: the model's launch is its log density alone and a draw moves 56*D bytes; the same draws bit for bit
-  (``fuse_builtin=False`` keeps the model-opaque pair of launches).
+  (``path="opaque"`` keeps the model-opaque pair of launches).
 * **step by step** (everything else: a single-chain host model, PCG64 streams, odd shapes):
   proposal, gradient, proposal densities, accept and select as separate kernels.
 
@@ -43,10 +43,18 @@ class MALA(ManyChainSampler):
     STATE_PAD_COLUMNS = 144
     SINGLE_LAUNCH_MAX_DIMS = 4096  # (one lane walks the coordinates: the single-chain mode is for small models)
 
+    TUNING = ("graph", "prefetch_rng", "tune_placement", "two_pass", "single_launch")
+
     def __init__(self, model, epsilon: float, init=None, seed=None, *, chains: Optional[int] = None,
-                 chain_id0: int = 0, graph: Optional[bool] = None, prefetch_rng: Optional[bool] = None,
-                 tune_placement: Optional[bool] = None, two_pass: Optional[bool] = None,
-                 single_launch: Optional[bool] = None, fuse_builtin: bool = True, ops=None):
+                 chain_id0: int = 0, path: str = "auto", tuning: Optional[dict] = None, ops=None, **knobs):
+        """The reference's arguments (mala.py:15-21), then the engine's (ManyChainSampler: chains, chain_id0, path, tuning,
+        ops; path "step" and "opaque" both keep the model-opaque pair {gradient op, step kernel}).  Tuning knobs (none
+        changes a result): ``graph``, ``prefetch_rng``, ``tune_placement``, ``two_pass`` (gradient op + ONE step kernel
+        per draw; default where the shape allows), ``single_launch`` (one chain: one launch per draw)."""
+        fuse_builtin, _ = self._resolve_path(path)
+        tn = self._resolve_tuning(tuning, knobs)
+        graph, prefetch_rng, tune_placement = tn.get("graph"), tn.get("prefetch_rng"), tn.get("tune_placement")
+        two_pass, single_launch = tn.get("two_pass"), tn.get("single_launch")
         self._epsilon = epsilon
         self._setup(model, None, init, seed, chains, chain_id0, ops)
         self._init_graph(graph, prefetch_rng)

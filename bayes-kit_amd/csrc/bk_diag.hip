@@ -532,12 +532,7 @@ static int welford_launch(double* mean, double* m2, i64 ld, const double* theta,
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n, int64_t C,
-                      int64_t D, void* stream) {
-  return welford_launch(mean, m2, ld, theta, ld, n, nullptr, 0, C, D, stream);
-}
-
-int bk_welford_update_ld(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta, int64_t n,
+int bk_welford_update(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta, int64_t n,
                          int64_t C, int64_t D, void* stream) {
   return welford_launch(mean, m2, ld, theta, ld_theta, n, nullptr, 0, C, D, stream);
 }

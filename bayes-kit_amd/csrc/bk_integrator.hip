@@ -660,7 +660,7 @@ int bk_leapfrog_kick_drift_n(const double* theta_in, double* theta_out, const do
   BK_RETURN_LAUNCH_STATUS();
 }
 
-int bk_leapfrog_first_step_gather_n(const double* theta_in, const double* rho_in, const double* grad_in,
+int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, const double* grad_in,
                                     int64_t ld_in, const int32_t* src_index, double* theta_out, double* rho_out,
                                     int64_t ld_out, const double* metric, double eps, double pre, int64_t n,
                                     int64_t D, const uint32_t* n_dev, void* stream) {
@@ -672,14 +672,6 @@ int bk_leapfrog_first_step_gather_n(const double* theta_in, const double* rho_in
                                                                     theta_out, rho_out, ld_out, metric, eps, 1, pre, 0,
                                                                     0.0, n, D, n_dev);
   BK_RETURN_LAUNCH_STATUS();
-}
-
-int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, const double* grad_in,
-                                  int64_t ld_in, const int32_t* src_index, double* theta_out,
-                                  double* rho_out, int64_t ld_out, const double* metric, double eps,
-                                  double pre, int64_t n, int64_t D, void* stream) {
-  return bk_leapfrog_first_step_gather_n(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, ld_out,
-                                         metric, eps, pre, n, D, nullptr, stream);
 }
 
 int bk_leapfrog_finish_level(const double* rho_in, double* rho_out, int64_t ld, const double* grad, int64_t ldg_d,

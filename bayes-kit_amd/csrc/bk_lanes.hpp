@@ -211,7 +211,7 @@ struct TrajCtx {
   }
 };
 
-// What a proposal launch carries besides the trajectory (include/bkhip.h: bk_dr_proposal_funnel_job).
+// What a proposal launch carries besides the trajectory (include/bkhip.h: bk_dr_proposal_funnel).
 struct TrajArgs {
   const double* th_in; const double* rho_in; const double* g_in; i64 ld_in; const int32_t* idx;
   double* th_out; double* rho_out; double* g_out; double* logp_out; double* kin_out; i64 ld_out;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(BLOCK) void k_lane_traj(TrajArgs a, bk_scatter_job 
   else traj_body<DEN, 16, SL, HM>(a, n, ghost, g0, lane, wave);
 }
 
-// Host side of bk_dr_proposal_funnel_job for any density (include/bkhip.h documents the arguments).
+// Host side of bk_dr_proposal_funnel for any density (include/bkhip.h documents the arguments).
 // SL_ONLY > 0: only that slot count is instantiated (a generated translation unit knows its D).
 template <class DEN, int SL_ONLY = 0>
 static int dr_proposal_launch(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,

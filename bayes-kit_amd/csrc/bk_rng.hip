@@ -916,11 +916,6 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
 }
 
 int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
-                           int64_t D, uint64_t* snapshot, void* stream) {
-  return bk_normals_chain_major_bg(rng_kind, state, ldr, zt, ldz, C, D, snapshot, 0, stream);
-}
-
-int bk_normals_chain_major_bg(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
                               int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream) {
   if (!state || !zt || C < 0 || D < 0 || ldr < C || ldz < D || max_workgroups < 0) return BK_E_ARG;
   if (rng_kind != BK_RNG_PHILOX) return BK_E_ARG;

@@ -322,7 +322,7 @@ int bk_hmc_trajectory_funnel(const double* theta_in, double* rho, const double* 
                                                    eps, steps, C, D, nullptr, stream);
 }
 
-int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
                               const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
                               double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
                               int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
@@ -332,17 +332,6 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
   return bkl::dr_proposal_launch<FunnelDensity>(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out,
                                                 logp_out, kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out,
                                                 lanes_total, H_out, h_out, live_out, job_in, ghost_in, g0_in, nullptr, stream);
-}
-
-
-int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
-                          const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
-                          double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
-                          int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,
-                          uint64_t* lanes_total, double* H_out, double* h_out, uint8_t* live_out, void* stream) {
-  return bk_dr_proposal_funnel_job(theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out,
-                                   kin_out, ld_out, metric, h, steps, n, D, n_dev, lanes_out, lanes_total, H_out, h_out,
-                                   live_out, nullptr, nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -36,7 +36,7 @@ struct GaussStepTerm {
 
 extern "C" {
 
-int bk_dr_proposal_gaussian_job(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
+int bk_dr_proposal_gaussian(const double* theta_in, const double* rho_in, const double* grad_in, int64_t ld_in,
                                 const int32_t* src_index, double* theta_out, double* rho_out, double* grad_out,
                                 double* logp_out, double* kin_out, int64_t ld_out, const double* metric, double h,
                                 int64_t steps, int64_t n, int64_t D, const uint32_t* n_dev, uint32_t* lanes_out,

@@ -247,9 +247,9 @@ def make_cfg3_sampler(chains, chain_id0, device, D=D_CFG3, L=L_CFG3, eps=EPS_CFG
     lam = torch.logspace(0, 4, D, dtype=torch.float64)
     model = bk.DiagGaussian(lam)
     s = bk.HMCDiag(model, eps, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=SEED_CFG3,
-                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile, fuse_builtin=fused,
+                   chains=chains, chain_id0=chain_id0, chain_tile=chain_tile,
                    # (the headline's path: the gradient a SEPARATE op per leapfrog step, whatever the model offers)
-                   fuse_steps=fused,
+                   path="auto" if fused else "opaque",
                    prefetch_rng=prefetch_rng, tune_placement=tune_placement)
     # theta0_i ~ N(0,1)/sqrt(lam_i): z comes from each chain's own stream (init=None
     # semantics, hmc.py:24-28), scaled to the target's marginal widths (synthetic start)

@@ -25,10 +25,9 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
                    "of all chains is the figure"}
     # model_opaque: the gradient a separate op per leapfrog step; one_launch_per_step: {gradient, kick, drift} one
     # launch (bk_leapfrog_step_gaussian); fused_builtin: the whole draw in registers
-    for name, fused, steps_fused in (("model_opaque", False, False), ("one_launch_per_step", False, True),
-                                     ("fused_builtin", True, True)):
+    for name, path in (("model_opaque", "opaque"), ("one_launch_per_step", "step"), ("fused_builtin", "auto")):
         s = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
-                       chains=C, chain_id0=ctx.rank * C, fuse_builtin=fused, fuse_steps=steps_fused)
+                       chains=C, chain_id0=ctx.rank * C, path=path)
         for _ in range(warmup):
             s.sample()
         el = ctx.timed_loop(s.sample, steps)
@@ -45,7 +44,7 @@ def bench_cfg2(ctx, steps=200, warmup=6, chains=4096):
         build_s = time.perf_counter() - t0
         ref = bk.HMCDiag(bk.IsoGaussian(D), 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240,
                          chains=C,
-                         chain_id0=ctx.rank * C, fuse_builtin=False)
+                         chain_id0=ctx.rank * C, path="step")
         s = bk.HMCDiag(model, 0.05, L, metric_diag=torch.ones(D, dtype=torch.float64), seed=20240, chains=C,
                        chain_id0=ctx.rank * C)
         for _ in range(warmup):
@@ -290,8 +289,8 @@ def bench_hmc_lanes(ctx, C, D, eps=0.05, L=32, draws=20):
     for key, mk, k2 in (("one_launch_trajectory", lambda: bk.Funnel(D), {}),
                         ("one_launch_trajectory_from_source",
                          lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1), {}),
-                        ("one_launch_per_step", lambda: bk.Funnel(D), dict(fuse_builtin=False)),
-                        ("gradient_separate_op", lambda: bk.Funnel(D), dict(fuse_builtin=False, fuse_steps=False))):
+                        ("one_launch_per_step", lambda: bk.Funnel(D), dict(path="step")),
+                        ("gradient_separate_op", lambda: bk.Funnel(D), dict(path="opaque"))):
         s = bk.HMCDiag(mk(), eps, L, **kw, **k2)
         for _ in range(3):
             s.sample()
@@ -364,7 +363,7 @@ def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=F
 
 def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
     """Config 4 through the interface north_star names: the gradient a SEPARATE device op called once per leapfrog
-    step (drghmc.py:280-283) -- the library's own funnel op with fuse_builtin=False, and a user plugin behind the
+    step (drghmc.py:280-283) -- the library's own funnel op with path="step", and a user plugin behind the
     counted plugin ABI (bk_target_fn_n) -- every lane count on the device, the draw one hipGraph.  Same warm-up as the
     fused figure above (draws 4..), so the two are comparable; the fused sampler run beside it must end
     bit-identical."""
@@ -394,7 +393,7 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
                        "lane counts on the device)",
            "bound": "launch latency (dependent chain of ~580 small launches per draw inside one hipGraph)",
            "fused_one_launch_proposals_same_draws": fused}
-    so, r = run(bk.Funnel(D), draws, fuse_builtin=False, fuse_steps=False)
+    so, r = run(bk.Funnel(D), draws, path="opaque")
     r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
                                    and torch.equal(so._rng_state, ref._rng_state))
     out["builtin_gradient_op"] = r
@@ -402,7 +401,7 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
     # the same path with a leapfrog step {gradient, kick, drift} as ONE launch (bk_leapfrog_step_funnel: the model's
     # density inside the library's step kernel, csrc/bk_lanes.hpp) -- what the step-by-step path runs by default for a
     # model that has it
-    so, r = run(bk.Funnel(D), draws, fuse_builtin=False)
+    so, r = run(bk.Funnel(D), draws, path="step")
     r["identical_to_fused"] = bool(torch.equal(so._theta_dc, ref._theta_dc) and torch.equal(so._rho_dc, ref._rho_dc)
                                    and torch.equal(so._rng_state, ref._rng_state))
     out["builtin_one_launch_steps"] = r
@@ -414,16 +413,16 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
         out["plugin_ctarget"] = r
         del so
     # the same density from SOURCE on the counted path: form="lanes" (a chain spread over 4 / 8 / 16 lanes, DPP sums;
-    # fuse_builtin=False keeps it off its one-launch path) and form="chain" (one lane per chain walking D coordinates)
+    # path="step" keeps it off its one-launch path) and form="chain" (one lane per chain walking D coordinates)
     # ("_one_launch_steps": the lanes form also gives the step-by-step path {gradient, kick, drift} as ONE launch per
     # leapfrog step)
     lanes = dict(form="lanes", head=1)
     # ("_one_launch_trajectories": the per-chain form -- ANY coupled density -- runs the whole trajectory of a proposal as one
     # launch, theta in its lane's registers and rho in LDS through all the steps, followed by the library's finish launch)
-    off = dict(fuse_builtin=False)
-    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(off, fuse_steps=False)),
+    off = dict(path="step")
+    for key, src, kws, k2 in (("compiled_source_lanes", FUNNEL_LANES_SRC, lanes, dict(off, path="opaque")),
                               ("compiled_source_lanes_one_launch_steps", FUNNEL_LANES_SRC, lanes, off),
-                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), dict(off, fuse_steps=False)),
+                              ("compiled_source_chain", FUNNEL_CHAIN_SRC, dict(form="chain"), dict(off, path="opaque")),
                               ("compiled_source_chain_one_launch_steps", FUNNEL_CHAIN_SRC, dict(form="chain"), off),
                               ("compiled_source_chain_one_launch_trajectories", FUNNEL_CHAIN_SRC, dict(form="chain"), {})):
         try:
@@ -438,7 +437,7 @@ def bench_cfg4_model_opaque(ctx, C, D, warmup, draws=20):
             out[key] = {"error": repr(e)}
     # the same draws with launches sized by host reads (three lane counts read back per draw; the path every model
     # had before the counted entry points, and the one PyTorch-autograd models still take)
-    so, r = run(bk.Funnel(D), 5, fuse_builtin=False, fuse_steps=False, device_counts=False)
+    so, r = run(bk.Funnel(D), 5, path="opaque", device_counts=False)
     out["host_sized_launches"] = r
     out["ms_per_draw"] = out["builtin_gradient_op"]["ms_per_draw"]
     return out
@@ -462,7 +461,7 @@ def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
             s.sample()
         return s, ctx.timed_loop(s.sample, draws) / draws
 
-    s, per = run(fuse_builtin=False)
+    s, per = run(path="step")
     out = {"workload": "MALA eps=5e-5 on the config-3 target (D=1024, 65,536 chains per GPU), "
                        "model-opaque gradient op",
            "bound": "hbm", "ms_per_draw": 1e3 * per, "draws_per_sec": C * ctx.world / per,
@@ -547,7 +546,7 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         build_s = time.perf_counter() - t0
         s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
                        # (model-opaque: the gradient a separate op per step, priced on the 56 D model like the headline)
-                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False, fuse_steps=False)
+                       metric_diag=torch.ones(D, dtype=torch.float64), path="opaque")
         s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             s.sample()
@@ -563,7 +562,7 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         out["compiled_source"] = {"error": repr(e)}
     # TorchModel(compile=True): the SAME PyTorch lambda as the autograd figure above, read once with torch.fx, its
     # per-coordinate term and hand-differentiated derivative emitted as bk_term source and compiled (trace.py):
-    # model-opaque step-by-step path (fuse_builtin=False: priced on the 56*D model like the headline) and the whole-draw
+    # model-opaque step-by-step path (path="step": priced on the 56*D model like the headline) and the whole-draw
     # kernel it also unlocks (separately)
     try:
         t0 = time.perf_counter()
@@ -572,7 +571,7 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         if model.compiled is None:
             raise RuntimeError("not traced: " + str(model.compile_note))
         s = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
-                       metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False, fuse_steps=False)
+                       metric_diag=torch.ones(D, dtype=torch.float64), path="opaque")
         s._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             s.sample()
@@ -595,7 +594,7 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         # (the same model with {gradient, kick, drift} as ONE launch per leapfrog step: 32 D bytes per chain-step
         # instead of 56 D, so NOT on the 56 D model either)
         h1 = bk.HMCDiag(model, EPS_CFG3, L, chains=C, chain_id0=ctx.rank * C, seed=SEED_CFG3,
-                        metric_diag=torch.ones(D, dtype=torch.float64), fuse_builtin=False)
+                        metric_diag=torch.ones(D, dtype=torch.float64), path="step")
         h1._theta_dc.mul_((1.0 / torch.sqrt(lam))[:, None])
         for _ in range(warmup + 1):
             h1.sample()
@@ -678,8 +677,8 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         rec = {"what": "AR(1) state-space model D=101 written with shifted slices in PyTorch, DRGHMC K=3 L=(10,40,160) on 32,768 "
                        "chains: TorchModel(compile=True) -> per-chain form -> one launch per trajectory",
                "compiled_form": getattr(tm, "compiled_form", None), "construction_s_incl_trace_hipcc_or_cache": build_s}
-        for key, kw in (("ms_per_draw", {}), ("ms_per_draw_one_launch_per_step", dict(fuse_builtin=False)),
-                        ("ms_per_draw_gradient_separate_op", dict(fuse_steps=False))):
+        for key, kw in (("ms_per_draw", {}), ("ms_per_draw_one_launch_per_step", dict(path="step")),
+                        ("ms_per_draw_gradient_separate_op", dict(path="opaque"))):
             s = bk.DrGhmcDiag(bk.TorchModel(ar1, Da, compile=True), *args, chains=Ca, seed=20246, init=th0, **kw)
             for _ in range(3):
                 s.sample()

@@ -119,12 +119,11 @@ int bk_leapfrog_kick_drift(const double* theta_in, double* theta_out,
  * src_index[j] of the inputs (leading dimension ld_in): gathers the active chains of a
  * delayed-rejection stage into a dense buffer while taking their first leapfrog step
  * (drghmc.py:276-278 for the chains that reach proposal k). n = number of gathered chains. */
-int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in,
-                                  const double* grad_in, int64_t ld_in,
-                                  const int32_t* src_index,
-                                  double* theta_out, double* rho_out, int64_t ld_out,
-                                  const double* metric, double eps, double pre,
-                                  int64_t n, int64_t D, void* stream);
+int bk_leapfrog_first_step_gather(const double* theta_in, const double* rho_in, const double* grad_in,
+                                  int64_t ld_in, const int32_t* src_index, double* theta_out,
+                                  double* rho_out, int64_t ld_out, const double* metric, double eps,
+                                  double pre, int64_t n, int64_t D, const uint32_t* n_dev, void* stream);
+/* (n_dev may be NULL: all n lanes; otherwise min(n, *n_dev), see "Lane counts on the device" below.) */
 
 /* Final half-kick and kinetic energy of a trajectory:
  *     r = rho_in + half * (metric[d] * grad)      hmc.py:52, drghmc.py:286
@@ -153,10 +152,6 @@ int bk_leapfrog_kick_drift_n(const double* theta_in, double* theta_out, const do
                              int64_t ld, const double* grad, int64_t ldg_d, int64_t ldg_c,
                              const double* metric, double eps, int use_pre, double pre, int use_kick,
                              double kick, int64_t C, int64_t D, const uint32_t* n_dev, void* stream);
-int bk_leapfrog_first_step_gather_n(const double* theta_in, const double* rho_in, const double* grad_in,
-                                    int64_t ld_in, const int32_t* src_index, double* theta_out,
-                                    double* rho_out, int64_t ld_out, const double* metric, double eps,
-                                    double pre, int64_t n, int64_t D, const uint32_t* n_dev, void* stream);
 /* bk_leapfrog_finish for such a set, plus what the end of a delayed-rejection trajectory owes its level:
  * H_out / h_out / live_out (all or none; needs logp = the log density at the end point and kin_out):
  * bk_dr_level_begin for the produced lanes (H = -((-logp) + kin), h = 0, live = 1; drghmc.py:421 -> :249-251);
@@ -337,15 +332,12 @@ int bk_mala_propose_from_normals(const double* theta, const double* grad, const 
  * `snapshot` (may be NULL; a second table with the same ldr) receives the stream table as it was BEFORE
  * the call: a sampler that generates a draw's normals one draw ahead keeps its logical stream
  * position (where the reference's generator stands between two sample() calls) that way, without a
- * separate copy of the table. */
-int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz,
-                           int64_t C, int64_t D, uint64_t* snapshot, void* stream);
-
-/* The same as a BACKGROUND launch: at most max_workgroups workgroups (0 = no bound), each walking several groups
- * of chains.  With one workgroup per CU (256 on MI355X) the generator keeps one wavefront per SIMD and the rest of
- * every CU stays free for a bandwidth-bound kernel running beside it on another stream.  Same stream of normals. */
-int bk_normals_chain_major_bg(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
-                              int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream);
+ * separate copy of the table.
+ * max_workgroups (0 = no bound): a BACKGROUND launch of at most that many workgroups, each walking several groups of
+ * chains -- with one workgroup per CU (256 on MI355X) the generator keeps one wavefront per SIMD and the rest of every CU
+ * stays free for a bandwidth-bound kernel running beside it on another stream.  Same stream of normals. */
+int bk_normals_chain_major(int rng_kind, uint64_t* state, int64_t ldr, double* zt, int64_t ldz, int64_t C,
+                           int64_t D, uint64_t* snapshot, int64_t max_workgroups, void* stream);
 
 /* ONE chain driven by a host model (the reference's own call shape, README.md:13-32; mala.py:40-66): everything of a
  * draw that follows the model call, and the next draw's proposal, in ONE launch of one lane.
@@ -524,12 +516,7 @@ int bk_mala_step_gaussian(const double* theta, double* theta_out, double* theta_
  * gradient evaluations = steps * lanes); lanes_total (may be NULL): the same count is ADDED to it.
  * H_out, h_out, live_out (all or none): additionally perform bk_dr_level_begin for the produced
  * lanes in the same launch (H = -((-logp) + kin), h = 0, live = 1). */
-int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in,
-                          int64_t ld_in, const int32_t* src_index, double* theta_out,
-                          double* rho_out, double* grad_out, double* logp_out, double* kin_out,
-                          int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
-                          int64_t D, const uint32_t* n_dev, uint32_t* lanes_out, uint64_t* lanes_total,
-                          double* H_out, double* h_out, uint8_t* live_out, void* stream);
+/* (prototype below, after the structs its optional jobs are described by.) */
 
 /* The arguments of one bk_scatter_columns call, as a job a trajectory launch can carry along. */
 typedef struct bk_scatter_job {
@@ -574,7 +561,7 @@ typedef struct bk_ghost0 {
   uint64_t* lanes_total;
 } bk_ghost0;
 
-/* bk_dr_proposal_funnel with a scatter job (may be NULL) run by surplus workgroups of the SAME launch: the
+/* job (may be NULL): a scatter job run by surplus workgroups of the SAME launch: the
  * previous stage's accepted columns move into the chains' current point (drghmc.py:379-381) while this stage's
  * trajectories -- a sparse, latency-bound lane set -- integrate.  The caller guarantees that the job and the
  * proposal touch disjoint memory: the job writes columns of accepted chains and reads the previous stage's
@@ -584,7 +571,7 @@ typedef struct bk_ghost0 {
  * ghost0 (may be NULL; needs H_out): the launch also integrates the first ghost of every produced lane (bk_ghost0) and
  * applies it to the produced level; together with `ghost` only for a level whose ONLY ghost it is
  * (ghost0->next_index NULL) -- the link then sees the level after that ghost. */
-int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, const double* grad_in,
+int bk_dr_proposal_funnel(const double* theta_in, const double* rho_in, const double* grad_in,
                           int64_t ld_in, const int32_t* src_index, double* theta_out,
                           double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                           int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
@@ -593,12 +580,12 @@ int bk_dr_proposal_funnel_job(const double* theta_in, const double* rho_in, cons
                               const bk_ghost_link* ghost, const bk_ghost0* ghost0, void* stream);
 
 /* The separable Gaussians through the same kernel templates (a separable density is a lanes-form density without head
- * coordinates): bk_dr_proposal_funnel_job and bk_leapfrog_step_funnel for logp = -1/2 sum th*(lam*th), lam NULL = the
+ * coordinates): bk_dr_proposal_funnel and bk_leapfrog_step_funnel for logp = -1/2 sum th*(lam*th), lam NULL = the
  * isotropic Gaussian.  D <= 128 for the proposal (BK_E_ARG otherwise), any D for the step.  theta and rho are bit-identical to
  * the step-by-step path; the log density is summed in the lanes' class order (csrc/bk_lanes.hpp), not in four quarters.
  * The step of a separable density needs no sums: bk_leapfrog_step_gaussian is a STREAMING launch (csrc/bk_elementwise.hpp,
  * every (d, c) element on its own, 16 bytes per lane): 32*D bytes per chain-step, min(n, *n_dev) chains. */
-int bk_dr_proposal_gaussian_job(const double* theta_in, const double* rho_in, const double* grad_in,
+int bk_dr_proposal_gaussian(const double* theta_in, const double* rho_in, const double* grad_in,
                                 int64_t ld_in, const int32_t* src_index, double* theta_out,
                                 double* rho_out, double* grad_out, double* logp_out, double* kin_out,
                                 int64_t ld_out, const double* metric, double h, int64_t steps, int64_t n,
@@ -680,16 +667,12 @@ int bk_relayout(const double* src, int64_t lds_d, int64_t lds_c, double* dst, in
 /* ---- streaming diagnostics --------------------------------------------------------------
  * Welford update with the n-th draw (n >= 1) of every chain and dimension: per-chain mean
  * and M2 from which rhat.py:163-166 (np.mean, np.var(ddof=1)) follow. */
-int bk_welford_update(double* mean, double* m2, const double* theta, int64_t ld, int64_t n,
-                      int64_t C, int64_t D, void* stream);
-
-/* bk_welford_update with the update count in device memory: n = *n_dev - n_offset (e.g. a sampler's draw counter), and
- * with theta's own row pitch.  A launch like this can be part of a captured draw (hipGraph): nothing of it changes
- * from one replay to the next on the host side. */
-/* bk_welford_update with a row pitch of its own for theta (a sampler's state rows may be padded off a
- * power-of-two pitch while the moments are dense): no staging copy of the draw. */
-int bk_welford_update_ld(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
-                         int64_t n, int64_t C, int64_t D, void* stream);
+/* theta has a row pitch of its own (a sampler's state rows may be padded off a power-of-two pitch while the moments are
+ * dense: no staging copy of the draw). */
+int bk_welford_update(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
+                      int64_t n, int64_t C, int64_t D, void* stream);
+/* ... with the update count in device memory: n = *n_dev - n_offset (e.g. a sampler's draw counter).  A launch like this
+ * can be part of a captured draw (hipGraph): nothing of it changes from one replay to the next on the host side. */
 int bk_welford_update_dev(double* mean, double* m2, int64_t ld, const double* theta, int64_t ld_theta,
                           const int64_t* n_dev, int64_t n_offset, int64_t C, int64_t D, void* stream);
 

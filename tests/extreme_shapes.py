@@ -11,7 +11,7 @@ for (C, D, L) in ((1_000_000, 8, 3), (3, 20000, 2), (131072, 300, 2), (65, 70000
         lam = np.linspace(1.0, 2.0, D)
         try:
             if alg == "hmc":
-                s = bk.HMCDiag(bk.DiagGaussian(lam), 0.01, L, chains=C, seed=5, fuse_builtin=False)
+                s = bk.HMCDiag(bk.DiagGaussian(lam), 0.01, L, chains=C, seed=5, path="step")
                 mk = lambda sd: osamp.HMCDiag(om.DiagGaussian(lam), 0.01, L, seed=sd)
             elif alg == "mala":
                 s = bk.MALA(bk.DiagGaussian(lam), 1e-4, chains=C, seed=5)

@@ -66,7 +66,7 @@ def build_sampler(case, model, ops, seed, chains=None, chain_id0=0, **extra):
                           case["leapfrog_step_counts"], case["damping"],
                           prob_retry=case.get("prob_retry", True), **kw)
     elif alg in ("metropolis", "mh"):
-        kw.pop("fuse_builtin", None)
+        kw.pop("path", None)
         if chains is not None:  # every chain in one sampler: batched callbacks on device streams
             proposal_fn, transition_lp_fn = device_proposal(case["proposal"], chains, chain_id0, ops)
         else:
@@ -207,7 +207,7 @@ def check_dense_metric_hmc(ops, C=40, D=24, draws=6, rtol=1e-10):
     assert 0.3 < s.accept_rate() <= 1.0
     # M = I: the dense path IS the reference path (multiplying by 1 and adding zeros is exact)
     a = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, metric_dense=np.eye(D), ops=ops)
-    b = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, fuse_builtin=False, ops=ops)
+    b = bk.HMCDiag(bk.DiagGaussian(lam, ops=ops), 0.05, 7, chains=C, seed=31, path="step", ops=ops)
     for _ in range(3):
         ta, la = a.sample()
         tb, lb = b.sample()

@@ -92,24 +92,24 @@ def funnel_paths(rng):
     desc["opaque"] = opaque
     o = a2 = None
     if opaque != "none":
-        a2 = mk(device_counts=False, fuse_builtin=False, fuse_steps=bool(rng.integers(0, 2)))
+        a2 = mk(device_counts=False, path=("step", "opaque")[int(rng.integers(0, 2))])
         if opaque.startswith("source"):
             src = bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1)
-            kw = dict(source=dict(fuse_builtin=False), source_op=dict(fuse_builtin=False, fuse_steps=False), source_fused=dict())[opaque]
+            kw = dict(source=dict(path="step"), source_op=dict(path="opaque"), source_fused=dict())[opaque]
             o = bk.DrGhmcDiag(src, K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed, prob_retry=pr,
                               device_counts=True, graph=graph, **kw)
             if opaque == "source_fused":
                 a2 = mk(device_counts=True, graph=graph)   # (the fused kernels sum the kinetic energy in their lanes' order)
         elif opaque.startswith("chain"):
             src = bk.CTarget.from_source(FUNNEL_CHAIN_CLASS_ORDER_SRC, D, form="chain")
-            kw = dict(chain=dict(), chain_step=dict(fuse_builtin=False), chain_op=dict(fuse_steps=False))[opaque]
+            kw = dict(chain=dict(), chain_step=dict(path="step"), chain_op=dict(path="opaque"))[opaque]
             dc = bool(rng.integers(0, 2))
             desc["chain_device_counts"] = dc
             o = bk.DrGhmcDiag(src, K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed, prob_retry=pr,
                               device_counts=dc, graph=graph and dc, **kw)
             assert o._traj_hook == (opaque == "chain" and D <= 128), desc
         elif opaque == "builtin_op":
-            o = mk(device_counts=True, graph=graph, fuse_builtin=False, fuse_steps=False)
+            o = mk(device_counts=True, graph=graph, path="opaque")
         elif opaque == "plugin":
             import os as _os
 
@@ -117,7 +117,7 @@ def funnel_paths(rng):
             o = bk.DrGhmcDiag(bk.CTarget(lib, "funnel_target", D, counted_symbol="funnel_target_n"), K, sizes, counts, damp,
                               metric_diag=metric, chains=C, seed=seed, prob_retry=pr, device_counts=True, graph=graph)
         else:
-            o = mk(device_counts=True, graph=graph, fuse_builtin=False)
+            o = mk(device_counts=True, graph=graph, path="step")
     for n in range(N):
         ta, la = a.sample()
         tb, lb = b.sample()
@@ -193,7 +193,7 @@ def hmc_funnel(rng):
     model = (lambda: bk.Funnel(D), lambda: bk.CTarget.from_source(FUNNEL_LANES_SRC, D, form="lanes", head=1),
              lambda: bk.CTarget.from_source(FUNNEL_CHAIN_CLASS_ORDER_SRC, D, form="chain"))[kind]
     mk = lambda **kw: bk.HMCDiag(model(), eps, L, metric_diag=metric, chains=C, seed=seed, graph=graph, **kw)  # noqa: E731
-    f, h, s_ = mk(), mk(fuse_builtin=False), mk(fuse_builtin=False, fuse_steps=False)
+    f, h, s_ = mk(), mk(path="step"), mk(path="opaque")
     for n in range(N):
         tf, lf = f.sample()
         th_, lh = h.sample()
@@ -285,7 +285,7 @@ def one(rng, it):
     del HISTORY[:-8]
     if alg == "hmc":
         L = int(rng.integers(0, 7))
-        kw = dict(fuse_builtin=bool(rng.integers(0, 2)), graph=bool(rng.integers(0, 2)) and not NO_GRAPH,
+        kw = dict(path=("step", "auto")[int(rng.integers(0, 2))], graph=bool(rng.integers(0, 2)) and not NO_GRAPH,
                   prefetch_rng=bool(rng.integers(0, 2)) and not NO_PREFETCH)
         desc.update(L=L, **kw)
         s = bk.HMCDiag(tgt, eps, L, metric_diag=metric, chains=C, seed=seed, **kw)

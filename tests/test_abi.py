@@ -126,7 +126,7 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_select_columns(p, p, p, None, None, None, 0, 0, 8, None) == OK
     assert lib.bk_mala_logq(p, p, p, p, 0, 0.1, p, p, 0, 8, None) == OK
     assert lib.bk_target_diag_gaussian_grad(p, p, None, 0, p, 0, 8, None) == OK
-    assert lib.bk_welford_update(p, p, p, 0, 1, 0, 8, None) == OK
+    assert lib.bk_welford_update(p, p, 0, p, 0, 1, 0, 8, None) == OK
     assert lib.bk_ess(p, 0, 8, 0, p, None, 0, None) == OK
     assert lib.bk_end_pos_pairs(p, 0, 0, p, 0, None) == OK
     # argument errors
@@ -139,8 +139,8 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_target_diag_gaussian_grad(p, p, None, 4, None, 4, 8, None) == E_ARG  # lam required
     assert lib.bk_ess(p, 4, 3, 0, p, None, 4, None) == E_ARG                     # N < 4 (ess.py:67-68)
     assert lib.bk_autocorr(p, 4, 1, p, 4, 4, None) == E_ARG                      # N < 2 (autocorr.py:23-24)
-    assert lib.bk_normals_chain_major(1, p, 4, p, 8, 4, 8, None, None) == E_ARG        # Philox streams only
-    assert lib.bk_normals_chain_major(0, p, 4, p, 7, 4, 8, None, None) == E_ARG        # ldz < D
+    assert lib.bk_normals_chain_major(1, p, 4, p, 8, 4, 8, None, 0, None) == E_ARG        # Philox streams only
+    assert lib.bk_normals_chain_major(0, p, 4, p, 7, 4, 8, None, 0, None) == E_ARG        # ldz < D
     # round-3 entry points
     assert lib.bk_autocorr_fft(p, 4, 1, p, 4, 4, p, 1 << 20, None) == E_ARG         # N < 2
     assert lib.bk_autocorr_fft(p, 4, 8, p, 4, 4, p, 16, None) == E_ARG              # scratch too small
@@ -153,7 +153,7 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, p, 0, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
                                    None, None) == OK                                 # no chains
     g0 = _lib.Ghost0(0.1, 0, None, 1.0, None, None, None, None)                      # a ghost of zero steps
-    assert lib.bk_dr_proposal_funnel_job(p, p, p, 4, None, p, p, p, p, p, 4, None, 0.1, 3, 4, 8, None, None, None, p, p, p,
+    assert lib.bk_dr_proposal_funnel(p, p, p, 4, None, p, p, p, p, p, 4, None, 0.1, 3, 4, 8, None, None, None, p, p, p,
                                          None, None, ctypes.byref(g0), None) == E_ARG
     # layout errors
     assert lib.bk_leapfrog_kick_drift(p, p, p, p, 3, p, 4, 1, None, 0.1, 0, 0.0, 1, 0.1, 4, 8, None) == E_ALIGN

@@ -65,7 +65,7 @@ def test_config4_at_its_stated_length_leaves_the_funnel_invariant():
     assert float(ess[1].mean()) > 300 and 2.0 < float(ess[0].mean()) < 100.0, (float(ess[1].mean()), float(ess[0].mean()))
     # (5) same bits through the counted step-by-step path (gradient op per leapfrog step) for the first 60 of those draws
     a = bk.DrGhmcDiag(bk.Funnel(D), *ARGS, chains=C, seed=20242, init=init)
-    b = bk.DrGhmcDiag(bk.Funnel(D), *ARGS, chains=C, seed=20242, init=init, fuse_builtin=False)
+    b = bk.DrGhmcDiag(bk.Funnel(D), *ARGS, chains=C, seed=20242, init=init, path="step")
     assert a._one_launch and not b._one_launch and b._dev_counts
     for _ in range(60):
         a.advance()
@@ -79,7 +79,7 @@ def test_config2_at_its_stated_length():
     every marginal N(0, 1), R-hat 1, through the whole-draw kernel and the step-by-step path (same bits)."""
     Dg, Cg, Ng = 128, 4096, 200
     f = bk.HMCDiag(bk.IsoGaussian(Dg), 0.05, 32, chains=Cg, seed=20240)
-    s = bk.HMCDiag(bk.IsoGaussian(Dg), 0.05, 32, chains=Cg, seed=20240, fuse_builtin=False)
+    s = bk.HMCDiag(bk.IsoGaussian(Dg), 0.05, 32, chains=Cg, seed=20240, path="step")
     mom = bk.RunningMoments(Dg, Cg)
     last = None
     for n in range(Ng):

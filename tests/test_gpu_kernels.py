@@ -1000,7 +1000,7 @@ def test_funnel_ghost_with_its_own_ghost_applies_itself_to_its_parent(D, n):
 
 
 def test_background_generator_launch_gives_the_same_stream():
-    """bk_normals_chain_major_bg: a bounded number of workgroups, each walking several groups of chains
+    """bk_normals_chain_major: a bounded number of workgroups, each walking several groups of chains
     (a background kernel beside a streaming one), against the one-workgroup-per-group launch."""
     ops = bk._lib.default_ops()
     for C, D in ((1000, 70), (4096, 128), (333, 1000)):

@@ -105,22 +105,20 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     src = lambda: bk.CTarget.from_source(DIAG_SRC, D, params=lam_d)  # noqa: E731
     assert src().bk_counted
     pairs = [
-        (bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=C, seed=3, fuse_builtin=False), bk.HMCDiag(src(), 0.02, 9, chains=C, seed=3)),
+        (bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=C, seed=3, path="step"), bk.HMCDiag(src(), 0.02, 9, chains=C, seed=3)),
         (bk.MALA(bk.DiagGaussian(lam), 2e-3, chains=C, seed=4), bk.MALA(src(), 2e-3, chains=C, seed=4)),
         (bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5),
          bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5)),
     ]
     # (round 5) a separable density is also a lane-spread one without head coordinates: DrGhmcDiag runs its proposals as ONE
-    # launch each (D <= 128); with fuse_builtin=False it steps, one launch per leapfrog step; fuse_steps=False: gradient op per step
-    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False)))
-    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False,
-                                             fuse_steps=False)))
+    # launch each (D <= 128); with path="step" it steps, one launch per leapfrog step; path="opaque": gradient op per step
+    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, path="step")))
+    pairs.append((pairs[2][0], bk.DrGhmcDiag(src(), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, path="opaque")))
     assert pairs[2][1]._dev_counts and pairs[2][1]._use_graph and pairs[2][1]._one_launch and pairs[2][1].host_syncs_per_draw == 0
     assert pairs[3][1]._step_hook and not pairs[3][1]._one_launch and not pairs[4][1]._step_hook
     for i, (a, b) in enumerate(pairs):
         if i >= 3:   # (pairs 3, 4 share their reference sampler with pair 2: a fresh one, stepping with the gradient op)
-            a = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, fuse_builtin=False,
-                              fuse_steps=False)
+            a = bk.DrGhmcDiag(bk.DiagGaussian(lam), 3, [0.2, 0.08, 0.03], [3, 6, 12], 0.3, chains=C, seed=5, path="opaque")
         for n in range(8):
             ta, la = a.sample()
             tb, lb = b.sample()
@@ -143,21 +141,21 @@ def test_density_compiled_from_source_under_every_sampler(ops):
     # global memory as the user's loops ask for them (larger D) -- the same values
     for Df in (150, 101, 17, 128, 350):
         fs = bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain")
-        a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
+        a = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, path="step", device_counts=False)
         b = bk.DrGhmcDiag(fs, 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9)
         b2 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
-                           fuse_steps=False, metric_diag=None)
+                           path="opaque", metric_diag=None)
         hm = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4,
                         metric_diag=np.linspace(0.8, 1.3, Df))
-        hs = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, fuse_steps=False,
+        hs = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, path="opaque",
                         metric_diag=np.linspace(0.8, 1.3, Df))
         # (D <= 128) the whole trajectory of a proposal is one launch (bk_leapfrog_trajectory: theta in registers, rho in LDS);
-        # fuse_builtin=False: one launch per leapfrog step; fuse_steps=False: gradient op + kick+drift per step
+        # path="step": one launch per leapfrog step; path="opaque": gradient op + kick+drift per step
         b3 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
-                           fuse_builtin=False)
+                           path="step")
         b4 = bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9,
                            device_counts=False)
-        h3 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, fuse_builtin=False,
+        h3 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, 5, chains=333, seed=4, path="step",
                         metric_diag=np.linspace(0.8, 1.3, Df))
         assert b._dev_counts and b._use_graph and b._step_hook == (Df <= 128) and not b2._step_hook and hm._step_hook == (Df <= 128)
         assert b._traj_hook == (Df <= 128) and hm._traj_hook == (Df <= 128) and b4._traj_hook == (Df <= 128) and not b4._dev_counts
@@ -179,7 +177,7 @@ def test_density_compiled_from_source_under_every_sampler(ops):
         # a trajectory of ONE step (no in-kernel step loop: the gathering first step, then the last gradient) and of two
         for L in (1, 2):
             k1 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, L, chains=333, seed=14)
-            k2 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, L, chains=333, seed=14, fuse_steps=False)
+            k2 = bk.HMCDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain"), 0.05, L, chains=333, seed=14, path="opaque")
             for n in range(3):
                 t1, l1 = k1.sample()
                 t2, l2 = k2.sample()
@@ -189,8 +187,8 @@ def test_density_compiled_from_source_under_every_sampler(ops):
             # long functions; measured slower for this short one) -- the same draws
             mk_l = lambda **kw: bk.DrGhmcDiag(bk.CTarget.from_source(FUNNEL_SRC, Df, form="chain", stage="lds"), 2, [0.3, 0.1], [3, 6],  # noqa: E731
                                               0.3, chains=700, seed=9, **kw)
-            c0 = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, fuse_builtin=False, device_counts=False)
-            l1, l2, l3 = mk_l(), mk_l(fuse_builtin=False), mk_l(fuse_steps=False)
+            c0 = bk.DrGhmcDiag(bk.Funnel(Df), 2, [0.3, 0.1], [3, 6], 0.3, chains=700, seed=9, path="step", device_counts=False)
+            l1, l2, l3 = mk_l(), mk_l(path="step"), mk_l(path="opaque")
             assert l1._traj_hook and l2._step_hook and not l2._traj_hook and not l3._step_hook
             for n in range(5):
                 t0, p0 = c0.sample()
@@ -299,9 +297,9 @@ def test_lanes_form_gradient_op_is_the_plugin_on_the_counted_path(ops):
     for D, C, metric in ((101, 2500, None), (40, 13000, "m"), (130, 800, None), (300, 500, "m")):
         one = D - 1 <= 128
         kw = dict(chains=C, seed=21, metric_diag=None if metric is None else np.linspace(0.6, 1.7, D))
-        a = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, fuse_steps=False, **kw)  # gradient op per step
-        b = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, **kw)  # {gradient, kick, drift} ONE launch per step
-        h = bk.DrGhmcDiag(funnel_lanes(D), *args, fuse_builtin=False, device_counts=False, **kw)  # the same, host-sized
+        a = bk.DrGhmcDiag(funnel_lanes(D), *args, path="opaque", **kw)  # gradient op per step
+        b = bk.DrGhmcDiag(funnel_lanes(D), *args, path="step", **kw)  # {gradient, kick, drift} ONE launch per step
+        h = bk.DrGhmcDiag(funnel_lanes(D), *args, path="step", device_counts=False, **kw)  # the same, host-sized
         p = bk.DrGhmcDiag(funnel_plugin(D), *args, **kw)
         f = bk.DrGhmcDiag(funnel_lanes(D), *args, **kw) if one else None
         assert a._dev_counts and a._use_graph and not a._one_launch and (f is None or f._one_launch)
@@ -362,8 +360,8 @@ def test_lanes_form_hierarchical_model_with_two_head_coordinates(ops):
     args = (3, [0.15, 0.05, 0.02], [4, 8, 16], 0.2)
     m = np.linspace(0.7, 1.4, D)
     f = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31)
-    c = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False)
-    h = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, fuse_builtin=False, device_counts=False, fuse_steps=False)
+    c = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, path="step")
+    h = bk.DrGhmcDiag(mk(), *args, metric_diag=m, chains=C, seed=31, path="opaque", device_counts=False)
     assert f._one_launch and c._dev_counts and not c._one_launch and not h._dev_counts and c._step_hook and not h._step_hook
     for n in range(6):
         tf, lf = f.sample()
@@ -388,7 +386,7 @@ def test_elementwise_form_runs_the_whole_draw_hmc_kernel(ops):
         src = lambda: bk.CTarget.from_source(DIAG_SRC, D, params=lam_d)  # noqa: E731
         kw = dict(metric_diag=m, chains=C, seed=3)
         f = bk.HMCDiag(src(), eps, L, **kw)
-        s = bk.HMCDiag(src(), eps, L, fuse_builtin=False, **kw)
+        s = bk.HMCDiag(src(), eps, L, path="step", **kw)
         b = bk.HMCDiag(bk.DiagGaussian(lam), eps, L, **kw)
         g = bk.HMCDiag(src(), eps, L, graph=True, **kw)
         assert f._fused_draw and not s._fused and b._fused_draw and g._fused_draw
@@ -436,8 +434,8 @@ def test_hmc_on_lane_spread_densities_one_launch_per_trajectory(ops):
         m = None if metric is None else np.linspace(0.7, 1.4, D)
         kw = dict(metric_diag=m, chains=C, seed=41)
         f = bk.HMCDiag(mk(D), eps, L, **kw)                                         # one launch per trajectory
-        h = bk.HMCDiag(mk(D), eps, L, fuse_builtin=False, **kw)                     # one launch per leapfrog step
-        s = bk.HMCDiag(mk(D), eps, L, fuse_builtin=False, fuse_steps=False, **kw)   # gradient a separate op per step
+        h = bk.HMCDiag(mk(D), eps, L, path="step", **kw)                     # one launch per leapfrog step
+        s = bk.HMCDiag(mk(D), eps, L, path="opaque", **kw)   # gradient a separate op per step
         g = bk.HMCDiag(mk(D), eps, L, graph=True, **kw)
         one = D <= 129 or name == "hierarchical"
         assert f._lanes_traj == one and h._step_hook and not h._lanes_traj and not s._step_hook and not s._lanes_traj, name
@@ -542,8 +540,8 @@ def test_torch_model_traces_hierarchical_densities_into_the_lanes_form(ops):
         np.testing.assert_allclose(g.cpu().numpy(), g_t.cpu().numpy(), rtol=1e-10, atol=1e-11 * float(g_t.abs().max()))
         args = (3, [0.15, 0.05, 0.02], [4, 8, 16], 0.2)
         f = bk.DrGhmcDiag(m, *args, chains=1500, seed=51)
-        c = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, fuse_builtin=False)
-        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, fuse_builtin=False, fuse_steps=False,
+        c = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, path="step")
+        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=51, path="opaque",
                            device_counts=False)
         assert f._one_launch and f.host_syncs_per_draw == 0 and c._step_hook and not c._one_launch and not hs._dev_counts
         for n in range(6):
@@ -605,7 +603,7 @@ def test_torch_model_traces_coupled_densities_into_the_per_chain_form(ops):
         args = (3, [0.03, 0.012, 0.005], [4, 8, 16], 0.2)
         th0 = 0.3 * torch.randn((1500, dims), dtype=torch.float64, device=dev)
         mk = lambda **kw: bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=71, init=th0, **kw)  # noqa: E731
-        f, c, op, hs = mk(), mk(fuse_builtin=False), mk(fuse_steps=False), mk(device_counts=False)
+        f, c, op, hs = mk(), mk(path="step"), mk(path="opaque"), mk(device_counts=False)
         assert f._traj_hook == (dims <= 128) and c._step_hook == (dims <= 128) and not c._traj_hook and not op._step_hook
         assert f._dev_counts and not hs._dev_counts and f.host_syncs_per_draw == 0
         for n in range(5):
@@ -615,7 +613,7 @@ def test_torch_model_traces_coupled_densities_into_the_per_chain_form(ops):
                 to, lo = other.sample()
                 assert torch.equal(tf, to) and torch.equal(lf, lo), (fn.__name__, dims, n)
         ha = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.02, 8, chains=1500, seed=72, init=th0)
-        hb = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.02, 8, chains=1500, seed=72, init=th0, fuse_steps=False)
+        hb = bk.HMCDiag(bk.TorchModel(fn, dims, compile=True), 0.02, 8, chains=1500, seed=72, init=th0, path="opaque")
         assert ha._traj_hook == (dims <= 128)
         for _ in range(4):
             ta, la = ha.sample()
@@ -676,7 +674,7 @@ def test_torch_model_traces_distributions_row_groups_and_piecewise_densities(ops
         args = (3, [0.06, 0.025, 0.01], [4, 8, 16], 0.2)
         th0 = 0.5 * torch.randn((1500, dims), dtype=torch.float64, device=dev)
         f = bk.DrGhmcDiag(m, *args, chains=1500, seed=61, init=th0)
-        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=61, fuse_builtin=False, fuse_steps=False,
+        hs = bk.DrGhmcDiag(bk.TorchModel(fn, dims, compile=True), *args, chains=1500, seed=61, path="opaque",
                            device_counts=False, init=th0)
         assert f._one_launch and f.host_syncs_per_draw == 0 and not hs._one_launch
         for n in range(5):

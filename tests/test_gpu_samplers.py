@@ -35,7 +35,7 @@ def test_many_chain_vs_reference_golden(name, ops):
 def test_drghmc_model_opaque_device_counts_vs_reference_golden(name, ops):
     """The reference's DRGHMC fixtures through the model-opaque path with lane counts on the device: one counted
     gradient op + one counted kick+drift launch per leapfrog step (drghmc.py:280-283), no host read, one hipGraph."""
-    s = check_many_chain(name, ops, fuse_builtin=False, device_counts=True)
+    s = check_many_chain(name, ops, path="step", device_counts=True)
     assert s._dev_counts and not s._one_launch and s._use_graph and s.host_syncs_per_draw == 0
 
 
@@ -43,7 +43,7 @@ def test_drghmc_model_opaque_device_counts_vs_reference_golden(name, ops):
 def test_hmc_step_by_step_path_vs_reference_golden(name, ops):
     """The model-opaque path (one kick+drift launch and one gradient op per leapfrog step),
     which is what bench.py measures; the default for built-in Gaussians is the fused one."""
-    s = check_many_chain(name, ops, fuse_builtin=False)
+    s = check_many_chain(name, ops, path="step")
     assert not s._fused
 
 
@@ -251,7 +251,7 @@ def test_full_size_cfg4_properties(ops):
     # the same draws with the gradient as a SEPARATE counted op per leapfrog step -- the library's own and the user plugin's
     # (bk_target_fn_n) -- 581 launches per draw inside one hipGraph, no host read: theta, rho and stream positions of all
     # 32,768 chains equal the one-launch path bit for bit (round 4)
-    for model, kw in ((bk.Funnel(101), dict(fuse_builtin=False)), (funnel_plugin(101), {})):
+    for model, kw in ((bk.Funnel(101), dict(path="step")), (funnel_plugin(101), {})):
         o = bk.DrGhmcDiag(model, *args, chains=32768, seed=20242, **kw)
         assert o._dev_counts and not o._one_launch and o._use_graph and o.host_syncs_per_draw == 0
         for _ in range(3):
@@ -271,7 +271,7 @@ def test_hipgraph_replay_equals_eager(ops, prefetch):
     for make in (lambda g, p: bk.HMCDiag(bk.IsoGaussian(128), 0.05, 32, chains=4096, seed=20240, graph=g,
                                          prefetch_rng=p),
                  lambda g, p: bk.HMCDiag(bk.DiagGaussian(np.logspace(0, 1, 40)), 0.05, 7, chains=700, seed=2,
-                                         graph=g, prefetch_rng=p, fuse_builtin=False),
+                                         graph=g, prefetch_rng=p, path="step"),
                  lambda g, p: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 16)), 0.02, chains=512, seed=3, graph=g,
                                       prefetch_rng=p),
                  lambda g, p: bk.MALA(bk.DiagGaussian(np.logspace(0, 1, 48)), 0.02, chains=300, seed=5, graph=g,
@@ -293,8 +293,8 @@ def test_rng_prefetch_stream_is_only_a_schedule(ops):
     """Generating draw n+1's randomness on a side stream during draw n changes nothing."""
     lam = np.logspace(0, 2, 64)
     for fused in (False, True):
-        a = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=False, fuse_builtin=fused)
-        b = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=True, fuse_builtin=fused)
+        a = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=False, path="auto" if fused else "step")
+        b = bk.HMCDiag(bk.DiagGaussian(lam), 0.02, 9, chains=3000, seed=8, prefetch_rng=True, path="auto" if fused else "step")
         assert b._prefetch and not a._prefetch
         for n in range(8):
             if n == 4:  # a metric assigned between draws must reach the prefetched kinetic energy
@@ -314,8 +314,8 @@ def test_drghmc_fused_proposal_equals_step_by_step(ops):
     differ only through the kinetic-energy sum order."""
     args = (3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1)
     for D, metric in ((11, None), (101, np.linspace(0.9, 1.1, 101)), (129, None)):
-        a = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, fuse_builtin=False)
-        b = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, fuse_builtin=True)
+        a = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, path="step")
+        b = bk.DrGhmcDiag(bk.Funnel(D), *args, chains=1500, seed=77, path="auto")
         assert b._fused and not a._fused
         if metric is not None:
             a._metric = metric
@@ -338,7 +338,7 @@ def test_checkpoint_resume(ops):
     lam = np.logspace(0, 1, 24)
     check_checkpoint_resume(ops, lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.1, 4, chains=700, seed=2))
     check_checkpoint_resume(ops, lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.1, 4, chains=700, seed=2,
-                                                    fuse_builtin=False, prefetch_rng=False))
+                                                    path="step", prefetch_rng=False))
     check_checkpoint_resume(ops, lambda: bk.MALA(bk.DiagGaussian(lam), 0.05, chains=700, seed=2))
     check_checkpoint_resume(ops, lambda: bk.DrGhmcDiag(bk.Funnel(21), 3, [0.3, 0.1, 0.03], [3, 9, 27], 0.3,
                                                        chains=700, seed=2))
@@ -372,7 +372,7 @@ def test_funnel_fixtures_bit_identical_to_the_canonical_order_oracle(ops, name, 
     proposal kernel and through counted leapfrog steps."""
     from tests.sampler_parity import check_funnel_vs_canonical_oracle
 
-    extra = {} if path == "one_launch" else dict(fuse_builtin=False)
+    extra = {} if path == "one_launch" else dict(path="step")
     check_funnel_vs_canonical_oracle(name, ops, **extra)
 
 
@@ -510,7 +510,7 @@ def test_odd_shapes_all_samplers_vs_oracle(ops, C, D):
 
     key = lambda c: np.random.Philox(key=[seed, c])
     for fused in (True, False):
-        compare(bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=C, seed=seed, fuse_builtin=fused),
+        compare(bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=C, seed=seed, path="auto" if fused else "step"),
                 lambda c: osamp.HMCDiag(om.DiagGaussian(lam), 0.05, 5, seed=key(c)), 4)
     compare(bk.MALA(bk.DiagGaussian(lam), 0.01, chains=C, seed=seed),
             lambda c: osamp.MALA(om.DiagGaussian(lam), 0.01, seed=key(c)), 4)
@@ -519,7 +519,7 @@ def test_odd_shapes_all_samplers_vs_oracle(ops, C, D):
             lambda c: osamp.DrGhmcDiag(om.DiagGaussian(lam), *args, seed=key(c)), 6)
     if D >= 2:
         for fused in (True, False):
-            compare(bk.DrGhmcDiag(bk.Funnel(D), *args, chains=C, seed=seed, fuse_builtin=fused),
+            compare(bk.DrGhmcDiag(bk.Funnel(D), *args, chains=C, seed=seed, path="auto" if fused else "step"),
                     lambda c: osamp.DrGhmcDiag(om.Funnel(D), *args, seed=key(c)), 5, exact=False, tol=funnel_tol)
     # dense metric on a ragged shape (MFMA tiles with bounds checks)
     if D <= 64:
@@ -534,7 +534,7 @@ def test_moments_many_chains_hmc_and_mala(ops):
     lam = np.array([1.0, 4.0, 0.25])
     for s, burn, keep in (
         (bk.HMCDiag(bk.DiagGaussian(lam), 0.25, 10, chains=8192, seed=12), 20, 30),
-        (bk.HMCDiag(bk.DiagGaussian(lam), 0.25, 10, chains=8192, seed=12, fuse_builtin=False), 20, 30),
+        (bk.HMCDiag(bk.DiagGaussian(lam), 0.25, 10, chains=8192, seed=12, path="step"), 20, 30),
         (bk.MALA(bk.DiagGaussian(lam), 0.2, chains=8192, seed=13), 150, 50),
     ):
         acc = []
@@ -672,7 +672,7 @@ def test_long_run_stays_bit_identical_to_the_oracle(ops, alg):
     C, D, N, seed = 96, 40, 4000, 8675309
     lam = np.logspace(0, 0.7, D)
     if alg == "hmc":
-        s = bk.HMCDiag(bk.DiagGaussian(lam), 0.2, 3, chains=C, seed=seed, fuse_builtin=False)
+        s = bk.HMCDiag(bk.DiagGaussian(lam), 0.2, 3, chains=C, seed=seed, path="step")
         mk = lambda sd: osamp.HMCDiag(om.DiagGaussian(lam), 0.2, 3, seed=sd)  # noqa: E731
     elif alg == "mala":
         s = bk.MALA(bk.DiagGaussian(lam), 0.05, chains=C, seed=seed)
@@ -732,7 +732,7 @@ def test_plain_c_host_program_equals_the_python_driver(ops):
     accept = float(lines[0].split()[-1])
     cols = {int(ln.split("]")[0].split("[")[1]): np.array([int(w, 16) for w in ln.split()[1:]], dtype=np.uint64)
             for ln in lines[1:]}
-    s = bk.HMCDiag(bk.DiagGaussian(np.linspace(1.0, 2.0, D)), 0.05, L, chains=C, seed=seed, fuse_builtin=False,
+    s = bk.HMCDiag(bk.DiagGaussian(np.linspace(1.0, 2.0, D)), 0.05, L, chains=C, seed=seed, path="step",
                    prefetch_rng=False, graph=False)
     for _ in range(draws):
         th, _ = s.sample()
@@ -745,9 +745,9 @@ def test_plain_c_host_program_equals_the_python_driver(ops):
 def test_placement_tuning_is_only_a_choice_of_buffers(ops):
     """tune_placement picks which scratch allocation plays which role by timing; draws are unchanged."""
     lam = np.logspace(0, 1, 40)
-    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, fuse_builtin=False, graph=False,
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, path="step", graph=False,
                    tune_placement=False)
-    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, fuse_builtin=False, graph=False,
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 7, chains=700, seed=2, path="step", graph=False,
                    tune_placement=True)
     assert a.placement is None and b.placement["assignments_tried"] == bk.HMCDiag.TUNE_PLACEMENT_TRIALS
     for n in range(6):
@@ -764,7 +764,7 @@ def test_placement_tuning_leaves_the_users_allocator_alone(ops):
     import gc
 
     lam = np.logspace(0, 1, 64)
-    mk = lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 3, chains=4096, seed=2, fuse_builtin=False, graph=False,  # noqa: E731
+    mk = lambda: bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 3, chains=4096, seed=2, path="step", graph=False,  # noqa: E731
                             tune_placement=True)
     mk().sample()   # (first use: code objects, the runtime's own pools)
     gc.collect()
@@ -840,7 +840,7 @@ def test_mala_step_kernel_with_the_density_inlined_equals_the_model_opaque_pair(
         models.append(lambda: bk.TorchModel(lambda Th: -0.5 * (Th * Th * lam_d).sum(dim=1), D, compile=True))
     for mi, model_of in enumerate(models):
         for kw in (dict(prefetch_rng=False, graph=False), dict(prefetch_rng=True, graph=False), dict(graph=True)):
-            a = bk.MALA(model_of(), eps, chains=C, seed=78, two_pass=True, fuse_builtin=False, prefetch_rng=False, graph=False)
+            a = bk.MALA(model_of(), eps, chains=C, seed=78, two_pass=True, path="step", prefetch_rng=False, graph=False)
             b = bk.MALA(model_of(), eps, chains=C, seed=78, two_pass=True, **kw)
             assert b._sep_step and not a._sep_step and "recomputed" in b.path, (mi, b.path)
             for n in range(6):
@@ -855,7 +855,7 @@ def test_mala_step_kernel_with_the_density_inlined_equals_the_model_opaque_pair(
             assert torch.equal(a._log_p_grad_theta, b._log_p_grad_theta) and torch.equal(a._log_p_theta, b._log_p_theta)
             if mi == 0 and not kw.get("graph"):   # checkpoint of the inlined path -> resumed on the model-opaque one
                 sd = b.state_dict()
-                c = bk.MALA(model_of(), eps, chains=C, seed=1, two_pass=True, fuse_builtin=False, graph=False)
+                c = bk.MALA(model_of(), eps, chains=C, seed=1, two_pass=True, path="step", graph=False)
                 c.load_state_dict(sd)
                 for n in range(3):
                     tb, lb = b.sample()
@@ -876,7 +876,7 @@ def test_mala_inlined_step_narrow_workgroups_give_the_same_draws():
         "import bayes_kit_amd as bk\n"
         "for C, D in ((130, 129), (48, 1024), (4096, 100)):\n"
         "    lam = np.logspace(0, 1.5, D)\n"
-        "    a = bk.MALA(bk.DiagGaussian(lam), 0.3 / D, chains=C, seed=5, two_pass=True, fuse_builtin=False)\n"
+        "    a = bk.MALA(bk.DiagGaussian(lam), 0.3 / D, chains=C, seed=5, two_pass=True, path='step')\n"
         "    b = bk.MALA(bk.DiagGaussian(lam), 0.3 / D, chains=C, seed=5, two_pass=True)\n"
         "    assert b._sep_step and not a._sep_step\n"
         "    for n in range(6):\n"
@@ -895,8 +895,8 @@ def test_whole_draw_hmc_rebinds_its_state_and_keeps_returned_draws(ops):
     state (bk_blend_columns): draws handed out earlier are never written again, not by later draws and
     not by load_state_dict(); the chain equals the in-place path's bit for bit."""
     lam = np.logspace(0, 1, 48)
-    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, fuse_builtin=False)
-    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, fuse_builtin=True)
+    a = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, path="step")
+    b = bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 5, chains=130, seed=9, graph=False, path="auto")
     assert b._fused_draw and not a._fused
     kept, sd = [], None
     for n in range(8):
@@ -924,7 +924,7 @@ def test_identity_metric_is_not_multiplied_in_but_changes_nothing(ops, graph):
     D, C = 40, 130
     lam = np.logspace(0, 1, D)
     mk = lambda fused, metric: bk.HMCDiag(bk.DiagGaussian(lam), 0.05, 4, metric_diag=metric, chains=C, seed=21,
-                                          graph=graph and fused, fuse_builtin=fused)
+                                          graph=graph and fused, path="auto" if fused else "step")
     a, b, c = mk(False, np.ones(D)), mk(True, np.ones(D)), mk(True, None)
     assert b._fused_draw and b._metric_identity and a._metric_dev is not None
     for n in range(10):
@@ -1030,8 +1030,8 @@ def test_hmc_whole_draw_kernel_equals_step_by_step(ops, C, D):
                              (lambda: bk.IsoGaussian(D), None)):
         for prefetch in (False, True):
             kw = dict(metric_diag=metric, chains=C, seed=31, graph=False)
-            a = bk.HMCDiag(model_of(), 0.11, 5, fuse_builtin=False, prefetch_rng=False, **kw)
-            b = bk.HMCDiag(model_of(), 0.11, 5, fuse_builtin=True, prefetch_rng=prefetch, **kw)
+            a = bk.HMCDiag(model_of(), 0.11, 5, path="step", prefetch_rng=False, **kw)
+            b = bk.HMCDiag(model_of(), 0.11, 5, path="auto", prefetch_rng=prefetch, **kw)
             assert b._fused_draw and b._fused_zt == (D >= 32) and not a._fused
             for n in range(6):
                 ta, la = a.sample()
@@ -1130,12 +1130,12 @@ def test_drghmc_model_opaque_device_counts_equal_host_sized_and_one_launch(ops, 
     sizes, counts = [0.3, 0.1, 0.03, 0.01][:K], [3, 6, 12, 24][:K]
     for C in (700, 64):
         mk = lambda model, **kw: bk.DrGhmcDiag(model, K, sizes, counts, 0.3, chains=C, seed=5, **kw)  # noqa: E731
-        a = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False, fuse_steps=False)  # host-sized, gradient op per step
-        a1 = mk(bk.Funnel(D), device_counts=False, fuse_builtin=False)  # host-sized, {gradient, kick, drift} one launch
-        e0 = mk(bk.Funnel(D), fuse_builtin=False, fuse_steps=False)     # counted, gradient op per step, one hipGraph
+        a = mk(bk.Funnel(D), device_counts=False, path="opaque")  # host-sized, gradient op per step
+        a1 = mk(bk.Funnel(D), device_counts=False, path="step")  # host-sized, {gradient, kick, drift} one launch
+        e0 = mk(bk.Funnel(D), path="opaque")     # counted, gradient op per step, one hipGraph
         f = mk(bk.Funnel(D)) if D <= 129 else None                       # one launch per proposal (+ graph)
-        e = mk(bk.Funnel(D), fuse_builtin=False, graph=False)           # counted steps, eager
-        g = mk(bk.Funnel(D), fuse_builtin=False)                        # counted steps, one hipGraph (the default)
+        e = mk(bk.Funnel(D), path="step", graph=False)           # counted steps, eager
+        g = mk(bk.Funnel(D), path="step")                        # counted steps, one hipGraph (the default)
         p = mk(funnel_plugin(D))                                        # the user's plugin, counted, one hipGraph
         h = mk(funnel_plugin(D), device_counts=False)                   # the plugin, host-sized
         for s_ in (e, g, p, e0):
@@ -1188,9 +1188,9 @@ def test_drghmc_counted_steps_on_gaussians_with_metric(ops):
         lam, met = np.linspace(0.5, 3.0, D), np.linspace(0.8, 1.3, D)
         for model, kw in ((lambda: bk.DiagGaussian(lam), dict(metric_diag=met)), (lambda: bk.IsoGaussian(D), dict(prob_retry=False))):
             mk = lambda **k2: bk.DrGhmcDiag(model(), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, chains=C, seed=3, **kw, **k2)  # noqa: E731
-            a = mk(device_counts=False, fuse_builtin=False, fuse_steps=False)
-            g = mk(fuse_builtin=False, fuse_steps=False)
-            h = mk(fuse_builtin=False)
+            a = mk(device_counts=False, path="opaque")
+            g = mk(path="opaque")
+            h = mk(path="step")
             f = mk()
             assert g._dev_counts and g._use_graph and not g._one_launch and not a._dev_counts and h._step_hook and not g._step_hook
             assert f._one_launch == (D <= 128) and f._dev_counts

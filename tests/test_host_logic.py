@@ -32,7 +32,7 @@ def test_many_chain_driver_vs_golden(name):
 
 @pytest.mark.parametrize("name", [n for n in MANY if n.startswith("hmc")])
 def test_many_chain_driver_vs_golden_step_by_step(name):
-    s = check_many_chain(name, FakeOps(), fuse_builtin=False)
+    s = check_many_chain(name, FakeOps(), path="step")
     assert not s._fused
 
 
@@ -323,7 +323,7 @@ def test_batched_model_output_is_validated():
 
     ops = FakeOps()
     a = bk.HMCDiag(F32(), 0.1, 3, chains=5, seed=1, ops=ops)
-    b = bk.HMCDiag(bk.IsoGaussian(4, ops=ops), 0.1, 3, chains=5, seed=1, fuse_builtin=False, ops=ops)
+    b = bk.HMCDiag(bk.IsoGaussian(4, ops=ops), 0.1, 3, chains=5, seed=1, path="step", ops=ops)
     ta, _ = a.sample()
     tb, _ = b.sample()
     np.testing.assert_allclose(ta.numpy(), tb.numpy(), rtol=1e-6)  # gradient rounded through f32
@@ -445,7 +445,7 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
     # model-opaque: the gradient a separate, COUNTED op per leapfrog step (drghmc.py:280-283), lane counts on the device
     ops_o = FakeOps()
     o = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_o), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,
-                      fuse_builtin=False, ops=ops_o)
+                      path="step", ops=ops_o)
     assert b._dev_counts and not a._dev_counts and b._one_launch
     assert o._dev_counts and not o._one_launch and not o._fused and o.host_syncs_per_draw == 0
     seen = set()
@@ -477,9 +477,9 @@ def test_drghmc_counted_steps_on_a_gaussian_with_metric_equal_host_sized_launche
     met = np.linspace(0.8, 1.3, 9)
     mk = lambda ops, dc, **kw: bk.DrGhmcDiag(bk.DiagGaussian(lam, ops=ops), 3, [0.9, 0.4, 0.15], [2, 4, 6], 0.5, metric_diag=met,  # noqa: E731
                                              chains=33, seed=3, prob_retry=False, device_counts=dc, ops=ops, **kw)
-    a = mk(FakeOps(), False, fuse_builtin=False, fuse_steps=False)
-    o = mk(FakeOps(), True, fuse_builtin=False, fuse_steps=False)
-    h = mk(FakeOps(), True, fuse_builtin=False)
+    a = mk(FakeOps(), False, path="opaque")
+    o = mk(FakeOps(), True, path="opaque")
+    h = mk(FakeOps(), True, path="step")
     f = mk(FakeOps(), True)
     assert o._dev_counts and not o._one_launch and not a._dev_counts and h._step_hook and not o._step_hook and f._one_launch
     for n in range(12):

@@ -7,11 +7,18 @@ P, I = ctypes.c_void_p, ctypes.c_int64
 
 
 def load(path, snap_arg=True):
+    """abi: --old-abi = before the `snapshot` argument; round 6 added `max_workgroups` (BK_ZIG_ABI=r5 for an older build)."""
+    import os
     lib = ctypes.CDLL(path)
     lib.bk_rng_init_philox.argtypes = [P, I, ctypes.c_uint64, ctypes.c_uint64, I, P]
-    n = 9 if snap_arg else 8
-    lib.bk_normals_chain_major.argtypes = [ctypes.c_int, P, I, P, I, I, I] + [P] * (n - 7)
-    lib._tail = (None, ) if snap_arg else ()
+    r6 = snap_arg and not (os.environ.get("BK_ZIG_ABI") == "r5" or "base" in os.path.basename(path))
+    if r6:
+        lib.bk_normals_chain_major.argtypes = [ctypes.c_int, P, I, P, I, I, I, P, I, P]
+        lib._tail = (None, 0)
+    else:
+        n = 9 if snap_arg else 8
+        lib.bk_normals_chain_major.argtypes = [ctypes.c_int, P, I, P, I, I, I] + [P] * (n - 7)
+        lib._tail = (None, ) if snap_arg else ()
     return lib
 
 

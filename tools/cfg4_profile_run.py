@@ -30,9 +30,9 @@ elif opaque in ("lanes", "lanes_fused"):  # the funnel as a lane-spread density 
     import bench_secondary as bs
     model = bk.CTarget.from_source(bs.FUNNEL_LANES_SRC, D, form="lanes", head=1)
     if opaque == "lanes":
-        kw["fuse_builtin"] = False
+        kw["path"] = "step"
 elif opaque != "0":
-    kw["fuse_builtin"] = False
+    kw["path"] = "step"
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
                   device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
                   fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)

@@ -7,7 +7,7 @@ import torch
 import bayes_kit_amd as bk
 C, D, N = int(os.environ.get("C", 65536)), int(os.environ.get("D", 1024)), int(os.environ.get("N", 20))
 metric = np.ones(D) if os.environ.get("METRIC", "1") == "1" else None  # (BASELINE config 3: diag metric of ones)
-s = bk.HMCDiag(bk.DiagGaussian(np.logspace(0, 4, D)), 0.006, 64, metric_diag=metric, chains=C, seed=1, fuse_builtin=True,
+s = bk.HMCDiag(bk.DiagGaussian(np.logspace(0, 4, D)), 0.006, 64, metric_diag=metric, chains=C, seed=1, path="auto",
                prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None))
 for _ in range(5):
     s.sample()

@@ -9,7 +9,7 @@ lam = torch.logspace(0, 4, D, dtype=torch.float64)
 s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, graph=os.environ.get("GRAPH", "0") == "1",
             prefetch_rng={"0": False, "1": True}.get(os.environ.get("PREFETCH", ""), None),
             two_pass={"0": False, "1": True}.get(os.environ.get("TWO_PASS", ""), None),
-            fuse_builtin=os.environ.get("INLINED", "1") == "1")  # INLINED=0: the model-opaque pair {gradient op, bk_mala_step}
+            path="auto" if os.environ.get("INLINED", "1") == "1" else "opaque")  # INLINED=0: the model-opaque pair {gradient op, bk_mala_step}
 for k in ("serialize_step", "generate_with", "generator_workgroups"):   # e.g. serialize_step=0 generate_with=step
     if os.environ.get(k):
         setattr(s, k, os.environ[k] if k == "generate_with" else int(os.environ[k]))

@@ -9,7 +9,7 @@ C, D = 65536, 1024
 lam = torch.logspace(0, 4, D, dtype=torch.float64)
 
 def run(fuse, **attrs):
-    s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, fuse_builtin=fuse)
+    s = bk.MALA(bk.DiagGaussian(lam), 5e-5, chains=C, seed=7, path="auto" if fuse else "opaque")
     for k, v in attrs.items():
         setattr(s, k, v)
     s._theta_dc.mul_((1.0 / torch.sqrt(lam)).cuda()[:, None])
