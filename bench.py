@@ -934,7 +934,7 @@ def run_rank(args):
         from bench_secondary import run_secondary
 
         out["secondary"] = run_secondary(ctx,
-            ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"])
+            ["cfg2", "cfg4", "mala", "torch_model", "cfg5"] if world == 1 else ["cfg4"], extras=args.full_secondary)
     if cpu is not None:
         out["cpu_baseline"] = cpu
     if pinned is not None:
@@ -962,6 +962,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-fused-extra", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs' records (N=1 only)")
+    ap.add_argument("--full-secondary", action="store_true",
+                    help="also the provider variants (plugin / from-source / traced models) of configs 4 and 3: what "
+                         "--only cfg4 / --only torch_model run; the default line keeps the entries SURVEY 8's rows need")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling leg (N>1 only)")
     ap.add_argument("--no-strong-shard", action="store_true",
                     help="skip config 3 at the per-rank shard sizes of the metric (8,192 / 16,384 / 32,768 chains; N=1 only)")

@@ -104,7 +104,7 @@ __device__ double bk_chain(const BkTheta& th, const BkGrad& g, i64 D, const doub
 """
 
 
-def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_length=True):
+def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_length=True, extras=True):
     """configs[3]: Neal's funnel D=101, DRGHMC K=3, 32,768 chains PER RANK (chain ids rank*C ..), R-hat over
     ALL ranks' chains and the summed ESS through the process group (bayes_kit/rhat.py:163-171: the
     cross-chain reduction north_star assigns to RCCL)."""
@@ -179,18 +179,23 @@ def bench_cfg4(ctx, draws=40, warmup=3, chains=32768, full_rhat=False, spec_leng
                           "(advance)", "timed_draws_follow_warmup_draws": warmup}
     if full_rhat:
         out["rhat"] = [float(v) for v in rh]
-    try:
-        out["model_opaque"] = bench_cfg4_model_opaque(ctx, C, D, warmup)
-    except Exception as e:  # context only
-        out["model_opaque"] = {"error": repr(e)}
-    try:
-        out["compiled_source_fused"] = bench_cfg4_compiled_source(ctx, C, D, warmup, draws)
-    except Exception as e:  # context only
-        out["compiled_source_fused"] = {"error": repr(e)}
-    try:
-        out["hmc_on_funnel"] = bench_hmc_lanes(ctx, C, D)
-    except Exception as e:  # context only
-        out["hmc_on_funnel"] = {"error": repr(e)}
+    # (extras: the provider variants of the same draws -- plugin, densities compiled from source, plain HMC on the funnel;
+    # `bench.py --only cfg4` and `--full-secondary` run them, the default line keeps what SURVEY 8's rows need)
+    if extras:
+        try:
+            out["model_opaque"] = bench_cfg4_model_opaque(ctx, C, D, warmup)
+        except Exception as e:  # context only
+            out["model_opaque"] = {"error": repr(e)}
+        try:
+            out["compiled_source_fused"] = bench_cfg4_compiled_source(ctx, C, D, warmup, draws)
+        except Exception as e:  # context only
+            out["compiled_source_fused"] = {"error": repr(e)}
+        try:
+            out["hmc_on_funnel"] = bench_hmc_lanes(ctx, C, D)
+        except Exception as e:  # context only
+            out["hmc_on_funnel"] = {"error": repr(e)}
+    else:
+        out["extras"] = "model_opaque / compiled_source_fused / hmc_on_funnel: python bench.py --only cfg4 (or --full-secondary)"
     if spec_length and ctx.world == 1 and C >= 32768:
         try:
             out["spec_length"] = bench_cfg4_spec_length(ctx, C, D)
@@ -480,7 +485,7 @@ def bench_mala(ctx, draws=20, warmup=3, chains=C_CFG3):
     return out
 
 
-def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
+def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3, extras=True):
     """Config-3 workload with the gradient supplied by user PyTorch code through autograd."""
     import torch
 
@@ -621,6 +626,9 @@ def bench_torch_model(ctx, draws=2, warmup=1, chains=C_CFG3):
         out["traced_source"] = {"error": repr(e)}
     # ... and a HIERARCHICAL density written in PyTorch (Neal's funnel, config-4 shape): traced into the lane-spread
     # form (trace_lanes.py), every delayed-rejection proposal one launch -- against the same function through autograd
+    if not extras:
+        out["extras"] = "traced_hierarchical / traced_coupled (the tracers beyond a separable density): python bench.py --only torch_model (or --full-secondary)"
+        return out
     try:
         Df, Cf = 101, 32768
 
@@ -790,10 +798,11 @@ def run_secondary(ctx, which, **kw):
     table = {"cfg2": bench_cfg2, "cfg4": bench_cfg4, "mala": bench_mala, "torch_model": bench_torch_model,
              "cfg5": bench_cfg5}
     out = {}
+    extras = kw.pop("extras", True)
     for name in which:
         t0 = time.perf_counter()
         try:
-            out[name] = table[name](ctx, **kw)
+            out[name] = table[name](ctx, **dict(kw, extras=extras) if name in ("cfg4", "torch_model") else kw)
         except Exception as e:  # a secondary figure must never cost the headline line
             out[name] = {"error": repr(e)}
         out[name]["bench_wall_s"] = round(time.perf_counter() - t0, 2)
