@@ -499,6 +499,13 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
     import subprocess
 
     text = _source_text(user_source, form, int(dims), int(head), stage)
+    rec = os.environ.get("BK_SOURCE_RECORD")
+    if rec:   # (a log of what was asked for, one JSON object per line: `prewarm_sources` builds such a list in parallel)
+        import json
+
+        with open(rec, "a") as f:
+            f.write(json.dumps(dict(user_source=user_source, form=form, contract=bool(contract), dims=int(dims),
+                                    head=int(head), stage=stage)) + "\n")
     csrc = _csrc_dir()
     inc = os.path.abspath(os.path.join(csrc, "..", "..", "include"))
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
@@ -548,6 +555,41 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
             except OSError:
                 pass
     return lib
+
+
+def prewarm_sources(specs, workers=None):
+    """Build the libraries of many from_source densities AHEAD, in parallel (one hipcc each, `workers` at a time): a job of
+    several models -- or a test-suite -- then finds them in the cache instead of compiling them one after the other at
+    construction.  specs: dicts with the arguments of a from_source call as `BK_SOURCE_RECORD=<file>` logs them
+    (user_source, form, contract, dims, head, stage).  Returns (built or found, failed)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
+    seen, todo = set(), []
+    for sp in specs:
+        key = (sp["user_source"], sp["form"], bool(sp.get("contract", False)), int(sp["dims"]), int(sp.get("head", 0)),
+               sp.get("stage", "auto"))
+        if key not in seen:
+            seen.add(key)
+            todo.append(key)
+    if workers is None:
+        try:
+            workers = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            workers = os.cpu_count() or 1
+    ok = bad = 0
+
+    def one(key):
+        try:
+            _compile_source_target(*key)
+            return True
+        except _lib.BkHipError:
+            return False
+
+    with ThreadPoolExecutor(max_workers=max(1, min(int(workers), 32))) as ex:
+        for good in ex.map(one, todo):
+            ok, bad = ok + bool(good), bad + (not good)
+    return ok, bad
 
 
 def _bind_source_fast_paths(t):
