@@ -349,6 +349,23 @@ def device_identity(index):
     return out
 
 
+def _device_record(index, clocks):
+    """The `device` object of the line; whatever cannot be read is None (it must never cost the headline)."""
+    rec = {"name": None, "identity": None, "clocks": None, "lib_sha256_16": None}
+    try:
+        import torch
+
+        rec["name"] = torch.cuda.get_device_name(index)
+    except Exception:
+        pass
+    for key, fn in (("identity", lambda: device_identity(index)), ("clocks", clocks.summary), ("lib_sha256_16", lib_hash)):
+        try:
+            rec[key] = fn()
+        except Exception:
+            pass
+    return rec
+
+
 class ClockSampler:
     """Shader / memory clock of one card sampled from sysfs by a sleeping thread while a timed region runs (a read every
     `period` seconds: a few dozen samples per region, no HIP, nothing on the GPU's queues)."""
@@ -356,20 +373,42 @@ class ClockSampler:
     def __init__(self, index, period=0.02):
         import threading
 
-        cards = _amd_cards()
+        try:
+            cards = _amd_cards()
+        except Exception:
+            cards = []
         self._dev = cards[index] if index < len(cards) else None
-        self._period, self._stop, self.sclk, self.mclk = period, threading.Event(), [], []
+        self._period, self._stop, self.sclk, self.mclk, self.power = period, threading.Event(), [], [], []
+        # hwmon reports the clocks the part actually runs at (freq1_input / freq2_input, Hz) and the socket power; the
+        # pp_dpm_* files only say which DPM level is selected
+        self._hw = None
+        if self._dev:
+            import glob
+
+            hw = sorted(glob.glob(os.path.join(self._dev, "hwmon", "hwmon*")))
+            self._hw = hw[0] if hw else None
         self._thread = threading.Thread(target=self._run, daemon=True) if self._dev else None
 
     def _run(self):
         while not self._stop.is_set():
-            a = _current_mhz(os.path.join(self._dev, "pp_dpm_sclk"))
-            b = _current_mhz(os.path.join(self._dev, "pp_dpm_mclk"))
+            a = self._hwmon("freq1_input", 1e-6) or _current_mhz(os.path.join(self._dev, "pp_dpm_sclk"))
+            b = self._hwmon("freq2_input", 1e-6) or _current_mhz(os.path.join(self._dev, "pp_dpm_mclk"))
+            w = self._hwmon("power1_average", 1e-6) or self._hwmon("power1_input", 1e-6)
+            if w is not None:
+                self.power.append(w)
             if a is not None:
                 self.sclk.append(a)
             if b is not None:
                 self.mclk.append(b)
             self._stop.wait(self._period)
+
+    def _hwmon(self, name, scale):
+        if not self._hw:
+            return None
+        try:
+            return float(open(os.path.join(self._hw, name)).read()) * scale
+        except (OSError, ValueError):
+            return None
 
     def __enter__(self):
         if self._thread:
@@ -387,7 +426,9 @@ class ClockSampler:
                 return None
             w = sorted(v)
             return {"min": w[0], "median": w[len(w) // 2], "max": w[-1], "samples": len(w)}
-        return {"sclk_mhz": stat(self.sclk), "mclk_mhz": stat(self.mclk), "source": "sysfs pp_dpm_sclk / pp_dpm_mclk during the timed region"}
+        return {"sclk_mhz": stat(self.sclk), "mclk_mhz": stat(self.mclk), "power_w": stat(self.power),
+                "source": ("sysfs hwmon freq1_input / freq2_input / power1_average" if self._hw else
+                           "sysfs pp_dpm_sclk / pp_dpm_mclk (selected DPM level)") + " during the timed region"}
 
 
 def _cpu_model():
@@ -762,8 +803,7 @@ def run_rank(args):
         # whole-path figure: 56*D algorithmic bytes per chain-step over the wall clock
         "path_hbm_frac": value / world * 56.0 * D / 1e9 / HBM_PEAK_GBPS,
         # which box and at which clocks (box-to-box spread of this pool is a few per cent: VERDICT r5 item 7)
-        "device": {"name": torch.cuda.get_device_name(ctx.local), "identity": device_identity(ctx.local),
-                   "clocks": clocks.summary(), "lib_sha256_16": lib_hash()},
+        "device": _device_record(ctx.local, clocks),
     }
     if timed:
         kd = [a.elapsed_time(b) for a, b in timed["bk_leapfrog_kick_drift"]]

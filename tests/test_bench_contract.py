@@ -66,6 +66,16 @@ def test_device_identity_and_clock_sampler_read_sysfs_only(tmp_path, monkeypatch
         time.sleep(0.05)
     sm = c.summary()
     assert sm["sclk_mhz"]["median"] == 2104.0 and sm["mclk_mhz"]["max"] == 2000.0 and sm["sclk_mhz"]["samples"] >= 2
+    assert sm["power_w"] is None and "pp_dpm" in sm["source"]
+    hw = dev / "hwmon" / "hwmon3"           # with hwmon: the clocks the part runs at, and the power
+    hw.mkdir(parents=True)
+    (hw / "freq1_input").write_text("1987000000\n")
+    (hw / "freq2_input").write_text("2000000000\n")
+    (hw / "power1_average").write_text("742000000\n")
+    with bench.ClockSampler(0, period=0.005) as c:
+        time.sleep(0.03)
+    sm = c.summary()
+    assert sm["sclk_mhz"]["median"] == 1987.0 and sm["power_w"]["max"] == 742.0 and "hwmon" in sm["source"]
     with bench.ClockSampler(3) as c:   # no such card: an empty summary, no thread
         pass
     assert c.summary()["sclk_mhz"] is None
