@@ -427,6 +427,7 @@ class ClockSampler:
             w = sorted(v)
             return {"min": w[0], "median": w[len(w) // 2], "max": w[-1], "samples": len(w)}
         return {"sclk_mhz": stat(self.sclk), "mclk_mhz": stat(self.mclk), "power_w": stat(self.power),
+                "power_cap_w": self._hwmon("power1_cap", 1e-6),
                 "source": ("sysfs hwmon freq1_input / freq2_input / power1_average" if self._hw else
                            "sysfs pp_dpm_sclk / pp_dpm_mclk (selected DPM level)") + " during the timed region"}
 
