@@ -14,6 +14,12 @@
  *   - Arithmetic is IEEE fp64 with every * and + individually rounded (the library is
  *     built with -ffp-contract=off) in the operation order of the cited reference lines,
  *     so elementwise results are bit-identical to the reference's NumPy expressions.
+ *   - Two FORMS of every streaming kernel, one entry point: an even number of chains, an even ld and 16-byte aligned
+ *     pointers get the 16-bytes-per-lane form (two chains per lane: `k_*_v2` in the sources -- what the many-chain
+ *     samplers always pass); an odd chain count, an odd pitch or an unaligned view gets the 8-byte form (`k_*`), same
+ *     arithmetic, same results.  The split is by SHAPE, decided inside the entry point (bk_leapfrog_kick_drift,
+ *     bk_leapfrog_finish, bk_select_columns, bk_blend_columns, bk_welford_update, the Gaussian targets); the `_n`
+ *     variants are the 8-byte form sized by a device-side lane count.  Neither is a superseded generation of the other.
  *
  * Each entry point cites the reference code (flatironinstitute/bayes-kit) it replaces.
  */
