@@ -203,3 +203,29 @@ def test_generated_libraries_match_the_header_of_their_abi(cache):
 
     subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", "-I", os.path.join(root, "include"),
                            os.path.join(root, "include", "bkhip_source.h")])
+
+
+def test_prewarm_builds_a_list_of_sources_in_parallel_and_records_what_was_asked_for(cache, tmp_path, monkeypatch):
+    """targets.prewarm_sources: a list of from_source specs (as BK_SOURCE_RECORD logs them) built concurrently; duplicates once;
+    a source that does not compile is counted, not raised; afterwards the libraries are cache hits."""
+    import json
+    import time
+
+    rec = tmp_path / "asked.jsonl"
+    monkeypatch.setenv("BK_SOURCE_RECORD", str(rec))
+    specs = [dict(user_source=TERM, form="elementwise", contract=False, dims=12, head=0, stage="auto"),
+             dict(user_source=CHAIN, form="chain", contract=False, dims=12, head=0, stage="auto"),
+             dict(user_source=TERM, form="elementwise", contract=False, dims=12, head=0, stage="auto"),   # duplicate
+             dict(user_source="__device__ void bk_term(double th) { this does not compile }", form="elementwise",
+                  contract=False, dims=12, head=0, stage="auto")]
+    ok, bad = T.prewarm_sources(specs, workers=3)
+    assert (ok, bad) == (2, 1)
+    asked = [json.loads(line) for line in open(rec)]
+    assert len(asked) == 3 and {a["form"] for a in asked} == {"elementwise", "chain"}   # (the duplicate was not asked for twice)
+    t0 = time.perf_counter()
+    lib = T._compile_source_target(TERM, "elementwise", False, 12, 0)
+    assert os.path.exists(lib) and time.perf_counter() - t0 < 2.0     # a cache hit
+    # the committed manifest of the GPU test-suite parses and has the fields prewarm_sources reads
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    manifest = [json.loads(line) for line in open(os.path.join(root, "tests", "golden", "from_source_manifest.jsonl"))]
+    assert len(manifest) > 40 and all({"user_source", "form", "dims"} <= set(m) for m in manifest)
