@@ -196,11 +196,11 @@ __device__ __forceinline__ bool zig_fast2(uint64_t w, const ZigKW* kw, double& x
   return rabs < e.ki;  // 99.2 %
 }
 
-// Positional access to the words that follow a lane's own block: offset j counts from the lane's first word.  Words
-// of the segment's window come from the LDS copy; beyond it the block is generated on demand (a wedge on the last word
-// of a window: 3 % of the passes; a long tail attempt).  NOT inlined: inlined, the compiler hoists "the block after
-// mine" out of the branches that need it and every pass pays for a second Philox block (160 v_mad_u64_u32 in the
-// pass's main basic block instead of 80).
+// Positional access to the words that follow a lane's own: the segment's window is staged in LDS, `mine[j]` is word j
+// counted from the lane's first.  NOTHING generates words beyond the window: an inlined "block after mine" in the wedge and
+// tail branches is hoisted out of them by the compiler (common code of both) and every pass then pays for a second Philox
+// block -- 160 v_mad_u64_u32 in the pass's main basic block instead of 80 (the round-5 kernel).  The window's last word and
+// a tail that runs out of window are left to the next pass instead (zig_parallel_wave).
 // The ziggurat's tail (idx == 0: one word in 4,000): pairs of the words that follow until the tail test passes, read
 // from the segment's staged window (`mine` = the lane's first word there, `room` = words from it to the window's end).
 // len = 0: the window ran out before the test passed -- the caller starts the next window at this attempt instead.
