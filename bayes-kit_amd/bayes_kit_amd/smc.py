@@ -477,7 +477,12 @@ class TemperedLikelihoodSMC:
         if multi:
             self._resample_across_ranks(w, th)
         else:
-            self.last_ess = float((w.sum() ** 2 / (w * w).sum()).item())
+            tot = float(w.sum().item())
+            if not (tot > 0.0 and math.isfinite(tot)):
+                # (the reference: np.random.choice raises "probabilities contain NaN" / "do not sum to 1" here)
+                raise FloatingPointError(f"SMC reweighting at t = {t_next}: the weights sum to {tot} (every particle has zero "
+                                         "weight, or a log density is NaN / +inf): nothing to resample from")
+            self.last_ess = float((tot ** 2 / (w * w).sum()).item())
             ops.resample_indices(w, self._u, self._cdf, self._idx)   # smc.py:73: choice(p = w / w.sum()), its arithmetic
             ops.gather_columns(self._idx, th, self._prop_dc)         # thetas[idxs], smc.py:75
             if hasattr(self.kernel, "resampled"):

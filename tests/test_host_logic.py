@@ -527,6 +527,15 @@ def test_smc_reference_stream_refuses_what_the_reference_cannot_do():
                                  ops=FakeOps())
 
 
+def test_smc_reweighting_with_no_weight_left_raises_like_numpy_choice():
+    import torch
+
+    model = bk.TorchPriorLikelihoodModel(lambda T: -(T * T).sum(1), lambda T: torch.full((T.shape[0],), float("-inf"), dtype=torch.float64), 1)
+    smc = bk.TemperedLikelihoodSMC(model, 6, 3, np.zeros((6, 1)), bk.metropolis_kernel(0.1), seed=np.random.RandomState(3), ops=FakeOps())
+    with pytest.raises(FloatingPointError, match="weights sum to"):
+        smc.transition(1)
+
+
 def test_adaptive_ladder_accepts_zero_weight_particles():
     # a -inf log likelihood is a hard constraint (weight 0), not an error; NaN / +inf are
     import torch
