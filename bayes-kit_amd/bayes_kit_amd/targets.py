@@ -429,7 +429,33 @@ def _source_cache_dir():
             _PROCESS_CACHE_DIR = tempfile.mkdtemp(prefix="bayes_kit_amd_src_")  # (0700, unique: nobody can have planted it)
         return _PROCESS_CACHE_DIR
     _check_private(root, "the cache directory", True)
+    _check_ancestors(root)
     return root
+
+
+def _check_ancestors(path):
+    """The directories ABOVE the cache directory: whoever can rename or replace one of them can swap the whole cache under a
+    running process (a check of the leaf alone leaves that window).  Every ancestor must belong to this user or to root and
+    must not be writable by group or others -- unless it is sticky (/tmp-like: others cannot rename or delete an entry they
+    do not own, and the entry below it has just been checked to be ours)."""
+    import os
+    import stat
+
+    me = os.getuid()
+    p = os.path.realpath(path)
+    while True:
+        parent = os.path.dirname(p)
+        if parent == p:
+            return
+        st = os.stat(parent)
+        if st.st_uid not in (0, me):
+            raise _lib.BkHipError(f"CTarget.from_source: {parent}, a directory above the cache directory {path}, is owned by uid "
+                                  f"{st.st_uid} (neither this user nor root): refusing to load code from below it")
+        if (st.st_mode & 0o022) and not (st.st_mode & stat.S_ISVTX):
+            raise _lib.BkHipError(f"CTarget.from_source: {parent}, a directory above the cache directory {path}, is group- or "
+                                  f"world-writable without the sticky bit (mode {stat.S_IMODE(st.st_mode):o}): whoever can write "
+                                  "it can replace the cache; refusing to load code from below it")
+        p = parent
 
 
 _PROCESS_CACHE_DIR = None

@@ -229,3 +229,18 @@ def test_prewarm_builds_a_list_of_sources_in_parallel_and_records_what_was_asked
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     manifest = [json.loads(line) for line in open(os.path.join(root, "tests", "golden", "from_source_manifest.jsonl"))]
     assert len(manifest) > 40 and all({"user_source", "form", "dims"} <= set(m) for m in manifest)
+
+
+def test_cache_below_a_directory_others_can_write_is_refused(tmp_path, monkeypatch):
+    """a leaf that is private is not enough -- a group / world-writable directory ABOVE the cache (without the sticky
+    bit) lets somebody else swap the cache directory itself.  A sticky one (/tmp-like) is fine: the leaf is ours."""
+    loose = tmp_path / "shared"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    monkeypatch.setenv("BK_SOURCE_TARGET_DIR", str(loose / "cache"))
+    with pytest.raises(bk._lib.BkHipError, match="above the cache directory"):
+        T._source_cache_dir()
+    os.chmod(loose, 0o1777)   # sticky, like /tmp
+    assert T._source_cache_dir() == str(loose / "cache")
+    os.chmod(loose, 0o755)
+    assert T._source_cache_dir() == str(loose / "cache")
