@@ -419,17 +419,29 @@ def _source_cache_dir():
     else:
         base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
         root = os.path.join(base, "bayes_kit_amd")
+    global _PROCESS_CACHE_DIR
     try:
         os.makedirs(root, mode=0o700, exist_ok=True)
     except OSError:
         if explicit:
             raise
-        global _PROCESS_CACHE_DIR
         if _PROCESS_CACHE_DIR is None:
             _PROCESS_CACHE_DIR = tempfile.mkdtemp(prefix="bayes_kit_amd_src_")  # (0700, unique: nobody can have planted it)
         return _PROCESS_CACHE_DIR
     _check_private(root, "the cache directory", True)
-    _check_ancestors(root)
+    try:
+        _check_ancestors(root)
+    except _lib.BkHipError as e:
+        if explicit:
+            raise
+        # the default location sits below a directory somebody else can write: do not trust what is cached there, and do
+        # not fail either -- a fresh private directory serves this process (nothing is reused across processes then)
+        import warnings
+
+        warnings.warn(f"{e}; compiling into a private temporary directory instead (no cache across processes)", stacklevel=3)
+        if _PROCESS_CACHE_DIR is None:
+            _PROCESS_CACHE_DIR = tempfile.mkdtemp(prefix="bayes_kit_amd_src_")
+        return _PROCESS_CACHE_DIR
     return root
 
 

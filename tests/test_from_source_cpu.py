@@ -244,3 +244,17 @@ def test_cache_below_a_directory_others_can_write_is_refused(tmp_path, monkeypat
     assert T._source_cache_dir() == str(loose / "cache")
     os.chmod(loose, 0o755)
     assert T._source_cache_dir() == str(loose / "cache")
+
+
+def test_default_cache_below_a_loose_directory_falls_back_to_a_private_temporary_one(tmp_path, monkeypatch):
+    """The DEFAULT location ($XDG_CACHE_HOME) below a world-writable directory: not trusted, but not fatal either."""
+    loose = tmp_path / "xdg"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    monkeypatch.delenv("BK_SOURCE_TARGET_DIR", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(loose))
+    monkeypatch.setattr(T, "_PROCESS_CACHE_DIR", None)
+    with pytest.warns(UserWarning, match="private temporary directory"):
+        d = T._source_cache_dir()
+    assert not d.startswith(str(loose)) and stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    os.chmod(loose, 0o755)
