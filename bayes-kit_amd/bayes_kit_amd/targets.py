@@ -566,10 +566,14 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
     if os.path.lexists(lib):
         _check_private(lib, "the cached library", False)
         return lib
-    # (several ranks may compile the same source at once: everything is written under per-process names, the finished
-    # library is checked for its exports and only then published with an atomic rename)
-    src = os.path.join(root, f"t_{tag}.{os.getpid()}.hip")
-    tmp = lib + f".{os.getpid()}.tmp"
+    # (several ranks -- or several threads of prewarm_sources: two dims of one D-independent source -- may compile the same
+    # text at once: everything is written under per-process, per-thread names, the finished library is checked for its
+    # exports and only then published with an atomic rename)
+    import threading
+
+    me = f"{os.getpid()}.{threading.get_ident():x}"
+    src = os.path.join(root, f"t_{tag}.{me}.hip")
+    tmp = lib + f".{me}.tmp"
     try:
         fd = os.open(src, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
         with os.fdopen(fd, "w") as f:
@@ -595,11 +599,12 @@ def _compile_source_target(user_source: str, form: str, contract: bool, dims: in
     return lib
 
 
-def prewarm_sources(specs, workers=None):
+def prewarm_sources(specs, workers=None, errors=None):
     """Build the libraries of many from_source densities AHEAD, in parallel (one hipcc each, `workers` at a time): a job of
     several models -- or a test-suite -- then finds them in the cache instead of compiling them one after the other at
     construction.  specs: dicts with the arguments of a from_source call as `BK_SOURCE_RECORD=<file>` logs them
-    (user_source, form, contract, dims, head, stage).  Returns (built or found, failed)."""
+    (user_source, form, contract, dims, head, stage).  Returns (built or found, failed); `errors`: a list that receives
+    (form, dims, message tail) of every failed build."""
     import os
     from concurrent.futures import ThreadPoolExecutor
 
@@ -621,7 +626,9 @@ def prewarm_sources(specs, workers=None):
         try:
             _compile_source_target(*key)
             return True
-        except _lib.BkHipError:
+        except _lib.BkHipError as e:
+            if errors is not None:
+                errors.append((key[1], key[3], str(e)[-400:]))
             return False
 
     with ThreadPoolExecutor(max_workers=max(1, min(int(workers), 32))) as ex:

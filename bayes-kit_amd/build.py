@@ -80,7 +80,8 @@ def build_example_plugin(force=False, verbose=True):
     for name in PLUGINS:
         src = os.path.abspath(os.path.join(PLUGIN_DIR, name + ".hip"))
         lib = os.path.abspath(os.path.join(PLUGIN_DIR, "lib" + name + ".so"))
-        if force or _stale(lib, [src]):
+        public = [os.path.abspath(os.path.join(HERE, "..", "include", h)) for h in ("bkhip.h", "bkhip_math.h")]
+        if force or _stale(lib, [src] + public):  # (the plugins include the public headers: bk_exp lives there)
             cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                    src, "-o", lib]
             if verbose:

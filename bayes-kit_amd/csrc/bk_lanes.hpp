@@ -62,6 +62,7 @@ __device__ __forceinline__ double dpp_f64(double old, double src) {
 }
 constexpr int DPP_ROW_SHL = 0x100;  // + n: lane i reads lane i + n of its row
 constexpr int DPP_ROW_SHR = 0x110;  // + n: lane i reads lane i - n of its row
+constexpr int DPP_ROW_NEWBCAST = 0x150;  // + n: every lane reads lane n of its row (64-bit operands allowed)
 // the same for controls under which every lane that matters has a source lane: no `old` operand, so no copy
 // of the source in front of the move (lanes without a source read 0)
 template <int CTRL>
@@ -112,14 +113,15 @@ __device__ __forceinline__ double reduce_lanes(const double* cs) {
     const double c = dpp_f64_all<DPP_ROW_SHL + 8>(cs[0]);
     const double d = dpp_f64_all<DPP_ROW_SHL + 12>(cs[0]);
     q = ((cs[0] + b) + c) + d;
+    // lane 0 of the row adds q[0..3] in order and hands s to the whole row in ONE 64-bit move (row_newbcast): 19
+    // instructions for the reduction instead of the 25 of four quad broadcasts + two masked shifts -- the latency geometry
+    // runs one wavefront per SIMD, where the leapfrog step costs what it issues
+    const double s0 = ((q + dpp_f64_all<DPP_ROW_SHL + 1>(q)) + dpp_f64_all<DPP_ROW_SHL + 2>(q)) + dpp_f64_all<DPP_ROW_SHL + 3>(q);
+    return __builtin_amdgcn_update_dpp(s0, s0, DPP_ROW_NEWBCAST + 0, 0xF, 0xF, false);
   }
   // lane p of the quad holds q[p]
   double s = ((quad_bcast<0>(q) + quad_bcast<1>(q)) + quad_bcast<2>(q)) + quad_bcast<3>(q);
-  if (LPC == 16) {
-    // s is right in lanes 0..3 of the row: hand it to lanes 4..7, then lanes 0..7 hand it to 8..15
-    s = dpp_f64<DPP_ROW_SHR + 4, 0xF, 0x2>(s, s);
-    s = dpp_f64<DPP_ROW_SHR + 8, 0xF, 0xC>(s, s);
-  } else if (LPC == 8) {
+  if (LPC == 8) {
     // s is right in lanes 0..3 of each 8-lane group: hand it to lanes 4..7 (banks 1 and 3 of the row)
     s = dpp_f64<DPP_ROW_SHR + 4, 0xF, 0xA>(s, s);
   }
@@ -219,6 +221,7 @@ struct TrajArgs {
   unsigned long long* lanes_total; double* H_out; double* hh_out; uint8_t* live_out; unsigned traj_blocks;
   const double* params;
   int hmc_first;  // the FIRST kick as bayes_kit/hmc.py:46,48 writes it: (rho + (-h/2) t) + h t, instead of rho + (h/2) t
+  i64 auto_mid, auto_wide;  // geometry thresholds of a device-counted set (auto_geo())
 };
 
 // One whole delayed-rejection proposal (drghmc.py:319-346 -> :253-289) for n chains in ONE launch: gather chain
@@ -230,17 +233,31 @@ struct TrajArgs {
 // A wavefront-step costs ~580 / ~700 / ~1100 cycles with 16 / 8 / 4 lanes per chain and serves 4 / 8 / 16
 // chains; up to one wavefront per SIMD (1024 of them) the fewest cycles win, beyond that the fewest cycles per
 // chain: 16 lanes per chain below AUTO_MID lanes, 8 below AUTO_WIDE, 4 from there on.
+// (the thresholds travel with the launch -- TrajArgs -- so that tools/cfg4_geometry_scan.py can move them:
+// BK_LANES_AUTO_MID / BK_LANES_AUTO_WIDE, read once per process)
 constexpr i64 AUTO_MID = 4608, AUTO_WIDE = 12288;
+struct AutoGeo { i64 mid, wide; };
+static inline AutoGeo auto_geo() {
+  static const AutoGeo g = []() {
+    AutoGeo v = {AUTO_MID, AUTO_WIDE};
+    if (const char* e = getenv("BK_LANES_AUTO_MID")) v.mid = atoll(e);
+    if (const char* e = getenv("BK_LANES_AUTO_WIDE")) v.wide = atoll(e);
+    if (v.mid < 1) v.mid = 1;
+    if (v.wide < v.mid) v.wide = v.mid;
+    return v;
+  }();
+  return g;
+}
 
 // Workgroups a launch needs for a set of at most n chains.  geo = 4 / 8 / 16: that many lanes per chain.  geo = 0 (the kernel
 // picks the geometry from the count on the device): the most any admissible count needs -- fewer than AUTO_MID chains at 16 per
 // workgroup, fewer than AUTO_WIDE at 32, n at 64 -- a quarter of sizing for 16 lanes per chain throughout (surplus workgroups
 // exit after one scalar load and cost nothing measurable -- profiles/r5_cfg4_counted.md -- but fewer are never worse).
-static inline unsigned blocks_for(i64 n, int geo) {
+static inline unsigned blocks_for(i64 n, int geo, const AutoGeo& t) {
   if (geo != 0) return (unsigned)bk_cdiv(n, WAVES * (BK_WAVE / geo));
-  const i64 a = bk_cdiv(n < AUTO_MID ? n : AUTO_MID - 1, WAVES * (BK_WAVE / 16));
-  const i64 b = n < AUTO_MID ? 0 : bk_cdiv(n < AUTO_WIDE ? n : AUTO_WIDE - 1, WAVES * (BK_WAVE / 8));
-  const i64 c = n < AUTO_WIDE ? 0 : bk_cdiv(n, WAVES * (BK_WAVE / 4));
+  const i64 a = bk_cdiv(n < t.mid ? n : t.mid - 1, WAVES * (BK_WAVE / 16));
+  const i64 b = n < t.mid ? 0 : bk_cdiv(n < t.wide ? n : t.wide - 1, WAVES * (BK_WAVE / 8));
+  const i64 c = n < t.wide ? 0 : bk_cdiv(n, WAVES * (BK_WAVE / 4));
   const i64 m = a > b ? (a > c ? a : c) : (b > c ? b : c);
   return (unsigned)m;
 }
@@ -498,8 +515,8 @@ __global__ __launch_bounds__(BLOCK) void k_lane_traj(TrajArgs a, bk_scatter_job 
       if (g0.lanes_total) *reinterpret_cast<unsigned long long*>(g0.lanes_total) += (unsigned long long)n;
     }
   }
-  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= AUTO_WIDE)) traj_body<DEN, 4, SL, HM>(a, n, ghost, g0, lane, wave);
-  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= AUTO_MID)) traj_body<DEN, 8, SL, HM>(a, n, ghost, g0, lane, wave);
+  if (LPC_ARG == 4 || (LPC_ARG == 0 && n >= a.auto_wide)) traj_body<DEN, 4, SL, HM>(a, n, ghost, g0, lane, wave);
+  else if (LPC_ARG == 8 || (LPC_ARG == 0 && n >= a.auto_mid)) traj_body<DEN, 8, SL, HM>(a, n, ghost, g0, lane, wave);
   else traj_body<DEN, 16, SL, HM>(a, n, ghost, g0, lane, wave);
 }
 
@@ -572,14 +589,15 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
   }();
   // 16: 16 lanes per chain; 4: 4 lanes per chain; 0: the kernel decides from *n_dev
   int geo;
+  const AutoGeo thr = auto_geo();
   if (forced) geo = forced == 2 ? 16 : (forced == 3 ? 8 : 4);
-  else if (n_dev) geo = n >= AUTO_MID ? 0 : 16;
-  else geo = n >= AUTO_WIDE ? 4 : (n >= AUTO_MID ? 8 : 16);
-  const unsigned traj_blocks = n == 0 ? 0u : blocks_for(n, geo);
+  else if (n_dev) geo = n >= thr.mid ? 0 : 16;
+  else geo = n >= thr.wide ? 4 : (n >= thr.mid ? 8 : 16);
+  const unsigned traj_blocks = n == 0 ? 0u : blocks_for(n, geo, thr);
   const TrajArgs a = {theta_in, rho_in, grad_in, ld_in, src_index, theta_out, rho_out, grad_out, logp_out, kin_out,
                       ld_out, metric, h, (int)steps, n, D, n_dev, lanes_out,
                       reinterpret_cast<unsigned long long*>(lanes_total), H_out, h_out, live_out, traj_blocks, params,
-                      hmc_first ? 1 : 0};
+                      hmc_first ? 1 : 0, thr.mid, thr.wide};
   dim3 grid(traj_blocks + job_blocks);
 #define BKL_FT(LPC, R, M) k_lane_traj<DEN, LPC, R, M><<<grid, dim3(BLOCK), 0, s>>>(a, job, ghost, g0)
 #define BKL_FT_ROWS(R)                 \

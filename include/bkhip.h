@@ -765,7 +765,7 @@ int bk_host_normals(int rng_kind, uint64_t* state_words /*[BK_RNG_WORDS]*/, doub
                     int64_t n);
 int bk_host_uniforms(int rng_kind, uint64_t* state_words, double* out, int64_t n);
 double bk_host_log1p(double x);
-/* bk_exp of include/bkhip_math.h (fdlibm's e_exp.c: the funnel's exp, restated in oracle/rng.py), host build. */
+/* bk_exp of include/bkhip_math.h (the funnel's exp: a specified fma sequence, restated in oracle/rng.py), host build. */
 double bk_host_exp(double x);
 
 #ifdef __cplusplus

@@ -8,18 +8,26 @@
  * bit on the funnel fixtures (tests/test_gpu_samplers.py), and what is left between them and the reference is the
  * reference's own libm / BLAS.
  *
- * The algorithm, its thresholds and its constants are Sun fdlibm 5.3 `e_exp.c` (__ieee754_exp): argument reduction
- * x = k ln2 + r with ln2 split in two, r = hi - lo, the rational approximation exp(r) = 1 + r + r c / (2 - c) with
- * c = r - r^2 (P1 + r^2 (P2 + ... P5)), scaling by 2^k through the exponent field.  < 1 ulp.  Compile with
- * -ffp-contract=off (as the library is): every * and + below is one rounding.
- *   Copyright (C) 2004 by Sun Microsystems, Inc. All rights reserved.
- *   Permission to use, copy, modify, and distribute this software is freely granted,
- *   provided that this notice is preserved.                                   (see THIRD_PARTY.md)
+ * The sequence (every line one IEEE-754 operation, rounded to nearest even; fma = the fused multiply-add of IEEE 754-2008,
+ * ONE rounding -- v_fma_f64 on the device, fma() of the C library on the host, exact rational arithmetic in the oracle):
+ *
+ *     k = rint(x * log2(e))                                   x = k ln2 + r,  |r| <= ln2 / 2
+ *     r = fma(-k, LN2_HI, x);  r = fma(-k, LN2_LO, r)         ln2 = LN2_HI + LN2_LO to 107 bits (the first fma is exact)
+ *     q = 1/13!;  q = fma(q, r, 1/n!)  for n = 12 .. 2        Taylor: exp(r) = 1 + r + r^2 q, truncation < 0.04 ulp
+ *     p = fma(r * r, q, r);  p = p + 1
+ *     exp(x) = ldexp(p, k)                                     correctly rounded scaling, gradual underflow
+ *
+ * run on min(max(x, -746), 710): beyond those ldexp returns 0 / +inf by itself (so exp(x) = +inf from x = 709.7827128933841
+ * on, 0 below -745.1332191019412); NaN gives NaN.  Measured against the host libm's (correctly rounded in all but a
+ * handful of cases) exp: never more than 1 ulp off, equal for 91 % of arguments (tests/test_oracle_rng.py).
+ * A sequence with a division (the classical rational approximation of exp) costs the funnel's one-wavefront-per-SIMD
+ * trajectory kernels twice this one's time per leapfrog step (profiles/r6_cfg4_exp.md): on the device this is 20 instructions
+ * without a branch.
  */
 #ifndef BKHIP_MATH_H
 #define BKHIP_MATH_H
+#include <math.h>
 #include <stdint.h>
-#include <string.h>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define BKHIP_MATH_FN static inline __host__ __device__
@@ -27,56 +35,46 @@
 #define BKHIP_MATH_FN static inline
 #endif
 
+/* One step of the polynomial: q r + c with ONE rounding.  On the device the three-operand form is written out: the compiler
+ * otherwise picks the two-operand v_fmac_f64 and copies the coefficient into its destination first (11 extra moves per exp). */
+#if defined(__HIP_DEVICE_COMPILE__)
+static inline __device__ double bk_fma_(double a, double b, double c) {
+  double o;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c));
+  return o;
+}
+#else
+static inline double bk_fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
+
 BKHIP_MATH_FN double bk_exp(double x) {
-  const double one = 1.0, huge = 1.0e+300, twom1000 = 9.33263618503218878990e-302, /* 2**-1000 */
-      o_threshold = 7.09782712893383973096e+02, u_threshold = -7.45133219101941108420e+02,
-      ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00,
-      P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-      P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
-  uint64_t bits;
-  memcpy(&bits, &x, 8);
-  uint32_t hx = (uint32_t)(bits >> 32);
-  const uint32_t lx = (uint32_t)bits;
-  const int xsb = (int)((hx >> 31) & 1u); /* sign bit of x */
-  hx &= 0x7fffffffu;                      /* high word of |x| */
-  double hi = 0.0, lo = 0.0, t, c, y;
-  int k = 0;
-  if (hx >= 0x40862E42u) { /* |x| >= 709.78... */
-    if (hx >= 0x7ff00000u) {
-      if (((hx & 0xfffffu) | lx) != 0) return x + x; /* NaN */
-      return xsb == 0 ? x : 0.0;                     /* exp(+-inf) = {inf, 0} */
-    }
-    if (x > o_threshold) return huge * huge;         /* overflow */
-    if (x < u_threshold) return twom1000 * twom1000; /* underflow */
-  }
-  if (hx > 0x3fd62e42u) {   /* |x| > 0.5 ln2 */
-    if (hx < 0x3FF0A2B2u) { /* and |x| < 1.5 ln2 */
-      hi = xsb ? x + ln2HI : x - ln2HI;
-      lo = xsb ? -ln2LO : ln2LO;
-      k = 1 - xsb - xsb;
-    } else {
-      k = (int)(invln2 * x + (xsb ? -0.5 : 0.5));
-      t = (double)k;
-      hi = x - t * ln2HI; /* t*ln2HI is exact here */
-      lo = t * ln2LO;
-    }
-    x = hi - lo;
-  } else if (hx < 0x3e300000u) { /* |x| < 2**-28 */
-    if (huge + x > one) return one + x;
-  }
-  t = x * x;
-  c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
-  if (k == 0) return one - ((x * c) / (c - 2.0) - x);
-  y = one - ((lo - (x * c) / (2.0 - c)) - hi);
-  memcpy(&bits, &y, 8);
-  if (k >= -1021) {
-    bits += (uint64_t)(int64_t)k << 52; /* add k to y's exponent */
-    memcpy(&y, &bits, 8);
-    return y;
-  }
-  bits += (uint64_t)(int64_t)(k + 1000) << 52;
-  memcpy(&y, &bits, 8);
-  return y * twom1000;
+  const double log2e = 0x1.71547652b82fep+0, ln2_hi = 0x1.62e42fefa39efp-1, ln2_lo = 0x1.abc9e3b39803fp-56;
+  /* 1/n!, n = 2 .. 13, each rounded to nearest */
+  const double c2 = 0x1.0000000000000p-1, c3 = 0x1.5555555555555p-3, c4 = 0x1.5555555555555p-5,
+               c5 = 0x1.1111111111111p-7, c6 = 0x1.6c16c16c16c17p-10, c7 = 0x1.a01a01a01a01ap-13,
+               c8 = 0x1.a01a01a01a01ap-16, c9 = 0x1.71de3a556c734p-19, c10 = 0x1.27e4fb7789f5cp-22,
+               c11 = 0x1.ae64567f544e4p-26, c12 = 0x1.1eed8eff8d898p-29, c13 = 0x1.6124613a86d09p-33;
+  /* [-746, 710] holds every argument whose exp is neither 0 nor +inf; at the ends ldexp gives exactly those (NaN: below) */
+  const double xs = __builtin_fmin(__builtin_fmax(x, -746.0), 710.0);
+  const double k = __builtin_rint(xs * log2e);
+  double r = __builtin_fma(-k, ln2_hi, xs);
+  r = __builtin_fma(-k, ln2_lo, r);
+  double q = c13;
+  q = bk_fma_(q, r, c12);
+  q = bk_fma_(q, r, c11);
+  q = bk_fma_(q, r, c10);
+  q = bk_fma_(q, r, c9);
+  q = bk_fma_(q, r, c8);
+  q = bk_fma_(q, r, c7);
+  q = bk_fma_(q, r, c6);
+  q = bk_fma_(q, r, c5);
+  q = bk_fma_(q, r, c4);
+  q = bk_fma_(q, r, c3);
+  q = bk_fma_(q, r, c2);
+  double p = __builtin_fma(r * r, q, r);
+  p = p + 1.0;
+  const double y = __builtin_ldexp(p, (int)k);
+  return x != x ? x + x : y;
 }
 
 #endif /* BKHIP_MATH_H */

@@ -165,7 +165,7 @@ class FunnelCanonical(Funnel):
     then held to SURVEY 8c's 1e-9 over every draw, and the chaos-widened bound stays where it belongs: between this
     order and the reference's own ``np.dot`` (tests/test_oracle_golden.py).
 
-    exp() is the library's ``bk_exp`` (``oracle.rng.exp_fdlibm``): with the summation order AND the exponential shared,
+    exp() is the library's ``bk_exp`` (``oracle.rng.exp_bk``): with the summation order AND the exponential shared,
     the device and this oracle run the same sequence of rounded operations and agree BIT FOR BIT."""
 
     def _parts(self, theta):
@@ -176,9 +176,9 @@ class FunnelCanonical(Funnel):
             cs[i % 16] = cs[i % 16] + xi * xi
         q = [((cs[g] + cs[g + 4]) + cs[g + 8]) + cs[g + 12] for g in range(4)]
         s = ((q[0] + q[1]) + q[2]) + q[3]
-        from .rng import exp_fdlibm
+        from .rng import exp_bk
 
-        ev = exp_fdlibm(-v)
+        ev = exp_bk(-v)
         hn = 0.5 * (self._D - 1)
         he = 0.5 * ev
         return v, x, ev, s, hn, he

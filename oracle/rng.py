@@ -358,55 +358,46 @@ def legacy_choice(p, u) -> np.ndarray:
     return out
 
 
-def exp_fdlibm(x: float) -> float:
-    """The HIP library's ``bk_exp`` (``include/bkhip_math.h``: Sun fdlibm 5.3 ``e_exp.c``) restated operation for
-    operation on Python floats -- every ``*`` and ``+`` one IEEE rounding, as in the library (-ffp-contract=off) -- so
-    that an oracle-side density with an exp() inside can be evaluated with the device's own double
-    (``oracle.models.FunnelCanonical``).  ``tests/test_abi.py`` checks it against the library's host build of the same
-    header."""
-    one, huge, twom1000 = 1.0, 1.0e300, 9.33263618503218878990e-302
-    o_threshold, u_threshold = 7.09782712893383973096e02, -7.45133219101941108420e02
-    ln2HI, ln2LO, invln2 = 6.93147180369123816490e-01, 1.90821492927058770002e-10, 1.44269504088896338700e00
-    P1, P2, P3 = 1.66666666666666019037e-01, -2.77777777770155933842e-03, 6.61375632143793436117e-05
-    P4, P5 = -1.65339022054652515390e-06, 4.13813679705723846039e-08
+def fma_exact(a: float, b: float, c: float) -> float:
+    """IEEE 754-2008 fusedMultiplyAdd on finite doubles: a * b + c evaluated exactly (integer ratios; every double is
+    one) and rounded ONCE to nearest even -- CPython's int / int is correctly rounded.  (``math.fma`` is Python >= 3.13.)"""
+    na, da = float(a).as_integer_ratio()
+    nb, db = float(b).as_integer_ratio()
+    nc, dc = float(c).as_integer_ratio()
+    num, den = na * nb * dc + nc * da * db, da * db * dc
+    if num == 0:  # IEEE: the sign of an exact zero sum (round to nearest: +0 unless both addends are -0)
+        prod_neg = (math.copysign(1.0, a) * math.copysign(1.0, b)) < 0
+        return -0.0 if (prod_neg and math.copysign(1.0, c) < 0) else 0.0
+    return num / den
+
+
+_EXP_BK_C = tuple(float.fromhex(h) for h in (
+    "0x1.0000000000000p-1", "0x1.5555555555555p-3", "0x1.5555555555555p-5", "0x1.1111111111111p-7",
+    "0x1.6c16c16c16c17p-10", "0x1.a01a01a01a01ap-13", "0x1.a01a01a01a01ap-16", "0x1.71de3a556c734p-19",
+    "0x1.27e4fb7789f5cp-22", "0x1.ae64567f544e4p-26", "0x1.1eed8eff8d898p-29", "0x1.6124613a86d09p-33"))  # 1/2! .. 1/13!
+
+
+def exp_bk(x: float) -> float:
+    """The HIP library's ``bk_exp`` (``include/bkhip_math.h``) restated operation for operation on Python floats --
+    x clamped to [-746, 710]; k = rint(x log2 e); r = fma(-k, LN2_HI, x); r = fma(-k, LN2_LO, r); Horner with fma over 1/13! .. 1/2!;
+    p = fma(r r, q, r) + 1; ldexp(p, k) -- so that an oracle-side density with an exp() inside is evaluated with the
+    device's own double (``oracle.models.FunnelCanonical``).  ``tests/test_abi.py`` checks it against the library's host
+    build of the header; the GPU tests check the device build against it."""
+    log2e, ln2_hi, ln2_lo = float.fromhex("0x1.71547652b82fep+0"), float.fromhex("0x1.62e42fefa39efp-1"), \
+        float.fromhex("0x1.abc9e3b39803fp-56")
     x = float(x)
-    bits = struct.unpack("<Q", struct.pack("<d", x))[0]
-    hx, lx = bits >> 32, bits & 0xFFFFFFFF
-    xsb = (hx >> 31) & 1
-    hx &= 0x7FFFFFFF
-    hi = lo = 0.0
-    k = 0
-    if hx >= 0x40862E42:
-        if hx >= 0x7FF00000:
-            if ((hx & 0xFFFFF) | lx) != 0:
-                return x + x
-            return x if xsb == 0 else 0.0
-        if x > o_threshold:
-            return float("inf")
-        if x < u_threshold:
-            return 0.0
-    if hx > 0x3FD62E42:
-        if hx < 0x3FF0A2B2:
-            hi = x + ln2HI if xsb else x - ln2HI
-            lo = -ln2LO if xsb else ln2LO
-            k = 1 - xsb - xsb
-        else:
-            k = int(invln2 * x + (-0.5 if xsb else 0.5))  # (C's conversion truncates toward zero, as int() does)
-            t = float(k)
-            hi = x - t * ln2HI
-            lo = t * ln2LO
-        x = hi - lo
-    elif hx < 0x3E300000:
-        if huge + x > one:
-            return one + x
-    t = x * x
-    c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))))
-    if k == 0:
-        return one - ((x * c) / (c - 2.0) - x)
-    y = one - ((lo - (x * c) / (2.0 - c)) - hi)
-    bits = struct.unpack("<Q", struct.pack("<d", y))[0]
-    if k >= -1021:
-        bits = (bits + (k << 52)) & M64
-        return struct.unpack("<d", struct.pack("<Q", bits))[0]
-    bits = (bits + ((k + 1000) << 52)) & M64
-    return struct.unpack("<d", struct.pack("<Q", bits))[0] * twom1000
+    if x != x:
+        return x + x
+    x = min(max(x, -746.0), 710.0)  # beyond these ldexp returns 0 / inf by itself
+    k = float(round(x * log2e))  # (round() of a float: to nearest, ties to even, as rint in the default mode)
+    r = fma_exact(-k, ln2_hi, x)
+    r = fma_exact(-k, ln2_lo, r)
+    q = _EXP_BK_C[11]
+    for n in range(10, -1, -1):
+        q = fma_exact(q, r, _EXP_BK_C[n])
+    p = fma_exact(r * r, q, r)
+    p = p + 1.0
+    try:
+        return math.ldexp(p, int(k))
+    except OverflowError:  # (C's ldexp returns +inf)
+        return float("inf")

@@ -69,8 +69,11 @@ def _prewarm_from_source_cache(session):
         import time
 
         t0 = time.perf_counter()
-        ok, bad = targets.prewarm_sources(specs, workers=_usable_cpus())
+        errors = []
+        ok, bad = targets.prewarm_sources(specs, workers=_usable_cpus(), errors=errors)
         print(f"[conftest] from_source cache: {ok} libraries ready, {bad} failed, {time.perf_counter() - t0:.0f} s")
+        for form, dims, msg in errors:  # (the suite holds sources that must NOT compile; anything else shows here)
+            print(f"[conftest]   failed: form={form} D={dims}: ...{msg[-160:]!r}")
     except Exception as e:  # pragma: no cover  (the tests compile what they need themselves)
         print("[conftest] from_source prewarm skipped:", e)
 

@@ -218,10 +218,15 @@ def test_prewarm_builds_a_list_of_sources_in_parallel_and_records_what_was_asked
              dict(user_source=TERM, form="elementwise", contract=False, dims=12, head=0, stage="auto"),   # duplicate
              dict(user_source="__device__ void bk_term(double th) { this does not compile }", form="elementwise",
                   contract=False, dims=12, head=0, stage="auto")]
-    ok, bad = T.prewarm_sources(specs, workers=3)
-    assert (ok, bad) == (2, 1)
+    errors = []
+    ok, bad = T.prewarm_sources(specs, workers=3, errors=errors)
+    assert (ok, bad) == (2, 1) and len(errors) == 1 and errors[0][:2] == ("elementwise", 12)
     asked = [json.loads(line) for line in open(rec)]
     assert len(asked) == 3 and {a["form"] for a in asked} == {"elementwise", "chain"}   # (the duplicate was not asked for twice)
+    # two dims of a source whose generated text does not depend on D are ONE library built by two threads at once: both must
+    # succeed (per-thread temporary names; the GPU suite's manifest holds such pairs)
+    twins = [dict(user_source=TERM.replace("th", "th "), form="elementwise", contract=False, dims=d, head=0, stage="auto") for d in (20, 21)]
+    assert T.prewarm_sources(twins, workers=2) == (2, 0)
     t0 = time.perf_counter()
     lib = T._compile_source_target(TERM, "elementwise", False, 12, 0)
     assert os.path.exists(lib) and time.perf_counter() - t0 < 2.0     # a cache hit

@@ -840,6 +840,27 @@ def test_sample_sort_and_rhat_collectives_run_on_rccl(ops):
         dist.destroy_process_group()
 
 
+def test_device_bk_exp_equals_the_oracle_restatement_bit_for_bit():
+    """bk_exp (include/bkhip_math.h) as the DEVICE evaluates it against oracle.rng.exp_bk (exact rational fma): read off the
+    built-in funnel's gradient -- at theta = (v, -1) the entry of the row is -(bk_exp(-v) * -1) = bk_exp(-v) exactly."""
+    from oracle.rng import exp_bk
+
+    ops = bk._lib.default_ops()
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.normal(size=6000) * 4.0, rng.uniform(-0.4, 0.4, 1500), rng.uniform(-746.5, 710.5, 3000),
+                         rng.normal(size=500) * 1e-9,
+                         [0.0, -0.0, 1e-300, -1e-300, 709.78, 709.782712893384, 709.7827128933841, 709.79, 710.0, 711.0, -745.13,
+                          -745.1332191019412, -745.14, -746.0, -747.0, -708.4, -740.0, 1e308, -1e308, float("inf"), float("-inf"),
+                          float("nan")]])
+    th = torch.from_numpy(np.stack([-xs, -np.ones_like(xs)])).to(ops.device)
+    grad, lp = torch.empty_like(th), torch.empty(th.shape[1], dtype=torch.float64, device=ops.device)
+    ops.target_grad("funnel", None, th, grad, lp)
+    got = grad[1].cpu().numpy()
+    want = np.array([exp_bk(float(x)) for x in xs])
+    assert np.array_equal(got.view(np.uint64)[:-1], want.view(np.uint64)[:-1])
+    assert np.isnan(got[-1]) and np.isnan(want[-1])
+
+
 def test_funnel_proposal_geometries_give_the_same_values():
     """bk_dr_proposal_funnel picks 4, 8 or 16 lanes of a wavefront per chain from the size of the lane set (on the
     host when it knows the size, on the device otherwise); the sum over a chain's coordinates has one canonical

@@ -94,3 +94,37 @@ def test_numpy_sum_and_choice_restatements():
         idx = rs.choice(n, size=n, replace=True, p=p)
         rs.set_state(st)
         assert np.array_equal(idx, legacy_choice(p, rs.random_sample(n))), n
+
+
+def test_exact_fma_and_the_library_exp_restatement():
+    """oracle.rng.fma_exact is the correctly rounded a*b+c (checked where the answer is known exactly); oracle.rng.exp_bk --
+    the HIP library's bk_exp restated -- stays within one ulp of the host libm's exp and equals it for most arguments."""
+    import math
+
+    from oracle.rng import exp_bk, fma_exact
+
+    rng = np.random.default_rng(8)
+    for a, b in rng.normal(size=(2000, 2)):
+        a, b = float(a), float(b)
+        p = a * b
+        e = fma_exact(a, b, -p)                     # the rounding error of the product, exactly representable
+        na, da = a.as_integer_ratio()
+        nb, db = b.as_integer_ratio()
+        npn, dp = p.as_integer_ratio()
+        ne, de = e.as_integer_ratio()
+        assert na * nb * dp * de == (npn * de + ne * dp) * da * db          # a * b == p + e exactly
+        assert fma_exact(a, b, 0.0) == p and fma_exact(a, 1.0, b) == a + b
+    assert fma_exact(1.0 + 2.0 ** -52, 1.0 + 2.0 ** -52, -1.0) == 2.0 ** -51 + 2.0 ** -104   # (a * b rounds the last term away)
+    assert fma_exact(2.0 ** -600, 2.0 ** -600, 0.0) == 0.0 and fma_exact(3.0, 2.0 ** -1074, 2.0 ** -1074) == 4 * 2.0 ** -1074
+    assert math.copysign(1.0, fma_exact(-1.0, 0.0, -0.0)) == -1.0 and math.copysign(1.0, fma_exact(1.0, 0.0, -0.0)) == 1.0
+    xs = np.concatenate([rng.normal(size=4000) * 4.0, rng.uniform(-700.0, 700.0, 2000), rng.uniform(-0.35, 0.35, 1000)])
+    same = 0
+    for x in xs:
+        x = float(x)
+        got, ref = exp_bk(x), math.exp(x)
+        assert abs(got - ref) <= abs(np.nextafter(ref, np.inf) - ref), x
+        same += got == ref
+    assert same >= 0.85 * len(xs)
+    assert exp_bk(0.0) == 1.0 and exp_bk(-0.0) == 1.0 and exp_bk(float("inf")) == float("inf") and exp_bk(float("-inf")) == 0.0
+    assert exp_bk(709.782712893384) == 1.7976931348622732e308 and exp_bk(709.7827128933841) == float("inf")
+    assert exp_bk(-745.13) == 5e-324 and exp_bk(-745.14) == 0.0 and math.isnan(exp_bk(float("nan")))

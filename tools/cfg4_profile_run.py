@@ -33,16 +33,23 @@ elif opaque in ("lanes", "lanes_fused"):  # the funnel as a lane-spread density 
         kw["path"] = "step"
 elif opaque != "0":
     kw["path"] = "step"
+init = None
+if os.environ.get("STATIONARY") == "1":   # exact draws of the funnel, as bench_secondary's spec_length_stationary_start
+    g = torch.Generator().manual_seed(5)
+    v0 = 3.0 * torch.randn(C, generator=g, dtype=torch.float64)
+    init = torch.cat([v0[:, None], torch.exp(0.5 * v0)[:, None] * torch.randn((C, D - 1), generator=g, dtype=torch.float64)], dim=1)
+    kw["init"] = init
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
                   device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
                   fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)
+draw = s.advance if os.environ.get("ADVANCE") == "1" else s.sample   # advance(): a draw without returned copies
 for _ in range(int(os.environ.get("WARM", 100))):
-    s.sample()
+    draw()
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
 for _ in range(N):
-    s.sample()
+    draw()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print({"ms_per_draw": 1e3 * el / N, "opaque": opaque, "one_launch": s._one_launch, "fuse_first_ghost": s._fuse_first_ghost, "device_counts": s._dev_counts, "graph": s._use_graph, "lane_steps_last": s.last_lane_steps,
