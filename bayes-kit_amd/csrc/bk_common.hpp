@@ -91,6 +91,33 @@ __device__ __forceinline__ void bk_append(bool take, int32_t value, int32_t* lis
   if (take) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = value;
 }
 
+// The same for a whole WORKGROUP of NW wavefronts: ONE atomic per workgroup.  Atomics of different wavefronts on one
+// counter are served one after the other, ~10 ns each on MI355X (device scope: eight L2s, so they resolve at the memory
+// side): 2,048 wavefronts appending to one list cost 20 us, 512 workgroups 5 (profiles/r6_cfg4_exp.md).  EVERY thread of
+// the workgroup must call it (two barriers); positions inside the workgroup in wavefront, then lane order.
+template <int NW>
+__device__ __forceinline__ void bk_append_wg(bool take, int32_t value, int32_t* list, uint32_t* count) {
+  __shared__ uint32_t wave_count[NW];
+  __shared__ uint32_t wg_base;
+  const unsigned long long b = __ballot(take);
+  const int lane = threadIdx.x & (BK_WAVE - 1), wave = (int)(threadIdx.x / BK_WAVE);
+  if (lane == 0) wave_count[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) total += wave_count[w];
+    wg_base = total ? atomicAdd(count, total) : 0u;
+  }
+  __syncthreads();
+  if (take) {
+    uint32_t base = wg_base;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < wave) base += wave_count[w];
+    list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = value;
+  }
+}
 
 // joint log density of (theta, rho) from log p(theta) and the kinetic energy (drghmc.py:249-251)
 __device__ __forceinline__ double dr_joint(double logp, double kin) {

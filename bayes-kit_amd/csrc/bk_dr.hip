@@ -154,7 +154,7 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob_ghost(const double*
     }
   }
   // the parent lanes that go on to their next ghost (drghmc.py:424): the lane set of that trajectory
-  if (next_idx) bk_append(still_live, (int32_t)p, next_idx, next_count);
+  if (next_idx) bk_append_wg<SC_BLOCK / BK_WAVE>(still_live, (int32_t)p, next_idx, next_count);  // (next_idx: the same for all)
 }
 
 __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, const double* cur_H,
@@ -170,14 +170,15 @@ __global__ __launch_bounds__(SC_BLOCK) void k_dr_accept_prob(const double* H, co
 
 // h / live given: the stage's accept probability (k_dr_accept_prob against the chain's current point) is
 // evaluated here first, one launch less per stage; `a` is then an output as well
+constexpr int AT_BLOCK = 256;  // (one list atomic per 256 lanes: bk_append_wg)
 template <typename G>
-__global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, const int32_t* cidx,
+__global__ __launch_bounds__(AT_BLOCK) void k_dr_accept_test(uint64_t* st, i64 ldr, const int32_t* cidx,
                                                        double* a, const double* H, i64 n,
                                                        double* cur_H, double* cur_h, double* rej,
                                                        uint8_t* alive, uint8_t* accepted, const uint32_t* n_dev,
                                                        const double* h, const uint8_t* live, double pr,
                                                        int32_t* next_idx, uint32_t* next_count) {
-  i64 j = (i64)blockIdx.x * 64 + threadIdx.x;
+  i64 j = (i64)blockIdx.x * AT_BLOCK + threadIdx.x;
   const bool on = j < bk_lanes(n, n_dev);
   bool again = false;
   i64 c = 0;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64) void k_dr_accept_test(uint64_t* st, i64 ldr, co
     g.store(st, ldr, c);
   }
   // the chains that propose again: the lane set of the next stage
-  if (next_idx) bk_append(again, (int32_t)c, next_idx, next_count);
+  if (next_idx) bk_append_wg<AT_BLOCK / BK_WAVE>(again, (int32_t)c, next_idx, next_count);
 }
 
 // lane = chain of the compacted set, blockIdx.y = a block of BK_SCT_ROWS dimensions (bk_scatter_unit)
@@ -289,7 +290,7 @@ static int dr_accept_test(int rng_kind, uint64_t* state, int64_t ldr, const int3
                           int32_t* next_idx, uint32_t* next_count, void* stream) {
   if (!state || !a || !H || !cur_H || !cur_h || !rej || !alive || !accepted || n < 0) return BK_E_ARG;
   if (n == 0) return BK_OK;
-  dim3 grid((unsigned)bk_cdiv(n, 64)), block(64);
+  dim3 grid((unsigned)bk_cdiv(n, AT_BLOCK)), block(AT_BLOCK);
   if (rng_kind == BK_RNG_PHILOX)
     k_dr_accept_test<bk::Philox><<<grid, block, 0, bk_stream(stream)>>>(state, ldr, chain_index, a, H, n, cur_H,
                                                                        cur_h, rej, alive, accepted, n_dev, h, live, pr,

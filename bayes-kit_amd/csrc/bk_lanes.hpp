@@ -271,7 +271,9 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
   constexpr int NU = G::NU, H1 = HEAD > 0 ? HEAD : 1;
   constexpr bool hm = HM;
   const i64 j0 = ((i64)blockIdx.x * WAVES + wave) * G::CHAINS;  // first chain of this wavefront
-  if (j0 >= n) return;  // whole wavefront past the set (uniform; the wavefronts of a workgroup are independent)
+  // A whole WORKGROUP past the set leaves (uniform).  A wavefront past the set inside the set's last workgroup stays: its
+  // lanes are off (they read chain 0 and store nothing), and it takes part in the workgroup's list appends (barriers).
+  if ((i64)blockIdx.x * WAVES * G::CHAINS >= n) return;
   const int pos = lane & (LPC - 1);
   const i64 j = j0 + lane / LPC;
   const bool on = j < n;
@@ -446,7 +448,7 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
         goes_on = true;
       }
     }
-    if (g0.next_index) bk_append(goes_on, (int32_t)j, g0.next_index, g0.next_count);
+    if (g0.next_index) bk_append_wg<WAVES>(goes_on, (int32_t)j, g0.next_index, g0.next_count);
   }
   if (writer && a.H_out) {
     a.hh_out[j] = h_own;
@@ -474,7 +476,7 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
       }
     }
     // the parent lanes that go on to their next ghost: the lane set of that trajectory (every lane takes part)
-    if (ghost.next_index) bk_append(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
+    if (ghost.next_index) bk_append_wg<WAVES>(parent_goes_on, (int32_t)src, ghost.next_index, ghost.next_count);
   }
 #undef BKL_IN
 #undef BKL_OUT

@@ -4,6 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "bayes-kit_amd")]
 import torch
 import bayes_kit_amd as bk
+if os.environ.get("BK_LIB"):  # A/B against another build of the library
+    bk._lib._LIB_PATH = os.path.abspath(os.environ["BK_LIB"])
 C, D, N = int(os.environ.get("C", 32768)), 101, int(os.environ.get("N", 200))
 # OPAQUE=1: the gradient as a separate (counted) op per leapfrog step; OPAQUE=plugin: the same through the user plugin
 opaque = os.environ.get("OPAQUE", "0")
@@ -42,6 +44,8 @@ if os.environ.get("STATIONARY") == "1":   # exact draws of the funnel, as bench_
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
                   device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
                   fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)
+if os.environ.get("ATTACH") == "1":   # the diagnostics bench_secondary feeds from inside the draw's graph
+    s.attach(moments=bk.RunningMoments(D, C), recorder=bk.DrawRecorder([0, 1, D - 1], 4000, C))
 draw = s.advance if os.environ.get("ADVANCE") == "1" else s.sample   # advance(): a draw without returned copies
 for _ in range(int(os.environ.get("WARM", 100))):
     draw()
