@@ -150,6 +150,7 @@ class DrGhmcDiag(ManyChainSampler):
         # that ghost a launch of its own -- same results, for A/B timing and the tests
         self._fuse_first_ghost = bool(fuse_first_ghost) and self._one_launch
         self._init_graph(graph)
+        self._graph_many = {}  # advance(n): graphs of several consecutive draws, by their number
         self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
             max(0, k - 1) for k in range(int(max_proposals)))
         # Row padding (one-launch-proposal path).  The proposal kernel walks the ROWS of a few chains: with a
@@ -414,10 +415,62 @@ class DrGhmcDiag(ManyChainSampler):
                 self._attached[i] = (kind, obj, now)
                 self._drop_graphs()  # (the offset is a scalar argument of the captured launches)
 
-    def advance(self):
-        """One draw of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed
-        by attached diagnostics only.  ``sample()`` = ``advance()`` + the returned (theta, logp) copies."""
-        self._step()
+    DRAWS_PER_GRAPH = 10  # advance(n): draws replayed per hipGraph launch (each launch costs ~8 us between graphs)
+
+    def advance(self, n: int = 1):
+        """n draws of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed
+        by attached diagnostics only.  ``sample()`` = ``advance()`` + the returned (theta, logp) copies.
+        Where a draw replays as a hipGraph, n > 1 replays graphs of up to DRAWS_PER_GRAPH consecutive draws: the same
+        launches in the same order (a replay IS the next draws: every per-draw quantity lives on the device), without
+        the ~8 us the device idles between two graph launches."""
+        n = int(n)
+        if n < 1:
+            raise ValueError("advance(n): n >= 1")
+        while n > 0:
+            m = min(n, int(self.DRAWS_PER_GRAPH))
+            # a multi-draw graph needs the settled regime: first evaluation done, momentum sign lazy, single draw captured
+            if m > 1 and self._dev_counts and self._use_graph and self._graph is not None and self._rho_sign == -1.0 \
+                    and self._have_cache and self._replay_many(m):
+                n -= m
+            else:
+                self._step()
+                n -= 1
+
+    def _replay_many(self, m):
+        """m draws as ONE graph replay; False (nothing done) where the single-draw path has work to do first."""
+        self._count_attached()
+        for kind, obj, off in self._attached:
+            if kind == "recorder" and obj.n + m > obj.series.shape[1]:
+                return False
+        if (self._graph is None or self._graph_key() != self._graph_scalars
+                or tuple(int(k) for k in self._leapfrog_step_counts) != self._schedule_counts):
+            return False  # (_step() captures again / rebuilds the schedule)
+        g = self._graph_many.get(m)
+        if g is None:
+            import gc
+
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            gc_was_on = gc.isenabled()
+            gc.disable()  # (see _run_draw: no collection while the stream is capturing)
+            try:
+                with torch.cuda.graph(g):
+                    for _ in range(m):
+                        self._draw_dev()
+            finally:
+                if gc_was_on:
+                    gc.enable()
+            self._graph_many[m] = g
+        g.replay()
+        self._first_eval = 0
+        self._draws += m
+        for kind, obj, off in self._attached:
+            obj.n += m
+        return True
+
+    def _drop_graphs(self):
+        super()._drop_graphs()
+        self._graph_many = {}
 
     def _graph_key(self):
         return (float(self._damping), float(self._rho_sign), bool(self._prob_retry),

@@ -631,6 +631,92 @@ __global__ __launch_bounds__(256) void k_refresh_apply_kin(const double* zt, i64
   }
 }
 
+// k_refresh_apply_kin for SHORT rows (a chain's padded row of normals <= 120 doubles: config 4's 101).  The 64 chains of a
+// workgroup are one contiguous piece of the chain-major zt: the wavefronts bring it in row by row (16-byte loads, a whole
+// 832-byte row per instruction instead of four 128-byte pieces of four rows) into ONE LDS tile with an odd row pitch, and
+// each wavefront then walks its quarter of the dimensions with lane = chain exactly as k_refresh_apply_kin does: the same
+// operations in the same order on the same values.
+template <bool BEGIN>
+__global__ __launch_bounds__(256) void k_refresh_apply_kin_rows(const double* zt, i64 ldz, const double* loc_in,
+                                                                double loc_mul, double scale, double* out, i64 ld,
+                                                                const double* metric, double* kin_out, i64 C, i64 D,
+                                                                DrBegin b) {
+  extern __shared__ double rk_sm[];  // tile[64][ldz + 1], part[4][64]
+  const int TS = (int)ldz + 1;
+  double* part = rk_sm + 64 * TS;
+  const int lane = threadIdx.x & 63, w = bk_wave_id();
+  const i64 c0 = (i64)blockIdx.x * 64, c = c0 + lane;
+  if (BEGIN) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < b.n_counters) b.counters[threadIdx.x] = 0;
+    if (b.draw_counter && blockIdx.x == 0 && threadIdx.x == 0) *b.draw_counter += 1;
+  }
+  const int nch = (int)((C - c0 < 64) ? C - c0 : 64);
+  if (2 * lane < ldz) {  // (ldz is a multiple of 8 and <= 128: a row is at most 64 double2)
+#pragma unroll 4
+    for (int cc = w; cc < nch; cc += 4) {
+      const double2 v = *reinterpret_cast<const double2*>(zt + (c0 + cc) * ldz + 2 * lane);
+      rk_sm[cc * TS + 2 * lane] = v.x;
+      rk_sm[cc * TS + 2 * lane + 1] = v.y;
+    }
+  }
+  __syncthreads();
+  const i64 Dq = (D + 3) / 4;
+  const i64 dlo = w * Dq, dhi = (dlo + Dq < D) ? dlo + Dq : D;
+  double kin = 0.0;
+  if (c < C) {
+    for (i64 d0 = dlo; d0 < dhi; d0 += 8) {
+      double loc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) loc[u] = (loc_in && d0 + u < dhi) ? loc_in[(d0 + u) * ld + c] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (d0 + u < dhi) {
+          double lo = loc_in ? loc[u] * loc_mul : 0.0;
+          double v = lo + scale * rk_sm[lane * TS + (int)(d0 + u)];
+          out[(d0 + u) * ld + c] = v;
+          double mv = metric ? metric[d0 + u] * v : v;
+          kin = kin + v * mv;
+        }
+      }
+    }
+  }
+  part[w * 64 + lane] = kin;
+  __syncthreads();
+  if (w != 0 || c >= C) return;
+  double s = part[lane];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) s = s + part[k * 64 + lane];
+  const double kc = 0.5 * s;
+  kin_out[c] = kc;
+  if (BEGIN) {
+    b.H[c] = dr_joint(b.logp[c], kc);
+    b.h[c] = 0.0;
+    const double r0 = 0.0;
+    b.rej[c] = r0;
+    bk::Philox g;
+    g.load(b.state, b.ldr, c);
+    double lu = log(bk::next_double(g));
+    g.store(b.state, b.ldr, c);
+    double retry = b.pr * r0;
+    b.alive[c] = (lu < retry) ? 1 : 0;
+  }
+}
+
+// launch of k_refresh_apply_kin / _rows
+template <bool BEGIN>
+static void refresh_apply_kin_launch(const double* work, i64 dp, const double* loc_in, double loc_mul, double scale,
+                                     double* out, i64 ld, const double* metric, double* kin_out, i64 C, i64 D,
+                                     const DrBegin& b, hipStream_t s) {
+  const size_t lds = (size_t)(64 * (dp + 1) + 256) * sizeof(double);
+  static const bool rows_off = getenv("BK_REFRESH_ROWS_OFF") != nullptr;  // (A/B: tools/r6_cfg4_refresh_ab.sh)
+  if (dp <= 128 && lds <= 65536 && !rows_off)
+    k_refresh_apply_kin_rows<BEGIN><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), lds, s>>>(work, dp, loc_in, loc_mul, scale,
+                                                                                          out, ld, metric, kin_out, C, D, b);
+  else
+    k_refresh_apply_kin<BEGIN><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out,
+                                                                                   ld, metric, kin_out, C, D, b);
+}
+
 // theta' = (theta + eps*grad) + s*z with z already drawn (mala.py:41-45), two rows per thread
 __global__ __launch_bounds__(256) void k_mala_propose_z(const double* th, const double* g, const double* z,
                                                         double* prop, i64 ld, double eps, double s, i64 C, i64 D) {
@@ -804,8 +890,7 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr, const double
       i64 dp = (D + 7) / 8 * 8;
       zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
       if (kin_out) {
-        k_refresh_apply_kin<false><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), 0, s>>>(
-            work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, DrBegin{});
+        refresh_apply_kin_launch<false>(work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, DrBegin{}, s);
       } else {
         dim3 g2((unsigned)bk_cdiv(C, 64), (unsigned)bk_cdiv(D, 64));
         k_refresh_apply<<<g2, dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out, ld, C, D);
@@ -837,8 +922,7 @@ int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double
     i64 dp = (D + 7) / 8 * 8;
     zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
     DrBegin b = {logp, cur_H, cur_h, rej, alive, prob_retry, counters, (int)n_counters, draw_counter, state, ldr};
-    k_refresh_apply_kin<true><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), 0, s>>>(work, dp, loc_in, loc_mul, scale, out,
-                                                                                  ld, metric, kin_out, C, D, b);
+    refresh_apply_kin_launch<true>(work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, b, s);
     BK_RETURN_LAUNCH_STATUS();
   }
   int rc = bk_momentum_refresh(rng_kind, state, ldr, loc_in, loc_mul, scale, out, ld, metric, kin_out, nullptr, C, D,

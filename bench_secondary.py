@@ -330,23 +330,31 @@ def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=F
     s = bk.DrGhmcDiag(bk.Funnel(D), *CFG4_ARGS, chains=C, chain_id0=ctx.rank * C, seed=20242, init=init)
     for _ in range(warmup):
         s.advance()
+    # The timed draws replay as graphs of `per` consecutive draws (DrGhmcDiag.advance(n): one graph launch per `per` draws).
+    # attach() drops captured graphs, so `pre` untimed draws follow it: the eager / single-draw-graph ones a run starts
+    # with and one replay of the multi-draw graph; they are recorded like the rest (the diagnostics below cover draws + pre).
+    per = int(s.DRAWS_PER_GRAPH) if draws % int(s.DRAWS_PER_GRAPH) == 0 else 1
+    pre = 2 + per
     mom = bk.RunningMoments(D, C)
-    rec = bk.DrawRecorder([0, 1, D - 1], draws, C)
+    rec = bk.DrawRecorder([0, 1, D - 1], draws + pre, C)
     s.attach(moments=mom, recorder=rec)
+    s.advance(pre)
+    torch.cuda.synchronize()
     base = float(s.lane_steps_total.item())
-    el = ctx.timed_loop(s.advance, draws)
+    el = ctx.timed_loop(lambda: s.advance(per), draws // per)
     lane = float(s.lane_steps_total.item()) - base
+    recorded = draws + pre
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rh = torch.as_tensor(mom.rhat())
     ess = rec.ess()                                    # [4 series, C]
     torch.cuda.synchronize()
     summary_s = time.perf_counter() - t0
-    ess = torch.where(ess > 0, ess, torch.full_like(ess, float(draws))).clamp(max=float(draws))
+    ess = torch.where(ess > 0, ess, torch.full_like(ess, float(recorded))).clamp(max=float(recorded))
     per_series = ess.sum(dim=1)
     mcse = (ess.var(dim=1, unbiased=True) * C).sqrt()  # between-chain standard error of each summed ESS
     ess_min = ess.min(dim=0).values
-    v = rec.series[0, :draws]                          # theta_0 of every chain, every draw  [draws, C]
+    v = rec.series[0, :recorded]                       # theta_0 of every chain, every draw  [draws, C]
     v_mean, v_var = float(v.mean()), float(v.var())
     ess_v = float(per_series[0])
     names = ["theta[0] (v)", "theta[1]", f"theta[{D - 1}]", "joint logp"]
@@ -355,7 +363,8 @@ def bench_cfg4_spec_length(ctx, C, D, draws=1000, warmup=100, stationary_start=F
                     "diagnostics inside the draw's hipGraph; start: "
                     + ("exact draws of the funnel (invariance check)" if stationary_start
                        else "N(0, I) as the reference (hmc.py:24-28)"),
-            "draws": draws, "burn_in": warmup, "seconds": el, "ms_per_draw": 1e3 * el / draws,
+            "draws": draws, "burn_in": warmup, "untimed_recorded_draws": pre, "draws_per_graph_launch": per,
+            "seconds": el, "ms_per_draw": 1e3 * el / draws,
             "grad_evals_per_sec": lane / el, "mean_grad_evals_per_draw": lane / (C * draws),
             "rhat_max": float(rh.max()), "rhat_v": float(rh[0]), "rhat_over_dims": int(rh.numel()),
             "ess_per_sec": {n: float(e) / el for n, e in zip(names, per_series)},

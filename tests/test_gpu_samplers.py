@@ -1391,6 +1391,38 @@ def test_drghmc_attached_diagnostics_equal_manual_updates(ops):
     check_attached_diagnostics(ops, C=4096, D=21, draws=6)  # padded rows: theta's row pitch differs from the moments'
 
 
+def test_drghmc_advance_n_replays_graphs_of_several_draws(ops):
+    """advance(n): hipGraphs of up to DRAWS_PER_GRAPH consecutive draws (one graph launch instead of n) leave exactly what n
+    advance() calls leave -- state, momenta, stream positions, lane statistics, the attached moments and series."""
+    D, C, K = 21, 900, 3
+    mk = lambda: bk.DrGhmcDiag(bk.Funnel(D), K, [0.3, 0.1, 0.03], [3, 6, 12], 0.3, chains=C, seed=9)  # noqa: E731
+    a, b = mk(), mk()
+    ma, mb = bk.RunningMoments(D, C), bk.RunningMoments(D, C)
+    ra, rb = bk.DrawRecorder([0, D - 1], 64, C), bk.DrawRecorder([0, D - 1], 64, C)
+    a.attach(moments=ma, recorder=ra)
+    b.attach(moments=mb, recorder=rb)
+    for _ in range(37):
+        a.advance()
+    b.advance(37)          # 2 warm-up draws one by one, then graphs of 10, 10, 10 and 5 draws
+    assert b._graph_many and set(b._graph_many) <= {10, 5} and a._draws == b._draws == 37 and ma.n == mb.n == 37 and ra.n == rb.n == 37
+    assert torch.equal(a._theta_dc, b._theta_dc) and torch.equal(a._rho, b._rho) and torch.equal(a._cur_H, b._cur_H)
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    assert a.last_stage_lanes == b.last_stage_lanes and float(a.lane_steps_total.item()) == float(b.lane_steps_total.item())
+    assert torch.equal(torch.as_tensor(ma.rhat()), torch.as_tensor(mb.rhat())) and torch.equal(ra.series[:, :37], rb.series[:, :37])
+    # a changed step size is seen by the next call (the graphs bake it in), and sample() continues the same chain of draws
+    a._leapfrog_step_sizes = [0.25, 0.1, 0.03]
+    b._leapfrog_step_sizes = [0.25, 0.1, 0.03]
+    for _ in range(12):
+        a.advance()
+    b.advance(12)
+    ta, la = a.sample()
+    tb, lb = b.sample()
+    assert torch.equal(ta, tb) and torch.equal(la, lb) and ra.n == rb.n == 50
+    np.testing.assert_array_equal(a.rng_state(), b.rng_state())
+    with pytest.raises(IndexError):
+        b.advance(20)      # the recorder holds 64 draws
+
+
 def test_recorder_dims_square_draws_padded_moments_and_attach_after_restore(ops):
     from tests.sampler_parity import check_recorder_and_moments_edges
 

@@ -46,13 +46,18 @@ s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, s
                   fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)
 if os.environ.get("ATTACH") == "1":   # the diagnostics bench_secondary feeds from inside the draw's graph
     s.attach(moments=bk.RunningMoments(D, C), recorder=bk.DrawRecorder([0, 1, D - 1], 4000, C))
-draw = s.advance if os.environ.get("ADVANCE") == "1" else s.sample   # advance(): a draw without returned copies
+draw = s.advance if os.environ.get("ADVANCE") == "1" else s.sample
+if os.environ.get("PER"):   # advance(n): graphs of n consecutive draws
+    per = int(os.environ["PER"])
+    N = N // per * per
+    draw = lambda: s.advance(per)   # noqa: E731
+    reps = N // per   # advance(): a draw without returned copies
 for _ in range(int(os.environ.get("WARM", 100))):
     draw()
 torch.cuda.synchronize()
 import time
 t0 = time.perf_counter()
-for _ in range(N):
+for _ in range(reps if os.environ.get("PER") else N):
     draw()
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
