@@ -52,7 +52,7 @@ SIGNATURES = {
     "bk_dr_accept_prob_test": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost": [P, P, P, P, P, F, P, P, I, P, P, P, P],
     "bk_dr_begin_retry": [c_int, P, I, P, P, P, P, P, P, F, P, I, P, I, P],
-    "bk_dr_refresh_begin": [c_int, P, I, P, F, F, P, I, P, P, I, I, P, I, P, P, P, P, P, F, P, I, P, P],
+    "bk_dr_refresh_begin": [c_int, P, I, P, F, F, P, I, P, P, I, I, P, I, P, P, P, P, P, F, P, I, P, P, P],
     "bk_dr_accept_prob_test_next": [c_int, P, I, P, P, P, P, P, F, I, P, P, P, P, P, P, P, P, P],
     "bk_dr_accept_prob_ghost_next": [P, P, P, P, P, F, P, P, I, P, P, P, P, P, P],
     "bk_scatter_columns": [P, P, I, I, P, P, P, P, P, P, I, I, P, P, P, P],
@@ -127,6 +127,12 @@ class Ghost0(ctypes.Structure):
     """bk_ghost0 of include/bkhip.h: the first ghost of the proposals a launch produces, run by that launch."""
     _fields_ = [("h", F), ("steps", I), ("parent_a", P), ("prob_retry", F), ("next_index", P), ("next_count", P),
                 ("lanes_out", P), ("lanes_total", P)]
+
+
+class WelfordJob(ctypes.Structure):
+    """bk_welford_job of include/bkhip.h: one welford_update_dev call, carried along by a draw's generator launch."""
+    _fields_ = [("mean", P), ("m2", P), ("ld", I), ("theta", P), ("ld_theta", I), ("n_dev", P), ("n_offset", I), ("C", I),
+                ("D", I)]
 
 
 class ScatterJob(ctypes.Structure):
@@ -420,13 +426,21 @@ class Ops:
                    ptr(draw_counter), logp.shape[0], self._s())
 
     def dr_refresh_begin(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, work, logp, cur_H, cur_h, rej,
-                         alive, prob_retry, counters, draw_counter=None):
-        """momentum_refresh(..., kin_out) + dr_begin_retry(...): the generator's launch + one more."""
+                         alive, prob_retry, counters, draw_counter=None, side=None):
+        """momentum_refresh(..., kin_out) + dr_begin_retry(...): the generator's launch + one more.  side: a welford_job(...)
+        done by workgroups of the generator's launch (the previous draw's update of attached moments)."""
         D, C = out.shape
         self._call("bk_dr_refresh_begin", kind, ptr(state), state.stride(0), ptr(loc_in), loc_mul, scale, ptr(out),
                    _ld(out), ptr(metric), ptr(kin_out), C, D, ptr(work), 0 if work is None else work.numel(), ptr(logp),
                    ptr(cur_H), ptr(cur_h), ptr(rej), ptr(alive), float(prob_retry), ptr(counters),
-                   0 if counters is None else counters.numel(), ptr(draw_counter), self._s())
+                   0 if counters is None else counters.numel(), ptr(draw_counter),
+                   None if side is None else ctypes.cast(ctypes.pointer(side), P), self._s())
+
+    def welford_job(self, mean, m2, theta, n_dev, n_offset):
+        """The arguments of welford_update_dev(...) as a job for dr_refresh_begin(side=...)."""
+        D, C = theta.shape
+        assert _ld(m2) == _ld(mean) and n_dev.dtype == torch.int64
+        return WelfordJob(ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), ptr(n_dev), int(n_offset), C, D)
 
     def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
                                  accepted, next_index, next_count, n_dev=None):

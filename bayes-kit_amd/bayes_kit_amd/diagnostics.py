@@ -124,6 +124,10 @@ class RunningMoments:
         n = n_dev[0] - n_offset; the caller keeps self.n in step."""
         self._ops.welford_update_dev(self.mean, self.m2, theta_dc, n_dev, n_offset)
 
+    def _update_job(self, theta_dc, n_dev, n_offset):
+        """_update_dev(...) as a job the NEXT draw's generator launch carries along (DrGhmcDiag.advance(n))."""
+        return self._ops.welford_job(self.mean, self.m2, theta_dc, n_dev, n_offset)
+
     def rhat(self, group=None) -> np.ndarray:
         return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
 

@@ -391,18 +391,25 @@ class DrGhmcDiag(ManyChainSampler):
         self._attached = []
         self._drop_graphs()
 
-    def _feed_attached(self, theta_dc, logp, on_device):
-        """Inside the draw: the attached diagnostics see the new state (theta_dc [D, C], joint log density)."""
+    def _feed_attached(self, theta_dc, logp, on_device, defer=False):
+        """Inside the draw: the attached diagnostics see the new state (theta_dc [D, C], joint log density).
+        defer (device path, a draw that is followed by another one inside the same hipGraph): the first attached moments
+        object is not updated here -- its update is returned as a job for the next draw's generator launch."""
+        job = None
         for kind, obj, off in self._attached:
             if on_device:
                 if kind == "moments":
-                    obj._update_dev(theta_dc, self._draws_dev, off)
+                    if defer and job is None:
+                        job = obj._update_job(theta_dc, self._draws_dev, off)
+                    else:
+                        obj._update_dev(theta_dc, self._draws_dev, off)
                 else:
                     obj._record_dev(theta_dc, logp, self._draws_dev, off + 1)
             elif kind == "moments":
                 obj.update(theta_dc, layout="dc")
             else:
                 obj.record(theta_dc, logp)
+        return job
 
     def _count_attached(self):
         for i, (kind, obj, off) in enumerate(self._attached):
@@ -416,6 +423,7 @@ class DrGhmcDiag(ManyChainSampler):
                 self._drop_graphs()  # (the offset is a scalar argument of the captured launches)
 
     DRAWS_PER_GRAPH = 10  # advance(n): draws replayed per hipGraph launch (each launch costs ~8 us between graphs)
+    DEFER_MOMENTS = True  # ... and inside such a graph an attached moments update rides on the next draw's generator launch
 
     def advance(self, n: int = 1):
         """n draws of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed
@@ -455,8 +463,12 @@ class DrGhmcDiag(ManyChainSampler):
             gc.disable()  # (see _run_draw: no collection while the stream is capturing)
             try:
                 with torch.cuda.graph(g):
-                    for _ in range(m):
-                        self._draw_dev()
+                    # the moments update of every draw but the last rides on the NEXT draw's generator launch (memory-bound
+                    # beside issue-bound: the longer of the two times instead of their sum); the last one is its own launch,
+                    # so the attached objects are up to date when advance() returns
+                    job = None
+                    for i in range(m):
+                        job = self._draw_dev(pending=job, defer=self.DEFER_MOMENTS and i + 1 < m)
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -665,7 +677,9 @@ class DrGhmcDiag(ManyChainSampler):
                 ops.dr_accept_prob_ghost_next(P.H, parent.H, P.h, parent.h, sub, pr, P.live, P.a, C, parent.live,
                                               parent.a, parent_next[0], parent_next[1], n_dev=n_dev)
 
-    def _draw_dev(self):
+    def _draw_dev(self, pending=None, defer=False):
+        """One draw as a fixed launch sequence.  pending: the previous draw's deferred moments update (a welford job), done
+        by workgroups of this draw's generator launch; defer: hand this draw's update to the next one the same way (returned)."""
         ops = self._ops
         C, m, damping = self._C, self._metric_dev, self._damping
         pr = 1.0 if self._prob_retry else 0.0
@@ -673,7 +687,7 @@ class DrGhmcDiag(ManyChainSampler):
         # (always passed, its uniform drawn) :365-371: the generator's launch + one more
         ops.dr_refresh_begin(self._rng_kind, self._rng_state, self._rho_dc, self._rho_sign * math.sqrt(1 - damping),
                              math.sqrt(damping), self._rho_dc, m, self._kin, self._rng_work, self._lp, self._cur_H,
-                             self._cur_h, self._rej, self._alive, pr, self._counters, self._draws_dev)
+                             self._cur_h, self._rej, self._alive, pr, self._counters, self._draws_dev, side=pending)
         cur = _Cur(self)
         self._slot = 0
         self._list = 0
@@ -709,7 +723,7 @@ class DrGhmcDiag(ManyChainSampler):
             if k + 1 < K:
                 idx, n_dev = nidx, ncount
         self._levels[0] = level0[0]
-        self._feed_attached(self._theta_dc, self._cur_H, True)
+        return self._feed_attached(self._theta_dc, self._cur_H, True, defer=defer)
 
     @property
     def lane_steps_total(self):

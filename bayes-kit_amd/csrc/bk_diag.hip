@@ -2,19 +2,14 @@
 // (bayes_kit/rhat.py:111-171) and per-chain effective sample size (ess.py:52-69,
 // iat.py:7-43,95-135, autocorr.py:6-33).
 #include "bk_common.hpp"
+#include "bk_welford.hpp"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int EL_ROWS = 4;
+using bkw::EL_ROWS;
+using bkw::welford_elem;
 constexpr int PC_BLOCK = 64;
-
-// Welford: after the n-th draw, mean = np.mean(draws[:n]) and m2/(n-1) = np.var(ddof=1)
-__device__ __forceinline__ void welford_elem(double x, double& mu, double& q, double n) {
-  double delta = x - mu;
-  mu = mu + delta / n;
-  q = q + delta * (x - mu);
-}
 
 __global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const double* th, i64 ld, i64 ld_th,
                                                  double n, const int64_t* n_dev, i64 n_off, i64 C, i64 D) {
@@ -33,47 +28,13 @@ __global__ __launch_bounds__(256) void k_welford(double* mean, double* m2, const
     }
 }
 
-// two chains (16 B) per lane, 40 algorithmic bytes per element (R theta, mean, M2; W mean, M2);
-// non-temporal when the three arrays stream past the Infinity Cache
-typedef double dvec2 __attribute__((ext_vector_type(2)));
-// (ld_th: theta's own row pitch; n_dev != NULL: the update count is read from device memory -- n = *n_dev -
-// n_off -- so that the launch can sit inside a sampler's captured draw)
+// two chains (16 B) per lane (bkw::welford_unit_v2); n_dev != NULL: the update count is read from device memory -- n =
+// *n_dev - n_off -- so that the launch can sit inside a sampler's captured draw
 template <bool NT>
 __global__ __launch_bounds__(256) void k_welford_v2(double* mean, double* m2, const double* th, i64 ld, i64 ld_th,
                                                     double n, const int64_t* n_dev, i64 n_off, i64 C2, i64 D) {
-  i64 c2 = (i64)blockIdx.x * 256 + threadIdx.x;
-  i64 d0 = (i64)blockIdx.y * EL_ROWS;
-  if (c2 >= C2) return;
   if (n_dev) n = (double)(*n_dev - n_off);
-  dvec2 x[EL_ROWS], mu[EL_ROWS], q[EL_ROWS];
-#pragma unroll
-  for (int i = 0; i < EL_ROWS; ++i)
-    if (d0 + i < D) {
-      i64 o = (d0 + i) * ld + 2 * c2;
-      const dvec2 *px = reinterpret_cast<const dvec2*>(th + (d0 + i) * ld_th + 2 * c2), *pm = reinterpret_cast<const dvec2*>(mean + o),
-                  *pq = reinterpret_cast<const dvec2*>(m2 + o);
-      x[i] = NT ? __builtin_nontemporal_load(px) : *px;
-      mu[i] = NT ? __builtin_nontemporal_load(pm) : *pm;
-      q[i] = NT ? __builtin_nontemporal_load(pq) : *pq;
-    }
-#pragma unroll
-  for (int i = 0; i < EL_ROWS; ++i)
-    if (d0 + i < D) {
-      double m0 = mu[i].x, m1 = mu[i].y, q0 = q[i].x, q1 = q[i].y;
-      welford_elem(x[i].x, m0, q0, n);
-      welford_elem(x[i].y, m1, q1, n);
-      mu[i] = dvec2{m0, m1};
-      q[i] = dvec2{q0, q1};
-      i64 o = (d0 + i) * ld + 2 * c2;
-      dvec2 *pm = reinterpret_cast<dvec2*>(mean + o), *pq = reinterpret_cast<dvec2*>(m2 + o);
-      if (NT) {
-        __builtin_nontemporal_store(mu[i], pm);
-        __builtin_nontemporal_store(q[i], pq);
-      } else {
-        *pm = mu[i];
-        *pq = q[i];
-      }
-    }
+  bkw::welford_unit_v2<NT>(blockIdx.x, blockIdx.y, (int)threadIdx.x, mean, m2, th, ld, ld_th, n, C2, D);
 }
 
 // one workgroup per dimension; thread t owns chains t, t+256, ... (fixed order), then a
@@ -517,7 +478,7 @@ static int welford_launch(double* mean, double* m2, i64 ld, const double* theta,
   if (!mean || !m2 || !theta || (!n_dev && n < 1) || C < 0 || D < 0) return BK_E_ARG;
   if (ld < C || ld_th < C) return BK_E_ALIGN;
   if (C == 0 || D == 0) return BK_OK;
-  if (C % 2 == 0 && ld % 2 == 0 && ld_th % 2 == 0 && bk_aligned16(mean) && bk_aligned16(m2) && bk_aligned16(theta)) {
+  if (bkw::v2_applies(mean, m2, theta, ld, ld_th, C)) {
     dim3 grid((unsigned)bk_cdiv(C / 2, 256), (unsigned)bk_cdiv(D, EL_ROWS));
     if (bk_streams_past_llc(3 * C * D))
       k_welford_v2<true><<<grid, dim3(256), 0, bk_stream(stream)>>>(mean, m2, theta, ld, ld_th, (double)n, n_dev, n_off,

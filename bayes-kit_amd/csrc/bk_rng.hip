@@ -4,6 +4,7 @@
 // 64 lanes of a wavefront because the state layout is chain-contiguous.
 #include "bk_common.hpp"
 #include "bk_rng.hpp"
+#include "bk_welford.hpp"
 #include "ziggurat_tables.inc"
 
 namespace {
@@ -505,6 +506,62 @@ static int zp_lanes_per_chain(i64 C, i64 D) {
   return best;
 }
 
+// The generator with a SIDE JOB: of every `period` consecutive workgroups the last one runs a unit of a Welford update
+// (bkw::welford_unit_v2: memory-bound) until its units are used up, the others generate (instruction-issue-bound): the two
+// kinds are resident together and the launch takes about the longer of the two times (tools/zig_welford_overlap.py).
+// A kernel of its own: k_zig_parallel -- the generator of every other caller -- is untouched.
+struct WelfordSide {
+  double* mean; double* m2; const double* th; i64 ld, ld_th; const int64_t* n_dev; i64 n_off; i64 C2, D;
+  unsigned gx, units, period;
+};
+template <int LPC>
+__global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel_side(uint64_t* st, i64 ldr, double* zt, i64 ldz,
+                                                                         i64 C, i64 D, WelfordSide job) {
+  constexpr int G = BK_WAVE / LPC;  // chains per wavefront
+  const unsigned b = blockIdx.x, k = b / job.period;
+  if (b % job.period == job.period - 1 && k < job.units) {
+    const double n = (double)(*job.n_dev - job.n_off);
+    bkw::welford_unit_v2<false>(k % job.gx, k / job.gx, (int)threadIdx.x, job.mean, job.m2, job.th, job.ld, job.ld_th, n,
+                                job.C2, job.D);
+    return;
+  }
+  const unsigned before = (b + 1) / job.period;  // side workgroups among the blocks before this one
+  const i64 wg = (i64)b - (before < job.units ? before : job.units);
+  __shared__ ZigLds2 tab;
+  __shared__ __align__(16) uint64_t win[ZP_WAVES][4 * BK_WAVE];
+  __shared__ __align__(16) uint64_t rkeys[ZP_WAVES][G][20];
+  load_tables2(tab);
+  zig_parallel_wave<LPC>(st, ldr, zt, ldz, C, D, nullptr, tab, win[bk_wave_id()], &rkeys[bk_wave_id()][0][0], wg * ZP_WAVES + bk_wave_id());
+}
+
+static bool zig_side_applies(const bk_welford_job& j) {
+  return j.mean && j.m2 && j.theta && j.n_dev && j.C > 0 && j.D > 0 && j.ld >= j.C && j.ld_theta >= j.C &&
+         bkw::v2_applies(j.mean, j.m2, j.theta, j.ld, j.ld_theta, j.C) && !bk_streams_past_llc(3 * j.C * j.D);
+}
+
+static void zig_parallel_side_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, const bk_welford_job& j,
+                                     hipStream_t s) {
+  const int lpc = zp_lanes_per_chain(C, D);
+  const i64 chains_per_wg = (i64)ZP_WAVES * (BK_WAVE / lpc);
+  const i64 n_wg = bk_cdiv(C, chains_per_wg);
+  WelfordSide w = {j.mean, j.m2, j.theta, j.ld, j.ld_theta, j.n_dev, j.n_offset, j.C / 2, j.D, 0, 0, 0};
+  w.gx = (unsigned)bk_cdiv(j.C / 2, 256);
+  w.units = w.gx * (unsigned)bk_cdiv(j.D, bkw::EL_ROWS);
+  const i64 total = n_wg + w.units;
+  i64 period = total / w.units;  // (>= 1; the side units spread over the whole grid, or -- period 1 -- lead it)
+  if (period < 2) period = 2;
+  w.period = (unsigned)period;
+  // (every side unit must have a slot: units * period <= total + period holds; the last slots past `total` do not exist,
+  // so size the grid for the last side slot as well)
+  i64 grid_n = total;
+  const i64 last_side = (i64)(w.units - 1) * period + (period - 1);
+  if (last_side >= grid_n) grid_n = last_side + 1;
+  dim3 grid((unsigned)grid_n), block(ZP_WAVES * BK_WAVE);
+  if (lpc == 16) k_zig_parallel_side<16><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, w);
+  else if (lpc == 32) k_zig_parallel_side<32><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, w);
+  else k_zig_parallel_side<64><<<grid, block, 0, s>>>(state, ldr, zt, ldz, C, D, w);
+}
+
 static void zig_parallel_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, uint64_t* snap,
                                 hipStream_t s, i64 max_workgroups = 0) {
   const int lpc = zp_lanes_per_chain(C, D);
@@ -912,15 +969,24 @@ int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double
                         double* out, int64_t ld, const double* metric, double* kin_out, int64_t C, int64_t D,
                         double* work, int64_t work_elems, const double* logp, double* cur_H, double* cur_h,
                         double* rej, uint8_t* alive, double prob_retry, uint32_t* counters, int64_t n_counters,
-                        int64_t* draw_counter, void* stream) {
+                        int64_t* draw_counter, const bk_welford_job* side, void* stream) {
   if (!state || !out || !kin_out || !logp || !cur_H || !cur_h || !rej || !alive || C < 0 || D < 0 || ld < C ||
       ldr < C || n_counters < 0 || n_counters > 64 || (n_counters > 0 && !counters))
     return BK_E_ARG;
+  if (side && (!side->mean || !side->m2 || !side->theta || !side->n_dev || side->C < 0 || side->D < 0)) return BK_E_ARG;
+  const bool with_generator = rng_kind == BK_RNG_PHILOX && work && D >= 32 && work_elems >= bk_refresh_work_elems(C, D);
+  const bool ride = side && C > 0 && with_generator && zig_side_applies(*side);
+  if (side && !ride) {  // (a launch of its own, first: it reads the current point and the draw count as this draw finds them)
+    int rc = bk_welford_update_dev(side->mean, side->m2, side->ld, side->theta, side->ld_theta, side->n_dev, side->n_offset,
+                                   side->C, side->D, stream);
+    if (rc != BK_OK) return rc;
+  }
   if (C == 0) return BK_OK;
-  if (rng_kind == BK_RNG_PHILOX && work && D >= 32 && work_elems >= bk_refresh_work_elems(C, D)) {
+  if (with_generator) {
     hipStream_t s = bk_stream(stream);
     i64 dp = (D + 7) / 8 * 8;
-    zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
+    if (ride) zig_parallel_side_launch(state, ldr, work, dp, C, D, *side, s);
+    else zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
     DrBegin b = {logp, cur_H, cur_h, rej, alive, prob_retry, counters, (int)n_counters, draw_counter, state, ldr};
     refresh_apply_kin_launch<true>(work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, b, s);
     BK_RETURN_LAUNCH_STATUS();

@@ -81,12 +81,26 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
 /* DRGHMC: the partial momentum refresh with its kinetic energy (bk_momentum_refresh, no mask) followed by the
  * start of the draw (bk_dr_begin_retry with kin = kin_out) -- drghmc.py:360-371.  With `work` (Philox, D >= 32) the
  * transpose of the normals into the state layout, the kinetic energy and the start of the draw are ONE launch after
- * the generator's; otherwise the two calls in sequence.  Same values, same stream positions either way. */
+ * the generator's; otherwise the two calls in sequence.  Same values, same stream positions either way.
+ * side (may be NULL): one bk_welford_update_dev call -- the PREVIOUS draw's update of the running moments, whose input is
+ * the chains' current point as this draw finds it -- done by workgroups of the generator's launch: the generator is bound
+ * by instruction issue, the update by memory, and side by side they take the longer of the two times instead of the sum
+ * (a draw sequence inside one hipGraph: DrGhmcDiag.advance(n)).  Without `work` the update is a launch of its own, first. */
+typedef struct bk_welford_job {
+  double* mean;
+  double* m2;
+  int64_t ld;
+  const double* theta;
+  int64_t ld_theta;
+  const int64_t* n_dev;
+  int64_t n_offset;
+  int64_t C, D;
+} bk_welford_job;
 int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double* loc_in, double loc_mul,
                         double scale, double* out, int64_t ld, const double* metric, double* kin_out, int64_t C,
                         int64_t D, double* work, int64_t work_elems, const double* logp, double* cur_H,
                         double* cur_h, double* rej, uint8_t* alive, double prob_retry, uint32_t* counters,
-                        int64_t n_counters, int64_t* draw_counter, void* stream);
+                        int64_t n_counters, int64_t* draw_counter, const bk_welford_job* side, void* stream);
 
 /* out[c] = log(u), u = next double of chain c's stream: `np.log(self._rng.uniform())`
  * (hmc.py:60, metropolis.py:74, drghmc.py:370,378).  Inactive chains draw nothing and

@@ -149,9 +149,12 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
     assert lib.bk_sort_by_key(p, p, p, p, 4, p, 1 << 20, None) == E_ARG             # in and out must differ
     assert lib.bk_sort_by_key_work_bytes(1 << 31) == -1 and lib.bk_sort_by_key_work_bytes(0) == 0
     assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, None, 4, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
-                                   None, None) == E_ARG                              # kinetic energy output required
+                                   None, None, None) == E_ARG                        # kinetic energy output required
     assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, p, 0, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
-                                   None, None) == OK                                 # no chains
+                                   None, None, None) == OK                           # no chains
+    job = _lib.WelfordJob(p, p, 4, None, 4, p, 0, 4, 8)                              # a side job without its input
+    assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, p, 0, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
+                                   None, ctypes.addressof(job), None) == E_ARG
     g0 = _lib.Ghost0(0.1, 0, None, 1.0, None, None, None, None)                      # a ghost of zero steps
     assert lib.bk_dr_proposal_funnel(p, p, p, 4, None, p, p, p, p, p, 4, None, 0.1, 3, 4, 8, None, None, None, p, p, p,
                                          None, None, ctypes.byref(g0), None) == E_ARG
