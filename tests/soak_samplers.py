@@ -135,6 +135,25 @@ def funnel_paths(rng):
     if o is not None:
         assert torch.equal(a._rho.nan_to_num(), o._rho.nan_to_num()), ("opaque rho", desc)
         assert np.array_equal(a.rng_state(), o.rng_state()), ("opaque stream", desc)
+    # round 6: advance(n) -- graphs of several consecutive draws, an attached moments update riding on the next draw's
+    # generator launch -- against n advance() calls: state, momenta, streams, moments and series
+    if graph and rng.random() < 0.5:
+        M = int(rng.integers(3, 30))
+        desc["advance_n"] = M
+        mom_b, mom_a = bk.RunningMoments(D, C), bk.RunningMoments(D, C)
+        rec_b, rec_a = bk.DrawRecorder([0, D - 1], M, C), bk.DrawRecorder([0, D - 1], M, C)
+        b.attach(moments=mom_b, recorder=rec_b)
+        b.advance(M)
+        for _ in range(M):
+            ta, la = a.sample()
+            mom_a.update(ta)
+            rec_a.record(ta, la)
+        assert torch.equal(a._theta_dc.nan_to_num(), b._theta_dc.nan_to_num()) and torch.equal(a._rho.nan_to_num(), b._rho.nan_to_num()), ("advance(n) state", desc)
+        assert np.array_equal(a.rng_state(), b.rng_state()), ("advance(n) stream", desc)
+        assert mom_a.n == mom_b.n == M and torch.equal(mom_a.mean.nan_to_num(), mom_b.mean.nan_to_num()) \
+            and torch.equal(mom_a.m2.nan_to_num(), mom_b.m2.nan_to_num()), ("advance(n) moments", desc)
+        assert torch.equal(rec_a.series.nan_to_num(), rec_b.series.nan_to_num()), ("advance(n) series", desc)
+        b.detach()
     return "drfunnel"
 
 

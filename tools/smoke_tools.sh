@@ -9,6 +9,9 @@ run "cfg4_profile_run.py OPAQUE=plugin" env OPAQUE=plugin WARM=3 N=3 python3 too
 run "cfg4_profile_run.py OPAQUE=lanes" env OPAQUE=lanes WARM=3 N=3 python3 tools/cfg4_profile_run.py
 run "cfg4_profile_run.py OPAQUE=lanes_fused" env OPAQUE=lanes_fused WARM=3 N=3 python3 tools/cfg4_profile_run.py
 run "cfg4_profile_run.py OPAQUE=source" env OPAQUE=source WARM=3 N=3 python3 tools/cfg4_profile_run.py
+run "cfg4_profile_run.py STATIONARY ATTACH PER=10" env STATIONARY=1 ATTACH=1 ADVANCE=1 PER=10 WARM=5 N=20 python3 tools/cfg4_profile_run.py
+run "cfg4_geometry_scan.py" env WARM=5 python3 tools/cfg4_geometry_scan.py 4608:12288
+run "zig_welford_overlap.py" python3 tools/zig_welford_overlap.py
 run "funnel_traj_bench.py" python3 tools/funnel_traj_bench.py
 run "traj_q_bench.py ONLY_L=16" env ONLY_L=16 python3 tools/traj_q_bench.py
 run "counted_step_bench.py" env REPS=20 LANES=64,2228 python3 tools/counted_step_bench.py
