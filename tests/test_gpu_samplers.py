@@ -1391,10 +1391,13 @@ def test_drghmc_attached_diagnostics_equal_manual_updates(ops):
     check_attached_diagnostics(ops, C=4096, D=21, draws=6)  # padded rows: theta's row pitch differs from the moments'
 
 
-def test_drghmc_advance_n_replays_graphs_of_several_draws(ops):
+@pytest.mark.parametrize("D,C", [(21, 900), (40, 901), (101, 4096)])
+def test_drghmc_advance_n_replays_graphs_of_several_draws(ops, D, C):
     """advance(n): hipGraphs of up to DRAWS_PER_GRAPH consecutive draws (one graph launch instead of n) leave exactly what n
-    advance() calls leave -- state, momenta, stream positions, lane statistics, the attached moments and series."""
-    D, C, K = 21, 900, 3
+    advance() calls leave -- state, momenta, stream positions, lane statistics, the attached moments and series.  Inside such a
+    graph the moments update of a draw is a job of the next draw's generator launch (D = 101: padded state rows) or, where that
+    launch cannot carry it, a launch of its own ahead of it (D = 21: no wavefront-per-chain generator; C = 901: odd)."""
+    K = 3
     mk = lambda: bk.DrGhmcDiag(bk.Funnel(D), K, [0.3, 0.1, 0.03], [3, 6, 12], 0.3, chains=C, seed=9)  # noqa: E731
     a, b = mk(), mk()
     ma, mb = bk.RunningMoments(D, C), bk.RunningMoments(D, C)
