@@ -765,7 +765,7 @@ static void refresh_apply_kin_launch(const double* work, i64 dp, const double* l
                                      double* out, i64 ld, const double* metric, double* kin_out, i64 C, i64 D,
                                      const DrBegin& b, hipStream_t s) {
   const size_t lds = (size_t)(64 * (dp + 1) + 256) * sizeof(double);
-  static const bool rows_off = getenv("BK_REFRESH_ROWS_OFF") != nullptr;  // (A/B: tools/r6_cfg4_refresh_ab.sh)
+  static const bool rows_off = getenv("BK_REFRESH_ROWS_OFF") != nullptr;  // (A/B with tools/cfg4_profile_run.py)
   if (dp <= 128 && lds <= 65536 && !rows_off)
     k_refresh_apply_kin_rows<BEGIN><<<dim3((unsigned)bk_cdiv(C, 64)), dim3(256), lds, s>>>(work, dp, loc_in, loc_mul, scale,
                                                                                           out, ld, metric, kin_out, C, D, b);
