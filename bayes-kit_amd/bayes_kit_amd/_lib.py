@@ -129,10 +129,11 @@ class Ghost0(ctypes.Structure):
                 ("lanes_out", P), ("lanes_total", P)]
 
 
-class WelfordJob(ctypes.Structure):
-    """bk_welford_job of include/bkhip.h: one welford_update_dev call, carried along by a draw's generator launch."""
-    _fields_ = [("mean", P), ("m2", P), ("ld", I), ("theta", P), ("ld_theta", I), ("n_dev", P), ("n_offset", I), ("C", I),
-                ("D", I)]
+class DiagJob(ctypes.Structure):
+    """bk_diag_job of include/bkhip.h: the previous draw's welford_update_dev and / or record_series_dev call, carried along
+    by a draw's generator launch."""
+    _fields_ = [("theta", P), ("ld_theta", I), ("C", I), ("D", I), ("n_dev", P), ("mean", P), ("m2", P), ("ld", I),
+                ("n_offset", I), ("series", P), ("dims", P), ("K", I), ("logp", P), ("capacity", I), ("row_offset", I)]
 
 
 class ScatterJob(ctypes.Structure):
@@ -427,8 +428,8 @@ class Ops:
 
     def dr_refresh_begin(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, work, logp, cur_H, cur_h, rej,
                          alive, prob_retry, counters, draw_counter=None, side=None):
-        """momentum_refresh(..., kin_out) + dr_begin_retry(...): the generator's launch + one more.  side: a welford_job(...)
-        done by workgroups of the generator's launch (the previous draw's update of attached moments)."""
+        """momentum_refresh(..., kin_out) + dr_begin_retry(...): the generator's launch + one more.  side: a diag_job(...)
+        done by workgroups of the generator's launch (the previous draw's update of attached moments / tracked series)."""
         D, C = out.shape
         self._call("bk_dr_refresh_begin", kind, ptr(state), state.stride(0), ptr(loc_in), loc_mul, scale, ptr(out),
                    _ld(out), ptr(metric), ptr(kin_out), C, D, ptr(work), 0 if work is None else work.numel(), ptr(logp),
@@ -436,11 +437,22 @@ class Ops:
                    0 if counters is None else counters.numel(), ptr(draw_counter),
                    None if side is None else ctypes.cast(ctypes.pointer(side), P), self._s())
 
-    def welford_job(self, mean, m2, theta, n_dev, n_offset):
-        """The arguments of welford_update_dev(...) as a job for dr_refresh_begin(side=...)."""
+    def diag_job(self, theta, n_dev, welford=None, record=None):
+        """welford_update_dev(mean, m2, theta, n_dev, n_offset) and / or record_series_dev(theta, dims, logp, series, n_dev,
+        row_offset) as ONE job for dr_refresh_begin(side=...).  welford = (mean, m2, n_offset); record = (dims, logp, series,
+        row_offset)."""
         D, C = theta.shape
-        assert _ld(m2) == _ld(mean) and n_dev.dtype == torch.int64
-        return WelfordJob(ptr(mean), ptr(m2), _ld(mean), ptr(theta), _ld(theta), ptr(n_dev), int(n_offset), C, D)
+        assert n_dev.dtype == torch.int64 and (welford is not None or record is not None)
+        j = DiagJob(ptr(theta), _ld(theta), C, D, ptr(n_dev), None, None, 0, 0, None, None, 0, None, 0, 0)
+        if welford is not None:
+            mean, m2, n_offset = welford
+            assert _ld(m2) == _ld(mean)
+            j.mean, j.m2, j.ld, j.n_offset = ptr(mean), ptr(m2), _ld(mean), int(n_offset)
+        if record is not None:
+            dims, logp, series, row_offset = record
+            j.series, j.dims, j.K, j.logp = ptr(series), ptr(dims), (0 if dims is None else dims.numel()), ptr(logp) or None
+            j.capacity, j.row_offset = series.shape[1], int(row_offset)
+        return j
 
     def dr_accept_prob_test_next(self, kind, state, chain_index, H, h, live, a, prob_retry, n, cur_H, cur_h, rej, alive,
                                  accepted, next_index, next_count, n_dev=None):

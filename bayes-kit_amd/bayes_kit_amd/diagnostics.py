@@ -124,9 +124,10 @@ class RunningMoments:
         n = n_dev[0] - n_offset; the caller keeps self.n in step."""
         self._ops.welford_update_dev(self.mean, self.m2, theta_dc, n_dev, n_offset)
 
-    def _update_job(self, theta_dc, n_dev, n_offset):
-        """_update_dev(...) as a job the NEXT draw's generator launch carries along (DrGhmcDiag.advance(n))."""
-        return self._ops.welford_job(self.mean, self.m2, theta_dc, n_dev, n_offset)
+    def _update_job(self, n_offset):
+        """_update_dev(...) as the Welford part of a job the NEXT draw's generator launch carries along
+        (DrGhmcDiag.advance(n); ops.diag_job)."""
+        return (self.mean, self.m2, n_offset)
 
     def rhat(self, group=None) -> np.ndarray:
         return rhat_from_moments(self.mean, self.m2, self.n, self._ops, group)
@@ -206,6 +207,11 @@ class DrawRecorder:
         self._check_dims(theta_dc.shape[0])
         self._ops.record_series_dev(theta_dc, self._dims_dev, logp if self.with_logp else None, self.series, row_dev,
                                     row_offset)
+
+    def _record_job(self, D, logp, row_offset):
+        """_record_dev(...) as the tracked-series part of a job the NEXT draw's generator launch carries along."""
+        self._check_dims(D)
+        return (self._dims_dev, logp if self.with_logp else None, self.series, row_offset)
 
     def names(self):
         return [f"theta[{d}]" for d in self.dims] + (["logp"] if self.with_logp else [])

@@ -394,22 +394,28 @@ class DrGhmcDiag(ManyChainSampler):
     def _feed_attached(self, theta_dc, logp, on_device, defer=False):
         """Inside the draw: the attached diagnostics see the new state (theta_dc [D, C], joint log density).
         defer (device path, a draw that is followed by another one inside the same hipGraph): the first attached moments
-        object is not updated here -- its update is returned as a job for the next draw's generator launch."""
-        job = None
+        object and the first attached recorder are not fed here -- their calls are returned as ONE job for the next draw's
+        generator launch (ops.diag_job: it reads theta_dc, the joint log density and the draw count as that draw finds them,
+        i.e. as this draw leaves them)."""
+        welford = record = None
         for kind, obj, off in self._attached:
             if on_device:
                 if kind == "moments":
-                    if defer and job is None:
-                        job = obj._update_job(theta_dc, self._draws_dev, off)
+                    if defer and welford is None:
+                        welford = obj._update_job(off)
                     else:
                         obj._update_dev(theta_dc, self._draws_dev, off)
+                elif defer and record is None:
+                    record = obj._record_job(theta_dc.shape[0], logp, off + 1)
                 else:
                     obj._record_dev(theta_dc, logp, self._draws_dev, off + 1)
             elif kind == "moments":
                 obj.update(theta_dc, layout="dc")
             else:
                 obj.record(theta_dc, logp)
-        return job
+        if welford is None and record is None:
+            return None
+        return self._ops.diag_job(theta_dc, self._draws_dev, welford=welford, record=record)
 
     def _count_attached(self):
         for i, (kind, obj, off) in enumerate(self._attached):
@@ -423,7 +429,7 @@ class DrGhmcDiag(ManyChainSampler):
                 self._drop_graphs()  # (the offset is a scalar argument of the captured launches)
 
     DRAWS_PER_GRAPH = 10  # advance(n): draws replayed per hipGraph launch (each launch costs ~8 us between graphs)
-    DEFER_MOMENTS = True  # ... and inside such a graph an attached moments update rides on the next draw's generator launch
+    DEFER_MOMENTS = True  # ... and inside such a graph the attached moments / series of a draw ride on the next draw's generator launch
 
     def advance(self, n: int = 1):
         """n draws of every chain WITHOUT handing the state back (no copies): for runs whose draws are consumed

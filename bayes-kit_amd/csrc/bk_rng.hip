@@ -510,19 +510,30 @@ static int zp_lanes_per_chain(i64 C, i64 D) {
 // (bkw::welford_unit_v2: memory-bound) until its units are used up, the others generate (instruction-issue-bound): the two
 // kinds are resident together and the launch takes about the longer of the two times (tools/zig_welford_overlap.py).
 // A kernel of its own: k_zig_parallel -- the generator of every other caller -- is untouched.
-struct WelfordSide {
+struct DiagSide {
   double* mean; double* m2; const double* th; i64 ld, ld_th; const int64_t* n_dev; i64 n_off; i64 C2, D;
-  unsigned gx, units, period;
+  // tracked series (k_record_series of bk_diag.hip): series[k][row][c] = theta[dims[k]][c], series[K][row][c] = logp[c]
+  double* series; const int32_t* dims; int K; const double* logp; i64 cap, row_off, C;
+  unsigned gx, w_units, rx, units, period;
 };
 template <int LPC>
 __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel_side(uint64_t* st, i64 ldr, double* zt, i64 ldz,
-                                                                         i64 C, i64 D, WelfordSide job) {
+                                                                         i64 C, i64 D, DiagSide job) {
   constexpr int G = BK_WAVE / LPC;  // chains per wavefront
   const unsigned b = blockIdx.x, k = b / job.period;
   if (b % job.period == job.period - 1 && k < job.units) {
-    const double n = (double)(*job.n_dev - job.n_off);
-    bkw::welford_unit_v2<false>(k % job.gx, k / job.gx, (int)threadIdx.x, job.mean, job.m2, job.th, job.ld, job.ld_th, n,
-                                job.C2, job.D);
+    if (k < job.w_units) {
+      const double n = (double)(*job.n_dev - job.n_off);
+      bkw::welford_unit_v2<false>(k % job.gx, k / job.gx, (int)threadIdx.x, job.mean, job.m2, job.th, job.ld, job.ld_th, n,
+                                  job.C2, job.D);
+    } else {
+      const unsigned u = k - job.w_units;
+      const i64 c = (i64)(u % job.rx) * 256 + threadIdx.x;
+      const int kk = (int)(u / job.rx);
+      const i64 row = *job.n_dev - job.row_off;
+      if (c < job.C && row >= 0 && row < job.cap)
+        job.series[((i64)kk * job.cap + row) * job.C + c] = kk < job.K ? job.th[(i64)job.dims[kk] * job.ld_th + c] : job.logp[c];
+    }
     return;
   }
   const unsigned before = (b + 1) / job.period;  // side workgroups among the blocks before this one
@@ -534,25 +545,38 @@ __global__ __launch_bounds__(ZP_WAVES* BK_WAVE) void k_zig_parallel_side(uint64_
   zig_parallel_wave<LPC>(st, ldr, zt, ldz, C, D, nullptr, tab, win[bk_wave_id()], &rkeys[bk_wave_id()][0][0], wg * ZP_WAVES + bk_wave_id());
 }
 
-static bool zig_side_applies(const bk_welford_job& j) {
-  return j.mean && j.m2 && j.theta && j.n_dev && j.C > 0 && j.D > 0 && j.ld >= j.C && j.ld_theta >= j.C &&
+// which parts of a side job the generator's launch can carry (the others become launches of their own)
+static bool zig_side_welford(const bk_diag_job& j) {
+  return j.mean && j.m2 && j.C > 0 && j.D > 0 && j.ld >= j.C && j.ld_theta >= j.C &&
          bkw::v2_applies(j.mean, j.m2, j.theta, j.ld, j.ld_theta, j.C) && !bk_streams_past_llc(3 * j.C * j.D);
 }
+static bool zig_side_record(const bk_diag_job& j) {
+  return j.series && j.C > 0 && j.ld_theta >= j.C && j.K >= 0 && j.K + (j.logp ? 1 : 0) > 0 && (j.K == 0 || j.dims);
+}
 
-static void zig_parallel_side_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, const bk_welford_job& j,
-                                     hipStream_t s) {
+static void zig_parallel_side_launch(uint64_t* state, i64 ldr, double* zt, i64 ldz, i64 C, i64 D, const bk_diag_job& j,
+                                     bool welford, bool record, hipStream_t s) {
   const int lpc = zp_lanes_per_chain(C, D);
   const i64 chains_per_wg = (i64)ZP_WAVES * (BK_WAVE / lpc);
   const i64 n_wg = bk_cdiv(C, chains_per_wg);
-  WelfordSide w = {j.mean, j.m2, j.theta, j.ld, j.ld_theta, j.n_dev, j.n_offset, j.C / 2, j.D, 0, 0, 0};
-  w.gx = (unsigned)bk_cdiv(j.C / 2, 256);
-  w.units = w.gx * (unsigned)bk_cdiv(j.D, bkw::EL_ROWS);
+  DiagSide w = {};
+  w.th = j.theta; w.ld_th = j.ld_theta; w.n_dev = j.n_dev;
+  if (welford) {
+    w.mean = j.mean; w.m2 = j.m2; w.ld = j.ld; w.n_off = j.n_offset; w.C2 = j.C / 2; w.D = j.D;
+    w.gx = (unsigned)bk_cdiv(j.C / 2, 256);
+    w.w_units = w.gx * (unsigned)bk_cdiv(j.D, bkw::EL_ROWS);
+  }
+  w.units = w.w_units;
+  if (record) {
+    w.series = j.series; w.dims = j.dims; w.K = (int)j.K; w.logp = j.logp; w.cap = j.capacity; w.row_off = j.row_offset; w.C = j.C;
+    w.rx = (unsigned)bk_cdiv(j.C, 256);
+    w.units += w.rx * (unsigned)(j.K + (j.logp ? 1 : 0));
+  }
   const i64 total = n_wg + w.units;
-  i64 period = total / w.units;  // (>= 1; the side units spread over the whole grid, or -- period 1 -- lead it)
+  i64 period = total / w.units;  // (>= 1; the side units spread over the whole grid, or -- period 2 -- lead it)
   if (period < 2) period = 2;
   w.period = (unsigned)period;
-  // (every side unit must have a slot: units * period <= total + period holds; the last slots past `total` do not exist,
-  // so size the grid for the last side slot as well)
+  // (every side unit must have a slot: size the grid for the last one as well; generator blocks past the chains leave at once)
   i64 grid_n = total;
   const i64 last_side = (i64)(w.units - 1) * period + (period - 1);
   if (last_side >= grid_n) grid_n = last_side + 1;
@@ -969,23 +993,33 @@ int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double
                         double* out, int64_t ld, const double* metric, double* kin_out, int64_t C, int64_t D,
                         double* work, int64_t work_elems, const double* logp, double* cur_H, double* cur_h,
                         double* rej, uint8_t* alive, double prob_retry, uint32_t* counters, int64_t n_counters,
-                        int64_t* draw_counter, const bk_welford_job* side, void* stream) {
+                        int64_t* draw_counter, const bk_diag_job* side, void* stream) {
   if (!state || !out || !kin_out || !logp || !cur_H || !cur_h || !rej || !alive || C < 0 || D < 0 || ld < C ||
       ldr < C || n_counters < 0 || n_counters > 64 || (n_counters > 0 && !counters))
     return BK_E_ARG;
-  if (side && (!side->mean || !side->m2 || !side->theta || !side->n_dev || side->C < 0 || side->D < 0)) return BK_E_ARG;
+  if (side && (!side->theta || !side->n_dev || side->C < 0 || side->D < 0 || (side->mean && !side->m2) ||
+               (!side->mean && !side->series)))
+    return BK_E_ARG;
   const bool with_generator = rng_kind == BK_RNG_PHILOX && work && D >= 32 && work_elems >= bk_refresh_work_elems(C, D);
-  const bool ride = side && C > 0 && with_generator && zig_side_applies(*side);
-  if (side && !ride) {  // (a launch of its own, first: it reads the current point and the draw count as this draw finds them)
+  const bool ride_w = side && C > 0 && with_generator && zig_side_welford(*side);
+  const bool ride_r = side && C > 0 && with_generator && zig_side_record(*side);
+  // (what the generator's launch cannot carry: launches of their own, first -- they read the current point, the joint log
+  // density and the draw count as this draw finds them)
+  if (side && side->mean && !ride_w) {
     int rc = bk_welford_update_dev(side->mean, side->m2, side->ld, side->theta, side->ld_theta, side->n_dev, side->n_offset,
                                    side->C, side->D, stream);
+    if (rc != BK_OK) return rc;
+  }
+  if (side && side->series && !ride_r) {
+    int rc = bk_record_series_dev(side->theta, side->ld_theta, side->dims, side->K, side->logp, side->series, side->capacity,
+                                  side->n_dev, side->row_offset, side->C, stream);
     if (rc != BK_OK) return rc;
   }
   if (C == 0) return BK_OK;
   if (with_generator) {
     hipStream_t s = bk_stream(stream);
     i64 dp = (D + 7) / 8 * 8;
-    if (ride) zig_parallel_side_launch(state, ldr, work, dp, C, D, *side, s);
+    if (ride_w || ride_r) zig_parallel_side_launch(state, ldr, work, dp, C, D, *side, ride_w, ride_r, s);
     else zig_parallel_launch(state, ldr, work, dp, C, D, nullptr, s);
     DrBegin b = {logp, cur_H, cur_h, rej, alive, prob_retry, counters, (int)n_counters, draw_counter, state, ldr};
     refresh_apply_kin_launch<true>(work, dp, loc_in, loc_mul, scale, out, ld, metric, kin_out, C, D, b, s);

@@ -82,25 +82,32 @@ int bk_momentum_refresh(int rng_kind, uint64_t* state, int64_t ldr,
  * start of the draw (bk_dr_begin_retry with kin = kin_out) -- drghmc.py:360-371.  With `work` (Philox, D >= 32) the
  * transpose of the normals into the state layout, the kinetic energy and the start of the draw are ONE launch after
  * the generator's; otherwise the two calls in sequence.  Same values, same stream positions either way.
- * side (may be NULL): one bk_welford_update_dev call -- the PREVIOUS draw's update of the running moments, whose input is
- * the chains' current point as this draw finds it -- done by workgroups of the generator's launch: the generator is bound
- * by instruction issue, the update by memory, and side by side they take the longer of the two times instead of the sum
- * (a draw sequence inside one hipGraph: DrGhmcDiag.advance(n)).  Without `work` the update is a launch of its own, first. */
-typedef struct bk_welford_job {
-  double* mean;
+ * side (may be NULL): the PREVIOUS draw's diagnostics -- one bk_welford_update_dev call (mean NULL: none) and / or one
+ * bk_record_series_dev call (series NULL: none) on the chains' current point as this draw finds it -- done by workgroups of
+ * the generator's launch: the generator is bound by instruction issue, the Welford update by memory, and side by side they
+ * take the longer of the two times instead of the sum (a draw sequence inside one hipGraph: DrGhmcDiag.advance(n)).  Where
+ * the generator's launch cannot carry them (no `work`, odd C, ...) they are launches of their own, first. */
+typedef struct bk_diag_job {
+  const double* theta; /* [D][ld_theta]: the point both parts read */
+  int64_t ld_theta;
+  int64_t C, D;
+  const int64_t* n_dev; /* the sampler's device-side draw count */
+  double* mean;         /* bk_welford_update_dev(mean, m2, ld, theta, ld_theta, n_dev, n_offset, C, D) */
   double* m2;
   int64_t ld;
-  const double* theta;
-  int64_t ld_theta;
-  const int64_t* n_dev;
   int64_t n_offset;
-  int64_t C, D;
-} bk_welford_job;
+  double* series; /* bk_record_series_dev(theta, ld_theta, dims, K, logp, series, capacity, n_dev, row_offset, C) */
+  const int32_t* dims;
+  int64_t K;
+  const double* logp;
+  int64_t capacity;
+  int64_t row_offset;
+} bk_diag_job;
 int bk_dr_refresh_begin(int rng_kind, uint64_t* state, int64_t ldr, const double* loc_in, double loc_mul,
                         double scale, double* out, int64_t ld, const double* metric, double* kin_out, int64_t C,
                         int64_t D, double* work, int64_t work_elems, const double* logp, double* cur_H,
                         double* cur_h, double* rej, uint8_t* alive, double prob_retry, uint32_t* counters,
-                        int64_t n_counters, int64_t* draw_counter, const bk_welford_job* side, void* stream);
+                        int64_t n_counters, int64_t* draw_counter, const bk_diag_job* side, void* stream);
 
 /* out[c] = log(u), u = next double of chain c's stream: `np.log(self._rng.uniform())`
  * (hmc.py:60, metropolis.py:74, drghmc.py:370,378).  Inactive chains draw nothing and

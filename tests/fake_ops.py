@@ -710,13 +710,17 @@ class FakeOps:
         if draw_counter is not None:
             draw_counter += 1
 
-    def welford_job(self, mean, m2, theta, n_dev, n_offset):
-        return (mean, m2, theta, n_dev, n_offset)
+    def diag_job(self, theta, n_dev, welford=None, record=None):
+        return (theta, n_dev, welford, record)
 
     def dr_refresh_begin(self, kind, state, loc_in, loc_mul, scale, out, metric, kin_out, work, logp, cur_H, cur_h, rej,
                          alive, prob_retry, counters, draw_counter=None, side=None):
         if side is not None:  # (beside the generator on the device: it reads the current point and the count as the draw finds them)
-            self.welford_update_dev(*side)
+            theta, n_dev, welford, record = side
+            if welford is not None:
+                self.welford_update_dev(welford[0], welford[1], theta, n_dev, welford[2])
+            if record is not None:
+                self.record_series_dev(theta, record[0], record[1], record[2], n_dev, record[3])
         self.momentum_refresh(kind, state, loc_in, loc_mul, scale, out, metric, kin_out, None, work)
         self.dr_begin_retry(kind, state, logp, kin_out, cur_H, cur_h, rej, alive, prob_retry, counters, draw_counter)
 

@@ -152,7 +152,7 @@ def test_error_behaviour_of_the_c_abi_without_a_gpu():
                                    None, None, None) == E_ARG                        # kinetic energy output required
     assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, p, 0, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
                                    None, None, None) == OK                           # no chains
-    job = _lib.WelfordJob(p, p, 4, None, 4, p, 0, 4, 8)                              # a side job without its input
+    job = _lib.DiagJob(None, 4, 4, 8, p, p, p, 4, 0, None, None, 0, None, 0, 0)     # a side job without its input
     assert lib.bk_dr_refresh_begin(0, p, 4, p, 0.9, 0.4, p, 4, None, p, 0, 8, None, 0, p, p, p, p, p, 1.0, None, 0,
                                    None, ctypes.addressof(job), None) == E_ARG
     g0 = _lib.Ghost0(0.1, 0, None, 1.0, None, None, None, None)                      # a ghost of zero steps
