@@ -638,9 +638,9 @@ class Ops:
         D, n = theta_out.shape
         H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
-        assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
+        assert _ld(rho_in) == ld_in and (grad_in is None or _ld(grad_in) == ld_in)
         ld_out = _ld(theta_out)
-        assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
+        assert _ld(rho_out) == ld_out and (grad_out is None or _ld(grad_out) == ld_out)
         self._call("bk_dr_proposal_gaussian", ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                    ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                    h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live),
@@ -664,9 +664,9 @@ class Ops:
         D, n = theta_out.shape
         H, hh, live = level if level is not None else (None, None, None)
         ld_in = _ld(theta_in)
-        assert _ld(rho_in) == ld_in and _ld(grad_in) == ld_in
+        assert _ld(rho_in) == ld_in and (grad_in is None or _ld(grad_in) == ld_in)
         ld_out = _ld(theta_out)
-        assert _ld(rho_out) == ld_out and _ld(grad_out) == ld_out
+        assert _ld(rho_out) == ld_out and (grad_out is None or _ld(grad_out) == ld_out)
         args = (ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index),
                 ptr(theta_out), ptr(rho_out), ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric),
                 h, steps, n, D, ptr(n_dev), ptr(lanes_out), ptr(lanes_total), ptr(H), ptr(hh), ptr(live))

@@ -52,7 +52,7 @@ class _Level:
 
 
 class DrGhmcDiag(ManyChainSampler):
-    TUNING = ("graph", "device_counts", "fuse_first_ghost", "tune_placement")
+    TUNING = ("graph", "device_counts", "fuse_first_ghost", "recompute_gradient", "tune_placement")
 
     def __init__(
         self,
@@ -76,7 +76,9 @@ class DrGhmcDiag(ManyChainSampler):
         """The reference's arguments (drghmc.py:37-48), then the engine's (ManyChainSampler: chains, chain_id0, path, tuning,
         ops).  Tuning knobs (none changes a result): ``graph`` (replay a draw as one hipGraph; default on where the draw is a
         fixed launch sequence), ``device_counts`` (lane-set sizes stay on the device; default on where the model allows),
-        ``fuse_first_ghost`` (the first ghost proposal inside the stage's launch), ``tune_placement``."""
+        ``fuse_first_ghost`` (the first ghost proposal inside the stage's launch), ``recompute_gradient`` (one-launch path:
+        no gradient cache -- every proposal launch evaluates its source point's gradient itself, two arrays instead of three
+        per launch and per scatter), ``tune_placement``."""
         fuse_builtin, fuse_steps = self._resolve_path(path)
         tn = self._resolve_tuning(tuning, knobs)
         tune_placement, device_counts, graph = tn.get("tune_placement"), tn.get("device_counts"), tn.get("graph")
@@ -149,6 +151,11 @@ class DrGhmcDiag(ManyChainSampler):
         # (one-launch path) a proposal's launch also runs the first ghost of the lanes it produces; False keeps
         # that ghost a launch of its own -- same results, for A/B timing and the tests
         self._fuse_first_ghost = bool(fuse_first_ghost) and self._one_launch
+        # (one-launch path) no gradient cache: a proposal launch evaluates the gradient of its source point itself (the same
+        # values: a function of theta alone, sums in one order) instead of reading one that an earlier launch stored and a
+        # scatter moved -- the launches over all chains are memory launches, and this takes a third of their bytes away.
+        # self._grad is then NOT kept up to date between draws; state_dict() refreshes it.
+        self._regrad = bool(tn.get("recompute_gradient", True)) and self._one_launch
         self._init_graph(graph)
         self._graph_many = {}  # advance(n): graphs of several consecutive draws, by their number
         self.host_syncs_per_draw = 0 if self._dev_counts else max(0, int(max_proposals) - 1) + sum(
@@ -303,6 +310,14 @@ class DrGhmcDiag(ManyChainSampler):
 
     def _state_tensors(self):
         return {"theta": self._theta_dc, "rho": self._rho_dc, "grad": self._grad, "lp": self._lp}
+
+    def state_dict(self):
+        if getattr(self, "_regrad", False) and self._have_cache:
+            # the one-launch path keeps no gradient cache: bring self._grad up to date for the checkpoint (a sampler on
+            # another path may load it); the values are the ones that path would have cached
+            self._materialize(self._eval_grad(self._theta_dc, self._grad, None), self._grad)
+            self._grad_calls -= 1  # (bookkeeping of the checkpoint, not a model call of the sampler's)
+        return super().state_dict()
 
     def _state_extra(self):
         return {"rho_sign": self._rho_sign}
@@ -594,7 +609,8 @@ class DrGhmcDiag(ManyChainSampler):
         if ghost is not None:
             par, pr, nxt_list = ghost
             ghost = self._ops.ghost_link(par.H, par.h, par.live, par.a, dst.a, pr, *(nxt_list or (None, None)))
-        ok = self._model.bk_dr_proposal(src.theta, src.rho, src.grad, idx, dst.theta, dst.rho, dst.grad, dst.logp,
+        ok = self._model.bk_dr_proposal(src.theta, src.rho, None if self._regrad else src.grad, idx, dst.theta, dst.rho,
+                                        None if self._regrad else dst.grad, dst.logp,
                                         dst.kin, self._metric_dev, h, steps, n_dev=n_dev,
                                         lanes_out=self._slot_lanes[slot:slot + 1],
                                         lanes_total=self._slot_lanes_total[slot:slot + 1],
@@ -720,8 +736,9 @@ class DrGhmcDiag(ManyChainSampler):
             else:
                 ops.dr_accept_prob_test(self._rng_kind, self._rng_state, idx, P0.H, P0.h, P0.live, P0.a, pr, C,
                                         self._cur_H, self._cur_h, self._rej, self._alive, P0.accepted, n_dev=n_dev)
-            scatter = (P0.accepted, idx, C, [self._theta_dc, self._rho_dc, self._grad], [P0.theta, P0.rho, P0.grad],
-                       self._lp, P0.logp)                                                          # :379-381
+            moved = ([self._theta_dc, self._rho_dc], [P0.theta, P0.rho]) if self._regrad else \
+                ([self._theta_dc, self._rho_dc, self._grad], [P0.theta, P0.rho, P0.grad])
+            scatter = (P0.accepted, idx, C, moved[0], moved[1], self._lp, P0.logp)               # :379-381
             if k + 1 < K and self._one_launch:
                 job = ops.scatter_job(*scatter, n_dev=n_dev)   # rides on the next stage's proposal launch
             else:

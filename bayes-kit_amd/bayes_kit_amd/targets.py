@@ -764,8 +764,8 @@ def _bind_source_fast_paths(t):
             ld_in, ld_out = _lib._ld(theta_in), _lib._ld(theta_out)
             if max(ld_in, ld_out) * (16 + self._head) * 8 >= 2 ** 32:
                 return False
-            assert _lib._ld(rho_in) == ld_in and _lib._ld(grad_in) == ld_in
-            assert _lib._ld(rho_out) == ld_out and _lib._ld(grad_out) == ld_out
+            assert _lib._ld(rho_in) == ld_in and (grad_in is None or _lib._ld(grad_in) == ld_in)
+            assert _lib._ld(rho_out) == ld_out and (grad_out is None or _lib._ld(grad_out) == ld_out)
             H, hh, live = level if level is not None else (None, None, None)
             check(f_prop(ptr(theta_in), ptr(rho_in), ptr(grad_in), ld_in, ptr(src_index), ptr(theta_out), ptr(rho_out),
                          ptr(grad_out), ptr(logp_out), ptr(kin_out), ld_out, ptr(metric), h, steps, n, D, ptr(n_dev),

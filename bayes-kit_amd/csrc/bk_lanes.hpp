@@ -204,7 +204,7 @@ struct TrajCtx {
         const double t = HM ? metric_of(u) * gi : gi;
         r[u] = r[u] + hk * t;
         if (DRIFT) x[u] = x[u] + hd * r[u];
-        if (STORE && on)
+        if (STORE && on && g_out)
           *reinterpret_cast<double*>(reinterpret_cast<char*>(g_out + (i64)G::off(u) * ld_out) + bo_out) = gi;
       }
       // bound the live temporaries (registers -> occupancy)
@@ -292,6 +292,7 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
   for (int k = 0; k < G::KC; ++k) tail_ok[k] = HEAD + pos + G::off(k * SL + SL - 1) < D;
 #define BKL_OK(u) (!G::last_slot(u) || tail_ok[(u) / SL])
   double x[NU], r[NU], mt[HM && LPC == 16 ? NU : 1];
+  const bool regrad = a.g_in == nullptr;  // (uniform) the source's gradient is not cached: recomputed below
   // gather + first half-kick + drift (drghmc.py:276-278)
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
@@ -300,17 +301,19 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
     const bool ok = BKL_OK(u);
     x[u] = ok ? BKL_IN(a.th_in, u) : 0.0;
     r[u] = ok ? BKL_IN(a.rho_in, u) : 0.0;
-    double gin = ok ? BKL_IN(a.g_in, u) : 0.0;
     const double mi = (hm && BKL_OK(u)) ? metric[HEAD + pos + G::off(u)] : 1.0;
     if (HM && LPC == 16) mt[u] = mi;
-    double t = hm ? mi * gin : gin;
-    if (a.hmc_first) {
-      r[u] = r[u] + (-half) * t;  // hmc.py:46
-      r[u] = r[u] + h * t;        // hmc.py:48
-    } else {
-      r[u] = r[u] + half * t;
+    if (!regrad) {
+      double gin = ok ? BKL_IN(a.g_in, u) : 0.0;
+      double t = hm ? mi * gin : gin;
+      if (a.hmc_first) {
+        r[u] = r[u] + (-half) * t;  // hmc.py:46
+        r[u] = r[u] + h * t;        // hmc.py:48
+      } else {
+        r[u] = r[u] + half * t;
+      }
+      x[u] = x[u] + h * r[u];
     }
-    x[u] = x[u] + h * r[u];
     // the gather is issued in batches of 8 rows: all 3*NU loads in flight at once would set the
     // kernel's register count (and so its occupancy for the whole trajectory)
     if ((u & 7) == 7) __builtin_amdgcn_sched_barrier(0);
@@ -321,19 +324,31 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
     v[i] = a.th_in[(i64)i * ld_in + src];
     rv[i] = a.rho_in[(i64)i * ld_in + src];
     mvh[i] = hm ? metric[i] : 1.0;
-    const double gin = a.g_in[(i64)i * ld_in + src];
-    const double t = hm ? mvh[i] * gin : gin;
-    if (a.hmc_first) {
-      rv[i] = rv[i] + (-half) * t;
-      rv[i] = rv[i] + h * t;
-    } else {
-      rv[i] = rv[i] + half * t;
+    if (!regrad) {
+      const double gin = a.g_in[(i64)i * ld_in + src];
+      const double t = hm ? mvh[i] * gin : gin;
+      if (a.hmc_first) {
+        rv[i] = rv[i] + (-half) * t;
+        rv[i] = rv[i] + h * t;
+      } else {
+        rv[i] = rv[i] + half * t;
+      }
+      v[i] = v[i] + h * rv[i];
     }
-    v[i] = v[i] + h * rv[i];
   }
   using StepCtx = TrajCtx<LPC, SL, HM, HEAD, false, true>;
   using KickCtx = TrajCtx<LPC, SL, HM, HEAD, false, false>;
   using EndCtx = TrajCtx<LPC, SL, HM, HEAD, true, false>;
+  if (regrad) {
+    // no cached gradient of the source point was handed over: evaluate it here and deliver it into the first half-kick +
+    // drift (drghmc.py:276-278).  The same operations on the same values as the branch above -- the gradient is a function
+    // of theta alone and its sums have one order -- for one evaluation more and one array less to read (and, at the other
+    // end, to write and to scatter): the launches over all chains are memory launches.
+    StepCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, half, h, pos, D, nullptr, 0, 0u, false, false};
+    DEN::eval(c, a.params);
+#pragma unroll
+    for (int i = 0; i < HEAD; ++i) v[i] = v[i] + h * rv[i];
+  }
   // (steps-1) x {gradient, kick, drift} (drghmc.py:280-283)
   for (int step = 0; step + 1 < a.steps; ++step) {
     StepCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, h, h, pos, D, nullptr, 0, 0u, false, false};
@@ -347,8 +362,10 @@ __device__ __forceinline__ void traj_body(const TrajArgs& a, i64 n, const bk_gho
     EndCtx c{x, r, v, rv, gv, tail_ok, mt, mvh, metric, half, 0.0, pos, D, a.g_out, ld_out, bo_out, on, false};
     logp_j = DEN::eval(c, a.params);
     if (writer) {
+      if (a.g_out) {
 #pragma unroll
-      for (int i = 0; i < HEAD; ++i) a.g_out[(i64)i * ld_out + j] = gv[i];
+        for (int i = 0; i < HEAD; ++i) a.g_out[(i64)i * ld_out + j] = gv[i];
+      }
       a.logp_out[j] = logp_j;
     }
   }
@@ -533,7 +550,8 @@ static int dr_proposal_launch(const double* theta_in, const double* rho_in, cons
                               const bk_scatter_job* job_in, const bk_ghost_link* ghost_in, const bk_ghost0* g0_in,
                               const double* params, void* stream, bool hmc_first = false) {
   constexpr int HEAD = DEN::HEAD;
-  if (!theta_in || !rho_in || !grad_in || !theta_out || !rho_out || !grad_out || !logp_out || !kin_out ||
+  // (grad_in NULL: the source's gradient is evaluated by the launch; grad_out NULL: the end point's is not stored)
+  if (!theta_in || !rho_in || (!grad_in && hmc_first) || !theta_out || !rho_out || !logp_out || !kin_out ||
       steps < 1 || steps > 0x7fffffff || n < 0 || D < HEAD || D < 1)
     return BK_E_ARG;
   if (D - HEAD > MAX_ROWS) return BK_E_ARG;  // caller falls back to the step-by-step path

@@ -542,7 +542,11 @@ int bk_mala_step_gaussian(const double* theta, double* theta_out, double* theta_
  * lanes_out (may be NULL): receives the number of lanes the launch worked on (statistics:
  * gradient evaluations = steps * lanes); lanes_total (may be NULL): the same count is ADDED to it.
  * H_out, h_out, live_out (all or none): additionally perform bk_dr_level_begin for the produced
- * lanes in the same launch (H = -((-logp) + kin), h = 0, live = 1). */
+ * lanes in the same launch (H = -((-logp) + kin), h = 0, live = 1).
+ * grad_in NULL: the launch evaluates the source point's gradient itself instead of reading a cached one (the same
+ * values: the gradient is a function of theta alone and its sums have one order); grad_out NULL: the end point's gradient
+ * is not stored.  A caller that keeps no gradient cache at all (DrGhmcDiag's one-launch path) moves two arrays per launch
+ * and per scatter instead of three. */
 /* (prototype below, after the structs its optional jobs are described by.) */
 
 /* The arguments of one bk_scatter_columns call, as a job a trajectory launch can carry along. */

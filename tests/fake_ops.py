@@ -404,6 +404,12 @@ class FakeOps:
     def dr_proposal_funnel(self, theta_in, rho_in, grad_in, src_index, theta_out, rho_out, grad_out, logp_out,
                            kin_out, metric, h, steps, n_dev=None, lanes_out=None, lanes_total=None, level=None, job=None,
                            ghost=None, ghost0=None):
+        if grad_in is None:   # no cached gradient of the source point: the launch evaluates it
+            grad_in = torch.zeros_like(theta_in)
+            kind_, params_ = self._prop_target
+            self.target_grad(kind_, params_, theta_in, grad_in, None)
+        if grad_out is None:  # ... and does not store the end point's
+            grad_out = torch.empty_like(theta_out)
         # a scatter job runs BESIDE the trajectories on the device (disjoint memory): do it afterwards here, so
         # that a job which overlapped the proposal's inputs or outputs would be noticed
         if job is not None or ghost is not None or ghost0 is not None:

@@ -1092,8 +1092,9 @@ def test_drghmc_device_side_lane_counts_equal_host_sized_launches(ops, D, K):
         a = mk(device_counts=False)
         b = mk(device_counts=True, graph=False)
         g = mk()  # default: device counts + hipGraph replay
-        u = mk(graph=False, fuse_first_ghost=False)  # every ghost a launch of its own
+        u = mk(graph=False, fuse_first_ghost=False, recompute_gradient=False)  # every ghost a launch of its own, cached gradients
         assert g._dev_counts and g._use_graph and not a._dev_counts and g.host_syncs_per_draw == 0
+        assert g._regrad and b._regrad and not u._regrad and not a._regrad
         seen = set()
         for n in range(12):
             ta, la = a.sample()
@@ -1113,6 +1114,17 @@ def test_drghmc_device_side_lane_counts_equal_host_sized_launches(ops, D, K):
         assert g._graph is not None and len(seen) >= 3
         total = float(g.lane_steps_total.item())
         assert total > 0 and total == float(b.lane_steps_total.item())
+        # the one-launch path keeps no gradient cache (recompute_gradient): its checkpoint carries an up-to-date one all the
+        # same, and a sampler on the host-sized path resumes from it with the same draws
+        c = mk(device_counts=False)
+        c.load_state_dict(g.state_dict())
+        assert torch.equal(c._grad, a._grad) and torch.equal(c._lp, a._lp)
+        for n in range(3):
+            tg, lg = g.sample()
+            tc, lc = c.sample()
+            ta, la = a.sample()
+            assert torch.equal(tg, tc) and torch.equal(lg, lc) and torch.equal(ta, tc), (D, K, C, n, "resumed on another path")
+        np.testing.assert_array_equal(g.rng_state(), c.rng_state())
 
 
 def funnel_plugin(D):

@@ -441,7 +441,7 @@ def test_drghmc_device_side_lists_equal_host_sized_launches(K):
     b = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_b), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True, ops=ops_b)
     ops_u = FakeOps()
     u = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_u), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,
-                      fuse_first_ghost=False, ops=ops_u)   # every ghost a launch of its own
+                      fuse_first_ghost=False, recompute_gradient=False, ops=ops_u)   # every ghost a launch of its own, cached gradients
     # model-opaque: the gradient a separate, COUNTED op per leapfrog step (drghmc.py:280-283), lane counts on the device
     ops_o = FakeOps()
     o = bk.DrGhmcDiag(bk.Funnel(7, ops=ops_o), K, sizes, counts, 0.4, chains=40, seed=11, device_counts=True,

@@ -43,7 +43,7 @@ if os.environ.get("STATIONARY") == "1":   # exact draws of the funnel, as bench_
     kw["init"] = init
 s = bk.DrGhmcDiag(model, 3, [0.2, 0.05, 0.0125], [10, 40, 160], 0.1, chains=C, seed=20242,
                   device_counts={"0": False, "1": True}.get(os.environ.get("DEVCOUNTS", ""), None),
-                  fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", **kw)
+                  fuse_first_ghost=os.environ.get("FUSE_GHOST", "1") == "1", recompute_gradient=os.environ.get("REGRAD", "1") == "1", **kw)
 if os.environ.get("DEFER") == "0":
     bk.DrGhmcDiag.DEFER_MOMENTS = False
 if os.environ.get("ATTACH") == "1":   # the diagnostics bench_secondary feeds from inside the draw's graph
