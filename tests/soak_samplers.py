@@ -74,12 +74,13 @@ def funnel_paths(rng):
     N = int(rng.integers(2, 9))
     graph = bool(rng.integers(0, 2)) and not NO_GRAPH
     fuse = bool(rng.integers(0, 4))
+    regrad = bool(rng.integers(0, 4))   # (round 6) the one-launch path without a gradient cache, or with
     desc = dict(alg="drfunnel", D=D, C=C, K=K, sizes=sizes, counts=counts, damp=damp, prob_retry=pr, metric=metric is not None,
-                seed=seed, N=N, graph=graph, fuse_first_ghost=fuse)
+                seed=seed, N=N, graph=graph, fuse_first_ghost=fuse, recompute_gradient=regrad)
     mk = lambda **kw: bk.DrGhmcDiag(bk.Funnel(D), K, sizes, counts, damp, metric_diag=metric, chains=C, seed=seed,  # noqa: E731
                                     prob_retry=pr, **kw)
     a = mk(device_counts=False)
-    b = mk(device_counts=True, graph=graph, fuse_first_ghost=fuse)
+    b = mk(device_counts=True, graph=graph, fuse_first_ghost=fuse, recompute_gradient=regrad)
     # round 4: the gradient as a separate COUNTED op per leapfrog step (built-in op, or the user plugin), lane counts on
     # the device -- against the same host-sized path (step by step, so that the joint log densities agree bit for bit too)
     # round 5: "builtin" runs {gradient, kick, drift} as ONE launch per step (bk_leapfrog_step), "builtin_op" keeps the gradient a
